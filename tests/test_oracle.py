@@ -1,0 +1,149 @@
+"""Pin the oracle (oracle/gp_oracle.py) before anything is compared against it.
+
+* acquisition half: against fixtures produced by the REFERENCE'S OWN classes
+  (tests/golden/make_golden.py) -- bit-level/1e-13 agreement required;
+* GP half: the reference's only numeric pin on the george boundary, the posterior
+  identity of test/test_models/test_gaussian_process.py:44-49, plus the LCB value
+  pin (test_lcb.py:25) and incumbent == argmin (test_gaussian_process.py:77-82).
+"""
+import os
+
+import numpy as np
+import pytest
+from scipy.stats import norm
+
+from oracle import gp_oracle as O
+from _tol import assert_logei_close
+from make_golden import CASES, golden_inputs, mcmc_inputs
+
+
+def _load(golden_dir, name):
+    return np.load(os.path.join(golden_dir, name + ".npz"))
+
+
+def test_norm_formulas_match_scipy():
+    z = np.concatenate([np.linspace(-38, 9, 20001), [0.0, -1.0, 1.0]])
+    assert np.allclose(O.norm_cdf(z), norm.cdf(z), rtol=1e-13, atol=0)
+    assert np.allclose(O.norm_pdf(z), norm.pdf(z), rtol=1e-13, atol=0)
+    assert np.allclose(O.norm_logpdf(z), norm.logpdf(z), rtol=1e-14, atol=0)
+    lc = norm.logcdf(z)
+    assert np.all(np.abs(O.norm_logcdf(z) - lc) <= 5e-14 * np.abs(lc) + 1e-300)
+
+
+def test_demo_model_pins(golden_dir):
+    """Values quoted in SURVEY.md 8(c): 0.0204 / -3.891 / 0.1217 / 0.0168."""
+    g = _load(golden_dir, "demo_model_pins")
+    y = g["y"]
+    m = np.full(5, y.mean())
+    v = np.full(5, y.var())
+    eta = y.min()
+    assert abs(g["ei"][0] - 0.0204) < 1e-4 and abs(g["log_ei"][0] + 3.891) < 1e-3
+    np.testing.assert_allclose(O.ei(m, v, eta), g["ei"], rtol=1e-13)
+    np.testing.assert_allclose(O.log_ei(m, v, eta), g["log_ei"], rtol=1e-13)
+    np.testing.assert_allclose(O.pi(m, v, eta), g["pi"], rtol=1e-13)
+    np.testing.assert_allclose(O.lcb(m, v), g["lcb"], rtol=1e-13)
+    # reference pin test/test_acquisition_functions/test_lcb.py:25
+    np.testing.assert_almost_equal(g["lcb"][0], -np.mean(y) + np.std(y), decimal=3)
+
+
+def test_acq_elementwise_against_reference(golden_dir):
+    g = _load(golden_dir, "acq_elementwise")
+    m, v, eta = g["m"], g["v"], float(g["eta"])
+    with np.errstate(all="ignore"):
+        np.testing.assert_array_equal(O.log_ei(m, v, eta), g["log_ei"])
+        np.testing.assert_array_equal(O.log_ei(m, v, eta, par=0.1), g["log_ei_par"])
+        assert_logei_close(O.log_ei_vec(m, v, eta), g["log_ei"], (eta - m) / np.sqrt(v))
+        np.testing.assert_allclose(O.pi(m, v, eta), g["pi"], rtol=1e-13, atol=0)
+        np.testing.assert_allclose(O.lcb(m, v), g["lcb"], rtol=1e-15)
+    pos = g["pos"]
+    np.testing.assert_allclose(O.ei(m[pos], v[pos], eta), g["ei_pos"], rtol=1e-12, atol=1e-300)
+    # ei.py:72-74: one zero-sigma point collapses the whole batch
+    assert O.ei(m, v, eta).shape == (1, 1) and g["ei_collapsed"].shape == (1, 1)
+    assert np.isneginf(g["log_ei"]).any()
+
+
+@pytest.mark.parametrize("name", list(CASES))
+def test_gp_cases_regression(golden_dir, name):
+    g = _load(golden_dir, name)
+    inp = golden_inputs(name)
+    gp = O.OracleGP(inp["kind"], inp["theta"], normalize_output=inp["nout"],
+                    lower=inp["lower"], upper=inp["upper"])
+    gp.train(inp["X"], inp["y"])
+    mu, var = gp.predict(inp["Xc"], diag_only=True)
+    np.testing.assert_allclose(mu, g["mu"], rtol=1e-10, atol=1e-12)
+    np.testing.assert_allclose(var, g["var"], rtol=1e-9, atol=1e-13)
+    _, eta = gp.get_incumbent()
+    assert eta == g["eta"]
+    # oracle acquisitions on the stored (mu, var) == the reference classes' output
+    np.testing.assert_allclose(O.ei(g["mu"], g["var"], eta), g["ei"], rtol=1e-12, atol=1e-300)
+    assert_logei_close(O.log_ei_vec(g["mu"], g["var"], eta), g["log_ei"],
+                       (eta - g["mu"]) / np.sqrt(g["var"]))
+    np.testing.assert_allclose(O.pi(g["mu"], g["var"], eta), g["pi"], rtol=1e-12, atol=1e-300)
+    np.testing.assert_allclose(O.lcb(g["mu"], g["var"]), g["lcb"], rtol=1e-14)
+    np.testing.assert_allclose(O.ei(g["mu"], g["var"], eta, par=0.3), g["ei_par"], rtol=1e-12,
+                               atol=1e-300)
+    assert O.np_argmax(O.ei(g["mu"], g["var"], eta)) == int(g["argmax_ei"])
+    if "var_fullcov_path" in g:
+        # diag-only path == the reference's full-covariance-then-diag call sequence
+        np.testing.assert_allclose(g["var"], g["var_fullcov_path"], rtol=1e-7, atol=1e-10)
+        np.testing.assert_allclose(g["mu"], g["mu_fullcov_path"], rtol=1e-12, atol=1e-13)
+
+
+def test_posterior_identity_reference_pin():
+    """test/test_models/test_gaussian_process.py:44-49 restated: the oracle's
+    predictive covariance equals K_zz - K_zx (K_xx + noise I)^-1 K_zx^T (MSE < 1e-4)."""
+    rs = np.random.RandomState(3)
+    X = rs.rand(10, 2)
+    y = np.sinc(X * 10 - 5).sum(axis=1)
+    theta = np.array([np.log(2.0 / 2), 0.0, 0.0, np.log(1e-3)])
+    gp = O.OracleGP("matern52", theta, lower=np.zeros(2), upper=np.ones(2))
+    gp.train(X, y)
+    Xt = rs.rand(10, 2)
+    _, v = gp.predict(Xt, full_cov=True)
+    K_zz = O.kernel_matrix("matern52", theta[:-1], Xt)
+    K_zx = O.kernel_matrix("matern52", theta[:-1], Xt, X)
+    K_nz = O.kernel_matrix("matern52", theta[:-1], X) + (gp.noise + O.JITTER) * np.eye(10)
+    var = K_zz - K_zx @ np.linalg.inv(K_nz) @ K_zx.T
+    assert np.mean((np.clip(var, O.EPS, np.inf) - v) ** 2) < 1e-4
+    # test_gaussian_process.py:77-82
+    inc, inc_val = gp.get_incumbent()
+    b = np.argmin(y)
+    np.testing.assert_almost_equal(inc, X[b], decimal=5)
+    assert inc_val == y[b]
+
+
+def test_kernel_contract():
+    """metric = squared length scale; k(x,x) = amp; Matern-5/2 closed form."""
+    th = np.array([np.log(1.7), np.log(0.3), np.log(2.0)])
+    x1 = np.array([[0.1, 0.2]])
+    x2 = np.array([[0.4, -0.5]])
+    r2 = (0.3 ** 2) / 0.3 + (0.7 ** 2) / 2.0
+    k = O.kernel_matrix("matern52", th, x1, x2)[0, 0]
+    assert abs(k - 1.7 * (1 + np.sqrt(5 * r2) + 5 * r2 / 3) * np.exp(-np.sqrt(5 * r2))) < 1e-15
+    assert abs(O.kernel_matrix("rbf", th, x1, x2)[0, 0] - 1.7 * np.exp(-r2 / 2)) < 1e-15
+    assert O.kernel_matrix("matern52", th, x1)[0, 0] == pytest.approx(1.7, abs=1e-15)
+
+
+def test_loglik_against_dense_formula():
+    inp = golden_inputs("small_matern")
+    gp = O.OracleGP(inp["kind"], inp["theta"], lower=inp["lower"], upper=inp["upper"])
+    gp.train(inp["X"], inp["y"])
+    K = O.kernel_matrix(inp["kind"], inp["theta"][:-1], gp.X) + (gp.noise + O.JITTER) * np.eye(40)
+    r = gp.y - gp.mean
+    ll = -0.5 * (r @ np.linalg.solve(K, r) + np.linalg.slogdet(K)[1] + 40 * np.log(2 * np.pi))
+    assert abs(gp.loglikelihood(inp["theta"]) - ll) < 1e-9
+    assert gp.nll(inp["theta"]) == -gp.loglikelihood(inp["theta"])
+    assert gp.nll(np.full(5, 21.0)) == 1e25 and gp.loglikelihood(np.full(5, -21.0)) == -np.inf
+
+
+def test_mcmc_marginal_regression(golden_dir):
+    g = _load(golden_dir, "mcmc_marginal")
+    inp = mcmc_inputs()
+    eta = inp["y"].min()
+    acq = np.array([O.log_ei_vec(g["mu_s"][s], g["var_s"][s], eta) for s in range(6)])
+    np.testing.assert_allclose(O.marginalize(acq), g["marg_log_ei"], rtol=1e-8)
+    acq = np.array([O.ei(g["mu_s"][s], g["var_s"][s], eta) for s in range(6)])
+    np.testing.assert_allclose(O.marginalize(acq), g["marg_ei"], rtol=1e-12, atol=1e-300)
+    m, v = O.mcmc_mixture(g["mu_s"], g["var_s"])
+    np.testing.assert_array_equal(m, g["mix_m"])
+    np.testing.assert_array_equal(v, g["mix_v"])
