@@ -1,0 +1,150 @@
+/*
+ * robo_hip.h -- C ABI of librobo_hip.so: the MI355X (gfx950) GP-posterior + acquisition
+ * hot path of automl/RoBO.
+ *
+ * This is the drop-in boundary.  The reference has no native
+ * code; the arithmetic it delegates to the george C++ library through the call sites
+ * listed below is what these entry points replace.  A RoBO maintainer binds them with
+ * ctypes; robo_amd/_lib.py is exactly that binding.
+ *
+ * Conventions
+ *   - every function returns a robo_status (int32); 0 = OK
+ *   - all matrices are row-major (C order) IEEE fp64, exactly what NumPy hands over
+ *   - "host" pointers are caller-owned and only read/written during the call
+ *   - handles own all device memory; nothing is allocated per call on the hot path
+ *   - a handle is not thread-safe; one HIP stream per context; no callbacks
+ *   - theta is the reference's log-space hyper-parameter vector
+ *       [log amp, log m_1 .. log m_D, log sigma^2]           (P = D + 2)
+ *     (robo/models/gaussian_process.py:110-114,151-152; robo/priors/default_priors.py:28-35)
+ */
+#ifndef ROBO_HIP_H
+#define ROBO_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct robo_ctx robo_ctx;   /* one device + one HIP stream + event slots            */
+typedef struct robo_gp robo_gp;     /* one GP: training data, Cholesky factor, solve vector */
+typedef struct robo_cand robo_cand; /* one device-resident candidate batch + its workspace  */
+
+enum robo_status {
+    ROBO_OK = 0,
+    ROBO_NOT_POSITIVE_DEFINITE = 1, /* -> np.linalg.LinAlgError (gaussian_process.py:120,156;
+                                          gaussian_process_mcmc.py:194-197)                  */
+    ROBO_NOT_FITTED = 2,            /* -> Exception('Model has to be trained first!')
+                                          (gaussian_process.py:241,273,322)                  */
+    ROBO_BAD_SHAPE = 3,             /* the reference asserts (base_model.py:68-70,76)        */
+    ROBO_RUNTIME_ERROR = 4,         /* HIP error; text in robo_last_error_string()           */
+    ROBO_BAD_ARGUMENT = 5
+};
+
+enum robo_kernel_kind {
+    ROBO_KERNEL_MATERN52_ARD = 0, /* amp * george.kernels.Matern52Kernel(metric, ndim=D)
+                                     (robo/fmin/bayesian_optimization.py:75-81)              */
+    ROBO_KERNEL_RBF_ARD = 1       /* amp * george.kernels.ExpSquaredKernel(metric, ndim=D)   */
+};
+
+enum robo_acq_kind {
+    ROBO_ACQ_EI = 0,     /* robo/acquisition_functions/ei.py:65-88      */
+    ROBO_ACQ_LOG_EI = 1, /* robo/acquisition_functions/log_ei.py:74-120 */
+    ROBO_ACQ_PI = 2,     /* robo/acquisition_functions/pi.py:57-63      */
+    ROBO_ACQ_LCB = 3     /* robo/acquisition_functions/lcb.py:62-65     */
+};
+
+/* flags reported by the acquisition kernels (host shim applies the reference's guards) */
+#define ROBO_FLAG_ZERO_SIGMA 1u   /* some s == 0           (ei.py:72-74)  */
+#define ROBO_FLAG_NEGATIVE_EI 2u  /* some EI < 0           (ei.py:86-88)  */
+#define ROBO_FLAG_NAN 4u          /* some acquisition value is NaN        */
+
+/* ---- context ---------------------------------------------------------------------- */
+int32_t robo_device_count(int32_t* out_n);
+/* hip_stream: an existing hipStream_t to launch on (e.g. torch's current stream), or NULL
+ * to let the library create its own non-blocking stream.                                  */
+int32_t robo_ctx_create(int32_t device, void* hip_stream, robo_ctx** out);
+int32_t robo_ctx_destroy(robo_ctx* ctx);
+int32_t robo_ctx_synchronize(robo_ctx* ctx);
+int32_t robo_ctx_device_name(robo_ctx* ctx, char* buf, int32_t buf_len);
+/* HIP-event timing on the context's stream (what bench.py uses: 32 slots) */
+int32_t robo_ctx_event_record(robo_ctx* ctx, int32_t slot);
+int32_t robo_ctx_event_elapsed_ms(robo_ctx* ctx, int32_t slot_begin, int32_t slot_end, float* out_ms);
+const char* robo_last_error_string(void);
+const char* robo_version_string(void);
+
+/* ---- GP fit: replaces george.GP.compute + log_likelihood ---------------------------
+ * call sites: robo/models/gaussian_process.py:119,122,155,159,173;
+ *             robo/models/gaussian_process_mcmc.py:195,200-202                          */
+int32_t robo_gp_create(robo_ctx* ctx, int32_t kernel_kind, int32_t n_max, int32_t dim, robo_gp** out);
+int32_t robo_gp_destroy(robo_gp* gp);
+/* X: (n, dim) inputs as the GP sees them (already [0,1]-normalised by the caller,
+ * gaussian_process.py:91); y: (n,) targets.  Uploaded once; thousands of theta are then
+ * evaluated on the same data (the MCMC / L-BFGS loops).                                   */
+int32_t robo_gp_set_data(robo_gp* gp, const double* X, const double* y, int32_t n);
+/* un-normalisation applied to predictions: mu*y_std + y_mean, var*y_std^2
+ * (gaussian_process.py:282-284).  Default (0, 1).                                          */
+int32_t robo_gp_set_output_transform(robo_gp* gp, double y_mean, double y_std);
+/* K = k_theta(X,X) + (sigma^2 + 1.25e-12) I ; L = chol(K) ; z = L^-1 (y - mean_c);
+ * loglik = -1/2 (z.z + 2 sum log L_ii + n log 2pi).  On ROBO_NOT_POSITIVE_DEFINITE
+ * *out_fail_col is the 0-based failing column and the GP is left unfitted.
+ * out_loglik / out_fail_col may be NULL.                                                   */
+int32_t robo_gp_fit(robo_gp* gp, const double* theta, double mean_c, double* out_loglik, int32_t* out_fail_col);
+/* S independent fits on the same data; out_status[s] is a robo_status.  The GP is left in
+ * the state of the LAST fit of the batch (fitted iff out_status[S-1] == ROBO_OK).           */
+int32_t robo_gp_loglik_batch(robo_gp* gp, const double* thetas, int32_t S, double mean_c, double* out_loglik,
+                             int32_t* out_status);
+/* copy the lower Cholesky factor (n x n, row-major, upper zeroed) back -- diagnostics/tests */
+int32_t robo_gp_get_factor(robo_gp* gp, double* out_L);
+int32_t robo_gp_get_gram(robo_gp* gp, const double* theta, double* out_K); /* K incl. noise, n x n  */
+
+/* ---- candidates --------------------------------------------------------------------- */
+/* Xc: (m, dim) candidates in the GP's (normalised) input space; copied H2D here, once.    */
+int32_t robo_cand_create(robo_ctx* ctx, const double* Xc, int64_t m, int32_t dim, robo_cand** out);
+int32_t robo_cand_destroy(robo_cand* cand);
+/* device-side generation, no H2D: uniform [0,1)^dim, counter-based (Philox-4x32-10)         */
+int32_t robo_cand_create_uniform(robo_ctx* ctx, int64_t m, int32_t dim, uint64_t seed, robo_cand** out);
+int32_t robo_cand_get_points(robo_cand* cand, double* out_Xc);
+
+/* ---- posterior: replaces george.GP.predict (gaussian_process.py:280-294) ------------ */
+/* mean (m,), var (m,): diagonal only; var floored at DBL_EPSILON after the output
+ * transform, exactly gaussian_process.py:282-294.  Either output may be NULL.               */
+int32_t robo_gp_predict_cand(robo_gp* gp, robo_cand* cand, double* out_mean, double* out_var);
+int32_t robo_gp_predict(robo_gp* gp, const double* Xc, int64_t m, double* out_mean, double* out_var);
+/* full covariance (m x m), small m only (predict(full_cov=True), predict_variance,
+ * sample_functions: gaussian_process.py:221-248,298-332)                                    */
+int32_t robo_gp_predict_cov(robo_gp* gp, const double* Xc, int64_t m, double* out_mean, double* out_cov);
+
+/* ---- acquisition: replaces EI/LogEI/PI/LCB.compute + the argmax of
+ * RandomSampling.maximize (robo/maximizers/random_sampling.py:48-50) ------------------ */
+/* out_acq (m,) may be NULL when only the maximiser is wanted.  argmax follows np.argmax:
+ * first index of the maximum, NaN counts as maximal.  par = xi (EI/LogEI/PI) or kappa (LCB);
+ * eta = incumbent value (ignored by LCB).                                                     */
+int32_t robo_acq_eval_cand(robo_gp* gp, int32_t acq_kind, double par, double eta, robo_cand* cand, double* out_acq,
+                           double* out_max, int64_t* out_argmax, uint32_t* out_flags);
+int32_t robo_acq_eval(robo_gp* gp, int32_t acq_kind, double par, double eta, const double* Xc, int64_t m,
+                      double* out_acq, double* out_max, int64_t* out_argmax, uint32_t* out_flags);
+/* the element-wise half alone, for (mean, var) produced by any other BaseModel plugin
+ * (the reference's acquisition classes accept every model, e.g. test/dummy_model.py)          */
+int32_t robo_acq_eval_moments(robo_ctx* ctx, int32_t acq_kind, double par, double eta, const double* mean,
+                              const double* var, int64_t m, double* out_acq, double* out_max, int64_t* out_argmax,
+                              uint32_t* out_flags);
+/* MarginalizationGPMCMC.compute (marginalization.py:115-121): mean over S fitted GPs of
+ * the per-sample acquisition, accumulated in sample order (= NumPy's axis-0 mean).           */
+int32_t robo_acq_eval_marginal_cand(robo_gp* const* gps, int32_t S, int32_t acq_kind, double par, double eta,
+                                    robo_cand* cand, double* out_acq, double* out_max, int64_t* out_argmax,
+                                    uint32_t* out_flags);
+/* partial form for sample-sharded multi-GPU runs: returns sum_s acq_s (no division)          */
+int32_t robo_acq_eval_sum_cand(robo_gp* const* gps, int32_t S, int32_t acq_kind, double par, double eta,
+                               robo_cand* cand, double* out_acq_sum, uint32_t* out_flags);
+
+/* ---- self tests / micro benchmarks (used by tests and bench.py, not by the product) --- */
+/* runs one v_mfma_f64_16x16x4_f64 with asymmetric operands, returns max |D - A*B|          */
+int32_t robo_selftest_mfma_layout(robo_ctx* ctx, double* out_max_err);
+/* issues `iters` dependent-free MFMA f64 per wave on every CU; returns TFLOP/s               */
+int32_t robo_microbench_mfma_f64(robo_ctx* ctx, int32_t iters, double* out_tflops);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ROBO_HIP_H */

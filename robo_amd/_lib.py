@@ -1,0 +1,374 @@
+"""ctypes binding of librobo_hip.so -- the C ABI declared in include/robo_hip.h.
+
+This is the binding a RoBO maintainer would add.  There is no CPU
+implementation behind it: if the shared library is missing or no HIP device is visible the
+first use raises :class:`RoboHipUnavailable`.
+
+``use_library(path)`` lets the test-suite point the binding at the g++-interpreted build of
+the same sources (tests/hipemu) to exercise host logic in the GPU-less build container; the
+product never calls it.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+DEFAULT_LIBRARY = os.path.join(_HERE, "librobo_hip.so")
+
+OK, NOT_POSITIVE_DEFINITE, NOT_FITTED, BAD_SHAPE, RUNTIME_ERROR, BAD_ARGUMENT = range(6)
+KERNEL_KINDS = {"matern52": 0, "rbf": 1}
+ACQ_KINDS = {"ei": 0, "log_ei": 1, "pi": 2, "lcb": 3}
+FLAG_ZERO_SIGMA, FLAG_NEGATIVE_EI, FLAG_NAN = 1, 2, 4
+
+# every symbol include/robo_hip.h declares (tests check the library exports all of them)
+SYMBOLS = [
+    "robo_device_count", "robo_ctx_create", "robo_ctx_destroy", "robo_ctx_synchronize",
+    "robo_ctx_device_name", "robo_ctx_event_record", "robo_ctx_event_elapsed_ms",
+    "robo_last_error_string", "robo_version_string",
+    "robo_gp_create", "robo_gp_destroy", "robo_gp_set_data", "robo_gp_set_output_transform",
+    "robo_gp_fit", "robo_gp_loglik_batch", "robo_gp_get_factor", "robo_gp_get_gram",
+    "robo_cand_create", "robo_cand_destroy", "robo_cand_create_uniform", "robo_cand_get_points",
+    "robo_gp_predict_cand", "robo_gp_predict", "robo_gp_predict_cov",
+    "robo_acq_eval_cand", "robo_acq_eval", "robo_acq_eval_moments", "robo_acq_eval_marginal_cand", "robo_acq_eval_sum_cand",
+    "robo_selftest_mfma_layout", "robo_microbench_mfma_f64",
+]
+
+
+class RoboHipUnavailable(RuntimeError):
+    pass
+
+
+class RoboHipError(RuntimeError):
+    pass
+
+
+_lib = None
+_lib_path = None
+_dp = C.POINTER(C.c_double)
+
+
+def _arr(a):
+    return a.ctypes.data_as(_dp)
+
+
+def _f64(a, shape=None):
+    a = np.ascontiguousarray(a, dtype=np.float64)
+    if shape is not None and a.shape != shape:
+        raise AssertionError("expected shape %r, got %r" % (shape, a.shape))
+    return a
+
+
+def use_library(path):
+    """Point the binding at another build of the same C ABI (test hook)."""
+    global _lib, _lib_path, _default_ctx
+    _lib = None
+    _lib_path = path
+    _default_ctx = {}
+
+
+def library_path():
+    return _lib_path or DEFAULT_LIBRARY
+
+
+def lib():
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = library_path()
+    if not os.path.exists(path):
+        raise RoboHipUnavailable(
+            "%s not found: build it with `python -m robo_amd.build` (hipcc, gfx950). "
+            "robo_amd has no CPU fallback." % path)
+    try:
+        L = C.CDLL(path)
+    except OSError as e:
+        raise RoboHipUnavailable("cannot load %s: %s" % (path, e))
+    vp, i32, i64, dbl = C.c_void_p, C.c_int32, C.c_int64, C.c_double
+    pp = C.POINTER(vp)
+    sig = {
+        "robo_device_count": [C.POINTER(i32)],
+        "robo_ctx_create": [i32, vp, pp],
+        "robo_ctx_destroy": [vp],
+        "robo_ctx_synchronize": [vp],
+        "robo_ctx_device_name": [vp, C.c_char_p, i32],
+        "robo_ctx_event_record": [vp, i32],
+        "robo_ctx_event_elapsed_ms": [vp, i32, i32, C.POINTER(C.c_float)],
+        "robo_gp_create": [vp, i32, i32, i32, pp],
+        "robo_gp_destroy": [vp],
+        "robo_gp_set_data": [vp, _dp, _dp, i32],
+        "robo_gp_set_output_transform": [vp, dbl, dbl],
+        "robo_gp_fit": [vp, _dp, dbl, _dp, C.POINTER(i32)],
+        "robo_gp_loglik_batch": [vp, _dp, i32, dbl, _dp, C.POINTER(i32)],
+        "robo_gp_get_factor": [vp, _dp],
+        "robo_gp_get_gram": [vp, _dp, _dp],
+        "robo_cand_create": [vp, _dp, i64, i32, pp],
+        "robo_cand_destroy": [vp],
+        "robo_cand_create_uniform": [vp, i64, i32, C.c_uint64, pp],
+        "robo_cand_get_points": [vp, _dp],
+        "robo_gp_predict_cand": [vp, vp, _dp, _dp],
+        "robo_gp_predict": [vp, _dp, i64, _dp, _dp],
+        "robo_gp_predict_cov": [vp, _dp, i64, _dp, _dp],
+        "robo_acq_eval_cand": [vp, i32, dbl, dbl, vp, _dp, _dp, C.POINTER(i64), C.POINTER(C.c_uint32)],
+        "robo_acq_eval": [vp, i32, dbl, dbl, _dp, i64, _dp, _dp, C.POINTER(i64), C.POINTER(C.c_uint32)],
+        "robo_acq_eval_moments": [vp, i32, dbl, dbl, _dp, _dp, i64, _dp, _dp, C.POINTER(i64), C.POINTER(C.c_uint32)],
+        "robo_acq_eval_marginal_cand": [pp, i32, i32, dbl, dbl, vp, _dp, _dp, C.POINTER(i64),
+                                        C.POINTER(C.c_uint32)],
+        "robo_acq_eval_sum_cand": [pp, i32, i32, dbl, dbl, vp, _dp, C.POINTER(C.c_uint32)],
+        "robo_selftest_mfma_layout": [vp, _dp],
+        "robo_microbench_mfma_f64": [vp, i32, _dp],
+    }
+    for name, args in sig.items():
+        fn = getattr(L, name)
+        fn.argtypes = args
+        fn.restype = i32
+    L.robo_last_error_string.restype = C.c_char_p
+    L.robo_last_error_string.argtypes = []
+    L.robo_version_string.restype = C.c_char_p
+    L.robo_version_string.argtypes = []
+    n = i32(0)
+    L.robo_device_count(C.byref(n))
+    if n.value < 1:
+        raise RoboHipUnavailable("librobo_hip loaded but no HIP device is visible (robo_amd has no CPU fallback)")
+    _lib = L
+    return L
+
+
+def last_error():
+    return lib().robo_last_error_string().decode("utf-8", "replace")
+
+
+def check(status):
+    """Map a robo_status to the exception the reference raises at the same point."""
+    if status == OK:
+        return
+    msg = last_error()
+    if status == NOT_POSITIVE_DEFINITE:
+        raise np.linalg.LinAlgError(msg or "matrix is not positive definite")
+    if status == NOT_FITTED:
+        raise Exception('Model has to be trained first!')    # gaussian_process.py:241,273,322
+    if status == BAD_SHAPE:
+        raise AssertionError(msg)                             # base_model.py:68-70,76 use assert
+    if status == BAD_ARGUMENT:
+        raise ValueError(msg)
+    raise RoboHipError(msg)
+
+
+def device_count():
+    n = C.c_int32(0)
+    lib().robo_device_count(C.byref(n))
+    return n.value
+
+
+class Context(object):
+    """robo_ctx: one device, one HIP stream, 32 event slots."""
+
+    def __init__(self, device=0, stream=None):
+        self._h = C.c_void_p()
+        check(lib().robo_ctx_create(int(device), C.c_void_p(stream) if stream else None, C.byref(self._h)))
+        self.device = int(device)
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h:
+            lib().robo_ctx_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def synchronize(self):
+        check(lib().robo_ctx_synchronize(self._h))
+
+    @property
+    def name(self):
+        buf = C.create_string_buffer(256)
+        check(lib().robo_ctx_device_name(self._h, buf, 256))
+        return buf.value.decode()
+
+    def record(self, slot):
+        check(lib().robo_ctx_event_record(self._h, int(slot)))
+
+    def elapsed_ms(self, a, b):
+        ms = C.c_float(0)
+        check(lib().robo_ctx_event_elapsed_ms(self._h, int(a), int(b), C.byref(ms)))
+        return float(ms.value)
+
+    def selftest_mfma_layout(self):
+        e = C.c_double(0)
+        check(lib().robo_selftest_mfma_layout(self._h, C.byref(e)))
+        return e.value
+
+    def microbench_mfma_f64(self, iters=2000):
+        t = C.c_double(0)
+        check(lib().robo_microbench_mfma_f64(self._h, int(iters), C.byref(t)))
+        return t.value
+
+
+_default_ctx = {}
+
+
+def default_context(device=None):
+    if device is None:
+        device = int(os.environ.get("ROBO_DEVICE", os.environ.get("LOCAL_RANK", "0")))
+        if device >= device_count():
+            device = 0
+    if device not in _default_ctx:
+        _default_ctx[device] = Context(device)
+    return _default_ctx[device]
+
+
+class Candidates(object):
+    """robo_cand: a device-resident candidate batch (normalised input space) + workspace."""
+
+    def __init__(self, ctx, Xc=None, m=None, dim=None, seed=None):
+        self.ctx = ctx
+        self._h = C.c_void_p()
+        if Xc is not None:
+            Xc = _f64(Xc)
+            assert Xc.ndim == 2
+            self.m, self.dim = Xc.shape
+            check(lib().robo_cand_create(ctx._h, _arr(Xc), self.m, self.dim, C.byref(self._h)))
+        else:
+            self.m, self.dim = int(m), int(dim)
+            check(lib().robo_cand_create_uniform(ctx._h, self.m, self.dim, int(seed or 0), C.byref(self._h)))
+
+    def points(self):
+        out = np.empty((self.m, self.dim))
+        check(lib().robo_cand_get_points(self._h, _arr(out)))
+        return out
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h:
+            lib().robo_cand_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class DeviceGP(object):
+    """robo_gp: training data + Cholesky factor + z resident on the device."""
+
+    def __init__(self, ctx, kind, n_max, dim):
+        self.ctx, self.kind, self.n_max, self.dim = ctx, kind, int(n_max), int(dim)
+        self._h = C.c_void_p()
+        check(lib().robo_gp_create(ctx._h, KERNEL_KINDS[kind], self.n_max, self.dim, C.byref(self._h)))
+        self.n = 0
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h:
+            lib().robo_gp_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_data(self, X, y):
+        X, y = _f64(X), _f64(y)
+        assert X.ndim == 2 and y.ndim == 1 and X.shape[0] == y.shape[0] and X.shape[1] == self.dim
+        check(lib().robo_gp_set_data(self._h, _arr(X), _arr(y), X.shape[0]))
+        self.n = X.shape[0]
+
+    def set_output_transform(self, y_mean, y_std):
+        check(lib().robo_gp_set_output_transform(self._h, float(y_mean), float(y_std)))
+
+    def fit(self, theta, mean_c):
+        """-> log-likelihood; raises np.linalg.LinAlgError when K is not PD."""
+        theta = _f64(theta, (self.dim + 2,))
+        ll, col = C.c_double(0), C.c_int32(0)
+        check(lib().robo_gp_fit(self._h, _arr(theta), float(mean_c), C.byref(ll), C.byref(col)))
+        return ll.value
+
+    def loglik_batch(self, thetas, mean_c):
+        thetas = _f64(thetas)
+        assert thetas.ndim == 2 and thetas.shape[1] == self.dim + 2
+        S = thetas.shape[0]
+        ll = np.empty(S)
+        st = np.empty(S, dtype=np.int32)
+        check(lib().robo_gp_loglik_batch(self._h, _arr(thetas), S, float(mean_c), _arr(ll),
+                                         st.ctypes.data_as(C.POINTER(C.c_int32))))
+        return ll, st
+
+    def factor(self):
+        out = np.empty((self.n, self.n))
+        check(lib().robo_gp_get_factor(self._h, _arr(out)))
+        return out
+
+    def gram(self, theta):
+        theta = _f64(theta, (self.dim + 2,))
+        out = np.empty((self.n, self.n))
+        check(lib().robo_gp_get_gram(self._h, _arr(theta), _arr(out)))
+        return out
+
+    def predict(self, Xc):
+        if isinstance(Xc, Candidates):
+            mean, var = np.empty(Xc.m), np.empty(Xc.m)
+            check(lib().robo_gp_predict_cand(self._h, Xc._h, _arr(mean), _arr(var)))
+            return mean, var
+        Xc = _f64(Xc)
+        assert Xc.ndim == 2
+        mean, var = np.empty(Xc.shape[0]), np.empty(Xc.shape[0])
+        check(lib().robo_gp_predict(self._h, _arr(Xc), Xc.shape[0], _arr(mean), _arr(var)))
+        return mean, var
+
+    def predict_cov(self, Xc):
+        Xc = _f64(Xc)
+        assert Xc.ndim == 2
+        m = Xc.shape[0]
+        mean, cov = np.empty(m), np.empty((m, m))
+        check(lib().robo_gp_predict_cov(self._h, _arr(Xc), m, _arr(mean), _arr(cov)))
+        return mean, cov
+
+    def acq(self, kind, par, eta, Xc, want_values=True):
+        """-> (values or None, max, argmax, flags)"""
+        mx, am, fl = C.c_double(0), C.c_int64(0), C.c_uint32(0)
+        if isinstance(Xc, Candidates):
+            m = Xc.m
+            out = np.empty(m) if want_values else None
+            check(lib().robo_acq_eval_cand(self._h, ACQ_KINDS[kind], float(par), float(eta), Xc._h,
+                                           _arr(out) if want_values else None, C.byref(mx), C.byref(am),
+                                           C.byref(fl)))
+        else:
+            Xc = _f64(Xc)
+            assert Xc.ndim == 2
+            m = Xc.shape[0]
+            out = np.empty(m) if want_values else None
+            check(lib().robo_acq_eval(self._h, ACQ_KINDS[kind], float(par), float(eta), _arr(Xc), m,
+                                      _arr(out) if want_values else None, C.byref(mx), C.byref(am), C.byref(fl)))
+        return out, mx.value, am.value, fl.value
+
+
+def acq_from_moments(ctx, kind, par, eta, mean, var):
+    """element-wise acquisition on the device for (mean, var) of any model -> (values, max, argmax, flags)"""
+    mean, var = _f64(mean), _f64(var)
+    assert mean.ndim == 1 and mean.shape == var.shape
+    out = np.empty(mean.shape[0])
+    mx, am, fl = C.c_double(0), C.c_int64(0), C.c_uint32(0)
+    check(lib().robo_acq_eval_moments(ctx._h, ACQ_KINDS[kind], float(par), float(eta), _arr(mean), _arr(var),
+                                      mean.shape[0], _arr(out), C.byref(mx), C.byref(am), C.byref(fl)))
+    return out, mx.value, am.value, fl.value
+
+
+def acq_marginal(gps, kind, par, eta, cand, want_values=True, reduce="mean"):
+    """MarginalizationGPMCMC.compute over device GPs -> (values, max, argmax, flags)."""
+    S = len(gps)
+    arr = (C.c_void_p * S)(*[g._h for g in gps])
+    mx, am, fl = C.c_double(0), C.c_int64(0), C.c_uint32(0)
+    out = np.empty(cand.m) if (want_values or reduce == "sum") else None
+    if reduce == "sum":
+        check(lib().robo_acq_eval_sum_cand(arr, S, ACQ_KINDS[kind], float(par), float(eta), cand._h, _arr(out),
+                                           C.byref(fl)))
+        return out, None, None, fl.value
+    check(lib().robo_acq_eval_marginal_cand(arr, S, ACQ_KINDS[kind], float(par), float(eta), cand._h,
+                                            _arr(out) if want_values else None, C.byref(mx), C.byref(am),
+                                            C.byref(fl)))
+    return out, mx.value, am.value, fl.value

@@ -1,0 +1,93 @@
+"""Acquisition plugin surface -- the contract of
+robo/acquisition_functions/base_acquisition.py:4-69: ``__init__(model)``, ``update(model)``,
+``compute(X, derivative=False, **kw)``, ``__call__ = compute``, ``get_json_data()``.
+
+:class:`ClosedFormAcquisition` is the shared host shim of EI / LogEI / PI / LCB.  All
+arithmetic runs on the device:
+
+* model is a robo_amd GaussianProcess  -> fused path: cross-gram, triangular solve,
+  variance/mean, acquisition and argmax in one C-ABI call (robo_acq_eval);
+* any other BaseModel plugin            -> ``model.predict`` supplies (mean, var) and only the
+  element-wise kernel runs (robo_acq_eval_moments).
+"""
+import abc
+import logging
+
+import numpy as np
+
+from robo_amd import _lib
+
+logger = logging.getLogger(__name__)
+
+
+class BaseAcquisitionFunction(object):
+    __metaclass__ = abc.ABCMeta
+
+    def __init__(self, model):
+        self.model = model
+
+    def update(self, model):
+        """Called by the solver after the model was retrained."""
+        self.model = model
+
+    @abc.abstractmethod
+    def compute(self, x, derivative=False):
+        """Acquisition values at x (N, D) -> (N,)."""
+
+    def __call__(self, x, **kwargs):
+        return self.compute(x, **kwargs)
+
+    def get_json_data(self):
+        return {"type": __name__}
+
+
+class ClosedFormAcquisition(BaseAcquisitionFunction):
+    """EI / LogEI / PI / LCB on (mean, var, eta); subclasses set ``kind`` and the guards."""
+
+    kind = None
+    needs_eta = True
+
+    def __init__(self, model, par=0.0, **kwargs):
+        super(ClosedFormAcquisition, self).__init__(model)
+        self.par = par
+        self.last_max = None
+        self.last_argmax = None
+
+    def _is_native(self):
+        return hasattr(self.model, "acquisition") and hasattr(self.model, "gp")
+
+    def _eta(self, eta):
+        if not self.needs_eta:
+            return 0.0
+        if eta is None:
+            _, eta = self.model.get_incumbent()
+        return float(eta)
+
+    def _evaluate(self, X, eta):
+        """-> (values (N,), flags)"""
+        eta = self._eta(eta)
+        if self._is_native():
+            vals, mx, am, flags = self.model.acquisition(self.kind, self.par, eta, X)
+        else:
+            m, v = self.model.predict(X)
+            vals, mx, am, flags = _lib.acq_from_moments(_lib.default_context(), self.kind, self.par, eta,
+                                                        np.asarray(m, dtype=np.float64).ravel(),
+                                                        np.asarray(v, dtype=np.float64).ravel())
+        self.last_max, self.last_argmax = mx, am
+        return vals, flags
+
+    def argmax(self, X, eta=None):
+        """Index of the best candidate without copying the values back (large-M maximisers)."""
+        eta = self._eta(eta)
+        if self._is_native():
+            _, mx, am, _ = self.model.acquisition(self.kind, self.par, eta, X, want_values=False)
+            self.last_max, self.last_argmax = mx, am
+            return int(am)
+        return int(np.argmax(self.compute(X, eta=eta)))
+
+    def _no_derivative(self, derivative):
+        if derivative:
+            # the reference needs model.predictive_gradients, which no GP model in the tree
+            # implements
+            raise NotImplementedError("%s: derivative=True needs predictive_gradients, which no "
+                                      "reference GP model provides" % self.__class__.__name__)

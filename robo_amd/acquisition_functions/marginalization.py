@@ -1,0 +1,108 @@
+"""Acquisition marginalised over GP hyper-parameter samples.
+
+Semantics of robo/acquisition_functions/marginalization.py:11-121: one estimator (a deep
+copy of the wrapped acquisition function) per ``model.models[i]``; ``update`` re-points each
+estimator at the retrained sub-model; ``compute`` returns the mean over samples, accumulated
+in sample order (NumPy's axis-0 mean).
+
+When every sub-model is a device-resident robo_amd GaussianProcess and the wrapped function
+is EI/LogEI/PI/LCB, the S posteriors, S acquisition vectors, their ordered sum and the final
+argmax are produced by ONE C-ABI call on a shared candidate upload
+(robo_acq_eval_marginal_cand); otherwise the estimators are evaluated one by one exactly
+like the reference does.
+"""
+import logging
+from copy import deepcopy
+
+import numpy as np
+
+from robo_amd import _lib
+from robo_amd.acquisition_functions.base_acquisition import BaseAcquisitionFunction, ClosedFormAcquisition
+
+logger = logging.getLogger(__name__)
+
+
+class MarginalizationGPMCMC(BaseAcquisitionFunction):
+
+    def __init__(self, acquisition_func):
+        self.acquisition_func = acquisition_func
+        self.model = acquisition_func.model
+        self.cost_model = getattr(acquisition_func, "cost_model", None)
+        self.estimators = []
+        self._build_estimators()
+        self.last_max = None
+        self.last_argmax = None
+
+    def _build_estimators(self):
+        for i in range(len(self.model.models)):
+            # detach the (possibly device-resident) model while copying: the copy gets its own
+            # sub-model right below, as in marginalization.py:36-40
+            model, self.acquisition_func.model = self.acquisition_func.model, None
+            try:
+                estimator = deepcopy(self.acquisition_func)
+            finally:
+                self.acquisition_func.model = model
+            estimator.model = self.model.models[i]
+            if self.cost_model is not None and len(self.cost_model.models) > 0:
+                estimator.cost_model = self.cost_model.models[i]
+            self.estimators.append(estimator)
+
+    def update(self, model, cost_model=None, **kwargs):
+        self.model = model
+        if cost_model is not None:
+            self.cost_model = cost_model
+        if len(self.estimators) != len(self.model.models):
+            self.estimators = []
+            self._build_estimators()
+        for i in range(len(self.model.models)):
+            if cost_model is not None:
+                self.estimators[i].update(self.model.models[i], self.cost_model.models[i], **kwargs)
+            else:
+                self.estimators[i].update(self.model.models[i], **kwargs)
+
+    def _native(self):
+        if not isinstance(self.acquisition_func, ClosedFormAcquisition) or not self.estimators:
+            return False
+        gps = [getattr(e.model, "gp", None) for e in self.estimators]
+        return all(isinstance(g, _lib.DeviceGP) for g in gps) and len({id(g.ctx) for g in gps}) == 1 \
+            and all(getattr(e.model, "is_trained", False) for e in self.estimators)
+
+    def _native_eval(self, X_test, want_values):
+        est = self.estimators
+        models = [e.model for e in est]
+        gps = [m.gp for m in models]
+        eta = est[0]._eta(None)
+        cand = X_test if isinstance(X_test, _lib.Candidates) else \
+            _lib.Candidates(gps[0].ctx, models[0]._normalised(X_test))
+        try:
+            vals, mx, am, flags = _lib.acq_marginal(gps, est[0].kind, est[0].par, eta, cand, want_values)
+        finally:
+            if cand is not X_test:
+                cand.close()
+        self.last_max, self.last_argmax = mx, am
+        return vals, flags
+
+    def compute(self, X_test, derivative=False):
+        if not derivative and self._native():
+            vals, flags = self._native_eval(X_test, True)
+            if self.estimators[0].kind == "ei":
+                if flags & _lib.FLAG_ZERO_SIGMA:
+                    # some estimator would have returned [[0]] (ei.py:72-74); keep the reference's
+                    # per-estimator behaviour by falling through to the one-by-one evaluation
+                    pass
+                elif flags & _lib.FLAG_NEGATIVE_EI:
+                    raise ValueError
+                else:
+                    return vals
+            else:
+                return vals
+        acquisition_values = np.zeros([len(self.model.models), X_test.shape[0]])
+        for i in range(len(self.model.models)):
+            acquisition_values[i] = self.estimators[i].compute(X_test, derivative=derivative)
+        return acquisition_values.mean(axis=0)
+
+    def argmax(self, X_test):
+        if self._native():
+            self._native_eval(X_test, False)
+            return int(self.last_argmax)
+        return int(np.argmax(self.compute(X_test)))

@@ -1,0 +1,46 @@
+"""Build librobo_hip.so for gfx950 with hipcc (cross-compiles without a GPU).
+
+    python -m robo_amd.build [--force]
+
+The library is built IN TREE (robo_amd/librobo_hip.so) so that it travels to the GPU box
+with the repository snapshot.  There is no CPU build of this library: robo_amd fails
+loudly when it is missing.
+"""
+import glob
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+LIB = os.path.join(HERE, "librobo_hip.so")
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wall", "-Wno-unused-function",
+         "-munsafe-fp-atomics"]
+
+
+def sources():
+    return sorted(glob.glob(os.path.join(CSRC, "*.hip")))
+
+
+def _stale():
+    if not os.path.exists(LIB):
+        return True
+    t = os.path.getmtime(LIB)
+    deps = sources() + glob.glob(os.path.join(CSRC, "*.h")) + [os.path.join(HERE, "..", "include", "robo_hip.h")]
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build(force=False, verbose=True, extra_flags=()):
+    if not force and not _stale():
+        return LIB
+    cmd = [HIPCC] + FLAGS + list(extra_flags) + sources() + ["-o", LIB]
+    if verbose:
+        print(" ".join(cmd), flush=True)
+    subprocess.check_call(cmd)
+    return LIB
+
+
+if __name__ == "__main__":
+    build(force="--force" in sys.argv)
+    print(LIB)

@@ -1,0 +1,592 @@
+// C ABI of librobo_hip.so (see include/robo_hip.h for the contract and the reference call
+// sites each entry point replaces).  Host-side orchestration only: every number is
+// produced by the kernels in gram.hip / potrf.hip / predict.hip / acq.hip.
+#include <cmath>
+#include <cstdarg>
+#include <cstdlib>
+#include <vector>
+
+#include "common.h"
+
+namespace robo {
+
+static thread_local char g_err[1024] = "";
+
+void set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+static size_t workspace_bytes() {
+    const char* e = getenv("ROBO_WS_BYTES");
+    if (e && *e) {
+        const double v = atof(e);
+        if (v >= 1e6) return (size_t)v;
+    }
+    return (size_t)6 << 30;
+}
+
+template <class T>
+static int dev_alloc(T** p, size_t count) {
+    ROBO_HIP_CHECK(hipMalloc((void**)p, (count ? count : 1) * sizeof(T)));
+    return ROBO_OK;
+}
+
+#define ROBO_TRY(expr)                \
+    do {                              \
+        int _s = (expr);              \
+        if (_s != ROBO_OK) return _s; \
+    } while (0)
+
+}  // namespace robo
+
+using namespace robo;
+
+extern "C" {
+
+const char* robo_last_error_string(void) { return g_err; }
+const char* robo_version_string(void) { return "robo_hip 0.1 (gfx950, fp64 MFMA)"; }
+
+int32_t robo_device_count(int32_t* out_n) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) n = 0;
+    *out_n = n;
+    return ROBO_OK;
+}
+
+int32_t robo_ctx_create(int32_t device, void* hip_stream, robo_ctx** out) {
+    if (!out) return ROBO_BAD_ARGUMENT;
+    ROBO_HIP_CHECK(hipSetDevice(device));
+    robo_ctx* c = new robo_ctx();
+    memset(c, 0, sizeof(*c));
+    c->device = device;
+    if (hip_stream) {
+        c->stream = (hipStream_t)hip_stream;
+        c->own_stream = false;
+    } else {
+        ROBO_HIP_CHECK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+        c->own_stream = true;
+    }
+    for (int i = 0; i < 32; ++i) ROBO_HIP_CHECK(hipEventCreate(&c->events[i]));
+    hipDeviceProp_t prop;
+    ROBO_HIP_CHECK(hipGetDeviceProperties(&prop, device));
+    snprintf(c->name, sizeof(c->name), "%s (%s)", prop.name, prop.gcnArchName);
+    c->num_cu = prop.multiProcessorCount;
+    ROBO_TRY(dev_alloc(&c->d_scalars, 8));
+    ROBO_TRY(dev_alloc(&c->d_fail, 4));
+    ROBO_HIP_CHECK(hipHostMalloc((void**)&c->h_pinned, (MAX_DIM + 64) * sizeof(double), 0));
+    *out = c;
+    return ROBO_OK;
+}
+
+int32_t robo_ctx_destroy(robo_ctx* c) {
+    if (!c) return ROBO_OK;
+    hipSetDevice(c->device);
+    hipStreamSynchronize(c->stream);
+    for (int i = 0; i < 32; ++i) hipEventDestroy(c->events[i]);
+    hipFree(c->d_scalars);
+    hipFree(c->d_fail);
+    hipHostFree(c->h_pinned);
+    if (c->own_stream) hipStreamDestroy(c->stream);
+    delete c;
+    return ROBO_OK;
+}
+
+int32_t robo_ctx_synchronize(robo_ctx* c) {
+    ROBO_HIP_CHECK(hipStreamSynchronize(c->stream));
+    return ROBO_OK;
+}
+
+int32_t robo_ctx_device_name(robo_ctx* c, char* buf, int32_t len) {
+    if (!buf || len <= 0) return ROBO_BAD_ARGUMENT;
+    snprintf(buf, (size_t)len, "%s", c->name);
+    return ROBO_OK;
+}
+
+int32_t robo_ctx_event_record(robo_ctx* c, int32_t slot) {
+    if (slot < 0 || slot >= 32) return ROBO_BAD_ARGUMENT;
+    ROBO_HIP_CHECK(hipEventRecord(c->events[slot], c->stream));
+    return ROBO_OK;
+}
+
+int32_t robo_ctx_event_elapsed_ms(robo_ctx* c, int32_t a, int32_t b, float* out_ms) {
+    if (a < 0 || a >= 32 || b < 0 || b >= 32 || !out_ms) return ROBO_BAD_ARGUMENT;
+    ROBO_HIP_CHECK(hipEventSynchronize(c->events[b]));
+    ROBO_HIP_CHECK(hipEventElapsedTime(out_ms, c->events[a], c->events[b]));
+    return ROBO_OK;
+}
+
+// ---------------------------------------------------------------------------------------
+// GP
+// ---------------------------------------------------------------------------------------
+int32_t robo_gp_create(robo_ctx* ctx, int32_t kind, int32_t n_max, int32_t dim, robo_gp** out) {
+    if (!ctx || !out) return ROBO_BAD_ARGUMENT;
+    if (kind != ROBO_KERNEL_MATERN52_ARD && kind != ROBO_KERNEL_RBF_ARD) {
+        set_error("unknown kernel kind %d", kind);
+        return ROBO_BAD_ARGUMENT;
+    }
+    if (n_max < 1 || dim < 1 || dim > MAX_DIM) {
+        set_error("bad shape n_max=%d dim=%d (dim <= %d)", n_max, dim, MAX_DIM);
+        return ROBO_BAD_SHAPE;
+    }
+    ROBO_HIP_CHECK(hipSetDevice(ctx->device));
+    robo_gp* g = new robo_gp();
+    memset(g, 0, sizeof(*g));
+    g->ctx = ctx;
+    g->kind = kind;
+    g->dim = dim;
+    g->n_max = n_max;
+    g->n_pad_max = round_up(n_max + 1, NB);
+    g->y_mean = 0.0;
+    g->y_std = 1.0;
+    const size_t np = (size_t)g->n_pad_max;
+    ROBO_TRY(dev_alloc(&g->d_X, (size_t)n_max * dim));
+    ROBO_TRY(dev_alloc(&g->d_Xs, np * dim));
+    ROBO_TRY(dev_alloc(&g->d_y, (size_t)n_max));
+    ROBO_TRY(dev_alloc(&g->d_K, np * np));
+    ROBO_TRY(dev_alloc(&g->d_Linv, np * NB));
+    ROBO_TRY(dev_alloc(&g->d_theta, (size_t)2 * dim + 8));
+    ROBO_HIP_CHECK(hipHostMalloc((void**)&g->h_theta, ((size_t)2 * dim + 8) * sizeof(double), 0));
+    *out = g;
+    return ROBO_OK;
+}
+
+int32_t robo_gp_destroy(robo_gp* g) {
+    if (!g) return ROBO_OK;
+    hipSetDevice(g->ctx->device);
+    hipStreamSynchronize(g->ctx->stream);
+    hipFree(g->d_X);
+    hipFree(g->d_Xs);
+    hipFree(g->d_y);
+    hipFree(g->d_K);
+    hipFree(g->d_Linv);
+    hipFree(g->d_theta);
+    hipHostFree(g->h_theta);
+    delete g;
+    return ROBO_OK;
+}
+
+int32_t robo_gp_set_data(robo_gp* g, const double* X, const double* y, int32_t n) {
+    if (!g || !X || !y) return ROBO_BAD_ARGUMENT;
+    if (n < 1 || n > g->n_max) {
+        set_error("n=%d outside [1, n_max=%d]", n, g->n_max);
+        return ROBO_BAD_SHAPE;
+    }
+    robo_ctx* c = g->ctx;
+    ROBO_HIP_CHECK(hipSetDevice(c->device));
+    ROBO_HIP_CHECK(hipMemcpyAsync(g->d_X, X, (size_t)n * g->dim * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    ROBO_HIP_CHECK(hipMemcpyAsync(g->d_y, y, (size_t)n * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    ROBO_HIP_CHECK(hipStreamSynchronize(c->stream));
+    g->n = n;
+    g->n_pad = round_up(n + 1, NB);
+    g->has_data = true;
+    g->fitted = false;
+    return ROBO_OK;
+}
+
+int32_t robo_gp_set_output_transform(robo_gp* g, double y_mean, double y_std) {
+    if (!g) return ROBO_BAD_ARGUMENT;
+    g->y_mean = y_mean;
+    g->y_std = y_std;
+    return ROBO_OK;
+}
+
+// stage theta, scale inputs, build the gram matrix (asynchronous)
+static int gp_build_gram(robo_gp* g, const double* theta, double mean_c) {
+    robo_ctx* c = g->ctx;
+    const int D = g->dim, P = D + 2;
+    for (int p = 0; p < P; ++p)
+        if (!std::isfinite(theta[p])) {
+            set_error("theta[%d] is not finite", p);
+            return ROBO_BAD_ARGUMENT;
+        }
+    ROBO_HIP_CHECK(hipSetDevice(c->device));
+    // the pinned staging buffer is reused by every fit: the previous upload must have landed
+    ROBO_HIP_CHECK(hipStreamSynchronize(c->stream));
+    for (int d = 0; d < D; ++d) g->h_theta[d] = std::exp(-0.5 * theta[1 + d]);   // 1/sqrt(metric_d)
+    g->amp = std::exp(theta[0]);
+    g->noise = std::exp(theta[P - 1]) + JITTER;
+    g->mean_c = mean_c;
+    ROBO_HIP_CHECK(hipMemcpyAsync(g->d_theta, g->h_theta, (size_t)D * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    ROBO_TRY(launch_scale_inputs(c, g->d_X, g->d_Xs, g->d_theta, g->n, g->n_pad, D));
+    ROBO_TRY(launch_gram(g));
+    return ROBO_OK;
+}
+
+int32_t robo_gp_fit(robo_gp* g, const double* theta, double mean_c, double* out_loglik, int32_t* out_fail_col) {
+    if (!g || !theta) return ROBO_BAD_ARGUMENT;
+    if (!g->has_data) {
+        set_error("robo_gp_fit before robo_gp_set_data");
+        return ROBO_NOT_FITTED;
+    }
+    robo_ctx* c = g->ctx;
+    g->fitted = false;
+    ROBO_TRY(gp_build_gram(g, theta, mean_c));
+    ROBO_TRY(launch_potrf(g));
+    ROBO_TRY(launch_loglik(g));
+    double* hp = c->h_pinned;
+    ROBO_HIP_CHECK(hipMemcpyAsync(hp, c->d_scalars, 2 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    ROBO_HIP_CHECK(hipMemcpyAsync(hp + 4, c->d_fail, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    ROBO_HIP_CHECK(hipStreamSynchronize(c->stream));
+    int fail = 0;
+    memcpy(&fail, hp + 4, sizeof(int));
+    if (fail != 0) {
+        if (out_fail_col) *out_fail_col = fail - 1;
+        if (out_loglik) *out_loglik = -HUGE_VAL;
+        set_error("matrix is not positive definite (column %d)", fail - 1);
+        return ROBO_NOT_POSITIVE_DEFINITE;
+    }
+    const double quad = hp[0], logdet = hp[1];
+    g->loglik = -0.5 * (quad + logdet + (double)g->n * std::log(2.0 * M_PI));
+    g->fitted = true;
+    if (out_loglik) *out_loglik = g->loglik;
+    if (out_fail_col) *out_fail_col = -1;
+    return ROBO_OK;
+}
+
+int32_t robo_gp_loglik_batch(robo_gp* g, const double* thetas, int32_t S, double mean_c, double* out_loglik,
+                             int32_t* out_status) {
+    if (!g || !thetas || S < 0 || !out_loglik) return ROBO_BAD_ARGUMENT;
+    const int P = g->dim + 2;
+    for (int s = 0; s < S; ++s) {
+        double ll = -HUGE_VAL;
+        const int st = robo_gp_fit(g, thetas + (size_t)s * P, mean_c, &ll, nullptr);
+        if (st == ROBO_RUNTIME_ERROR) return st;
+        out_loglik[s] = ll;
+        if (out_status) out_status[s] = st;
+    }
+    return ROBO_OK;
+}
+
+int32_t robo_gp_get_factor(robo_gp* g, double* out_L) {
+    if (!g || !out_L) return ROBO_BAD_ARGUMENT;
+    if (!g->fitted) return ROBO_NOT_FITTED;
+    const size_t np = (size_t)g->n_pad;
+    std::vector<double> h(np * np);
+    ROBO_HIP_CHECK(hipMemcpyAsync(h.data(), g->d_K, np * np * sizeof(double), hipMemcpyDeviceToHost, g->ctx->stream));
+    ROBO_HIP_CHECK(hipStreamSynchronize(g->ctx->stream));
+    for (int i = 0; i < g->n; ++i)
+        for (int j = 0; j < g->n; ++j) out_L[(size_t)i * g->n + j] = j <= i ? h[(size_t)i * np + j] : 0.0;
+    return ROBO_OK;
+}
+
+int32_t robo_gp_get_gram(robo_gp* g, const double* theta, double* out_K) {
+    if (!g || !theta || !out_K) return ROBO_BAD_ARGUMENT;
+    if (!g->has_data) return ROBO_NOT_FITTED;
+    g->fitted = false;   // d_K is overwritten
+    ROBO_TRY(gp_build_gram(g, theta, 0.0));
+    const size_t np = (size_t)g->n_pad;
+    std::vector<double> h(np * np);
+    ROBO_HIP_CHECK(hipMemcpyAsync(h.data(), g->d_K, np * np * sizeof(double), hipMemcpyDeviceToHost, g->ctx->stream));
+    ROBO_HIP_CHECK(hipStreamSynchronize(g->ctx->stream));
+    for (int i = 0; i < g->n; ++i)
+        for (int j = 0; j < g->n; ++j)
+            out_K[(size_t)i * g->n + j] = j <= i ? h[(size_t)i * np + j] : h[(size_t)j * np + i];
+    return ROBO_OK;
+}
+
+// ---------------------------------------------------------------------------------------
+// candidates
+// ---------------------------------------------------------------------------------------
+static int cand_alloc(robo_ctx* ctx, int64_t m, int32_t dim, robo_cand** out) {
+    if (!ctx || !out) return ROBO_BAD_ARGUMENT;
+    if (m < 1 || dim < 1 || dim > MAX_DIM) {
+        set_error("bad candidate shape m=%lld dim=%d", (long long)m, dim);
+        return ROBO_BAD_SHAPE;
+    }
+    ROBO_HIP_CHECK(hipSetDevice(ctx->device));
+    robo_cand* k = new robo_cand();
+    memset(k, 0, sizeof(*k));
+    k->ctx = ctx;
+    k->dim = dim;
+    k->m = m;
+    k->m_pad = round_up64(m, NB);
+    const size_t mp = (size_t)k->m_pad;
+    ROBO_TRY(dev_alloc(&k->d_Xc, mp * dim));
+    ROBO_TRY(dev_alloc(&k->d_Xcs, mp * dim));
+    ROBO_TRY(dev_alloc(&k->d_q, mp));
+    ROBO_TRY(dev_alloc(&k->d_mu, mp));
+    ROBO_TRY(dev_alloc(&k->d_mean, mp));
+    ROBO_TRY(dev_alloc(&k->d_var, mp));
+    ROBO_TRY(dev_alloc(&k->d_acq, mp));
+    ROBO_TRY(dev_alloc(&k->d_acq_sum, mp));
+    k->n_part = (int)((m + 255) / 256);
+    ROBO_TRY(dev_alloc(&k->d_part_val, (size_t)k->n_part + 1));
+    ROBO_TRY(dev_alloc(&k->d_part_idx, (size_t)k->n_part + 1));
+    ROBO_TRY(dev_alloc(&k->d_flags, 4));
+    *out = k;
+    return ROBO_OK;
+}
+
+int32_t robo_cand_create(robo_ctx* ctx, const double* Xc, int64_t m, int32_t dim, robo_cand** out) {
+    if (!Xc) return ROBO_BAD_ARGUMENT;
+    robo_cand* k = nullptr;
+    ROBO_TRY(cand_alloc(ctx, m, dim, &k));
+    ROBO_HIP_CHECK(hipMemcpyAsync(k->d_Xc, Xc, (size_t)m * dim * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    ROBO_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    *out = k;
+    return ROBO_OK;
+}
+
+int32_t robo_cand_create_uniform(robo_ctx* ctx, int64_t m, int32_t dim, uint64_t seed, robo_cand** out) {
+    robo_cand* k = nullptr;
+    ROBO_TRY(cand_alloc(ctx, m, dim, &k));
+    ROBO_TRY(launch_uniform(ctx, k->d_Xc, m, k->m_pad, dim, seed));
+    ROBO_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    *out = k;
+    return ROBO_OK;
+}
+
+int32_t robo_cand_get_points(robo_cand* k, double* out_Xc) {
+    if (!k || !out_Xc) return ROBO_BAD_ARGUMENT;
+    ROBO_HIP_CHECK(hipMemcpyAsync(out_Xc, k->d_Xc, (size_t)k->m * k->dim * sizeof(double), hipMemcpyDeviceToHost,
+                                  k->ctx->stream));
+    ROBO_HIP_CHECK(hipStreamSynchronize(k->ctx->stream));
+    return ROBO_OK;
+}
+
+int32_t robo_cand_destroy(robo_cand* k) {
+    if (!k) return ROBO_OK;
+    hipSetDevice(k->ctx->device);
+    hipStreamSynchronize(k->ctx->stream);
+    hipFree(k->d_Xc);
+    hipFree(k->d_Xcs);
+    hipFree(k->d_V);
+    hipFree(k->d_q);
+    hipFree(k->d_mu);
+    hipFree(k->d_mean);
+    hipFree(k->d_var);
+    hipFree(k->d_acq);
+    hipFree(k->d_acq_sum);
+    hipFree(k->d_part_val);
+    hipFree(k->d_part_idx);
+    hipFree(k->d_flags);
+    delete k;
+    return ROBO_OK;
+}
+
+// size the (chunk x n_pad) solve workspace for this GP; grows, never shrinks
+static int cand_ensure_workspace(robo_cand* k, int n_pad, bool single_chunk) {
+    const size_t row = (size_t)n_pad * sizeof(double);
+    int64_t chunk = (int64_t)(workspace_bytes() / row) / NB * NB;
+    if (chunk < NB) chunk = NB;
+    if (chunk > k->m_pad || single_chunk) chunk = k->m_pad;
+    const size_t need = (size_t)chunk * row;
+    if (need > k->v_bytes) {
+        if (k->d_V) ROBO_HIP_CHECK(hipFree(k->d_V));
+        k->d_V = nullptr;
+        k->v_bytes = 0;
+        ROBO_HIP_CHECK(hipMalloc((void**)&k->d_V, need));
+        k->v_bytes = need;
+    }
+    k->chunk = chunk;
+    k->ldv = n_pad;
+    return ROBO_OK;
+}
+
+// K4 + K5: fills cand->d_mean / d_var (asynchronous)
+static int predict_core(robo_gp* g, robo_cand* k, bool single_chunk) {
+    if (!g || !k) return ROBO_BAD_ARGUMENT;
+    if (!g->fitted) {
+        set_error("Model has to be trained first!");
+        return ROBO_NOT_FITTED;
+    }
+    if (k->dim != g->dim || k->ctx != g->ctx) {
+        set_error("candidate batch (dim %d) does not match the GP (dim %d) or lives on another context", k->dim,
+                  g->dim);
+        return ROBO_BAD_SHAPE;
+    }
+    ROBO_HIP_CHECK(hipSetDevice(g->ctx->device));
+    ROBO_TRY(cand_ensure_workspace(k, g->n_pad, single_chunk));
+    ROBO_TRY(launch_scale_inputs(g->ctx, k->d_Xc, k->d_Xcs, g->d_theta, k->m, k->m_pad, g->dim));
+    for (int64_t c0 = 0; c0 < k->m_pad; c0 += k->chunk) {
+        const int64_t cn = k->m_pad - c0 < k->chunk ? k->m_pad - c0 : k->chunk;
+        ROBO_TRY(launch_cross_gram(g, k, c0, cn));
+        ROBO_TRY(launch_trsm(g, k, c0, cn));
+    }
+    ROBO_TRY(launch_post(g, k, 0, k->m_pad));
+    return ROBO_OK;
+}
+
+int32_t robo_gp_predict_cand(robo_gp* g, robo_cand* k, double* out_mean, double* out_var) {
+    ROBO_TRY(predict_core(g, k, false));
+    hipStream_t st = g->ctx->stream;
+    if (out_mean)
+        ROBO_HIP_CHECK(hipMemcpyAsync(out_mean, k->d_mean, (size_t)k->m * sizeof(double), hipMemcpyDeviceToHost, st));
+    if (out_var)
+        ROBO_HIP_CHECK(hipMemcpyAsync(out_var, k->d_var, (size_t)k->m * sizeof(double), hipMemcpyDeviceToHost, st));
+    ROBO_HIP_CHECK(hipStreamSynchronize(st));
+    return ROBO_OK;
+}
+
+int32_t robo_gp_predict(robo_gp* g, const double* Xc, int64_t m, double* out_mean, double* out_var) {
+    if (!g) return ROBO_BAD_ARGUMENT;
+    if (!g->fitted) {
+        set_error("Model has to be trained first!");
+        return ROBO_NOT_FITTED;
+    }
+    robo_cand* k = nullptr;
+    ROBO_TRY(robo_cand_create(g->ctx, Xc, m, g->dim, &k));
+    const int st = robo_gp_predict_cand(g, k, out_mean, out_var);
+    robo_cand_destroy(k);
+    return st;
+}
+
+int32_t robo_gp_predict_cov(robo_gp* g, const double* Xc, int64_t m, double* out_mean, double* out_cov) {
+    if (!g || !out_cov) return ROBO_BAD_ARGUMENT;
+    if (!g->fitted) {
+        set_error("Model has to be trained first!");
+        return ROBO_NOT_FITTED;
+    }
+    if (m > 16384) {
+        set_error("robo_gp_predict_cov is for small batches (m=%lld > 16384)", (long long)m);
+        return ROBO_BAD_SHAPE;
+    }
+    robo_cand* k = nullptr;
+    ROBO_TRY(robo_cand_create(g->ctx, Xc, m, g->dim, &k));
+    int st = predict_core(g, k, true);
+    double* d_cov = nullptr;
+    if (st == ROBO_OK && hipMalloc((void**)&d_cov, (size_t)m * m * sizeof(double)) != hipSuccess) {
+        set_error("hipMalloc of the %lld x %lld covariance failed", (long long)m, (long long)m);
+        st = ROBO_RUNTIME_ERROR;
+    }
+    if (st == ROBO_OK) st = launch_cov(g, k, d_cov);
+    if (st == ROBO_OK) {
+        hipStream_t s = g->ctx->stream;
+        hipError_t e = hipMemcpyAsync(out_cov, d_cov, (size_t)m * m * sizeof(double), hipMemcpyDeviceToHost, s);
+        if (e == hipSuccess && out_mean)
+            e = hipMemcpyAsync(out_mean, k->d_mean, (size_t)m * sizeof(double), hipMemcpyDeviceToHost, s);
+        if (e == hipSuccess) e = hipStreamSynchronize(s);
+        if (e != hipSuccess) {
+            set_error("predict_cov copy-out failed: %s", hipGetErrorString(e));
+            st = ROBO_RUNTIME_ERROR;
+        }
+    }
+    if (d_cov) hipFree(d_cov);
+    robo_cand_destroy(k);
+    return st;
+}
+
+// ---------------------------------------------------------------------------------------
+// acquisition
+// ---------------------------------------------------------------------------------------
+static int check_acq_kind(int kind) {
+    if (kind < ROBO_ACQ_EI || kind > ROBO_ACQ_LCB) {
+        set_error("unknown acquisition kind %d", kind);
+        return ROBO_BAD_ARGUMENT;
+    }
+    return ROBO_OK;
+}
+
+// D2H of (max, argmax, flags) [+ the acquisition vector] and the one synchronisation of the call
+static int acq_read_back(robo_cand* k, const double* d_vec, double* out_vec, double* out_max, int64_t* out_argmax,
+                         uint32_t* out_flags) {
+    robo_ctx* c = k->ctx;
+    double* hp = c->h_pinned;
+    ROBO_HIP_CHECK(hipMemcpyAsync(hp, k->d_part_val + k->n_part, sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    ROBO_HIP_CHECK(hipMemcpyAsync(hp + 1, k->d_part_idx + k->n_part, sizeof(long long), hipMemcpyDeviceToHost, c->stream));
+    ROBO_HIP_CHECK(hipMemcpyAsync(hp + 2, k->d_flags, sizeof(unsigned), hipMemcpyDeviceToHost, c->stream));
+    if (out_vec)
+        ROBO_HIP_CHECK(hipMemcpyAsync(out_vec, d_vec, (size_t)k->m * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    ROBO_HIP_CHECK(hipStreamSynchronize(c->stream));
+    if (out_max) *out_max = hp[0];
+    if (out_argmax) {
+        long long i;
+        memcpy(&i, hp + 1, sizeof(i));
+        *out_argmax = (int64_t)i;
+    }
+    if (out_flags) {
+        unsigned f;
+        memcpy(&f, hp + 2, sizeof(f));
+        *out_flags = f;
+    }
+    return ROBO_OK;
+}
+
+int32_t robo_acq_eval_cand(robo_gp* g, int32_t acq_kind, double par, double eta, robo_cand* k, double* out_acq,
+                           double* out_max, int64_t* out_argmax, uint32_t* out_flags) {
+    ROBO_TRY(check_acq_kind(acq_kind));
+    ROBO_TRY(predict_core(g, k, false));
+    ROBO_HIP_CHECK(hipMemsetAsync(k->d_flags, 0, sizeof(unsigned), g->ctx->stream));
+    ROBO_TRY(launch_acq(g->ctx, k, acq_kind, par, eta, false, false));
+    return acq_read_back(k, k->d_acq, out_acq, out_max, out_argmax, out_flags);
+}
+
+int32_t robo_acq_eval(robo_gp* g, int32_t acq_kind, double par, double eta, const double* Xc, int64_t m,
+                      double* out_acq, double* out_max, int64_t* out_argmax, uint32_t* out_flags) {
+    if (!g) return ROBO_BAD_ARGUMENT;
+    if (!g->fitted) {
+        set_error("Model has to be trained first!");
+        return ROBO_NOT_FITTED;
+    }
+    robo_cand* k = nullptr;
+    ROBO_TRY(robo_cand_create(g->ctx, Xc, m, g->dim, &k));
+    const int st = robo_acq_eval_cand(g, acq_kind, par, eta, k, out_acq, out_max, out_argmax, out_flags);
+    robo_cand_destroy(k);
+    return st;
+}
+
+static int acq_accumulate(robo_gp* const* gps, int32_t S, int32_t acq_kind, double par, double eta, robo_cand* k) {
+    if (!gps || S < 1 || !k) return ROBO_BAD_ARGUMENT;
+    ROBO_TRY(check_acq_kind(acq_kind));
+    ROBO_HIP_CHECK(hipSetDevice(k->ctx->device));
+    ROBO_HIP_CHECK(hipMemsetAsync(k->d_flags, 0, sizeof(unsigned), k->ctx->stream));
+    for (int s = 0; s < S; ++s) {
+        ROBO_TRY(predict_core(gps[s], k, false));
+        ROBO_TRY(launch_acq(k->ctx, k, acq_kind, par, eta, true, s == 0));
+    }
+    return ROBO_OK;
+}
+
+int32_t robo_acq_eval_marginal_cand(robo_gp* const* gps, int32_t S, int32_t acq_kind, double par, double eta,
+                                    robo_cand* k, double* out_acq, double* out_max, int64_t* out_argmax,
+                                    uint32_t* out_flags) {
+    ROBO_TRY(acq_accumulate(gps, S, acq_kind, par, eta, k));
+    ROBO_TRY(launch_argmax(k, k->d_acq_sum, (double)S));
+    return acq_read_back(k, k->d_acq, out_acq, out_max, out_argmax, out_flags);
+}
+
+int32_t robo_acq_eval_sum_cand(robo_gp* const* gps, int32_t S, int32_t acq_kind, double par, double eta,
+                               robo_cand* k, double* out_acq_sum, uint32_t* out_flags) {
+    ROBO_TRY(acq_accumulate(gps, S, acq_kind, par, eta, k));
+    ROBO_TRY(launch_argmax(k, k->d_acq_sum, 1.0));
+    return acq_read_back(k, k->d_acq_sum, out_acq_sum, nullptr, nullptr, out_flags);
+}
+
+int32_t robo_acq_eval_moments(robo_ctx* ctx, int32_t acq_kind, double par, double eta, const double* mean,
+                              const double* var, int64_t m, double* out_acq, double* out_max, int64_t* out_argmax,
+                              uint32_t* out_flags) {
+    if (!ctx || !mean || !var) return ROBO_BAD_ARGUMENT;
+    ROBO_TRY(check_acq_kind(acq_kind));
+    robo_cand* k = nullptr;
+    ROBO_TRY(cand_alloc(ctx, m, 1, &k));
+    int st = ROBO_OK;
+    hipError_t e = hipMemcpyAsync(k->d_mean, mean, (size_t)m * sizeof(double), hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(k->d_var, var, (size_t)m * sizeof(double), hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess) e = hipMemsetAsync(k->d_flags, 0, sizeof(unsigned), ctx->stream);
+    if (e != hipSuccess) {
+        set_error("robo_acq_eval_moments upload failed: %s", hipGetErrorString(e));
+        st = ROBO_RUNTIME_ERROR;
+    }
+    if (st == ROBO_OK) st = launch_acq(ctx, k, acq_kind, par, eta, false, false);
+    if (st == ROBO_OK) st = acq_read_back(k, k->d_acq, out_acq, out_max, out_argmax, out_flags);
+    robo_cand_destroy(k);
+    return st;
+}
+
+// ---------------------------------------------------------------------------------------
+int32_t robo_selftest_mfma_layout(robo_ctx* ctx, double* out_max_err) {
+    if (!ctx || !out_max_err) return ROBO_BAD_ARGUMENT;
+    ROBO_HIP_CHECK(hipSetDevice(ctx->device));
+    return launch_mfma_selftest(ctx, out_max_err);
+}
+
+int32_t robo_microbench_mfma_f64(robo_ctx* ctx, int32_t iters, double* out_tflops) {
+    if (!ctx || !out_tflops || iters < 1) return ROBO_BAD_ARGUMENT;
+    ROBO_HIP_CHECK(hipSetDevice(ctx->device));
+    return launch_mfma_microbench(ctx, iters, out_tflops);
+}
+
+}  // extern "C"

@@ -1,0 +1,132 @@
+// Shared declarations of librobo_hip (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+
+#include "../../include/robo_hip.h"
+
+namespace robo {
+
+// ---- tiling constants ---------------------------------------------------------------
+// Everything N x N is stored row-major fp64 with leading dimension n_pad, a multiple of
+// NB.  NB is the Cholesky panel width, the TRSM block and the GEMM workgroup tile edge.
+constexpr int NB = 128;
+constexpr int WG = 256;          // threads per workgroup of every tiled kernel (4 wave64)
+constexpr double JITTER = 1.25e-12;  // george's diagonal jitter
+constexpr int MAX_DIM = 256;
+
+// v_mfma_f64_16x16x4_f64 accumulator: 4 f64 per lane
+typedef double v4d __attribute__((vector_size(32)));
+
+__device__ __forceinline__ v4d mfma_f64(double a, double b, v4d c) {
+    return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0);
+}
+
+struct KernelParams {
+    int kind;          // robo_kernel_kind
+    int dim;
+    double amp;        // exp(theta[0])
+    double noise;      // exp(theta[P-1]) + JITTER  (added to the diagonal)
+};
+
+void set_error(const char* fmt, ...);
+
+#define ROBO_HIP_CHECK(expr)                                                                       \
+    do {                                                                                           \
+        hipError_t _e = (expr);                                                                    \
+        if (_e != hipSuccess) {                                                                    \
+            robo::set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__); \
+            return ROBO_RUNTIME_ERROR;                                                             \
+        }                                                                                          \
+    } while (0)
+
+#define ROBO_LAUNCH_CHECK()                                                                        \
+    do {                                                                                           \
+        hipError_t _e = hipGetLastError();                                                         \
+        if (_e != hipSuccess) {                                                                    \
+            robo::set_error("kernel launch failed: %s (%s:%d)", hipGetErrorString(_e), __FILE__, __LINE__); \
+            return ROBO_RUNTIME_ERROR;                                                             \
+        }                                                                                          \
+    } while (0)
+
+static inline int round_up(int x, int m) { return (x + m - 1) / m * m; }
+static inline int64_t round_up64(int64_t x, int64_t m) { return (x + m - 1) / m * m; }
+
+}  // namespace robo
+
+// ---- handle layouts --------------------------------------------------------------------
+struct robo_ctx {
+    int device;
+    hipStream_t stream;
+    bool own_stream;
+    hipEvent_t events[32];
+    char name[256];
+    int num_cu;
+    // scratch shared by every call on this context
+    double* d_scalars;   // [8]: quad, logdet, ...
+    int* d_fail;         // first failing column + 1, or 0
+    double* h_pinned;    // small pinned staging (64 doubles)
+};
+
+struct robo_gp {
+    robo_ctx* ctx;
+    int kind, dim, n_max;
+    int n;          // training points
+    int n_pad;      // round_up(n + 1, NB): row n is the augmented (y - mean) row, rest identity
+    int n_pad_max;
+    bool has_data, fitted;
+    double amp, noise, mean_c;
+    double y_mean, y_std;
+    double loglik;
+    double* d_X;        // (n_max, dim) raw inputs
+    double* d_Xs;       // (n_pad_max, dim) inputs scaled by 1/sqrt(metric_d)
+    double* d_y;        // (n_max)
+    double* d_K;        // (n_pad_max, n_pad_max) gram -> Cholesky factor in place (lower)
+    double* d_Linv;     // (n_pad_max / NB) x NB x NB inverses of the diagonal blocks
+    double* d_theta;    // (dim + 2) + inverse sqrt metric (dim)
+    double* h_theta;    // host copy
+};
+
+struct robo_cand {
+    robo_ctx* ctx;
+    int dim;
+    int64_t m;          // candidates
+    int64_t m_pad;      // round_up(m, NB)
+    double* d_Xc;       // (m_pad, dim) raw candidates (pad rows replicate row 0)
+    double* d_Xcs;      // (m_pad, dim) scaled for the GP being evaluated
+    double* d_V;        // (chunk, ldv) cross-gram -> L^-1 k_* in place
+    int64_t chunk;      // candidates per workspace pass (multiple of NB)
+    int ldv;            // n_pad the workspace was sized for
+    size_t v_bytes;
+    double* d_q;        // (m_pad) sum_n V^2
+    double* d_mu;       // (m_pad) V . z
+    double* d_mean;     // (m_pad) transformed mean
+    double* d_var;      // (m_pad) transformed, floored variance
+    double* d_acq;      // (m_pad)
+    double* d_acq_sum;  // (m_pad) marginal accumulator
+    double* d_part_val; // per-block argmax partials
+    long long* d_part_idx;
+    unsigned* d_flags;
+    int n_part;
+};
+
+// ---- launchers implemented in the .hip files (all asynchronous on ctx->stream) ------------
+namespace robo {
+int launch_scale_inputs(robo_ctx* ctx, const double* d_in, double* d_out, const double* d_inv_sqrt_metric,
+                        int64_t rows_real, int64_t rows_pad, int dim);
+int launch_gram(robo_gp* gp);
+int launch_potrf(robo_gp* gp);
+int launch_loglik(robo_gp* gp);
+int launch_cross_gram(robo_gp* gp, robo_cand* cand, int64_t c0, int64_t cn);
+int launch_trsm(robo_gp* gp, robo_cand* cand, int64_t c0, int64_t cn);
+int launch_post(robo_gp* gp, robo_cand* cand, int64_t c0, int64_t cn);
+int launch_acq(robo_ctx* ctx, robo_cand* cand, int acq_kind, double par, double eta, bool accumulate, bool first);
+int launch_argmax(robo_cand* cand, const double* d_vals, double scale);
+int launch_cov(robo_gp* gp, robo_cand* cand, double* d_cov);
+int launch_uniform(robo_ctx* ctx, double* d_out, int64_t m, int64_t m_pad, int dim, uint64_t seed);
+int launch_mfma_selftest(robo_ctx* ctx, double* out_err);
+int launch_mfma_microbench(robo_ctx* ctx, int iters, double* out_tflops);
+}  // namespace robo

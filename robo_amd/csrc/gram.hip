@@ -1,0 +1,185 @@
+// K1 gram_build and K4 cross_gram: pairwise scaled squared distances from LDS-tiled
+// X blocks, covariance function, coalesced fp64 row stores.
+//
+// Replaces the kernel-matrix assembly inside george.GP.compute / GP.predict
+// (reference call sites robo/models/gaussian_process.py:119,155,280).
+//
+// Both kernels use 64x64 output tiles, 256 threads, a 4x4 register micro-tile per thread.
+// Distances are accumulated as sum_d (x_d - x'_d)^2 on inputs pre-scaled by 1/sqrt(m_d)
+// (direct differences, not the |x|^2+|x'|^2-2xx' expansion: exact 0 on the diagonal, no
+// cancellation -- these values feed a Cholesky with sigma^2 = 1e-3).
+//
+// HBM traffic per launch: gram   8 * n_pad*(n_pad+64)/2 bytes written, 8*n*D read
+//                         cross  8 * rows*n_pad written, 8*(rows+n)*D read
+#include "common.h"
+#include "kern_math.h"
+
+namespace robo {
+
+constexpr int GT = 64;      // tile edge
+constexpr int GD = 16;      // dims per LDS pass
+constexpr int GLD = GT + 2; // LDS leading dimension (doubles)
+
+__global__ __launch_bounds__(256) void scale_inputs_kernel(const double* __restrict__ in, double* __restrict__ out,
+                                                           const double* __restrict__ inv_sqrt_m, long long rows_real,
+                                                           long long rows_pad, int dim) {
+    const long long total = rows_pad * dim;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (long long)gridDim.x * blockDim.x) {
+        const long long r = i / dim;
+        const int d = (int)(i - r * dim);
+        // pad rows replicate row 0 so that every lane of the tiled kernels computes on finite data
+        const long long src = r < rows_real ? r : 0;
+        out[i] = rows_real > 0 ? in[src * dim + d] * inv_sqrt_m[d] : 0.0;
+    }
+}
+
+// r2[a][b] = sum_d (Xi[i0 + ty*4 + a][d] - Xj[j0 + tx*4 + b][d])^2 ; Xi/Xj row-major (rows, dim)
+__device__ __forceinline__ void pair_r2(const double* __restrict__ Xi, const double* __restrict__ Xj, long long i0,
+                                        long long j0, int dim, double* sI, double* sJ, double (&r2)[4][4]) {
+    const int t = threadIdx.x, tx = t & 15, ty = t >> 4;
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) r2[a][b] = 0.0;
+    for (int d0 = 0; d0 < dim; d0 += GD) {
+        // stage 64 rows x 16 dims of both blocks, transposed to [d][row]
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int idx = t + e * 256;
+            const int row = idx >> 4, d = idx & 15;
+            const bool ok = d0 + d < dim;
+            sI[d * GLD + row] = ok ? Xi[(i0 + row) * dim + d0 + d] : 0.0;
+            sJ[d * GLD + row] = ok ? Xj[(j0 + row) * dim + d0 + d] : 0.0;
+        }
+        __syncthreads();
+        const int dn = dim - d0 < GD ? dim - d0 : GD;
+        for (int d = 0; d < dn; ++d) {
+            double xi[4], xj[4];
+#pragma unroll
+            for (int a = 0; a < 4; ++a) {
+                xi[a] = sI[d * GLD + ty * 4 + a];
+                xj[a] = sJ[d * GLD + tx * 4 + a];
+            }
+#pragma unroll
+            for (int a = 0; a < 4; ++a)
+#pragma unroll
+                for (int b = 0; b < 4; ++b) {
+                    const double df = xi[a] - xj[b];
+                    r2[a][b] = fma(df, df, r2[a][b]);
+                }
+        }
+        __syncthreads();
+    }
+}
+
+// map linear lower-triangular tile index to (bi, bj), bj <= bi
+__device__ __forceinline__ void tri_tile(int t, int& bi, int& bj) {
+    int i = (int)((sqrt(8.0 * (double)t + 1.0) - 1.0) * 0.5);
+    while ((i + 1) * (i + 2) / 2 <= t) ++i;
+    while (i * (i + 1) / 2 > t) --i;
+    bi = i;
+    bj = t - i * (i + 1) / 2;
+}
+
+// K[i][j] for j-tile <= i-tile.  Rows/cols >= n: row n is the augmented right-hand side
+// (y - mean), the rest identity, so that one Cholesky also yields z = L^-1 (y - mean)
+// as row n of the factor (DESIGN.md "augmented row").
+__global__ __launch_bounds__(256) void gram_kernel(const double* __restrict__ Xs, const double* __restrict__ y,
+                                                   double* __restrict__ K, int n, int n_pad, int dim, int kind,
+                                                   double amp, double noise, double mean_c) {
+    __shared__ double sI[GD * GLD];
+    __shared__ double sJ[GD * GLD];
+    int bi, bj;
+    tri_tile(blockIdx.x, bi, bj);
+    const long long i0 = (long long)bi * GT, j0 = (long long)bj * GT;
+    double r2[4][4];
+    pair_r2(Xs, Xs, i0, j0, dim, sI, sJ, r2);
+    const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+        const int gi = (int)i0 + ty * 4 + a;
+        double v[4];
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            const int gj = (int)j0 + tx * 4 + b;
+            double val;
+            if (gi < n && gj < n) {
+                val = cov_from_r2(kind, amp, r2[a][b]);
+                if (gi == gj) val += noise;
+            } else if (gi == gj) {
+                val = 1.0;
+            } else if (gi == n && gj < n) {
+                val = y[gj] - mean_c;
+            } else if (gj == n && gi < n) {
+                val = y[gi] - mean_c;
+            } else {
+                val = 0.0;
+            }
+            v[b] = val;
+        }
+        double2* dst = reinterpret_cast<double2*>(K + (size_t)gi * n_pad + j0 + tx * 4);
+        dst[0] = make_double2(v[0], v[1]);
+        dst[1] = make_double2(v[2], v[3]);
+    }
+}
+
+// V[c - c0][j] = k(xc_c, x_j) for j < n, 0 for n <= j < n_pad
+__global__ __launch_bounds__(256) void cross_gram_kernel(const double* __restrict__ Xcs,
+                                                         const double* __restrict__ Xs, double* __restrict__ V,
+                                                         long long c0, int n, int n_pad, int dim, int kind,
+                                                         double amp) {
+    __shared__ double sI[GD * GLD];
+    __shared__ double sJ[GD * GLD];
+    const long long i0 = (long long)blockIdx.y * GT;   // candidate tile (chunk local)
+    const long long j0 = (long long)blockIdx.x * GT;   // train tile
+    double r2[4][4];
+    pair_r2(Xcs, Xs, c0 + i0, j0, dim, sI, sJ, r2);
+    const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+        const long long ci = i0 + ty * 4 + a;
+        double v[4];
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            const int gj = (int)j0 + tx * 4 + b;
+            v[b] = gj < n ? cov_from_r2(kind, amp, r2[a][b]) : 0.0;
+        }
+        double2* dst = reinterpret_cast<double2*>(V + (size_t)ci * n_pad + j0 + tx * 4);
+        dst[0] = make_double2(v[0], v[1]);
+        dst[1] = make_double2(v[2], v[3]);
+    }
+}
+
+int launch_scale_inputs(robo_ctx* ctx, const double* d_in, double* d_out, const double* d_inv_sqrt_metric,
+                        int64_t rows_real, int64_t rows_pad, int dim) {
+    const long long total = (long long)rows_pad * dim;
+    int blocks = (int)((total + 255) / 256);
+    if (blocks > 4096) blocks = 4096;
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(scale_inputs_kernel, dim3(blocks), dim3(256), 0, ctx->stream, d_in, d_out, d_inv_sqrt_metric,
+                       (long long)rows_real, (long long)rows_pad, dim);
+    ROBO_LAUNCH_CHECK();
+    return ROBO_OK;
+}
+
+int launch_gram(robo_gp* gp) {
+    const int T = gp->n_pad / GT;
+    const int tiles = T * (T + 1) / 2;
+    hipLaunchKernelGGL(gram_kernel, dim3(tiles), dim3(256), 0, gp->ctx->stream, (const double*)gp->d_Xs,
+                       (const double*)gp->d_y, gp->d_K, gp->n, gp->n_pad, gp->dim, gp->kind, gp->amp, gp->noise,
+                       gp->mean_c);
+    ROBO_LAUNCH_CHECK();
+    return ROBO_OK;
+}
+
+int launch_cross_gram(robo_gp* gp, robo_cand* cand, int64_t c0, int64_t cn) {
+    // cn is a multiple of NB (=2*GT)
+    hipLaunchKernelGGL(cross_gram_kernel, dim3(gp->n_pad / GT, (unsigned)(cn / GT)), dim3(256), 0, gp->ctx->stream,
+                       (const double*)cand->d_Xcs, (const double*)gp->d_Xs, cand->d_V, (long long)c0, gp->n,
+                       gp->n_pad, gp->dim, gp->kind, gp->amp);
+    ROBO_LAUNCH_CHECK();
+    return ROBO_OK;
+}
+
+}  // namespace robo

@@ -1,0 +1,89 @@
+// Hardware self-checks used by the tests and by bench.py's roofline block:
+//   * one v_mfma_f64_16x16x4_f64 against a scalar product with ASYMMETRIC operands (a
+//     transposed fragment map would pass a symmetric test);
+//   * an MFMA-only loop to measure the fp64 matrix-pipe ceiling of the board the bench runs
+//     on (the local microarchitecture guide lists no fp64 MFMA peak; the datasheet figure is
+//     78.6 TFLOP/s).
+#include "common.h"
+
+namespace robo {
+
+__global__ __launch_bounds__(64) void mfma_layout_kernel(const double* __restrict__ A, const double* __restrict__ B,
+                                                         double* __restrict__ C) {
+    // A: 16x4 row-major, B: 4x16 row-major, C: 16x16 row-major
+    const int l = threadIdx.x;
+    v4d acc = {0.0, 0.0, 0.0, 0.0};
+    acc = mfma_f64(A[(l & 15) * 4 + (l >> 4)], B[(l >> 4) * 16 + (l & 15)], acc);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) C[((l >> 4) + 4 * r) * 16 + (l & 15)] = acc[r];
+}
+
+__global__ __launch_bounds__(256) void mfma_bench_kernel(double* __restrict__ sink, int iters, double seed) {
+    const int l = threadIdx.x & 63;
+    const double a = seed + 1e-3 * l, b = seed - 1e-3 * l;
+    v4d c0 = {0, 0, 0, 0}, c1 = {1, 1, 1, 1}, c2 = {2, 2, 2, 2}, c3 = {3, 3, 3, 3};
+    v4d c4 = {0, 0, 0, 0}, c5 = {1, 1, 1, 1}, c6 = {2, 2, 2, 2}, c7 = {3, 3, 3, 3};
+    for (int i = 0; i < iters; ++i) {
+        c0 = mfma_f64(a, b, c0);
+        c1 = mfma_f64(a, b, c1);
+        c2 = mfma_f64(a, b, c2);
+        c3 = mfma_f64(a, b, c3);
+        c4 = mfma_f64(a, b, c4);
+        c5 = mfma_f64(a, b, c5);
+        c6 = mfma_f64(a, b, c6);
+        c7 = mfma_f64(a, b, c7);
+    }
+    const v4d s = c0 + c1 + c2 + c3 + c4 + c5 + c6 + c7;
+    if (s[0] + s[1] + s[2] + s[3] == 12345.678) sink[threadIdx.x] = s[0];   // keep the chain live
+}
+
+int launch_mfma_selftest(robo_ctx* ctx, double* out_err) {
+    double hA[64], hB[64], hC[256];
+    for (int i = 0; i < 64; ++i) {
+        hA[i] = 0.25 * i + 1.0 + 0.01 * (i % 7);
+        hB[i] = 3.0 - 0.125 * i + 0.02 * (i % 5);
+    }
+    double* d = nullptr;
+    ROBO_HIP_CHECK(hipMalloc(&d, (64 + 64 + 256) * sizeof(double)));
+    ROBO_HIP_CHECK(hipMemcpyAsync(d, hA, sizeof(hA), hipMemcpyHostToDevice, ctx->stream));
+    ROBO_HIP_CHECK(hipMemcpyAsync(d + 64, hB, sizeof(hB), hipMemcpyHostToDevice, ctx->stream));
+    hipLaunchKernelGGL(mfma_layout_kernel, dim3(1), dim3(64), 0, ctx->stream, (const double*)d,
+                       (const double*)(d + 64), d + 128);
+    ROBO_HIP_CHECK(hipMemcpyAsync(hC, d + 128, sizeof(hC), hipMemcpyDeviceToHost, ctx->stream));
+    ROBO_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    ROBO_HIP_CHECK(hipFree(d));
+    double err = 0.0;
+    for (int i = 0; i < 16; ++i)
+        for (int j = 0; j < 16; ++j) {
+            double s = 0.0;
+            for (int k = 0; k < 4; ++k) s += hA[i * 4 + k] * hB[k * 16 + j];
+            const double e = s - hC[i * 16 + j];
+            if ((e < 0 ? -e : e) > err) err = e < 0 ? -e : e;
+        }
+    *out_err = err;
+    return ROBO_OK;
+}
+
+int launch_mfma_microbench(robo_ctx* ctx, int iters, double* out_tflops) {
+    const int blocks = 4096;
+    double* sink = nullptr;
+    ROBO_HIP_CHECK(hipMalloc(&sink, 256 * sizeof(double)));
+    hipEvent_t e0, e1;
+    ROBO_HIP_CHECK(hipEventCreate(&e0));
+    ROBO_HIP_CHECK(hipEventCreate(&e1));
+    hipLaunchKernelGGL(mfma_bench_kernel, dim3(blocks), dim3(256), 0, ctx->stream, sink, iters / 4 + 1, 0.5);  // warm
+    ROBO_HIP_CHECK(hipEventRecord(e0, ctx->stream));
+    hipLaunchKernelGGL(mfma_bench_kernel, dim3(blocks), dim3(256), 0, ctx->stream, sink, iters, 0.5);
+    ROBO_HIP_CHECK(hipEventRecord(e1, ctx->stream));
+    ROBO_HIP_CHECK(hipEventSynchronize(e1));
+    float ms = 0.f;
+    ROBO_HIP_CHECK(hipEventElapsedTime(&ms, e0, e1));
+    ROBO_HIP_CHECK(hipEventDestroy(e0));
+    ROBO_HIP_CHECK(hipEventDestroy(e1));
+    ROBO_HIP_CHECK(hipFree(sink));
+    const double flops = (double)blocks * 4.0 * (double)iters * 8.0 * 2048.0;
+    *out_tflops = flops / ((double)ms * 1e-3) / 1e12;
+    return ROBO_OK;
+}
+
+}  // namespace robo

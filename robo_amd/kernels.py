@@ -1,0 +1,88 @@
+"""george-free kernel descriptions with the slice of george's kernel API that RoBO uses.
+
+RoBO builds ``cov_amp * george.kernels.Matern52Kernel(np.ones(D), ndim=D)``
+(robo/fmin/bayesian_optimization.py:75-81) and then only touches
+``len(kernel)``, ``kernel.get_parameter_vector()``, ``kernel.set_parameter_vector(v)``,
+``kernel[:]`` (robo/models/gaussian_process.py:110,113,151,204;
+robo/models/gaussian_process_mcmc.py:115,145,154,193) and, in tests,
+``kernel.get_value`` (test/test_models/test_gaussian_process.py:44-46).  These classes
+provide exactly that on top of the (kind, log-parameter-vector) pair the device code takes.
+
+Parameterisation (the project's stated contract for the un-vendored george):
+vector = [log amp, log m_1 .. log m_D], m_d = squared length scale;
+``b * kernel`` multiplies the amplitude by ``b / ndim`` (george's ``__rmul__`` builds
+``ConstantKernel(log_constant=log(b / ndim))``).
+"""
+import numpy as np
+
+
+class Kernel(object):
+    kind = None
+
+    def __init__(self, metric, ndim=None, log_amp=0.0):
+        metric = np.atleast_1d(np.asarray(metric, dtype=np.float64))
+        if ndim is None:
+            ndim = metric.shape[0]
+        if metric.shape[0] == 1 and ndim > 1:
+            metric = np.full(ndim, metric[0])
+        assert metric.shape[0] == ndim, "metric must have ndim entries"
+        self.ndim = int(ndim)
+        self._vector = np.concatenate([[float(log_amp)], np.log(metric)])
+
+    # ---- george API slice -------------------------------------------------------------
+    def __len__(self):
+        return self._vector.shape[0]
+
+    def get_parameter_vector(self):
+        return self._vector.copy()
+
+    def set_parameter_vector(self, v):
+        v = np.asarray(v, dtype=np.float64)
+        assert v.shape == self._vector.shape
+        self._vector = v.copy()
+
+    def __getitem__(self, k):
+        return self._vector[k].copy() if isinstance(k, slice) else float(self._vector[k])
+
+    def __setitem__(self, k, v):
+        self._vector[k] = v
+
+    @property
+    def vector(self):
+        return self.get_parameter_vector()
+
+    def __rmul__(self, b):
+        out = self.__class__(np.exp(self._vector[1:]), ndim=self.ndim,
+                             log_amp=self._vector[0] + np.log(float(b) / self.ndim))
+        return out
+
+    __mul__ = __rmul__
+
+    def get_value(self, X1, X2=None):
+        """k(X1, X2), evaluated by the device cross-gram kernel."""
+        from robo_amd import _lib
+        X1 = np.ascontiguousarray(X1, dtype=np.float64)
+        ctx = _lib.default_context()
+        gp = _lib.DeviceGP(ctx, self.kind, X1.shape[0], self.ndim)
+        gp.set_data(X1, np.zeros(X1.shape[0]))
+        theta = np.concatenate([self._vector, [-700.0]])   # exp(-700) = 0 noise
+        K = gp.gram(theta) if X2 is None else None
+        if X2 is None:
+            K[np.diag_indices_from(K)] -= 1.25e-12
+            gp.close()
+            return K
+        raise NotImplementedError("get_value(X1, X2) is only provided for X2=None")
+
+    def __repr__(self):
+        return "%s(amp=%g, metric=%s)" % (self.__class__.__name__, np.exp(self._vector[0]),
+                                           np.exp(self._vector[1:]))
+
+
+class Matern52Kernel(Kernel):
+    """k = amp (1 + sqrt(5 r2) + 5 r2 / 3) exp(-sqrt(5 r2)),  r2 = sum_d (x_d - x'_d)^2 / m_d"""
+    kind = "matern52"
+
+
+class ExpSquaredKernel(Kernel):
+    """k = amp exp(-r2 / 2)"""
+    kind = "rbf"

@@ -1,0 +1,52 @@
+"""Acquisition maximisation by candidate sampling -- the batched caller of the hot path.
+
+``RandomSampling`` keeps the constructor and the candidate recipe of
+robo/maximizers/random_sampling.py:7-52: 70 % uniform points (``init_random_uniform``
+called WITHOUT the maximiser's rng, :38-39) and 30 % drawn from N(incumbent, 0.1) with the
+GLOBAL ``np.random`` and an absolute sigma (:43-45), clipped to the box; one batched
+``acq(X)`` call; ``X[y.argmax()]``.  ``n_samples`` may be far larger than the reference's
+500: the whole batch is evaluated by one device call and, when the acquisition function
+offers ``argmax``, only the winning index crosses PCIe.
+"""
+import numpy as np
+
+from robo_amd.initial_design import init_random_uniform
+
+
+class BaseMaximizer(object):
+    """robo/maximizers/base_maximizer.py:5-32."""
+
+    def __init__(self, objective_function, lower, upper, rng=None):
+        self.lower = lower
+        self.upper = upper
+        self.objective_func = objective_function
+        self.rng = np.random.RandomState(np.random.randint(10000)) if rng is None else rng
+
+    def maximize(self):
+        pass
+
+
+class RandomSampling(BaseMaximizer):
+
+    def __init__(self, objective_function, lower, upper, n_samples=500, rng=None, device_argmax=True):
+        self.n_samples = n_samples
+        self.device_argmax = device_argmax
+        super(RandomSampling, self).__init__(objective_function, lower, upper, rng)
+
+    def candidates(self):
+        n_uniform = int(self.n_samples * .7)
+        n_local = int(self.n_samples * 0.3)
+        rand = init_random_uniform(self.lower, self.upper, n_uniform)
+        loc = self.objective_func.model.get_incumbent()[0]
+        scale = np.ones([self.lower.shape[0]]) * 0.1
+        # one np.random.normal(loc, scale) call per point, like the reference's list comprehension
+        local = np.array([np.clip(np.random.normal(loc, scale), self.lower, self.upper)
+                          for _ in range(n_local)]).reshape(n_local, self.lower.shape[0])
+        return np.concatenate((rand, local), axis=0)
+
+    def maximize(self):
+        X = self.candidates()
+        if self.device_argmax and hasattr(self.objective_func, "argmax"):
+            return X[self.objective_func.argmax(X)]
+        y = self.objective_func(X)
+        return X[y.argmax()]

@@ -1,0 +1,216 @@
+"""ML-II Gaussian process on the MI355X hot path.
+
+Same constructor, attributes and method semantics as
+robo/models/gaussian_process.py:14-352; george's role (gp.compute / log_likelihood /
+predict) is played by the device GP behind the C ABI (include/robo_hip.h):
+
+  train            :70-124   normalise, mean = mean(y), [optimise], fit (retry at noise*10)
+  nll              :129-166  |theta|>20 -> 1e25; LinAlgError -> 1e25; non-finite -> 1e25
+  optimize         :193-219  scipy L-BFGS-B on nll (finite differences, like the reference)
+  predict          :251-296  un-normalise, variance floor eps (on device)
+  predict_variance :221-248, sample_functions :298-332, get_incumbent :334-352
+"""
+import copy
+import logging
+
+import numpy as np
+from scipy import optimize
+
+from robo_amd import _lib
+from robo_amd.models.base_model import BaseModel
+from robo_amd.util import normalization
+
+logger = logging.getLogger(__name__)
+
+
+class GaussianProcess(BaseModel):
+
+    def __init__(self, kernel, prior=None, noise=1e-3, use_gradients=False, normalize_output=False,
+                 normalize_input=True, lower=None, upper=None, rng=None, device=None):
+        if rng is None:
+            self.rng = np.random.RandomState(np.random.randint(0, 10000))
+        else:
+            self.rng = rng
+        self.kernel = kernel
+        self.gp = None                 # robo_amd._lib.DeviceGP (the reference holds a george.GP here)
+        self.prior = prior
+        self.noise = noise
+        self.use_gradients = use_gradients
+        self.normalize_output = normalize_output
+        self.normalize_input = normalize_input
+        self.X = None
+        self.y = None
+        self.hypers = []
+        self.is_trained = False
+        self.lower = lower
+        self.upper = upper
+        self.device = device
+        self._fitted_theta = None
+
+    # ---- device handle management ----------------------------------------------------------
+    def _ctx(self):
+        return _lib.default_context(self.device)
+
+    def _ensure_gp(self, n, dim):
+        if self.gp is None or self.gp.dim != dim or self.gp.n_max < n or self.gp.kind != self.kernel.kind:
+            if self.gp is not None:
+                self.gp.close()
+            cap = max(127, int(n))
+            if self.gp is not None and self.gp.n_max < n:
+                cap = max(cap, 2 * self.gp.n_max)     # amortise growth over a BO run
+            self.gp = _lib.DeviceGP(self._ctx(), self.kernel.kind, cap, dim)
+        return self.gp
+
+    def __deepcopy__(self, memo):
+        # device memory is not copied: the copy re-fits lazily from its host state on first use
+        # (MarginalizationGPMCMC deep-copies acquisition functions, marginalization.py:36,67)
+        new = self.__class__.__new__(self.__class__)
+        memo[id(self)] = new
+        for k, v in self.__dict__.items():
+            if k == "gp":
+                new.gp = None
+            else:
+                setattr(new, k, copy.deepcopy(v, memo))
+        return new
+
+    def __getstate__(self):
+        d = dict(self.__dict__)
+        d["gp"] = None
+        return d
+
+    def _materialise(self):
+        """(re)create the device state of a trained model that lost its handle (deepcopy/pickle)."""
+        if self.gp is None and self.is_trained:
+            gp = self._ensure_gp(self.X.shape[0], self.X.shape[1])
+            gp.set_data(self.X, self.y)
+            self._set_transform()
+            gp.fit(self._fitted_theta, self.mean)
+
+    def _set_transform(self):
+        if self.normalize_output:
+            self.gp.set_output_transform(self.y_mean, self.y_std)
+        else:
+            self.gp.set_output_transform(0.0, 1.0)
+
+    # ---- BaseModel ----------------------------------------------------------------------------
+    @BaseModel._check_shapes_train
+    def train(self, X, y, do_optimize=True):
+        if self.normalize_input:
+            self.X, self.lower, self.upper = normalization.zero_one_normalization(X, self.lower, self.upper)
+        else:
+            self.X = X
+        if self.normalize_output:
+            self.y, self.y_mean, self.y_std = normalization.zero_mean_unit_var_normalization(y)
+            if self.y_std == 0:
+                raise ValueError("Cannot normalize output. All targets have the same value")
+        else:
+            self.y = y
+        self.mean = np.mean(self.y, axis=0)
+
+        gp = self._ensure_gp(self.X.shape[0], self.X.shape[1])
+        gp.set_data(self.X, self.y)
+        self._set_transform()
+        self.is_trained = False
+
+        if do_optimize:
+            self.hypers = self.optimize()
+            self.kernel.set_parameter_vector(self.hypers[:-1])
+            self.noise = np.exp(self.hypers[-1])
+        else:
+            self.hypers = np.append(self.kernel.get_parameter_vector(), np.log(self.noise))
+        logger.debug("GP Hyperparameters: " + str(self.hypers))
+
+        try:
+            theta = np.append(self.kernel.get_parameter_vector(), np.log(self.noise))
+            gp.fit(theta, self.mean)
+        except np.linalg.LinAlgError:
+            self.noise *= 10
+            theta = np.append(self.kernel.get_parameter_vector(), np.log(self.noise))
+            gp.fit(theta, self.mean)
+        self._fitted_theta = theta
+        self.is_trained = True
+
+    def get_noise(self):
+        return self.noise
+
+    def nll(self, theta):
+        """Negative log marginal likelihood (+ prior) at theta; same failure protocol as the
+        reference (1e25)."""
+        theta = np.asarray(theta, dtype=np.float64)
+        if np.any((-20 > theta) + (theta > 20)):
+            return 1e25
+        try:
+            ll = self.gp.fit(theta, self.mean)
+        except np.linalg.LinAlgError:
+            return 1e25
+        if self.prior is not None:
+            ll += self.prior.lnprob(theta)
+        return -ll if np.isfinite(ll) else 1e25
+
+    def grad_nll(self, theta):
+        raise NotImplementedError("analytic grad_nll is a 'next' row (SURVEY.md 8f rank 1); "
+                                  "optimize() uses finite differences like the reference default")
+
+    def optimize(self):
+        p0 = np.append(self.kernel.get_parameter_vector(), np.log(self.noise))
+        try:
+            results = optimize.minimize(self.nll, p0, method='L-BFGS-B')
+            theta = results.x
+        except ValueError:
+            logging.error("Could not find a valid hyperparameter configuration! Use initial configuration")
+            theta = p0
+        return theta
+
+    def predict_variance(self, x1, X2):
+        """Covariance between the test point x1 (1, D) and X2 (N, D) -> (N, 1)."""
+        if not self.is_trained:
+            raise Exception('Model has to be trained first!')
+        x_ = np.concatenate((x1, X2))
+        _, var = self.predict(x_, full_cov=True)
+        return var[-1, :-1, np.newaxis]
+
+    def _normalised(self, X_test):
+        if self.normalize_input:
+            return normalization.zero_one_normalization(X_test, self.lower, self.upper)[0]
+        return X_test
+
+    @BaseModel._check_shapes_predict
+    def predict(self, X_test, full_cov=False, **kwargs):
+        if not self.is_trained:
+            raise Exception('Model has to be trained first!')
+        self._materialise()
+        Xn = self._normalised(X_test)
+        if not full_cov:
+            return self.gp.predict(Xn)          # transform + floor done on the device
+        mu, cov = self.gp.predict_cov(Xn)
+        # the reference clips the whole matrix, off-diagonals included (gaussian_process.py:290-294)
+        eps = np.finfo(cov.dtype).eps
+        cov = np.clip(cov, eps, np.inf)
+        return mu, cov
+
+    def sample_functions(self, X_test, n_funcs=1):
+        """Draw n_funcs functions from the posterior at X_test -> (F, N)."""
+        if not self.is_trained:
+            raise Exception('Model has to be trained first!')
+        self._materialise()
+        mu, cov = self.gp.predict_cov(self._normalised(X_test))   # already un-normalised
+        funcs = self.rng.multivariate_normal(mu, cov, size=n_funcs)
+        return funcs[None, :] if funcs.ndim == 1 else funcs
+
+    def get_incumbent(self):
+        inc, inc_value = super(GaussianProcess, self).get_incumbent()
+        if self.normalize_input:
+            inc = normalization.zero_one_unnormalization(inc, self.lower, self.upper)
+        if self.normalize_output:
+            inc_value = normalization.zero_mean_unit_var_unnormalization(inc_value, self.y_mean, self.y_std)
+        return inc, inc_value
+
+    # ---- fused device paths used by robo_amd's acquisition functions ----------------------------
+    def acquisition(self, kind, par, eta, X_test, want_values=True):
+        """(values, max, argmax, flags) of a closed-form acquisition at raw candidates X_test."""
+        if not self.is_trained:
+            raise Exception('Model has to be trained first!')
+        self._materialise()
+        if isinstance(X_test, _lib.Candidates):
+            return self.gp.acq(kind, par, eta, X_test, want_values)
+        return self.gp.acq(kind, par, eta, self._normalised(X_test), want_values)

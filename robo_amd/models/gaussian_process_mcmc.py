@@ -1,0 +1,168 @@
+"""GP with MCMC-marginalised hyper-parameters on the MI355X hot path.
+
+Same constructor, attributes (``models``, ``n_hypers``, ``chain_length``, ``burnin_steps``,
+``burned``, ``p0``, ``hypers``) and semantics as robo/models/gaussian_process_mcmc.py:16-269.
+The ensemble sampler evaluates each half-ensemble's log-likelihoods in ONE device call
+(robo_gp_loglik_batch) instead of one george fit per walker; every hyper-parameter sample
+then gets its own device-resident GaussianProcess (``self.models``), which is what
+MarginalizationGPMCMC iterates over (marginalization.py:34-46,118).
+"""
+import logging
+from copy import deepcopy
+
+import numpy as np
+
+from robo_amd import _lib
+from robo_amd.models.base_model import BaseModel
+from robo_amd.models.gaussian_process import GaussianProcess
+from robo_amd.util import normalization
+from robo_amd.util.ensemble_sampler import EnsembleSampler
+
+logger = logging.getLogger(__name__)
+
+
+class GaussianProcessMCMC(BaseModel):
+
+    def __init__(self, kernel, prior=None, n_hypers=20, chain_length=2000, burnin_steps=2000,
+                 normalize_output=False, normalize_input=True, rng=None, lower=None, upper=None, noise=-8,
+                 device=None):
+        if rng is None:
+            self.rng = np.random.RandomState(np.random.randint(0, 10000))
+        else:
+            self.rng = rng
+        self.kernel = kernel
+        self.prior = prior
+        self.noise = noise              # log scale here (gaussian_process_mcmc.py:20,144-147)
+        self.n_hypers = n_hypers
+        self.chain_length = chain_length
+        self.burned = False
+        self.burnin_steps = burnin_steps
+        self.models = []
+        self.normalize_output = normalize_output
+        self.normalize_input = normalize_input
+        self.X = None
+        self.y = None
+        self.is_trained = False
+        self.lower = lower
+        self.upper = upper
+        self.device = device
+        self.gp = None                  # scratch device GP for the likelihood evaluations
+
+    def _ensure_gp(self, n, dim):
+        if self.gp is None or self.gp.dim != dim or self.gp.n_max < n or self.gp.kind != self.kernel.kind:
+            if self.gp is not None:
+                self.gp.close()
+            cap = max(127, int(n)) if self.gp is None else max(int(n), 2 * self.gp.n_max)
+            self.gp = _lib.DeviceGP(_lib.default_context(self.device), self.kernel.kind, cap, dim)
+        return self.gp
+
+    def __deepcopy__(self, memo):
+        new = self.__class__.__new__(self.__class__)
+        memo[id(self)] = new
+        for k, v in self.__dict__.items():
+            setattr(new, k, None if k == "gp" else deepcopy(v, memo))
+        return new
+
+    def __getstate__(self):
+        d = dict(self.__dict__)
+        d["gp"] = None
+        return d
+
+    @BaseModel._check_shapes_train
+    def train(self, X, y, do_optimize=True, **kwargs):
+        if self.normalize_input:
+            self.X, self.lower, self.upper = normalization.zero_one_normalization(X, self.lower, self.upper)
+        else:
+            self.X = X
+        if self.normalize_output:
+            self.y, self.y_mean, self.y_std = normalization.zero_mean_unit_var_normalization(y)
+            if self.y_std == 0:
+                raise ValueError("Cannot normalize output. All targets have the same value")
+        else:
+            self.y = y
+        self.mean = np.mean(self.y, axis=0)
+        gp = self._ensure_gp(self.X.shape[0], self.X.shape[1])
+        gp.set_data(self.X, self.y)
+
+        if do_optimize:
+            sampler = EnsembleSampler(self.n_hypers, len(self.kernel) + 1, lnprob_batch=self.loglikelihood_batch)
+            sampler.random_state = self.rng.get_state()
+            if not self.burned:
+                if self.prior is None:
+                    self.p0 = self.rng.rand(self.n_hypers, len(self.kernel) + 1)
+                else:
+                    self.p0 = self.prior.sample_from_prior(self.n_hypers)
+                self.p0, _, _ = sampler.run_mcmc(self.p0, self.burnin_steps, rstate0=self.rng)
+                self.burned = True
+            pos, _, _ = sampler.run_mcmc(self.p0, self.chain_length, rstate0=self.rng)
+            self.p0 = pos
+            self.hypers = sampler.chain[:, -1]
+        else:
+            self.hypers = self.kernel[:].tolist()
+            self.hypers.append(self.noise)
+            self.hypers = [self.hypers]
+
+        # one device-resident GP per hyper-parameter sample; handles of the previous round are
+        # reused so a BO run does not re-allocate S factor buffers every iteration
+        old = self.models
+        self.models = []
+        for i, sample in enumerate(self.hypers):
+            sample = np.asarray(sample, dtype=np.float64)
+            kernel = deepcopy(self.kernel)
+            kernel.set_parameter_vector(sample[:-1])
+            if i < len(old) and isinstance(old[i], GaussianProcess):
+                model = old[i]
+                model.kernel = kernel
+                model.noise = np.exp(sample[-1])
+                model.lower, model.upper = self.lower, self.upper
+            else:
+                model = GaussianProcess(kernel, normalize_output=self.normalize_output,
+                                        normalize_input=self.normalize_input, noise=np.exp(sample[-1]),
+                                        lower=self.lower, upper=self.upper, rng=self.rng, device=self.device)
+            model.train(X, y, do_optimize=False)
+            self.models.append(model)
+        for m in old[len(self.models):]:
+            if getattr(m, "gp", None) is not None:
+                m.gp.close()
+        self.is_trained = True
+
+    # ---- likelihood ------------------------------------------------------------------------------
+    def loglikelihood_batch(self, thetas):
+        """log p(y | X, theta) + log prior for a batch (k, P); out-of-bounds / non-PD -> -inf
+        (gaussian_process_mcmc.py:185-202)."""
+        thetas = np.atleast_2d(np.asarray(thetas, dtype=np.float64))
+        out = np.full(thetas.shape[0], -np.inf)
+        ok = ~np.any((-20 > thetas) + (thetas > 20), axis=1) & np.all(np.isfinite(thetas), axis=1)
+        if np.any(ok):
+            ll, st = self.gp.loglik_batch(thetas[ok], self.mean)
+            ll = np.where(st == _lib.OK, ll, -np.inf)
+            if self.prior is not None:
+                ll = ll + np.array([self.prior.lnprob(t) for t in thetas[ok]])
+            out[ok] = ll
+        return out
+
+    def loglikelihood(self, theta):
+        return float(self.loglikelihood_batch(np.asarray(theta)[None, :])[0])
+
+    # ---- posterior ------------------------------------------------------------------------------
+    @BaseModel._check_shapes_predict
+    def predict(self, X_test, **kwargs):
+        if not self.is_trained:
+            raise Exception('Model has to be trained first!')
+        mu = np.zeros([len(self.models), X_test.shape[0]])
+        var = np.zeros([len(self.models), X_test.shape[0]])
+        for i, model in enumerate(self.models):
+            mu[i], var[i] = model.predict(X_test)
+        m = mu.mean(axis=0)
+        # total variance of the mixture (Hutter et al.), gaussian_process_mcmc.py:235-239
+        v = np.var(mu, axis=0) + np.mean(var, axis=0)
+        v = np.clip(v, np.finfo(v.dtype).eps, np.inf)
+        return m, v
+
+    def get_incumbent(self):
+        inc, inc_value = super(GaussianProcessMCMC, self).get_incumbent()
+        if self.normalize_input:
+            inc = normalization.zero_one_unnormalization(inc, self.lower, self.upper)
+        if self.normalize_output:
+            inc_value = normalization.zero_mean_unit_var_unnormalization(inc_value, self.y_mean, self.y_std)
+        return inc, inc_value

@@ -1,0 +1,119 @@
+"""Sequential Bayesian-optimisation loop (host control plane).
+
+robo_amd's models and acquisition functions drop into the reference's own
+``robo.solver.bayesian_optimization.BayesianOptimization`` unchanged (tests/test_dropin.py
+drives exactly that).  This module is the george-free equivalent for installations where
+the ``robo`` package cannot be imported; it keeps the constructor, ``run`` / ``choose_next``
+and the bookkeeping lists of robo/solver/bayesian_optimization.py:16-261
+(``time_overhead``, ``time_func_evals``, ``incumbents``, ``incumbents_values``,
+``runtime``, per-iteration ``robo_iter_%d.json``).
+"""
+import json
+import logging
+import os
+import time
+
+import numpy as np
+
+from robo_amd.initial_design import init_random_uniform
+
+logger = logging.getLogger(__name__)
+
+
+class BayesianOptimization(object):
+
+    def __init__(self, objective_func, lower, upper, acquisition_func, model, maximize_func,
+                 initial_design=init_random_uniform, initial_points=3, output_path=None, train_interval=1,
+                 n_restarts=1, rng=None):
+        self.rng = np.random.RandomState(np.random.randint(100000)) if rng is None else rng
+        self.model = model
+        self.acquisition_func = acquisition_func
+        self.maximize_func = maximize_func
+        self.start_time = time.time()
+        self.initial_design = initial_design
+        self.objective_func = objective_func
+        self.X = None
+        self.y = None
+        self.time_func_evals = []
+        self.time_overhead = []
+        self.train_interval = train_interval
+        self.lower = lower
+        self.upper = upper
+        self.output_path = output_path
+        self.time_start = None
+        self.incumbents = []
+        self.incumbents_values = []
+        self.n_restarts = n_restarts
+        self.init_points = initial_points
+        self.runtime = []
+
+    def _record_incumbent(self, X, y):
+        best = int(np.argmin(y))
+        self.incumbents.append(np.asarray(X[best]).tolist())
+        self.incumbents_values.append(y[best])
+        self.runtime.append(time.time() - self.start_time)
+
+    def run(self, num_iterations=10, X=None, y=None):
+        """-> (incumbent, incumbent value) after num_iterations evaluations in total."""
+        self.time_start = time.time()
+        if X is None and y is None:
+            Xl, yl = [], []
+            t0 = time.time()
+            init = self.initial_design(self.lower, self.upper, self.init_points, rng=self.rng)
+            design_overhead = (time.time() - t0) / self.init_points
+            for i, x in enumerate(init):
+                logger.info("Evaluate: %s", x)
+                t0 = time.time()
+                new_y = self.objective_func(x)
+                Xl.append(x)
+                yl.append(new_y)
+                self.time_func_evals.append(time.time() - t0)
+                self.time_overhead.append(design_overhead)
+                self._record_incumbent(Xl, yl)
+                if self.output_path is not None:
+                    self.save_output(i)
+            self.X, self.y = np.array(Xl), np.array(yl)
+        else:
+            self.X, self.y = X, y
+
+        for it in range(self.init_points, num_iterations):
+            logger.info("Start iteration %d ... ", it)
+            t0 = time.time()
+            new_x = self.choose_next(self.X, self.y, do_optimize=(it % self.train_interval == 0))
+            self.time_overhead.append(time.time() - t0)
+            logger.info("Optimization overhead was %f seconds", self.time_overhead[-1])
+            t0 = time.time()
+            new_y = self.objective_func(new_x)
+            self.time_func_evals.append(time.time() - t0)
+            logger.info("Configuration %s achieved a performance of %f", str(new_x), new_y)
+            self.X = np.append(self.X, new_x[None, :], axis=0)
+            self.y = np.append(self.y, new_y)
+            self._record_incumbent(self.X, self.y)
+            if self.output_path is not None:
+                self.save_output(it)
+        return self.incumbents[-1], self.incumbents_values[-1]
+
+    def choose_next(self, X=None, y=None, do_optimize=True):
+        """Train the model, update the acquisition function, maximise it -> next point (D,)."""
+        if (X is None and y is None) or X.shape[0] == 1:
+            # a GP needs at least two points (bayesian_optimization.py:226-231)
+            return self.initial_design(self.lower, self.upper, 1, rng=self.rng)[0, :]
+        try:
+            t0 = time.time()
+            self.model.train(X, y, do_optimize=do_optimize)
+            logger.info("Time to train the model: %f", (time.time() - t0))
+        except Exception:
+            logger.error("Model could not be trained!")
+            raise
+        self.acquisition_func.update(self.model)
+        t0 = time.time()
+        x = self.maximize_func.maximize()
+        logger.info("Time to maximize the acquisition function: %f", (time.time() - t0))
+        return x
+
+    def save_output(self, it):
+        data = {"optimization_overhead": self.time_overhead[it], "runtime": self.runtime[it],
+                "incumbent": self.incumbents[it], "incumbents_value": self.incumbents_values[it],
+                "time_func_eval": self.time_func_evals[it], "iteration": it}
+        with open(os.path.join(self.output_path, "robo_iter_%d.json" % it), "w") as fh:
+            json.dump(data, fh)

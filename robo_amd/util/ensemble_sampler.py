@@ -1,0 +1,116 @@
+"""Affine-invariant ensemble sampler (Goodman & Weare 2010 stretch move) with BATCHED
+log-probability evaluation.
+
+emcee (requirements.txt:3, ``>=2.1.0``, v2 API) is the sampler the reference drives in
+robo/models/gaussian_process_mcmc.py:114-142:
+
+    sampler = emcee.EnsembleSampler(n_walkers, ndim, lnprob)
+    sampler.random_state = rng.get_state()
+    pos, lnp, state = sampler.run_mcmc(p0, n_steps, rstate0=rng)
+    sampler.chain[:, -1]
+
+emcee is not installed here, and its one-walker-at-a-time ``lnprob(theta)`` callback is
+exactly the pattern the device path wants to avoid: each half-ensemble update proposes
+n_walkers/2 independent thetas, i.e. n_walkers/2 independent GP fits.  This class keeps the
+call shape above (so GaussianProcessMCMC.train reads like the reference) but hands each
+half-ensemble to ``lnprob_batch(thetas (k, ndim)) -> (k,)`` in one call, which
+GaussianProcessMCMC maps onto robo_gp_loglik_batch.
+
+Algorithm (emcee 2.x ``EnsembleSampler._propose_stretch``, restated from the paper): split
+the walkers into two halves; for each half S (complement C), for every walker x_k in S draw
+a partner c_j from C uniformly and z ~ g(z) ∝ 1/sqrt(z) on [1/a, a] (a = 2) via
+z = ((a - 1) u + 1)^2 / a; propose q = c_j - z (c_j - x_k); accept with probability
+min(1, z^(ndim-1) exp(lnp(q) - lnp(x_k))).  Random streams are NOT bit-compatible with
+emcee's (sample sequences differ; the stationary distribution is the same).
+"""
+import numpy as np
+
+
+class EnsembleSampler(object):
+
+    def __init__(self, nwalkers, dim, lnprob=None, lnprob_batch=None, a=2.0):
+        assert nwalkers % 2 == 0, "The number of walkers must be even."
+        assert nwalkers >= 2 * dim, "The number of walkers needs to be at least twice the dimension"
+        assert (lnprob is None) != (lnprob_batch is None)
+        self.k, self.dim, self.a = int(nwalkers), int(dim), float(a)
+        if lnprob_batch is None:
+            def lnprob_batch(thetas, _f=lnprob):
+                return np.array([_f(t) for t in thetas], dtype=np.float64)
+        self._lnprob_batch = lnprob_batch
+        self._random = np.random.RandomState()
+        self.naccepted = np.zeros(self.k)
+        self.iterations = 0
+        self._chain = np.empty((self.k, 0, self.dim))
+        self._lnprob = np.empty((self.k, 0))
+
+    # emcee-style attributes ---------------------------------------------------------------
+    @property
+    def random_state(self):
+        return self._random.get_state()
+
+    @random_state.setter
+    def random_state(self, state):
+        try:
+            self._random.set_state(state)
+        except Exception:
+            pass
+
+    @property
+    def chain(self):
+        return self._chain
+
+    @property
+    def lnprobability(self):
+        return self._lnprob
+
+    @property
+    def acceptance_fraction(self):
+        return self.naccepted / max(self.iterations, 1)
+
+    def _eval(self, thetas):
+        lp = np.asarray(self._lnprob_batch(thetas), dtype=np.float64)
+        if np.any(np.isnan(lp)):
+            raise ValueError("lnprob returned NaN.")
+        return lp
+
+    def run_mcmc(self, pos0, N, rstate0=None, lnprob0=None):
+        """-> (pos (k, dim), lnprob (k,), random state)"""
+        if rstate0 is not None:
+            # the reference passes its RandomState object (gaussian_process_mcmc.py:126-135)
+            self.random_state = rstate0.get_state() if hasattr(rstate0, "get_state") else rstate0
+        p = np.array(pos0, dtype=np.float64)
+        assert p.shape == (self.k, self.dim)
+        lnp = self._eval(p) if lnprob0 is None else np.array(lnprob0, dtype=np.float64)
+        if np.any(np.isinf(lnp) & (lnp > 0)):
+            raise ValueError("The initial lnprob was +inf.")
+        chain = np.empty((self.k, N, self.dim))
+        lnps = np.empty((self.k, N))
+        half = self.k // 2
+        first, second = slice(half), slice(half, self.k)
+        for it in range(N):
+            for S0, S1 in ((first, second), (second, first)):
+                s, c = p[S0], p[S1]
+                ns, nc = s.shape[0], c.shape[0]
+                zz = ((self.a - 1.0) * self._random.rand(ns) + 1.0) ** 2.0 / self.a
+                rint = self._random.randint(nc, size=(ns,))
+                q = c[rint] - zz[:, None] * (c[rint] - s)
+                newlnp = self._eval(q)
+                lnpdiff = (self.dim - 1.0) * np.log(zz) + newlnp - lnp[S0]
+                accept = lnpdiff > np.log(self._random.rand(ns))
+                if np.any(accept):
+                    idx = np.arange(self.k)[S0][accept]
+                    p[idx] = q[accept]
+                    lnp[idx] = newlnp[accept]
+                    self.naccepted[idx] += 1
+            chain[:, it] = p
+            lnps[:, it] = lnp
+            self.iterations += 1
+        self._chain = np.concatenate((self._chain, chain), axis=1)
+        self._lnprob = np.concatenate((self._lnprob, lnps), axis=1)
+        return p, lnp, self.random_state
+
+    def reset(self):
+        self.naccepted[:] = 0
+        self.iterations = 0
+        self._chain = np.empty((self.k, 0, self.dim))
+        self._lnprob = np.empty((self.k, 0))

@@ -1,0 +1,36 @@
+"""Build the TEST-ONLY g++ interpretation of the HIP sources (tests/hipemu/README.md).
+
+The product sources under robo_amd/csrc are compiled unmodified against the stand-in
+<hip/hip_runtime.h> of this directory.  Output: tests/hipemu/_build/librobo_emu.so.
+Never loaded by robo_amd; only by tests that pass an explicit library path.
+"""
+import glob
+import os
+import subprocess
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+OUT = os.path.join(HERE, "_build", "librobo_emu.so")
+
+
+def build(force=False):
+    srcs = sorted(glob.glob(os.path.join(ROOT, "robo_amd", "csrc", "*.hip")))
+    deps = srcs + glob.glob(os.path.join(ROOT, "robo_amd", "csrc", "*.h")) + \
+        [os.path.join(HERE, "hipemu.cpp"), os.path.join(HERE, "hip", "hip_runtime.h"),
+         os.path.join(ROOT, "include", "robo_hip.h")]
+    if not force and os.path.exists(OUT) and all(os.path.getmtime(d) <= os.path.getmtime(OUT) for d in deps):
+        return OUT
+    os.makedirs(os.path.dirname(OUT), exist_ok=True)
+    objs = []
+    for s in srcs + [os.path.join(HERE, "hipemu.cpp")]:
+        o = os.path.join(HERE, "_build", os.path.basename(s) + ".o")
+        cmd = ["g++", "-O2", "-g", "-std=c++17", "-fPIC", "-Wno-psabi", "-Wno-unknown-pragmas", "-I", HERE,
+               "-x", "c++", "-c", s, "-o", o]
+        subprocess.check_call(cmd)
+        objs.append(o)
+    subprocess.check_call(["g++", "-shared", "-o", OUT] + objs)
+    return OUT
+
+
+if __name__ == "__main__":
+    print(build(force=True))

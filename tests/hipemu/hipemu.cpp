@@ -1,0 +1,316 @@
+// hipemu runtime -- see hip/hip_runtime.h in this directory.  TEST-ONLY.
+#include <hip/hip_runtime.h>
+
+#include <sys/mman.h>
+
+#include <chrono>
+#include <vector>
+
+// ---------------------------------------------------------------------------------------
+// x86-64 SysV context switch (callee-saved registers only).
+// ---------------------------------------------------------------------------------------
+extern "C" void hipemu_switch(void** save_sp, void* load_sp);
+asm(R"(
+.text
+.globl hipemu_switch
+.type hipemu_switch,@function
+hipemu_switch:
+    pushq %rbp
+    pushq %rbx
+    pushq %r12
+    pushq %r13
+    pushq %r14
+    pushq %r15
+    movq %rsp, (%rdi)
+    movq %rsi, %rsp
+    popq %r15
+    popq %r14
+    popq %r13
+    popq %r12
+    popq %rbx
+    popq %rbp
+    ret
+.size hipemu_switch, .-hipemu_switch
+)");
+
+namespace hipemu {
+
+enum State { READY = 0, WAIT_BAR = 1, WAIT_WAVE = 2, DONE = 3 };
+
+struct Fiber {
+    void* sp;
+    char* stack;
+    Lane lane;
+    int state;
+    int linear;
+    // wave-collective mailboxes
+    unsigned char in[64];
+    unsigned char out[64];
+    int op;
+};
+
+static const size_t STACK_BYTES = 512 * 1024;
+static std::vector<Fiber> g_fibers;
+static Fiber* g_cur = nullptr;
+static void* g_sched_sp = nullptr;
+static dim3 g_block, g_bdim, g_gdim;
+static std::function<void()> g_body;
+static std::vector<char> g_dyn;
+static int g_live = 0, g_bar_wait = 0;
+static int g_wave_alive[64], g_wave_wait[64];  // up to 4096 threads / 64
+
+Lane& cur() { return g_cur->lane; }
+dim3& cur_block() { return g_block; }
+dim3& cur_bdim() { return g_bdim; }
+dim3& cur_gdim() { return g_gdim; }
+void* dyn_smem() { return g_dyn.data(); }
+int lane_id() { return g_cur->linear & 63; }
+
+static void yield_to_sched() { hipemu_switch(&g_cur->sp, g_sched_sp); }
+
+static void fiber_entry() {
+    g_body();
+    g_cur->state = DONE;
+    yield_to_sched();
+    std::abort();
+}
+
+static void release_barrier() {
+    for (auto& f : g_fibers)
+        if (f.state == WAIT_BAR) f.state = READY;
+    g_bar_wait = 0;
+}
+
+void barrier() {
+    g_cur->state = WAIT_BAR;
+    ++g_bar_wait;
+    if (g_bar_wait == g_live) {
+        release_barrier();
+        return;  // last arriver continues
+    }
+    yield_to_sched();
+}
+
+static void eval_wave(int w) {
+    Fiber* base = &g_fibers[(size_t)w * 64];
+    int n = (int)g_fibers.size() - w * 64;
+    if (n > 64) n = 64;
+    int op = -1;
+    for (int l = 0; l < n; ++l)
+        if (base[l].state == WAIT_WAVE) {
+            if (op < 0) op = base[l].op;
+            else if (op != base[l].op) {
+                std::fprintf(stderr, "hipemu: wave %d lanes disagree on collective op (%d vs %d)\n", w, op, base[l].op);
+                std::abort();
+            }
+        }
+    switch (op) {
+    case OP_SHFL:
+        for (int l = 0; l < n; ++l) {
+            if (base[l].state != WAIT_WAVE) continue;
+            ShflIn in; std::memcpy(&in, base[l].in, sizeof(in));
+            int s = in.src & 63;
+            ShflIn sin; sin.bits = 0;
+            if (s < n) std::memcpy(&sin, base[s].in, sizeof(sin));   // dead lane: stale bits, like HW
+            std::memcpy(base[l].out, &sin.bits, 8);
+        }
+        break;
+    case OP_BALLOT: {
+        unsigned long long m = 0;
+        for (int l = 0; l < n; ++l)
+            if (base[l].state == WAIT_WAVE) { int p; std::memcpy(&p, base[l].in, 4); if (p) m |= 1ull << l; }
+        for (int l = 0; l < n; ++l) std::memcpy(base[l].out, &m, 8);
+        break;
+    }
+    case OP_MFMA_F64_16x16x4: {
+        if (n != 64) { std::fprintf(stderr, "hipemu: MFMA in a partial wave\n"); std::abort(); }
+        struct In { double a, b, c[4]; };
+        double A[16][4], B[4][16];
+        for (int l = 0; l < 64; ++l) {
+            if (base[l].state != WAIT_WAVE) { std::fprintf(stderr, "hipemu: MFMA with inactive lane %d\n", l); std::abort(); }
+            In in; std::memcpy(&in, base[l].in, sizeof(in));
+            A[l & 15][l >> 4] = in.a;
+            B[l >> 4][l & 15] = in.b;
+        }
+        for (int l = 0; l < 64; ++l) {
+            In in; std::memcpy(&in, base[l].in, sizeof(in));
+            double d[4];
+            for (int r = 0; r < 4; ++r) {
+                int row = (l >> 4) + 4 * r, col = l & 15;
+                double acc = in.c[r];
+                for (int k = 0; k < 4; ++k) acc = std::fma(A[row][k], B[k][col], acc);
+                d[r] = acc;
+            }
+            std::memcpy(base[l].out, d, sizeof(d));
+        }
+        break;
+    }
+    default:
+        std::fprintf(stderr, "hipemu: unknown collective %d\n", op);
+        std::abort();
+    }
+    for (int l = 0; l < n; ++l)
+        if (base[l].state == WAIT_WAVE) base[l].state = READY;
+    g_wave_wait[w] = 0;
+}
+
+void wave_collective(Op op, const void* in, void* out) {
+    static const size_t in_bytes[] = {sizeof(ShflIn), 4, 48, 0};
+    static const size_t out_bytes[] = {8, 8, 32, 0};
+    Fiber* f = g_cur;
+    int w = f->linear >> 6;
+    std::memcpy(f->in, in, in_bytes[op]);
+    f->op = op;
+    f->state = WAIT_WAVE;
+    ++g_wave_wait[w];
+    if (g_wave_wait[w] == g_wave_alive[w]) eval_wave(w);   // last arriver evaluates and continues
+    else yield_to_sched();
+    std::memcpy(out, f->out, out_bytes[op]);
+}
+
+static void init_fiber(Fiber& f) {
+    if (!f.stack) {
+        f.stack = (char*)mmap(nullptr, STACK_BYTES, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS | MAP_NORESERVE, -1, 0);
+        if (f.stack == (char*)MAP_FAILED) { std::perror("hipemu mmap"); std::abort(); }
+    }
+    uintptr_t top = ((uintptr_t)f.stack + STACK_BYTES) & ~(uintptr_t)15;
+    void** sp = (void**)top;
+    *--sp = nullptr;                 // fake return address (keeps entry's rsp = 8 mod 16)
+    *--sp = (void*)&fiber_entry;     // popped by `ret`
+    for (int i = 0; i < 6; ++i) *--sp = nullptr;
+    f.sp = (void*)sp;
+    f.state = READY;
+}
+
+void launch(std::function<void()> body, dim3 grid, dim3 block, size_t shmem) {
+    if (g_cur) { std::fprintf(stderr, "hipemu: nested launch\n"); std::abort(); }
+    size_t nt = (size_t)block.x * block.y * block.z;
+    if (nt == 0 || nt > 1024) { std::fprintf(stderr, "hipemu: bad block size %zu\n", nt); std::abort(); }
+    if (g_fibers.size() < nt) g_fibers.resize(nt);
+    g_body = std::move(body);
+    g_bdim = block; g_gdim = grid;
+    g_dyn.assign(shmem + 64, 0);
+    std::vector<Fiber> saved;  // keep stacks of fibers beyond nt
+    size_t total = g_fibers.size();
+    (void)total;
+    for (unsigned bz = 0; bz < grid.z; ++bz)
+    for (unsigned by = 0; by < grid.y; ++by)
+    for (unsigned bx = 0; bx < grid.x; ++bx) {
+        g_block = dim3(bx, by, bz);
+        // only the first nt fibers take part
+        std::vector<Fiber>& F = g_fibers;
+        size_t keep = F.size();
+        (void)keep;
+        for (size_t i = 0; i < nt; ++i) {
+            F[i].linear = (int)i;
+            F[i].lane.tid = dim3((unsigned)(i % block.x), (unsigned)((i / block.x) % block.y), (unsigned)(i / ((size_t)block.x * block.y)));
+            init_fiber(F[i]);
+        }
+        for (size_t i = nt; i < F.size(); ++i) F[i].state = DONE;
+        g_live = (int)nt; g_bar_wait = 0;
+        int nw = (int)((nt + 63) / 64);
+        for (int w = 0; w < nw; ++w) { int a = (int)nt - w * 64; g_wave_alive[w] = a > 64 ? 64 : a; g_wave_wait[w] = 0; }
+        while (g_live > 0) {
+            bool progressed = false;
+            for (size_t i = 0; i < nt; ++i) {
+                Fiber& f = F[i];
+                if (f.state != READY) continue;
+                progressed = true;
+                g_cur = &f;
+                hipemu_switch(&g_sched_sp, f.sp);
+                g_cur = nullptr;
+                if (f.state == DONE) {
+                    --g_live;
+                    int w = f.linear >> 6;
+                    --g_wave_alive[w];
+                    if (g_wave_alive[w] > 0 && g_wave_wait[w] == g_wave_alive[w]) eval_wave(w);
+                    if (g_live > 0 && g_bar_wait == g_live) release_barrier();
+                }
+            }
+            if (!progressed) {
+                std::fprintf(stderr, "hipemu: deadlock in block (%u,%u,%u): live=%d at_barrier=%d\n", bx, by, bz, g_live, g_bar_wait);
+                std::abort();
+            }
+        }
+    }
+    g_body = nullptr;
+}
+
+}  // namespace hipemu
+
+// ---------------------------------------------------------------------------------------
+// runtime API
+// ---------------------------------------------------------------------------------------
+struct hipemuStream { int dummy; };
+struct hipemuEvent { std::chrono::steady_clock::time_point t; };
+
+hipError_t hipMalloc(void** p, size_t n) {
+    void* q = nullptr;
+    if (posix_memalign(&q, 256, n ? n : 1)) return hipErrorOutOfMemory;
+    std::memset(q, 0xCD, n);  // poison: uninitialised reads show up as garbage
+    *p = q;
+    return hipSuccess;
+}
+hipError_t hipFree(void* p) { std::free(p); return hipSuccess; }
+hipError_t hipHostMalloc(void** p, size_t n, unsigned) { return hipMalloc(p, n); }
+hipError_t hipHostFree(void* p) { std::free(p); return hipSuccess; }
+hipError_t hipMemcpy(void* d, const void* s, size_t n, hipMemcpyKind) { std::memmove(d, s, n); return hipSuccess; }
+hipError_t hipMemcpyAsync(void* d, const void* s, size_t n, hipMemcpyKind, hipStream_t) { std::memmove(d, s, n); return hipSuccess; }
+hipError_t hipMemset(void* d, int v, size_t n) { std::memset(d, v, n); return hipSuccess; }
+hipError_t hipMemsetAsync(void* d, int v, size_t n, hipStream_t) { std::memset(d, v, n); return hipSuccess; }
+hipError_t hipStreamCreate(hipStream_t* s) { *s = new hipemuStream(); return hipSuccess; }
+hipError_t hipStreamCreateWithFlags(hipStream_t* s, unsigned) { return hipStreamCreate(s); }
+hipError_t hipStreamDestroy(hipStream_t s) { delete s; return hipSuccess; }
+hipError_t hipStreamSynchronize(hipStream_t) { return hipSuccess; }
+hipError_t hipStreamWaitEvent(hipStream_t, hipEvent_t, unsigned) { return hipSuccess; }
+hipError_t hipDeviceSynchronize() { return hipSuccess; }
+hipError_t hipSetDevice(int) { return hipSuccess; }
+hipError_t hipGetDevice(int* d) { *d = 0; return hipSuccess; }
+hipError_t hipGetDeviceCount(int* n) { *n = 1; return hipSuccess; }
+hipError_t hipGetDeviceProperties(hipDeviceProp_t* p, int) {
+    std::memset(p, 0, sizeof(*p));
+    std::snprintf(p->name, sizeof(p->name), "hipemu (CPU lockstep interpreter, test only)");
+    std::snprintf(p->gcnArchName, sizeof(p->gcnArchName), "hipemu");
+    p->multiProcessorCount = 1;
+    p->totalGlobalMem = (size_t)8 << 30;
+    p->clockRate = 1000000;
+    return hipSuccess;
+}
+hipError_t hipEventCreate(hipEvent_t* e) { *e = new hipemuEvent(); return hipSuccess; }
+hipError_t hipEventCreateWithFlags(hipEvent_t* e, unsigned) { return hipEventCreate(e); }
+hipError_t hipEventDestroy(hipEvent_t e) { delete e; return hipSuccess; }
+hipError_t hipEventRecord(hipEvent_t e, hipStream_t) { e->t = std::chrono::steady_clock::now(); return hipSuccess; }
+hipError_t hipEventSynchronize(hipEvent_t) { return hipSuccess; }
+hipError_t hipEventElapsedTime(float* ms, hipEvent_t a, hipEvent_t b) {
+    *ms = std::chrono::duration<float, std::milli>(b->t - a->t).count();
+    return hipSuccess;
+}
+hipError_t hipGetLastError() { return hipSuccess; }
+hipError_t hipPeekAtLastError() { return hipSuccess; }
+const char* hipGetErrorString(hipError_t e) { return e == hipSuccess ? "hipSuccess" : "hipemu error"; }
+hipError_t hipMemGetInfo(size_t* f, size_t* t) { *f = (size_t)8 << 30; *t = (size_t)8 << 30; return hipSuccess; }
+
+// ---------------------------------------------------------------------------------------
+// erfcx(x) = exp(x^2) erfc(x): not in libm.  Accurate to a few ulp (test-only quality).
+// ---------------------------------------------------------------------------------------
+double erfcx(double x) {
+    if (std::isnan(x)) return x;
+    if (x < 0) {
+        if (x < -26.7) return INFINITY;
+        return 2.0 * std::exp(x * x) - erfcx(-x);
+    }
+    if (x < 6.0) {
+        // exp(x^2) with the rounding error of x*x carried: x^2 = hi + lo
+        double hi = x * x, lo = std::fma(x, x, -hi);
+        return std::exp(hi) * std::erfc(x) * (1.0 + lo);
+    }
+    // asymptotic: 1/(x sqrt(pi)) * sum_k (-1)^k (2k-1)!! / (2x^2)^k
+    double inv2x2 = 1.0 / (2.0 * x * x), term = 1.0, sum = 1.0;
+    for (int k = 1; k < 60; ++k) {
+        double nt = -term * (2 * k - 1) * inv2x2;
+        if (std::fabs(nt) >= std::fabs(term) || std::fabs(nt) < 1e-18 * std::fabs(sum)) break;
+        term = nt;
+        sum += term;
+    }
+    return sum / (x * 1.7724538509055160273);
+}
