@@ -67,7 +67,10 @@ int32_t robo_ctx_create(int32_t device, void* hip_stream, robo_ctx** out);
 int32_t robo_ctx_destroy(robo_ctx* ctx);
 int32_t robo_ctx_synchronize(robo_ctx* ctx);
 int32_t robo_ctx_device_name(robo_ctx* ctx, char* buf, int32_t buf_len);
-/* HIP-event timing on the context's stream (what bench.py uses: 32 slots) */
+/* HIP-event timing on the context's stream (what bench.py uses).  Slots 0..19 are the
+ * caller's; the library itself records 20..23 around the phases of robo_gp_fit (gram,
+ * Cholesky, log-likelihood) and 24..27 around the phases of the posterior evaluation
+ * (cross-gram, triangular solve, post) of the last candidate chunk.                        */
 int32_t robo_ctx_event_record(robo_ctx* ctx, int32_t slot);
 int32_t robo_ctx_event_elapsed_ms(robo_ctx* ctx, int32_t slot_begin, int32_t slot_end, float* out_ms);
 const char* robo_last_error_string(void);

@@ -315,14 +315,14 @@ class DeviceGP(object):
             check(lib().robo_gp_predict_cand(self._h, Xc._h, _arr(mean), _arr(var)))
             return mean, var
         Xc = _f64(Xc)
-        assert Xc.ndim == 2
+        assert Xc.ndim == 2 and Xc.shape[1] == self.dim
         mean, var = np.empty(Xc.shape[0]), np.empty(Xc.shape[0])
         check(lib().robo_gp_predict(self._h, _arr(Xc), Xc.shape[0], _arr(mean), _arr(var)))
         return mean, var
 
     def predict_cov(self, Xc):
         Xc = _f64(Xc)
-        assert Xc.ndim == 2
+        assert Xc.ndim == 2 and Xc.shape[1] == self.dim
         m = Xc.shape[0]
         mean, cov = np.empty(m), np.empty((m, m))
         check(lib().robo_gp_predict_cov(self._h, _arr(Xc), m, _arr(mean), _arr(cov)))
@@ -339,7 +339,7 @@ class DeviceGP(object):
                                            C.byref(fl)))
         else:
             Xc = _f64(Xc)
-            assert Xc.ndim == 2
+            assert Xc.ndim == 2 and Xc.shape[1] == self.dim
             m = Xc.shape[0]
             out = np.empty(m) if want_values else None
             check(lib().robo_acq_eval(self._h, ACQ_KINDS[kind], float(par), float(eta), _arr(Xc), m,

@@ -223,9 +223,15 @@ int32_t robo_gp_fit(robo_gp* g, const double* theta, double mean_c, double* out_
     }
     robo_ctx* c = g->ctx;
     g->fitted = false;
+    // event slots 20..23: 20 -> 21 gram build, 21 -> 22 Cholesky, 22 -> 23 log-likelihood reduce
+    ROBO_HIP_CHECK(hipStreamSynchronize(c->stream));
+    ROBO_HIP_CHECK(hipEventRecord(c->events[20], c->stream));
     ROBO_TRY(gp_build_gram(g, theta, mean_c));
+    ROBO_HIP_CHECK(hipEventRecord(c->events[21], c->stream));
     ROBO_TRY(launch_potrf(g));
+    ROBO_HIP_CHECK(hipEventRecord(c->events[22], c->stream));
     ROBO_TRY(launch_loglik(g));
+    ROBO_HIP_CHECK(hipEventRecord(c->events[23], c->stream));
     double* hp = c->h_pinned;
     ROBO_HIP_CHECK(hipMemcpyAsync(hp, c->d_scalars, 2 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
     ROBO_HIP_CHECK(hipMemcpyAsync(hp + 4, c->d_fail, sizeof(int), hipMemcpyDeviceToHost, c->stream));
@@ -401,12 +407,19 @@ static int predict_core(robo_gp* g, robo_cand* k, bool single_chunk) {
     ROBO_HIP_CHECK(hipSetDevice(g->ctx->device));
     ROBO_TRY(cand_ensure_workspace(k, g->n_pad, single_chunk));
     ROBO_TRY(launch_scale_inputs(g->ctx, k->d_Xc, k->d_Xcs, g->d_theta, k->m, k->m_pad, g->dim));
+    // event slots 24..27 bracket the phases of the LAST chunk (bench.py reads them after a sync):
+    //   24 -> 25 cross-gram, 25 -> 26 triangular solve (the MFMA kernel), 26 -> 27 post
+    hipStream_t st = g->ctx->stream;
     for (int64_t c0 = 0; c0 < k->m_pad; c0 += k->chunk) {
         const int64_t cn = k->m_pad - c0 < k->chunk ? k->m_pad - c0 : k->chunk;
+        ROBO_HIP_CHECK(hipEventRecord(g->ctx->events[24], st));
         ROBO_TRY(launch_cross_gram(g, k, c0, cn));
+        ROBO_HIP_CHECK(hipEventRecord(g->ctx->events[25], st));
         ROBO_TRY(launch_trsm(g, k, c0, cn));
+        ROBO_HIP_CHECK(hipEventRecord(g->ctx->events[26], st));
     }
     ROBO_TRY(launch_post(g, k, 0, k->m_pad));
+    ROBO_HIP_CHECK(hipEventRecord(g->ctx->events[27], st));
     return ROBO_OK;
 }
 

@@ -1,0 +1,77 @@
+"""Multi-GPU sharding of the two independent axes of the hot path.
+
+One process per GPU (torch.distributed; backend "nccl" is RCCL over xGMI on ROCm, "gloo"
+in the CPU tests).  No data-path collective: every rank holds a full replica of the fitted
+GP (the fit is deterministic, so running it on every rank is cheaper than broadcasting L)
+and evaluates its own contiguous shard.  The only exchanges are
+
+* candidate shard:  all-gather of one (max, global index) pair per rank, then the same
+  np.argmax tie-break on every rank (lowest global index, NaN maximal);
+* sample shard:     all-gather of the per-rank partial sums of M acquisition values and a
+  RANK-ORDERED local sum: deterministic and identical on every rank (an all-reduce SUM
+  guarantees neither).  It equals the single-GPU sample-order accumulation of
+  MarginalizationGPMCMC.compute up to fp64 re-association (partial sums are formed per shard).
+"""
+import numpy as np
+
+
+def shard_range(n_items, rank, world):
+    """Contiguous [begin, end) of rank's shard; the first n_items % world ranks get one more
+    (config 3 of BASELINE.json: 50 samples over 4 GPUs -> 13/13/12/12)."""
+    base, rem = divmod(int(n_items), int(world))
+    begin = rank * base + min(rank, rem)
+    return begin, begin + base + (1 if rank < rem else 0)
+
+
+def better(v_a, i_a, v_b, i_b):
+    """np.argmax order: NaN beats everything, then larger value, then lower index."""
+    a_nan, b_nan = np.isnan(v_a), np.isnan(v_b)
+    if a_nan != b_nan:
+        return bool(a_nan)
+    if not a_nan and v_a != v_b:
+        return bool(v_a > v_b)
+    return i_a < i_b
+
+
+def reduce_argmax(pairs):
+    """pairs: iterable of (value, global_index) -> the winning (value, index)."""
+    best = None
+    for v, i in pairs:
+        if i < 0:
+            continue
+        if best is None or better(v, i, best[0], best[1]):
+            best = (float(v), int(i))
+    return best
+
+
+def allgather_argmax(local_max, local_global_index, device=None):
+    """Exchange the per-shard incumbents (16 B per rank) -> global (max, argmax)."""
+    import torch
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return float(local_max), int(local_global_index)
+    world = dist.get_world_size()
+    dev = device if device is not None else ("cuda" if dist.get_backend() == "nccl" else "cpu")
+    # the index travels as an exact float64 (< 2^53) next to the value: one 16-byte message
+    mine = torch.tensor([float(local_max), float(local_global_index)], dtype=torch.float64, device=dev)
+    out = [torch.empty_like(mine) for _ in range(world)]
+    dist.all_gather(out, mine)
+    pairs = [(float(t[0].item()), int(t[1].item())) for t in out]
+    return reduce_argmax(pairs)
+
+
+def allgather_ordered_sum(partial_sum, device=None):
+    """Sum per-rank partial acquisition sums in rank order (deterministic on every rank)."""
+    import torch
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return np.asarray(partial_sum, dtype=np.float64)
+    world = dist.get_world_size()
+    dev = device if device is not None else ("cuda" if dist.get_backend() == "nccl" else "cpu")
+    mine = torch.as_tensor(np.ascontiguousarray(partial_sum, dtype=np.float64)).to(dev)
+    out = [torch.empty_like(mine) for _ in range(world)]
+    dist.all_gather(out, mine)
+    total = out[0].clone()
+    for t in out[1:]:
+        total += t
+    return total.cpu().numpy()

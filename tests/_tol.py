@@ -12,6 +12,12 @@ def assert_logei_close(actual, desired, z, rtol=1e-12, tail_rtol=1e-8):
     """LogEI comparison.  For z < -30 the reference formula b + log(1 - exp(a - b))
     cancels catastrophically (log_ei.py:114-120), amplifying one ulp of logcdf to ~1e-9."""
     actual, desired, z = map(np.asarray, (actual, desired, z))
+    # beyond z ~ -1e5, a and b (both ~ -z^2/2 >= 5e9) differ by less than one ulp: whether the
+    # reference returns -inf (a >= b) or b + log(1 - exp(a - b)) is decided by rounding noise.
+    # Unreachable from a GP (variance floor 2.2e-16 caps |z|), kept in the fixture as a stress case.
+    noise = z < -1e5
+    assert np.all(np.isneginf(actual[noise]) | (np.abs(actual[noise] - desired[noise]) <= 1e-6 * np.abs(desired[noise])))
+    actual, desired, z = actual[~noise], desired[~noise], z[~noise]
     inf = np.isinf(desired)
     np.testing.assert_array_equal(actual[inf], desired[inf])
     core = ~(z < -30) & ~inf

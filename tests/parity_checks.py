@@ -1,0 +1,249 @@
+"""Parity checks of the HIP path against the oracle and the golden fixtures.
+
+The same functions run in two settings:
+  * tests/test_gpu_parity.py  (-m gpu): the real librobo_hip.so on an MI355X, through the C ABI;
+  * tests/test_emu_logic.py   (CPU)   : the g++-interpreted build of the same sources (tests/hipemu)
+    -- checks index arithmetic / host logic only, proves nothing about the hardware.
+Tolerances are the stated fp64 tolerances of tests/_tol.py.
+"""
+import os
+
+import numpy as np
+
+from _tol import ACQ_RTOL, LOGLIK_RTOL, MU_ATOL, MU_RTOL, VAR_ATOL_REL_AMP, assert_logei_close
+from make_golden import golden_inputs, mcmc_inputs
+from oracle import gp_oracle as O
+from robo_amd import _lib
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def load(name):
+    return np.load(os.path.join(GOLDEN, name + ".npz"))
+
+
+def oracle_gp(inp):
+    gp = O.OracleGP(inp["kind"], inp["theta"], normalize_output=inp["nout"], lower=inp["lower"],
+                    upper=inp["upper"])
+    gp.train(inp["X"], inp["y"])
+    return gp
+
+
+def device_gp(ctx, ogp, inp):
+    """device GP on the oracle's normalised data (the C-ABI sees what george would see)"""
+    g = _lib.DeviceGP(ctx, inp["kind"], ogp.X.shape[0], ogp.X.shape[1])
+    g.set_data(ogp.X, ogp.y)
+    if inp["nout"]:
+        g.set_output_transform(ogp.y_mean, ogp.y_std)
+    return g
+
+
+def check_case(ctx, name, full=True):
+    inp = golden_inputs(name)
+    gold = load(name)
+    ogp = oracle_gp(inp)
+    g = device_gp(ctx, ogp, inp)
+    amp = np.exp(inp["theta"][0]) * (ogp.y_std ** 2 if inp["nout"] else 1.0)
+    N = ogp.X.shape[0]
+
+    if full:
+        # K1 gram
+        K = g.gram(inp["theta"])
+        Ko = O.kernel_matrix(inp["kind"], inp["theta"][:-1], ogp.X) + (ogp.noise + O.JITTER) * np.eye(N)
+        np.testing.assert_allclose(K, Ko, rtol=1e-13, atol=1e-15)
+    # K2/K3 fit + log-likelihood
+    ll = g.fit(inp["theta"], ogp.mean)
+    np.testing.assert_allclose(ll, float(gold["loglik"]), rtol=LOGLIK_RTOL)
+    if full:
+        L = g.factor()
+        np.testing.assert_allclose(L, ogp.L, rtol=0, atol=1e-11 * np.abs(ogp.L).max())
+    # K4/K5 posterior
+    Xcn = O.zero_one_normalization(inp["Xc"], inp["lower"], inp["upper"])[0]
+    mu, var = g.predict(Xcn)
+    np.testing.assert_allclose(mu, gold["mu"], rtol=MU_RTOL, atol=MU_ATOL * max(1.0, np.abs(gold["mu"]).max()))
+    np.testing.assert_allclose(var, gold["var"], rtol=0, atol=VAR_ATOL_REL_AMP * amp)
+    assert np.all(var >= O.EPS)
+    # K6 acquisition + argmax, against the REFERENCE classes' outputs stored in the fixture
+    eta = float(gold["eta"])
+    z = (eta - gold["mu"]) / np.sqrt(gold["var"])
+    for kind, par, key in (("ei", 0.0, "ei"), ("pi", 0.0, "pi"), ("lcb", 1.0, "lcb"), ("ei", 0.3, "ei_par"),
+                           ("lcb", 2.5, "lcb_par")):
+        vals, mx, am, flags = g.acq(kind, par, eta, Xcn)
+        ref = gold[key]
+        np.testing.assert_allclose(vals, ref, rtol=ACQ_RTOL, atol=1e-12 * max(1.0, np.abs(ref).max()))
+        assert am == int(np.argmax(vals)) and mx == vals[am]
+        if key in ("ei", "pi", "lcb"):
+            gap = float(gold["gap_" + key])
+            want = int(gold["argmax_" + key])
+            # argmax index must be bit-exact unless the oracle's own top-2 gap is below tolerance
+            assert am == want or gap <= ACQ_RTOL * abs(ref[want]), (kind, am, want, gap)
+        assert not (flags & _lib.FLAG_NAN)
+    vals, mx, am, _ = g.acq("log_ei", 0.0, eta, Xcn)
+    # LogEI amplifies d(mu,var): compare on the GPU's own moments with the oracle formula (tight)
+    # and against the reference fixture (loose where |z| is large)
+    assert_logei_close(vals, O.log_ei_vec(mu, var, eta), (eta - mu) / np.sqrt(var), rtol=1e-11, tail_rtol=1e-7)
+    core = np.abs(z) < 8
+    np.testing.assert_allclose(vals[core], gold["log_ei"][core], rtol=1e-6, atol=1e-9)
+    want = int(gold["argmax_log_ei"])
+    assert am == want or float(gold["gap_log_ei"]) <= 1e-6 * abs(gold["log_ei"][want])
+    if full and "cov33" in gold.files:
+        _, cov = g.predict_cov(Xcn[:33])
+        eps = np.finfo(np.float64).eps
+        np.testing.assert_allclose(np.clip(cov, eps, np.inf), gold["cov33"], rtol=0, atol=VAR_ATOL_REL_AMP * amp)
+    g.close()
+
+
+def check_mcmc_marginal(ctx):
+    inp = mcmc_inputs()
+    gold = load("mcmc_marginal")
+    Xn = O.zero_one_normalization(inp["X"], inp["lower"], inp["upper"])[0]
+    Xcn = O.zero_one_normalization(inp["Xc"], inp["lower"], inp["upper"])[0]
+    y = inp["y"]
+    gps = []
+    for th in inp["thetas"]:
+        g = _lib.DeviceGP(ctx, inp["kind"], Xn.shape[0], Xn.shape[1])
+        g.set_data(Xn, y)
+        g.fit(th, float(np.mean(y)))
+        gps.append(g)
+    ll, st = gps[0].loglik_batch(inp["thetas"], float(np.mean(y)))
+    assert np.all(st == _lib.OK)
+    np.testing.assert_allclose(ll, gold["loglik_s"], rtol=LOGLIK_RTOL)
+    gps[0].fit(inp["thetas"][0], float(np.mean(y)))     # loglik_batch leaves the last theta fitted
+    cand = _lib.Candidates(ctx, Xcn)
+    eta = float(y.min())
+    for s, g in enumerate(gps):
+        mu, var = g.predict(cand)
+        np.testing.assert_allclose(mu, gold["mu_s"][s], rtol=MU_RTOL, atol=MU_ATOL)
+        np.testing.assert_allclose(var, gold["var_s"][s], rtol=0, atol=VAR_ATOL_REL_AMP * np.exp(inp["thetas"][s][0]))
+    for kind, par in (("ei", 0.0), ("pi", 0.0), ("lcb", 1.0)):
+        vals, mx, am, flags = _lib.acq_marginal(gps, kind, par, eta, cand)
+        ref = gold["marg_" + kind]
+        np.testing.assert_allclose(vals, ref, rtol=ACQ_RTOL, atol=1e-12)
+        assert am == int(np.argmax(vals)) and am == int(np.argmax(ref))
+    vals, mx, am, _ = _lib.acq_marginal(gps, "log_ei", 0.0, eta, cand)
+    # per-sample device LogEI, ordered host accumulation == device accumulation, bit for bit
+    per = np.array([g.acq("log_ei", 0.0, eta, cand)[0] for g in gps])
+    np.testing.assert_array_equal(vals, per.mean(axis=0))
+    z = (eta - gold["mix_m"]) / np.sqrt(gold["mix_v"])
+    core = np.abs(z) < 6
+    np.testing.assert_allclose(vals[core], gold["marg_log_ei"][core], rtol=1e-5, atol=1e-8)
+    # sample-shard partial sums (multi-GPU form) add up to the same thing
+    s0, _, _, _ = _lib.acq_marginal(gps[:3], "ei", 0.0, eta, cand, reduce="sum")
+    s1, _, _, _ = _lib.acq_marginal(gps[3:], "ei", 0.0, eta, cand, reduce="sum")
+    np.testing.assert_allclose((s0 + s1) / len(gps), gold["marg_ei"], rtol=ACQ_RTOL, atol=1e-12)
+    cand.close()
+    for g in gps:
+        g.close()
+
+
+def check_elementwise(ctx):
+    """device element-wise kernel on prescribed moments incl. every degenerate LogEI branch,
+    against the reference classes' outputs (tests/golden/acq_elementwise.npz)."""
+    gold = load("acq_elementwise")
+    m, v, eta = gold["m"], gold["v"], float(gold["eta"])
+    z = (eta - m) / np.sqrt(np.where(v > 0, v, 1.0))
+    vals, mx, am, flags = _lib.acq_from_moments(ctx, "log_ei", 0.0, eta, m, v)
+    assert_logei_close(vals, gold["log_ei"], z, rtol=1e-11, tail_rtol=1e-7)
+    vals, _, _, _ = _lib.acq_from_moments(ctx, "log_ei", 0.1, eta, m, v)
+    assert_logei_close(vals, gold["log_ei_par"], (eta - 0.1 - m) / np.sqrt(np.where(v > 0, v, 1.0)), rtol=1e-11,
+                       tail_rtol=1e-7)
+    with np.errstate(all="ignore"):
+        vals, _, am, flags = _lib.acq_from_moments(ctx, "pi", 0.0, eta, m, v)
+        ok = ~np.isnan(gold["pi"])
+        np.testing.assert_allclose(vals[ok], gold["pi"][ok], rtol=1e-11, atol=1e-300)
+        assert np.array_equal(np.isnan(vals), np.isnan(gold["pi"]))
+        assert am == int(np.argmax(gold["pi"]))          # NaN-first semantics of np.argmax
+        assert flags & _lib.FLAG_ZERO_SIGMA
+    vals, _, am, _ = _lib.acq_from_moments(ctx, "lcb", 1.0, eta, m, v)
+    np.testing.assert_allclose(vals, gold["lcb"], rtol=1e-14)
+    assert am == int(np.argmax(gold["lcb"]))
+    pos = gold["pos"]
+    vals, _, am, flags = _lib.acq_from_moments(ctx, "ei", 0.0, eta, m[pos], v[pos])
+    np.testing.assert_allclose(vals, gold["ei_pos"], rtol=1e-10, atol=1e-300)
+    assert am == int(np.argmax(gold["ei_pos"])) and not (flags & _lib.FLAG_ZERO_SIGMA)
+
+
+def check_argmax_semantics(ctx):
+    """np.argmax: first maximal index, NaN maximal, -inf everywhere -> 0; independent of geometry."""
+    rs = np.random.RandomState(4)
+    for n in (1, 63, 64, 65, 255, 256, 257, 1000, 70001):
+        m = rs.randn(n)
+        v = np.ones(n)
+        # LCB with par=0 is -mean: an exact map, so ties survive
+        m[rs.randint(n, size=max(1, n // 10))] = -7.0      # many ties at the maximum of -m
+        vals, mx, am, _ = _lib.acq_from_moments(ctx, "lcb", 0.0, 0.0, m, v)
+        assert am == int(np.argmax(-m)) and mx == 7.0
+        if n > 3:
+            m2 = m.copy()
+            m2[[n // 2, n - 1]] = np.nan
+            vals, mx, am, fl = _lib.acq_from_moments(ctx, "lcb", 0.0, 0.0, m2, v)
+            assert am == n // 2 and np.isnan(mx) and (fl & _lib.FLAG_NAN)
+        vals, mx, am, _ = _lib.acq_from_moments(ctx, "lcb", 0.0, 0.0, np.full(n, np.inf), v)
+        assert am == 0 and mx == -np.inf
+
+
+def check_errors(ctx):
+    import pytest
+    g = _lib.DeviceGP(ctx, "matern52", 64, 3)
+    with pytest.raises(Exception, match="trained first"):
+        g.predict(np.zeros((4, 3)))
+    rs = np.random.RandomState(0)
+    X = rs.rand(20, 3)
+    X[3, 0] = np.nan                              # NaN input -> NaN pivot (deterministic failure)
+    y = rs.rand(20)
+    g.set_data(X, y)
+    theta = np.array([0.0, 0.0, 0.0, 0.0, -60.0])
+    with pytest.raises(np.linalg.LinAlgError):
+        # a NaN pivot is "not positive definite", like LAPACK dpotrf
+        g.fit(np.array([10.0, 0.0, 0.0, 0.0, -60.0]), 0.0)
+    with pytest.raises(Exception, match="trained first"):
+        g.predict(np.zeros((4, 3)))               # failed fit leaves the GP unfitted
+    ll, st = g.loglik_batch(np.array([[10.0, 0, 0, 0, -60.0], [0.0, 0, 0, 0, np.log(1e-3)]]), 0.0)
+    assert np.all(st == _lib.NOT_POSITIVE_DEFINITE) and np.all(ll == -np.inf)
+    with pytest.raises(ValueError):
+        g.fit(np.array([np.nan, 0, 0, 0, 0]), 0.0)
+    with pytest.raises(AssertionError):
+        g.set_data(np.zeros((65, 3)), np.zeros(65))      # n > n_max
+    X[3, 0] = 0.5
+    g.set_data(X, y)
+    g.fit(np.array([0, 0, 0, 0, np.log(1e-2)]), 0.0)
+    with pytest.raises(AssertionError):
+        g.predict(np.zeros((4, 2)))                       # wrong dim, host array
+    with pytest.raises(AssertionError):
+        g.predict(_lib.Candidates(ctx, np.zeros((4, 2))))  # wrong dim, resident batch (C ABI: BAD_SHAPE)
+    g.close()
+
+
+def check_edge_sizes(ctx):
+    """ragged / tiny / block-boundary sizes: N in {1,2,127,128,129}, M in {1,127,128,129}."""
+    rs = np.random.RandomState(8)
+    D = 3
+    theta = np.array([0.3, np.log(0.5), np.log(0.7), np.log(0.9), np.log(1e-3)])
+    for N in (1, 2, 127, 128, 129):
+        X = rs.rand(N, D)
+        y = np.sin(3 * X.sum(axis=1))
+        ogp = O.OracleGP("matern52", theta, lower=np.zeros(D), upper=np.ones(D))
+        ogp.train(X, y)
+        g = _lib.DeviceGP(ctx, "matern52", N, D)
+        g.set_data(X, y)
+        ll = g.fit(theta, ogp.mean)
+        np.testing.assert_allclose(ll, ogp.loglikelihood(theta), rtol=LOGLIK_RTOL, atol=1e-10)
+        for M in (1, 127, 128, 129):
+            Xc = rs.rand(M, D)
+            mu, var = g.predict(Xc)
+            mo, vo = ogp.predict(Xc, diag_only=True)
+            np.testing.assert_allclose(mu, mo, rtol=MU_RTOL, atol=MU_ATOL)
+            np.testing.assert_allclose(var, vo, rtol=0, atol=VAR_ATOL_REL_AMP * np.exp(theta[0]))
+        g.close()
+
+
+def check_uniform_generator(ctx):
+    c = _lib.Candidates(ctx, m=5000, dim=7, seed=123)
+    P = c.points()
+    assert P.shape == (5000, 7) and P.min() >= 0.0 and P.max() < 1.0
+    assert abs(P.mean() - 0.5) < 0.01 and abs(P.var() - 1.0 / 12) < 0.005
+    assert len(np.unique(P)) == P.size
+    c2 = _lib.Candidates(ctx, m=5000, dim=7, seed=123)
+    np.testing.assert_array_equal(P, c2.points())
+    c3 = _lib.Candidates(ctx, m=5000, dim=7, seed=124)
+    assert not np.array_equal(P, c3.points())

@@ -1,0 +1,175 @@
+"""Parity tests proper: the HIP path on a real MI355X, through the C ABI, against the oracle
+and the golden fixtures (reference-class outputs).  Run with ``pytest -m gpu``.
+"""
+import os
+import time
+
+import numpy as np
+import pytest
+
+import parity_checks as P
+from _tol import LOGLIK_RTOL, MU_ATOL, MU_RTOL, VAR_ATOL_REL_AMP
+from oracle import gp_oracle as O
+from robo_amd import _lib
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    _lib.use_library(None)
+    assert os.path.exists(_lib.DEFAULT_LIBRARY), "librobo_hip.so missing: the GPU tests never fall back"
+    c = _lib.Context(0)
+    assert "hipemu" not in c.name
+    yield c
+    c.close()
+
+
+def test_mfma_layout_selftest(ctx):
+    """v_mfma_f64_16x16x4_f64 fragment maps on the real hardware, asymmetric operands"""
+    assert ctx.selftest_mfma_layout() < 1e-12
+
+
+@pytest.mark.parametrize("name", ["small_matern", "ragged_rbf_nout", "one_block_edge", "two_block"])
+def test_golden_cases(ctx, name):
+    P.check_case(ctx, name)
+
+
+def test_config2_subset(ctx):
+    """BASELINE config 2 shapes (N=1024, D=8), 8192 of the 65 536 candidates, vs the fixture"""
+    P.check_case(ctx, "config2_sub", full=True)
+
+
+def test_mcmc_marginal(ctx):
+    P.check_mcmc_marginal(ctx)
+
+
+def test_elementwise_and_degenerate_branches(ctx):
+    P.check_elementwise(ctx)
+
+
+def test_argmax_semantics(ctx):
+    P.check_argmax_semantics(ctx)
+
+
+def test_error_protocol(ctx):
+    P.check_errors(ctx)
+
+
+def test_edge_sizes(ctx):
+    P.check_edge_sizes(ctx)
+
+
+def test_uniform_generator(ctx):
+    P.check_uniform_generator(ctx)
+
+
+def _headline_inputs(N, D, M):
+    X = np.random.RandomState(0).rand(N, D)
+    y = np.sinc(X * 10 - 5).sum(axis=1)
+    y = (y - y.mean()) / y.std()
+    theta = np.concatenate([[0.0], np.full(D, np.log(0.25 * D)), [np.log(1e-3)]])
+    Xc = np.random.RandomState(1).rand(M, D)
+    return X, y, theta, Xc
+
+
+def test_headline_size_against_oracle(ctx):
+    """N=4096, D=16 (BASELINE headline): fit + 65 536-candidate EI on the GPU; the oracle
+    evaluates a 4096-candidate slice in full and re-scores the GPU's top candidates."""
+    N, D, M = 4096, 16, 65536
+    X, y, theta, Xc = _headline_inputs(N, D, M)
+    g = _lib.DeviceGP(ctx, "matern52", N, D)
+    g.set_data(X, y)
+    ll = g.fit(theta, float(y.mean()))
+    ogp = O.OracleGP("matern52", theta, lower=np.zeros(D), upper=np.ones(D))
+    ogp.train(X, y)
+    np.testing.assert_allclose(ll, ogp.loglikelihood(theta), rtol=LOGLIK_RTOL)
+    eta = float(y.min())
+    cand = _lib.Candidates(ctx, Xc)
+    vals, mx, am, flags = g.acq("ei", 0.0, eta, cand)
+    mu, var = g.predict(cand)
+    sl = slice(0, 4096)
+    mo, vo = ogp.predict(Xc[sl], diag_only=True)
+    np.testing.assert_allclose(mu[sl], mo, rtol=MU_RTOL, atol=MU_ATOL)
+    np.testing.assert_allclose(var[sl], vo, rtol=0, atol=VAR_ATOL_REL_AMP)
+    np.testing.assert_allclose(vals[sl], O.ei(mo, vo, eta), rtol=1e-6, atol=1e-12)
+    # argmax: the oracle re-scores the GPU's 64 best candidates; its winner must be the GPU's
+    top = np.argsort(-vals)[:64]
+    mo, vo = ogp.predict(Xc[top], diag_only=True)
+    eo = O.ei(mo, vo, eta)
+    assert am == int(np.argmax(vals))
+    assert top[int(np.argmax(eo))] == am or abs(eo.max() - eo[list(top).index(am)]) <= 1e-7 * eo.max()
+    cand.close()
+    g.close()
+
+
+def test_full_size_properties(ctx):
+    """size-independent properties at N=4096 (no oracle needed): L L^T == K; predicting at the
+    training inputs reproduces y to within the noise model: mu(X) = y - sigma^2 alpha."""
+    N, D = 4096, 16
+    X, y, theta, _ = _headline_inputs(N, D, 1)
+    g = _lib.DeviceGP(ctx, "matern52", N, D)
+    g.set_data(X, y)
+    K = g.gram(theta)
+    g.fit(theta, float(y.mean()))
+    L = g.factor()
+    R = L @ L.T - K
+    assert np.abs(R).max() < 1e-11 * np.abs(K).max()
+    # idempotence/consistency: posterior at training points, from the device's own factor
+    mu, var = g.predict(X[:2048])
+    r = y - y.mean()
+    from scipy.linalg import cho_solve
+    alpha = cho_solve((L, True), r)
+    noise = np.exp(theta[-1]) + O.JITTER
+    np.testing.assert_allclose(mu, (y - noise * alpha)[:2048], rtol=1e-8, atol=1e-9)
+    assert np.all(var >= O.EPS) and np.all(var < noise * 1.0001)
+    g.close()
+
+
+def test_mixed_sizes_mcmc_config3_shape(ctx):
+    """config 3 shapes (N=2048, D=16, LogEI marginal) at reduced S and M: device marginal ==
+    ordered mean of the device's per-sample values; per-sample posterior vs oracle."""
+    N, D, M, S = 2048, 16, 4096, 4
+    X, y, theta, Xc = _headline_inputs(N, D, M)
+    thetas = theta[None, :] + 0.3 * np.random.RandomState(2).randn(S, theta.size)
+    gps = []
+    for th in thetas:
+        g = _lib.DeviceGP(ctx, "matern52", N, D)
+        g.set_data(X, y)
+        g.fit(th, float(y.mean()))
+        gps.append(g)
+    cand = _lib.Candidates(ctx, Xc)
+    eta = float(y.min())
+    vals, mx, am, _ = _lib.acq_marginal(gps, "log_ei", 0.0, eta, cand)
+    per = np.array([g.acq("log_ei", 0.0, eta, cand)[0] for g in gps])
+    np.testing.assert_array_equal(vals, per.mean(axis=0))
+    assert am == int(np.argmax(vals))
+    ogp = O.OracleGP("matern52", thetas[1], lower=np.zeros(D), upper=np.ones(D))
+    ogp.train(X, y)
+    mo, vo = ogp.predict(Xc[:1024], diag_only=True)
+    mu, var = gps[1].predict(cand)
+    np.testing.assert_allclose(mu[:1024], mo, rtol=MU_RTOL, atol=MU_ATOL)
+    np.testing.assert_allclose(var[:1024], vo, rtol=0, atol=VAR_ATOL_REL_AMP * np.exp(thetas[1][0]))
+    cand.close()
+    for g in gps:
+        g.close()
+
+
+def test_host_classes_on_gpu(ctx):
+    """RoBO-surface classes end to end: GaussianProcess + EI + RandomSampling + solver"""
+    from robo_amd.fmin import bayesian_optimization
+
+    def branin(x):
+        x1, x2 = x
+        return (x2 - 5.1 * x1 ** 2 / (4 * np.pi ** 2) + 5 * x1 / np.pi - 6) ** 2 + \
+            10 * (1 - 1 / (8 * np.pi)) * np.cos(x1) + 10
+
+    np.random.seed(3)
+    r = bayesian_optimization(branin, np.array([-5., 0.]), np.array([10., 15.]), num_iterations=25,
+                              model_type="gp", acquisition_func="ei", rng=np.random.RandomState(1),
+                              n_candidates=20000)
+    assert r["f_opt"] < 1.5 and len(r["X"]) == 25
+    r = bayesian_optimization(branin, np.array([-5., 0.]), np.array([10., 15.]), num_iterations=8,
+                              model_type="gp_mcmc", acquisition_func="log_ei", rng=np.random.RandomState(1),
+                              chain_length=20, burnin_steps=20)
+    assert np.all(np.array(r["x_opt"]) >= [-5, 0]) and np.all(np.array(r["x_opt"]) <= [10, 15])
