@@ -63,14 +63,23 @@ def check_case(ctx, name, full=True):
     np.testing.assert_allclose(mu, gold["mu"], rtol=MU_RTOL, atol=MU_ATOL * max(1.0, np.abs(gold["mu"]).max()))
     np.testing.assert_allclose(var, gold["var"], rtol=0, atol=VAR_ATOL_REL_AMP * amp)
     assert np.all(var >= O.EPS)
-    # K6 acquisition + argmax, against the REFERENCE classes' outputs stored in the fixture
+    # K6 acquisition + argmax.  Two comparisons per function:
+    #  (a) element-wise kernel: device values vs the oracle formula on the DEVICE's own (mu, var)
+    #      -- tight, isolates the Phi/phi/log arithmetic from the posterior's conditioning;
+    #  (b) end to end vs the REFERENCE classes' outputs in the fixture, where the acquisition is
+    #      well conditioned w.r.t. (mu, var) (|z| < 8): abs tolerance = the posterior tolerance.
     eta = float(gold["eta"])
     z = (eta - gold["mu"]) / np.sqrt(gold["var"])
+    well = np.abs(z) < 8
+    scale = max(1.0, np.abs(gold["mu"]).max())
+    own = {"ei": lambda par: O.ei(mu, var, eta, par), "pi": lambda par: O.pi(mu, var, eta, par),
+           "lcb": lambda par: O.lcb(mu, var, par)}
     for kind, par, key in (("ei", 0.0, "ei"), ("pi", 0.0, "pi"), ("lcb", 1.0, "lcb"), ("ei", 0.3, "ei_par"),
                            ("lcb", 2.5, "lcb_par")):
         vals, mx, am, flags = g.acq(kind, par, eta, Xcn)
+        np.testing.assert_allclose(vals, own[kind](par), rtol=1e-10, atol=1e-14 * scale)       # (a)
         ref = gold[key]
-        np.testing.assert_allclose(vals, ref, rtol=ACQ_RTOL, atol=1e-12 * max(1.0, np.abs(ref).max()))
+        np.testing.assert_allclose(vals[well], ref[well], rtol=ACQ_RTOL, atol=1e-9 * scale)   # (b)
         assert am == int(np.argmax(vals)) and mx == vals[am]
         if key in ("ei", "pi", "lcb"):
             gap = float(gold["gap_" + key])

@@ -1,0 +1,155 @@
+"""Host-side pieces that sit next to the hot path: kernel descriptions, priors, initial
+designs, candidate recipe, ensemble sampler, sharding helpers.  Where the reference's own
+module is importable (/root/reference present, i.e. the build container) outputs are compared
+with it on seeded inputs; on the GPU box those comparisons are skipped."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+from robo_amd import sharding
+from robo_amd.initial_design import init_latin_hypercube_sampling, init_random_uniform
+from robo_amd.kernels import ExpSquaredKernel, Matern52Kernel
+from robo_amd.priors import DefaultPrior, HorseshoePrior, LognormalPrior, NormalPrior, TophatPrior
+from robo_amd.util.ensemble_sampler import EnsembleSampler
+
+HAVE_REF = os.path.isdir("/root/reference/robo")
+needs_ref = pytest.mark.skipif(not HAVE_REF, reason="reference tree not on this box")
+
+
+def _ref():
+    if "/root/reference" not in sys.path:
+        sys.path.insert(0, "/root/reference")
+
+
+def test_kernel_api_slice():
+    k = 2 * Matern52Kernel(np.ones(3), ndim=3)
+    assert len(k) == 4 and k.kind == "matern52"
+    np.testing.assert_allclose(k.get_parameter_vector(), [np.log(2.0 / 3), 0, 0, 0])
+    k.set_parameter_vector(np.array([0.1, 0.2, 0.3, 0.4]))
+    np.testing.assert_array_equal(k[:], [0.1, 0.2, 0.3, 0.4])
+    assert isinstance(k[:].tolist(), list)
+    assert ExpSquaredKernel(0.5, ndim=2).kind == "rbf"
+    import copy
+    k2 = copy.deepcopy(k)
+    k2.set_parameter_vector(np.zeros(4))
+    assert k[0] == 0.1
+
+
+@needs_ref
+def test_priors_match_reference():
+    _ref()
+    from robo.priors import base_prior as rb
+    from robo.priors.default_priors import DefaultPrior as RefDefault
+    th = np.array([0.3, -1.2, 0.7, 1.9, -4.0])
+    for mine, ref in ((TophatPrior(-10, 2), rb.TophatPrior(-10, 2)),
+                      (HorseshoePrior(0.1), rb.HorseshoePrior(0.1)),
+                      (LognormalPrior(1.0, 0.0), rb.LognormalPrior(1.0, 0.0)),
+                      (NormalPrior(2.0, 0.5), rb.NormalPrior(2.0, 0.5))):
+        np.testing.assert_array_equal(np.asarray(mine.lnprob(th[1:3])), np.asarray(ref.lnprob(th[1:3])))
+    assert DefaultPrior(5).lnprob(th) == RefDefault(5).lnprob(th)
+    assert DefaultPrior(5).lnprob(np.array([0.3, 3.0, 0.7, 1.9, -4.0])) == -np.inf
+    a = DefaultPrior(5, rng=np.random.RandomState(7)).sample_from_prior(6)
+    b = RefDefault(5, rng=np.random.RandomState(7)).sample_from_prior(6)
+    np.testing.assert_array_equal(a, b)
+
+
+@needs_ref
+def test_initial_designs_match_reference_draw_order():
+    _ref()
+    from robo.initial_design import init_latin_hypercube_sampling as ref_lhs
+    from robo.initial_design import init_random_uniform as ref_uni
+    lo, hi = np.array([-5.0, 0.0, 1.0]), np.array([10.0, 15.0, 2.0])
+    np.testing.assert_array_equal(init_random_uniform(lo, hi, 9, rng=np.random.RandomState(3)),
+                                  ref_uni(lo, hi, 9, rng=np.random.RandomState(3)))
+    np.testing.assert_array_equal(init_latin_hypercube_sampling(lo, hi, 7, rng=np.random.RandomState(3)),
+                                  ref_lhs(lo, hi, 7, rng=np.random.RandomState(3)))
+
+
+def test_initial_designs_properties():
+    lo, hi = np.array([-5.0, 0.0]), np.array([10.0, 15.0])
+    P = init_latin_hypercube_sampling(lo, hi, 10, rng=np.random.RandomState(0))
+    assert P.shape == (10, 2)
+    for d in range(2):   # exactly one point per stratum
+        strata = np.floor((P[:, d] - lo[d]) / (hi[d] - lo[d]) * 10).astype(int)
+        assert sorted(strata) == list(range(10))
+    U = init_random_uniform(lo, hi, 50, rng=np.random.RandomState(0))
+    assert np.all(U >= lo) and np.all(U <= hi)
+
+
+@needs_ref
+def test_random_sampling_candidates_match_reference():
+    """same candidate batch as robo/maximizers/random_sampling.py:38-47 under the same global seed"""
+    _ref()
+    from robo.maximizers.random_sampling import RandomSampling as RefRS
+    from robo_amd.maximizers import RandomSampling
+
+    class Acq(object):
+        class model(object):
+            @staticmethod
+            def get_incumbent():
+                return np.array([0.3, 0.6]), 0.0
+
+        def __init__(self):
+            self.seen = None
+
+        def __call__(self, X):
+            self.seen = X
+            return -np.sum((X - 0.4) ** 2, axis=1)
+
+    lo, hi = np.zeros(2), np.ones(2)
+    a, b = Acq(), Acq()
+    np.random.seed(11)
+    x_ref = RefRS(b, lo, hi, n_samples=200).maximize()
+    np.random.seed(11)
+    x = RandomSampling(a, lo, hi, n_samples=200).maximize()
+    np.testing.assert_array_equal(a.seen, b.seen)
+    np.testing.assert_array_equal(x, x_ref)
+
+
+def test_ensemble_sampler_recovers_gaussian():
+    mean = np.array([1.0, -2.0, 0.5])
+    std = np.array([0.5, 2.0, 1.0])
+    calls = []
+
+    def lnp_batch(th):
+        calls.append(th.shape[0])
+        return -0.5 * np.sum(((th - mean) / std) ** 2, axis=1)
+
+    s = EnsembleSampler(20, 3, lnprob_batch=lnp_batch)
+    rng = np.random.RandomState(0)
+    p0 = rng.randn(20, 3)
+    p, lnp, _ = s.run_mcmc(p0, 300, rstate0=rng)
+    p, lnp, _ = s.run_mcmc(p, 1500, rstate0=rng)
+    ch = s.chain[:, 300:, :].reshape(-1, 3)
+    assert np.all(np.abs(ch.mean(axis=0) - mean) < 0.15 * std + 0.05)
+    assert np.all(np.abs(ch.std(axis=0) / std - 1) < 0.15)
+    assert s.chain.shape == (20, 1800, 3) and set(calls) == {10, 20}   # initial lnprob of all walkers, then half-ensemble batches
+    assert 0.2 < s.acceptance_fraction.mean() < 0.9
+    # -inf proposals are rejected, walkers stay finite
+    s2 = EnsembleSampler(8, 2, lnprob_batch=lambda th: np.where(th[:, 0] > 0, -np.sum(th ** 2, axis=1), -np.inf))
+    p, lnp, _ = s2.run_mcmc(np.abs(rng.randn(8, 2)) + 0.1, 200, rstate0=rng)
+    assert np.all(p[:, 0] > 0) and np.all(np.isfinite(lnp))
+
+
+def test_shard_ranges():
+    assert [sharding.shard_range(50, r, 4) for r in range(4)] == [(0, 13), (13, 26), (26, 38), (38, 50)]
+    assert [sharding.shard_range(8, r, 8) for r in range(8)] == [(i, i + 1) for i in range(8)]
+    spans = [sharding.shard_range(65536 * 8, r, 8) for r in range(8)]
+    assert spans[0] == (0, 65536) and spans[-1][1] == 65536 * 8
+
+
+def test_reduce_argmax_matches_numpy():
+    rs = np.random.RandomState(0)
+    for trial in range(50):
+        y = rs.randint(0, 5, size=40).astype(float)
+        if trial % 3 == 0:
+            y[rs.randint(40)] = np.nan
+        pairs = []
+        for r in range(4):
+            b, e = sharding.shard_range(40, r, 4)
+            j = int(np.argmax(y[b:e]))
+            pairs.append((y[b + j], b + j))
+        v, i = sharding.reduce_argmax(reversed(pairs))     # arrival order must not matter
+        assert i == int(np.argmax(y))
