@@ -31,7 +31,7 @@ SYMBOLS = [
     "robo_cand_create", "robo_cand_destroy", "robo_cand_create_uniform", "robo_cand_get_points",
     "robo_gp_predict_cand", "robo_gp_predict", "robo_gp_predict_cov",
     "robo_acq_eval_cand", "robo_acq_eval", "robo_acq_eval_moments", "robo_acq_eval_marginal_cand", "robo_acq_eval_sum_cand",
-    "robo_selftest_mfma_layout", "robo_microbench_mfma_f64",
+    "robo_selftest_mfma_layout", "robo_microbench_mfma_f64", "robo_microbench_mfma_f64_detail",
 ]
 
 
@@ -117,6 +117,7 @@ def lib():
         "robo_acq_eval_sum_cand": [pp, i32, i32, dbl, dbl, vp, _dp, C.POINTER(C.c_uint32)],
         "robo_selftest_mfma_layout": [vp, _dp],
         "robo_microbench_mfma_f64": [vp, i32, _dp],
+        "robo_microbench_mfma_f64_detail": [vp, i32, _dp],
     }
     for name, args in sig.items():
         fn = getattr(L, name)
@@ -200,6 +201,12 @@ class Context(object):
         e = C.c_double(0)
         check(lib().robo_selftest_mfma_layout(self._h, C.byref(e)))
         return e.value
+
+    def microbench_mfma_f64_detail(self, iters=2000):
+        """-> dict(full-chip tflops, issue interval of one lone wave in shader cycles, MHz under load)"""
+        out = np.zeros(3)
+        check(lib().robo_microbench_mfma_f64_detail(self._h, int(iters), _arr(out)))
+        return {"tflops": out[0], "cycles_per_mfma_single_wave": out[1], "shader_mhz": out[2]}
 
     def microbench_mfma_f64(self, iters=2000):
         t = C.c_double(0)

@@ -128,5 +128,6 @@ int launch_argmax(robo_cand* cand, const double* d_vals, double scale);
 int launch_cov(robo_gp* gp, robo_cand* cand, double* d_cov);
 int launch_uniform(robo_ctx* ctx, double* d_out, int64_t m, int64_t m_pad, int dim, uint64_t seed);
 int launch_mfma_selftest(robo_ctx* ctx, double* out_err);
-int launch_mfma_microbench(robo_ctx* ctx, int iters, double* out_tflops);
+int launch_mfma_microbench(robo_ctx* ctx, int iters, double* out_tflops, double* out_cycles_per_mfma,
+                           double* out_shader_mhz);
 }  // namespace robo

@@ -18,8 +18,10 @@ __global__ __launch_bounds__(64) void mfma_layout_kernel(const double* __restric
     for (int r = 0; r < 4; ++r) C[((l >> 4) + 4 * r) * 16 + (l & 15)] = acc[r];
 }
 
-__global__ __launch_bounds__(256) void mfma_bench_kernel(double* __restrict__ sink, int iters, double seed) {
+__global__ __launch_bounds__(256) void mfma_bench_kernel(double* __restrict__ sink, int iters, double seed,
+                                                         long long* __restrict__ clocks) {
     const int l = threadIdx.x & 63;
+    const long long t0 = clock64(), w0 = wall_clock64();
     const double a = seed + 1e-3 * l, b = seed - 1e-3 * l;
     v4d c0 = {0, 0, 0, 0}, c1 = {1, 1, 1, 1}, c2 = {2, 2, 2, 2}, c3 = {3, 3, 3, 3};
     v4d c4 = {0, 0, 0, 0}, c5 = {1, 1, 1, 1}, c6 = {2, 2, 2, 2}, c7 = {3, 3, 3, 3};
@@ -35,6 +37,11 @@ __global__ __launch_bounds__(256) void mfma_bench_kernel(double* __restrict__ si
     }
     const v4d s = c0 + c1 + c2 + c3 + c4 + c5 + c6 + c7;
     if (s[0] + s[1] + s[2] + s[3] == 12345.678) sink[threadIdx.x] = s[0];   // keep the chain live
+    const long long t1 = clock64(), w1 = wall_clock64();
+    if (clocks && blockIdx.x == 0 && threadIdx.x == 0) {
+        clocks[0] = t1 - t0;   // shader clock ticks (s_memtime)
+        clocks[1] = w1 - w0;   // constant 100 MHz ticks (s_memrealtime)
+    }
 }
 
 int launch_mfma_selftest(robo_ctx* ctx, double* out_err) {
@@ -64,23 +71,35 @@ int launch_mfma_selftest(robo_ctx* ctx, double* out_err) {
     return ROBO_OK;
 }
 
-int launch_mfma_microbench(robo_ctx* ctx, int iters, double* out_tflops) {
+int launch_mfma_microbench(robo_ctx* ctx, int iters, double* out_tflops, double* out_cycles_per_mfma,
+                           double* out_shader_mhz) {
     const int blocks = 4096;
     double* sink = nullptr;
-    ROBO_HIP_CHECK(hipMalloc(&sink, 256 * sizeof(double)));
+    ROBO_HIP_CHECK(hipMalloc(&sink, (256 + 4) * sizeof(double)));
+    long long* clocks = reinterpret_cast<long long*>(sink + 256);
     hipEvent_t e0, e1;
     ROBO_HIP_CHECK(hipEventCreate(&e0));
     ROBO_HIP_CHECK(hipEventCreate(&e1));
-    hipLaunchKernelGGL(mfma_bench_kernel, dim3(blocks), dim3(256), 0, ctx->stream, sink, iters / 4 + 1, 0.5);  // warm
+    hipLaunchKernelGGL(mfma_bench_kernel, dim3(blocks), dim3(256), 0, ctx->stream, sink, iters / 4 + 1, 0.5,
+                       (long long*)nullptr);   // warm-up
     ROBO_HIP_CHECK(hipEventRecord(e0, ctx->stream));
-    hipLaunchKernelGGL(mfma_bench_kernel, dim3(blocks), dim3(256), 0, ctx->stream, sink, iters, 0.5);
+    hipLaunchKernelGGL(mfma_bench_kernel, dim3(blocks), dim3(256), 0, ctx->stream, sink, iters, 0.5, clocks);
     ROBO_HIP_CHECK(hipEventRecord(e1, ctx->stream));
     ROBO_HIP_CHECK(hipEventSynchronize(e1));
     float ms = 0.f;
     ROBO_HIP_CHECK(hipEventElapsedTime(&ms, e0, e1));
     ROBO_HIP_CHECK(hipEventDestroy(e0));
     ROBO_HIP_CHECK(hipEventDestroy(e1));
+    long long hclk[2] = {0, 0};
+    ROBO_HIP_CHECK(hipMemcpy(hclk, clocks, sizeof(hclk), hipMemcpyDeviceToHost));
+    // shader clock under full-chip MFMA load (block 0, wave 0 of the timed launch)
+    if (out_shader_mhz) *out_shader_mhz = hclk[1] > 0 ? (double)hclk[0] / ((double)hclk[1] / 100.0) : 0.0;
+    // issue interval: ONE wave alone on the chip, 8 independent accumulators
+    hipLaunchKernelGGL(mfma_bench_kernel, dim3(1), dim3(64), 0, ctx->stream, sink, iters, 0.5, clocks);
+    ROBO_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    ROBO_HIP_CHECK(hipMemcpy(hclk, clocks, sizeof(hclk), hipMemcpyDeviceToHost));
     ROBO_HIP_CHECK(hipFree(sink));
+    if (out_cycles_per_mfma) *out_cycles_per_mfma = (double)hclk[0] / ((double)iters * 8.0);
     const double flops = (double)blocks * 4.0 * (double)iters * 8.0 * 2048.0;
     *out_tflops = flops / ((double)ms * 1e-3) / 1e12;
     return ROBO_OK;

@@ -173,6 +173,8 @@ static inline void __builtin_amdgcn_s_setprio(int) {}
 static inline void __builtin_amdgcn_fence(int, const char*) {}
 static inline void __builtin_amdgcn_wave_barrier() {}
 static inline void __builtin_amdgcn_sched_barrier(int) {}
+static inline long long clock64() { return 0; }
+static inline long long wall_clock64() { return 0; }
 static inline void __threadfence() {}
 static inline void __threadfence_block() {}
 
