@@ -142,8 +142,7 @@ def main():
         elapsed = float(t.item())
 
     if rank == 0:
-        n_pad = (N + 1 + 127) // 128 * 128
-        nb = n_pad // 128
+        nb = (N + 127) // 128     # trsm_step_kernel launches per step (block rows holding training points)
         ms_per_step = elapsed / args.steps * 1e3
         value = world * M * args.steps / elapsed
         # dominant kernel: trsm_step_kernel (nb launches per step).  Algorithmic flops of one
@@ -157,6 +156,13 @@ def main():
             mfma_ceiling = mb["tflops"]
         except Exception:
             mb, mfma_ceiling = None, None
+        traffic = None
+        try:   # PMC-measured HBM bytes per launch for this exact workload (collected by tools/gpu_pmc.sh)
+            tj = json.load(open(os.path.join(ROOT, "profiles", "trsm_traffic.json")))
+            if tj["workload"] == {"n_train": N, "dim": D, "candidates_per_gpu": M}:
+                traffic = tj["bytes_per_launch"]
+        except Exception:
+            pass
         out = {
             "metric": "EI evals/sec + GP-fit ms at N=4096,D=16; 1/2/4/8 MI355X vs host CPU",
             "value": value, "unit": "EI evals/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -172,7 +178,8 @@ def main():
             "argmax": list(best),
             "roofline": {"bound": "mfma", "kernel": "trsm_step_kernel", "achieved": achieved,
                          "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / FP64_MFMA_PEAK_TFLOPS,
-                         "traffic": None, "launches_per_step": nb, "avg_launch_ms": trsm_avg_launch_ms,
+                         "traffic": traffic, "traffic_unit": "bytes per launch (PMC, profiles/trsm_traffic.json)",
+                         "algorithmic_flops_per_launch": float(M) * N * N / nb, "launches_per_step": nb, "avg_launch_ms": trsm_avg_launch_ms,
                          "mfma_f64_microbench_tflops": mfma_ceiling, "mfma_f64_microbench": mb},
             "device": ctx.name,
         }

@@ -143,7 +143,10 @@ __global__ __launch_bounds__(256) void cov_kernel(const double* __restrict__ V, 
 }
 
 int launch_trsm(robo_gp* gp, robo_cand* cand, int64_t c0, int64_t cn) {
-    const int nbk = gp->n_pad / NB;
+    // block rows that hold training points; a trailing block holding only the augmented row and
+    // identity padding (n % 128 == 0) solves to zeros and is skipped (its V columns stay the
+    // zeros cross_gram_kernel wrote)
+    const int nbk = (gp->n + NB - 1) / NB;
     for (int i = 0; i < nbk; ++i) {
         hipLaunchKernelGGL(trsm_step_kernel, dim3((unsigned)(cn / NB)), dim3(256), 0, gp->ctx->stream, cand->d_V,
                            gp->n_pad, (const double*)gp->d_K, gp->n_pad, (const double*)gp->d_Linv, i, gp->n,
