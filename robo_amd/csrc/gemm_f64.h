@@ -1,12 +1,12 @@
-// fp64 MFMA "NT" GEMM core:  acc(128x128) += A[0:128, k0:k1] * B[0:128, k0:k1]^T
+// fp64 MFMA "NT" GEMM core:  acc(BM x 128) += A[0:BM, k0:k1] * B[0:128, k0:k1]^T,  BM = 32*TM
 //
-// One workgroup (4 wave64, 2x2) owns a 128x128 output tile; each wave owns 64x64 =
-// 4x4 v_mfma_f64_16x16x4_f64 tiles (64 accumulator f64 per lane).  Both operands are
-// row-major with the contraction index contiguous ("NT"), which is the form every
-// product on the hot path takes:
-//     panel solve   A_ik * Linv_kk^T           (potrf.hip)
-//     trailing      A_ij -= P_i * P_j^T        (potrf.hip)
-//     TRSM update   T = K*_i - V * L_i^T       (predict.hip)
+// One workgroup (4 wave64, 2x2) owns a BM x 128 output tile; each wave owns (16*TM) x 64 =
+// TM x 4 v_mfma_f64_16x16x4_f64 tiles (16*TM accumulator f64 per lane).  Both operands are
+// row-major with the contraction index contiguous ("NT"), which is the form every product on
+// the hot path takes:
+//     panel solve   A_ik * Linv_kk^T           (potrf.hip, TM = 1: many small tiles, latency)
+//     trailing      A_ij -= P_i * P_j^T        (potrf.hip, TM = 2: tail balance)
+//     TRSM update   T = K*_i - V * L_i^T       (predict.hip, TM = 4: max operand reuse)
 //     TRSM solve    V_i = T * Linv_ii^T        (predict.hip)
 //     covariance    K** - V * V^T              (predict.hip)
 //
@@ -15,12 +15,14 @@
 //     B operand: lane l holds B[k = l >> 4][j = l & 15]   (here B^T row j, column k)
 //     C/D:       reg r of lane l is  (row = (l >> 4) + 4 r, col = l & 15)
 //
-// LDS: operand tiles are staged [128 rows][16 k] with leading dimension 18 doubles, so a
+// LDS: operand tiles are staged [rows][16 k] with leading dimension 18 doubles, so a
 // fragment read (ds_read_b64, bank = double index mod 32 per 32-lane half) touches
 // row*18 + {k, k+1}: 32 distinct banks.  Two stages (global->regs prefetch of tile t+1
-// overlaps the MFMAs of tile t; one barrier per k-tile).  The fp64 MFMA issues at most
-// once per 16+ cycles per SIMD, so eight ds_read_b64 per sixteen MFMAs and four 16-byte
-// global loads per 64 MFMAs leave the matrix pipe as the only busy resource.
+// overlaps the MFMAs of tile t; one barrier per k-tile).  The fp64 MFMA issues once per 64
+// cycles per SIMD (measured), so (TM+4) ds_read_b64 per 4*TM MFMAs and four 16-byte global
+// loads per k-tile leave the matrix pipe as the only busy resource.  Compiled with
+// -mllvm -amdgpu-mfma-vgpr-form: accumulators live in VGPRs (no v_accvgpr copies), <=256
+// registers for TM = 4, so two workgroups share a CU.
 #pragma once
 #include "common.h"
 
@@ -28,95 +30,116 @@ namespace robo {
 
 constexpr int BK = 16;
 constexpr int LDS_LD = BK + 2;
-constexpr int STAGE = NB * LDS_LD;             // doubles per operand per stage
-constexpr int GEMM_SMEM_DOUBLES = 4 * STAGE;   // [stage][A|B]
+constexpr int STAGE_B = NB * LDS_LD;                       // doubles of the B operand per stage
+template <int TM> constexpr int stage_a() { return 32 * TM * LDS_LD; }
+template <int TM> constexpr int gemm_smem_doubles() { return 2 * (stage_a<TM>() + STAGE_B); }
+constexpr int GEMM_SMEM_DOUBLES = 2 * (32 * 4 * LDS_LD + STAGE_B);   // TM = 4
 
-struct Acc {
-    v4d t[4][4];
+template <int TM>
+struct AccT {
+    v4d t[TM][4];
 };
+typedef AccT<4> Acc;
 
-__device__ __forceinline__ void acc_zero(Acc& c) {
+template <int TM>
+__device__ __forceinline__ void acc_zero(AccT<TM>& c) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j) c.t[i][j] = v4d{0.0, 0.0, 0.0, 0.0};
 }
 
-// position of this lane's accumulator element (tm, tn, r) inside the 128x128 tile
+// position of this lane's accumulator element (tm, tn, r) inside the BM x 128 tile
+template <int TM = 4>
 __device__ __forceinline__ int acc_row(int tm, int r) {
     const int lane = threadIdx.x & 63, wy = (threadIdx.x >> 6) >> 1;
-    return wy * 64 + tm * 16 + (lane >> 4) + 4 * r;
+    return wy * (16 * TM) + tm * 16 + (lane >> 4) + 4 * r;
 }
 __device__ __forceinline__ int acc_col(int tn) {
     const int lane = threadIdx.x & 63, wx = (threadIdx.x >> 6) & 1;
     return wx * 64 + tn * 16 + (lane & 15);
 }
 
+// rows x 16 doubles of a row-major operand -> registers: thread t takes row t/2, half t%2
+template <int ROWS>
 __device__ __forceinline__ void tile_load_regs(const double* __restrict__ G, int ld, int k0, double2 (&r)[4]) {
     const int row = threadIdx.x >> 1, kh = (threadIdx.x & 1) * 8;
-    const double2* p = reinterpret_cast<const double2*>(G + (size_t)row * ld + k0 + kh);
+    if (ROWS == 128 || row < ROWS) {
+        const double2* p = reinterpret_cast<const double2*>(G + (size_t)row * ld + k0 + kh);
 #pragma unroll
-    for (int i = 0; i < 4; ++i) r[i] = p[i];
+        for (int i = 0; i < 4; ++i) r[i] = p[i];
+    }
 }
 
+template <int ROWS>
 __device__ __forceinline__ void tile_store_lds(double* S, const double2 (&r)[4]) {
     const int row = threadIdx.x >> 1, kh = (threadIdx.x & 1) * 8;
-    double2* p = reinterpret_cast<double2*>(S + row * LDS_LD + kh);
+    if (ROWS == 128 || row < ROWS) {
+        double2* p = reinterpret_cast<double2*>(S + row * LDS_LD + kh);
 #pragma unroll
-    for (int i = 0; i < 4; ++i) p[i] = r[i];
+        for (int i = 0; i < 4; ++i) p[i] = r[i];
+    }
 }
 
-template <bool NEG>
-__device__ __forceinline__ void tile_mfma(const double* sA, const double* sB, Acc& acc) {
+template <int TM, bool NEG>
+__device__ __forceinline__ void tile_mfma(const double* sA, const double* sB, AccT<TM>& acc) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int wy = wave >> 1, wx = wave & 1;
-    const double* pa = sA + (wy * 64 + (lane & 15)) * LDS_LD + (lane >> 4);
+    const double* pa = sA + (wy * (16 * TM) + (lane & 15)) * LDS_LD + (lane >> 4);
     const double* pb = sB + (wx * 64 + (lane & 15)) * LDS_LD + (lane >> 4);
 #pragma unroll
     for (int kk = 0; kk < BK / 4; ++kk) {
-        double a[4], b[4];
+        double a[TM], b[4];
 #pragma unroll
-        for (int t = 0; t < 4; ++t) {
+        for (int t = 0; t < TM; ++t) {
             a[t] = pa[t * 16 * LDS_LD + kk * 4];
-            b[t] = pb[t * 16 * LDS_LD + kk * 4];
             if (NEG) a[t] = -a[t];
         }
 #pragma unroll
-        for (int tm = 0; tm < 4; ++tm)
+        for (int t = 0; t < 4; ++t) b[t] = pb[t * 16 * LDS_LD + kk * 4];
+#pragma unroll
+        for (int tm = 0; tm < TM; ++tm)
 #pragma unroll
             for (int tn = 0; tn < 4; ++tn) acc.t[tm][tn] = mfma_f64(a[tm], b[tn], acc.t[tm][tn]);
     }
 }
 
-// acc (+/-)= A[:, kbeg:kend] * B[:, kbeg:kend]^T.  A, B point at the first row of the
-// 128-row operand panels; kbeg/kend are multiples of BK and uniform over the workgroup.
-// smem: GEMM_SMEM_DOUBLES doubles, free for reuse on return (ends on a barrier).
-template <bool NEG>
-__device__ __forceinline__ void gemm_nt_128(const double* __restrict__ A, int lda, const double* __restrict__ B,
-                                            int ldb, int kbeg, int kend, Acc& acc, double* smem) {
+// acc (+/-)= A[:, kbeg:kend] * B[:, kbeg:kend]^T.  A (32*TM rows) and B (128 rows) point at the
+// first row of the operand panels; kbeg/kend are multiples of BK and uniform over the
+// workgroup.  smem: gemm_smem_doubles<TM>() doubles, free for reuse on return (ends on a barrier).
+template <int TM, bool NEG>
+__device__ __forceinline__ void gemm_nt(const double* __restrict__ A, int lda, const double* __restrict__ B, int ldb,
+                                        int kbeg, int kend, AccT<TM>& acc, double* smem) {
+    constexpr int SA = stage_a<TM>(), ST = SA + STAGE_B;
     const int nk = (kend - kbeg) / BK;
     if (nk <= 0) return;
     double2 ra[4], rb[4];
-    tile_load_regs(A, lda, kbeg, ra);
-    tile_load_regs(B, ldb, kbeg, rb);
-    tile_store_lds(smem, ra);
-    tile_store_lds(smem + STAGE, rb);
+    tile_load_regs<32 * TM>(A, lda, kbeg, ra);
+    tile_load_regs<128>(B, ldb, kbeg, rb);
+    tile_store_lds<32 * TM>(smem, ra);
+    tile_store_lds<128>(smem + SA, rb);
     __syncthreads();
     for (int kt = 0; kt < nk; ++kt) {
-        double* cur = smem + (kt & 1) * 2 * STAGE;
-        double* nxt = smem + ((kt + 1) & 1) * 2 * STAGE;
+        double* cur = smem + (kt & 1) * ST;
+        double* nxt = smem + ((kt + 1) & 1) * ST;
         const bool more = kt + 1 < nk;
         if (more) {
-            tile_load_regs(A, lda, kbeg + (kt + 1) * BK, ra);
-            tile_load_regs(B, ldb, kbeg + (kt + 1) * BK, rb);
+            tile_load_regs<32 * TM>(A, lda, kbeg + (kt + 1) * BK, ra);
+            tile_load_regs<128>(B, ldb, kbeg + (kt + 1) * BK, rb);
         }
-        tile_mfma<NEG>(cur, cur + STAGE, acc);
+        tile_mfma<TM, NEG>(cur, cur + SA, acc);
         if (more) {
-            tile_store_lds(nxt, ra);
-            tile_store_lds(nxt + STAGE, rb);
+            tile_store_lds<32 * TM>(nxt, ra);
+            tile_store_lds<128>(nxt + SA, rb);
         }
         __syncthreads();
     }
+}
+
+template <bool NEG>
+__device__ __forceinline__ void gemm_nt_128(const double* __restrict__ A, int lda, const double* __restrict__ B,
+                                            int ldb, int kbeg, int kend, Acc& acc, double* smem) {
+    gemm_nt<4, NEG>(A, lda, B, ldb, kbeg, kend, acc, smem);
 }
 
 }  // namespace robo

@@ -73,48 +73,53 @@ __device__ __forceinline__ v4d blk_mma_nn(const double* A, const double* B, int 
     return acc;
 }
 
-// One wave: unblocked Cholesky of the 16x16 block Ld (lower part valid) and its inverse.
-// Lane i (mod 16) owns row i in registers; columns are exchanged with wave shuffles.
+// broadcast lane `src`'s double to the whole wave through SGPRs (v_readlane_b32 x2; `src` is a
+// compile-time constant after unrolling) -- no LDS round trip, unlike ds_bpermute
+__device__ __forceinline__ double bcast_lane(double x, int src) {
+    const int lo = __builtin_amdgcn_readlane(__double2loint(x), src);
+    const int hi = __builtin_amdgcn_readlane(__double2hiint(x), src);
+    return __hiloint2double(hi, lo);
+}
+
+// One wave: unblocked Cholesky of the 16x16 block Ld (lower part valid) fused with its
+// inverse.  Lane i (mod 16) owns row i of L and column i of W = L^-1 in registers; columns
+// are exchanged with readlane broadcasts.  The inverse rides in the same unrolled loop
+// (row k of W only needs row k of L, complete after step k), so its broadcasts fill the
+// latency gaps of the pivot chain (rsqrt -> scale -> rank-1 update -> next pivot).
 // g0 = global index of the block's first row; rows >= n_real have their pivot forced to 1
 // (augmented row and identity padding).  Writes L (upper zeroed) to Ld, L^-1 (upper
 // zeroed) to Wd.  Returns the first failing global column + 1, or 0.
 __device__ __forceinline__ int potf2_inv_16(double* Ld, double* Wd, int lane, int g0, int n_real) {
     const int row = lane & 15;
-    double a[SB], rd[SB];
+    double a[SB], x[SB];
 #pragma unroll
     for (int j = 0; j < SB; ++j) a[j] = j <= row ? Ld[row * SB + j] : 0.0;
     int fail = 0;
 #pragma unroll
     for (int k = 0; k < SB; ++k) {
-        double p = __shfl(a[k], k);   // pivot after the previous rank-1 updates
+        double p = bcast_lane(a[k], k);   // pivot after the previous rank-1 updates
         const bool forced = g0 + k >= n_real;
         if (forced) p = 1.0;
-        if (!(p > 0.0)) {             // also catches NaN
+        if (!(p > 0.0)) {                 // also catches NaN
             if (fail == 0) fail = g0 + k + 1;
             p = 1.0;
         }
         const double ri = rsqrt(p);
-        rd[k] = ri;
-        const double lik = row == k ? p * ri : a[k] * ri;   // rows < k hold 0 here
+        const double lik = row == k ? p * ri : a[k] * ri;   // rows < k hold garbage here, never read
         a[k] = lik;
 #pragma unroll
         for (int j = k + 1; j < SB; ++j) {
-            const double ljk = __shfl(lik, j);
+            const double ljk = bcast_lane(lik, j);
             a[j] = fma(-lik, ljk, a[j]);
         }
-    }
-    // inverse, column `row` of W per lane: x_c = 1/l_cc, x_i = -(sum_{j=c}^{i-1} l_ij x_j)/l_ii
-    double x[SB], s[SB];
+        // W[k][c] for this lane's column c = row:  (delta_kc - sum_{j<k} L[k][j] W[j][c]) / L[k][k]
+        double acc = row == k ? 1.0 : 0.0;
 #pragma unroll
-    for (int i = 0; i < SB; ++i) s[i] = 0.0;
-#pragma unroll
-    for (int j = 0; j < SB; ++j) {
-        x[j] = j < row ? 0.0 : (j == row ? rd[j] : -rd[j] * s[j]);
-#pragma unroll
-        for (int i = j + 1; i < SB; ++i) {
-            const double lij = __shfl(a[j], i);   // l_ij lives in lane i, register j
-            s[i] = fma(lij, x[j], s[i]);
+        for (int j = 0; j < k; ++j) {
+            const double lkj = bcast_lane(a[j], k);         // L[k][j]: lane k, register j
+            acc = fma(-lkj, x[j], acc);
         }
+        x[k] = k < row ? 0.0 : acc * ri;
     }
     if (lane < SB) {
 #pragma unroll
@@ -140,13 +145,15 @@ __global__ __launch_bounds__(256) void potrf_diag_kernel(double* __restrict__ K,
             sL[blk_off(bi, bj) + tid] = Kd[(size_t)(bi * SB + (tid >> 4)) * ld + bj * SB + (tid & 15)];
     __syncthreads();
 
-    // ---- right-looking factorisation over 16-wide sub-panels ---------------------------
-    for (int s = 0; s < NSB; ++s) {
-        if (wave == 0) {
-            const int f = potf2_inv_16(sL + blk_off(s, s), sW + blk_off(s, s), lane, k * NB + s * SB, n_real);
-            if (f != 0 && lane == 0 && *fail == 0) *fail = f;
-        }
-        __syncthreads();
+    // ---- right-looking factorisation over 16-wide sub-panels, with look-ahead: after the
+    // sub-panel solve of step s, wave 0 updates the next diagonal block and factors it while
+    // waves 1-3 apply the rest of the trailing update (the pivot chain is the critical path).
+    if (wave == 0) {
+        const int f = potf2_inv_16(sL + blk_off(0, 0), sW + blk_off(0, 0), lane, k * NB, n_real);
+        if (f != 0 && lane == 0 && *fail == 0) *fail = f;
+    }
+    __syncthreads();
+    for (int s = 0; s < NSB - 1; ++s) {
         // sub-panel: L_is = A_is * W_ss^T
         for (int bi = s + 1 + wave; bi < NSB; bi += 4) {
             double* A = sL + blk_off(bi, s);
@@ -157,16 +164,26 @@ __global__ __launch_bounds__(256) void potrf_diag_kernel(double* __restrict__ K,
         __syncthreads();
         // trailing: A_ij -= L_is * L_js^T  for s < j <= i
         const int rem = NSB - 1 - s;
-        const int cnt = rem * (rem + 1) / 2;
-        for (int t = wave; t < cnt; t += 4) {
-            int ii = 0;
-            while ((ii + 1) * (ii + 2) / 2 <= t) ++ii;
-            const int jj = t - ii * (ii + 1) / 2;
-            const int bi = s + 1 + ii, bj = s + 1 + jj;
-            double* C = sL + blk_off(bi, bj);
+        const int cnt = rem * (rem + 1) / 2;     // tile 0 is (s+1, s+1)
+        if (wave == 0) {
+            double* C = sL + blk_off(s + 1, s + 1);
             v4d acc = blk_load_c(C, lane);
-            acc = blk_mma_nt<true>(sL + blk_off(bi, s), sL + blk_off(bj, s), lane, acc);
+            acc = blk_mma_nt<true>(sL + blk_off(s + 1, s), sL + blk_off(s + 1, s), lane, acc);
             blk_store_c(C, lane, acc);
+            wave_lds_fence();
+            const int f = potf2_inv_16(C, sW + blk_off(s + 1, s + 1), lane, k * NB + (s + 1) * SB, n_real);
+            if (f != 0 && lane == 0 && *fail == 0) *fail = f;
+        } else {
+            for (int t = wave; t < cnt; t += 3) {      // t = 1 .. cnt-1 over waves 1..3
+                int ii = 0;
+                while ((ii + 1) * (ii + 2) / 2 <= t) ++ii;
+                const int jj = t - ii * (ii + 1) / 2;
+                const int bi = s + 1 + ii, bj = s + 1 + jj;
+                double* C = sL + blk_off(bi, bj);
+                v4d acc = blk_load_c(C, lane);
+                acc = blk_mma_nt<true>(sL + blk_off(bi, s), sL + blk_off(bj, s), lane, acc);
+                blk_store_c(C, lane, acc);
+            }
         }
         __syncthreads();
     }
@@ -203,54 +220,61 @@ __global__ __launch_bounds__(256) void potrf_diag_kernel(double* __restrict__ K,
         }
 }
 
-// A_ik <- A_ik * W_k^T   (rows of block i > k, block column k)
+// A_ik <- A_ik * W_k^T for the rows below the diagonal block of panel k, 32 rows per workgroup
+// (4x more workgroups than 128-row tiles: with <= 32 block rows the panel would otherwise
+// occupy an eighth of the chip for a full 512-MFMA-deep tile)
 __global__ __launch_bounds__(256) void potrf_panel_kernel(double* __restrict__ K, int ld, int k,
                                                           const double* __restrict__ Linv) {
-    __shared__ double smem[GEMM_SMEM_DOUBLES];
-    const int i = k + 1 + blockIdx.x;
-    double* A = K + ((size_t)i * NB) * ld + (size_t)k * NB;
+    __shared__ double smem[gemm_smem_doubles<1>()];
+    const size_t row0 = (size_t)(k + 1) * NB + (size_t)blockIdx.x * 32;
+    double* A = K + row0 * ld + (size_t)k * NB;
     const double* W = Linv + (size_t)k * NB * NB;
-    Acc acc;
+    AccT<1> acc;
     acc_zero(acc);
-    gemm_nt_128<false>(A, ld, W, NB, 0, NB, acc, smem);
+    gemm_nt<1, false>(A, ld, W, NB, 0, NB, acc, smem);
 #pragma unroll
-    for (int tm = 0; tm < 4; ++tm)
+    for (int tn = 0; tn < 4; ++tn)
 #pragma unroll
-        for (int tn = 0; tn < 4; ++tn)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) A[(size_t)acc_row(tm, r) * ld + acc_col(tn)] = acc.t[tm][tn][r];
+        for (int r = 0; r < 4; ++r) A[(size_t)acc_row<1>(0, r) * ld + acc_col(tn)] = acc.t[0][tn][r];
 }
 
-// A_ij <- A_ij - A_ik * A_jk^T   for k < j <= i
+// A_ij <- A_ij - A_ik * A_jk^T   for k < j <= i (right-looking trailing update, K = 128).
+// Tile height 32*TM is chosen per step by the launcher: a 128x128x128 tile is 512 MFMAs deep
+// (>= 13.6 us per wave), so late steps with few blocks use shorter tiles to cover the chip.
+// (A two-level variant with 512-deep updates was measured slower: its strip updates put
+// <= 32 workgroups on the critical path.)
+template <int TM>
 __global__ __launch_bounds__(256) void potrf_syrk_kernel(double* __restrict__ K, int ld, int k) {
-    __shared__ double smem[GEMM_SMEM_DOUBLES];
+    __shared__ double smem[gemm_smem_doubles<TM>()];
+    constexpr int SPLIT = 4 / TM;                    // row sub-tiles per 128-row block
     int ii, jj;
     {
-        const int t = blockIdx.x;
+        const int t = blockIdx.x / SPLIT;
         int q = (int)((sqrt(8.0 * (double)t + 1.0) - 1.0) * 0.5);
         while ((q + 1) * (q + 2) / 2 <= t) ++q;
         while (q * (q + 1) / 2 > t) --q;
         ii = q;
         jj = t - q * (q + 1) / 2;
     }
-    const int i = k + 1 + ii, j = k + 1 + jj;
-    const double* A = K + ((size_t)i * NB) * ld + (size_t)k * NB;
+    const int i = k + 1 + ii, j = k + 1 + jj, h = blockIdx.x % SPLIT;
+    const size_t row0 = (size_t)i * NB + (size_t)h * (32 * TM);
+    const double* A = K + row0 * ld + (size_t)k * NB;
     const double* B = K + ((size_t)j * NB) * ld + (size_t)k * NB;
-    double* C = K + ((size_t)i * NB) * ld + (size_t)j * NB;
-    Acc acc;
+    double* C = K + row0 * ld + (size_t)j * NB;
+    AccT<TM> acc;
 #pragma unroll
-    for (int tm = 0; tm < 4; ++tm)
-#pragma unroll
-        for (int tn = 0; tn < 4; ++tn)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) acc.t[tm][tn][r] = C[(size_t)acc_row(tm, r) * ld + acc_col(tn)];
-    gemm_nt_128<true>(A, ld, B, ld, 0, NB, acc, smem);
-#pragma unroll
-    for (int tm = 0; tm < 4; ++tm)
+    for (int tm = 0; tm < TM; ++tm)
 #pragma unroll
         for (int tn = 0; tn < 4; ++tn)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) C[(size_t)acc_row(tm, r) * ld + acc_col(tn)] = acc.t[tm][tn][r];
+            for (int r = 0; r < 4; ++r) acc.t[tm][tn][r] = C[(size_t)acc_row<TM>(tm, r) * ld + acc_col(tn)];
+    gemm_nt<TM, true>(A, ld, B, ld, 0, NB, acc, smem);
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+        for (int tn = 0; tn < 4; ++tn)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) C[(size_t)acc_row<TM>(tm, r) * ld + acc_col(tn)] = acc.t[tm][tn][r];
 }
 
 // out[0] = z.z, out[1] = 2 sum_{i<n} log L_ii   (z = row n of the factor); fixed summation order
@@ -288,10 +312,15 @@ int launch_potrf(robo_gp* gp) {
                            ctx->d_fail);
         const int rem = nb - k - 1;
         if (rem > 0) {
-            hipLaunchKernelGGL(potrf_panel_kernel, dim3(rem), dim3(256), 0, ctx->stream, gp->d_K, ld, k,
+            hipLaunchKernelGGL(potrf_panel_kernel, dim3(rem * 4), dim3(256), 0, ctx->stream, gp->d_K, ld, k,
                                (const double*)gp->d_Linv);
-            hipLaunchKernelGGL(potrf_syrk_kernel, dim3(rem * (rem + 1) / 2), dim3(256), 0, ctx->stream, gp->d_K, ld,
-                               k);
+            const int blocks = rem * (rem + 1) / 2;
+            // measured (N = 4096): 128-row tiles 43 us/step at 384..528 blocks, 64-row tiles slower
+            // (55 us: B panel re-read twice), 32-row tiles 16 us vs 21 us once blocks < 96
+            if (blocks >= 96)
+                hipLaunchKernelGGL(potrf_syrk_kernel<4>, dim3(blocks), dim3(256), 0, ctx->stream, gp->d_K, ld, k);
+            else
+                hipLaunchKernelGGL(potrf_syrk_kernel<1>, dim3(blocks * 4), dim3(256), 0, ctx->stream, gp->d_K, ld, k);
         }
     }
     ROBO_LAUNCH_CHECK();

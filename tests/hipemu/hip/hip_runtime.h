@@ -66,7 +66,7 @@ void launch(std::function<void()> body, dim3 grid, dim3 block, size_t shmem);
 void barrier();
 // generic wave64 collective: every live lane of the wave deposits `in` (nbytes) and gets
 // `out` back once all arrived; `op` is evaluated once per rendezvous.
-enum Op { OP_SHFL, OP_BALLOT, OP_MFMA_F64_16x16x4, OP_MFMA_F32_16x16x4 };
+enum Op { OP_SHFL, OP_BALLOT, OP_MFMA_F64_16x16x4, OP_WAVE_BARRIER };
 void wave_collective(Op op, const void* in, void* out);
 int lane_id();
 }  // namespace hipemu
@@ -171,8 +171,19 @@ static inline v4d_emu __builtin_amdgcn_mfma_f64_16x16x4f64(double a, double b, v
 
 static inline void __builtin_amdgcn_s_setprio(int) {}
 static inline void __builtin_amdgcn_fence(int, const char*) {}
-static inline void __builtin_amdgcn_wave_barrier() {}
+// lanes are independent fibers here: the lock-step guarantee a real wave gives to
+// "store; wave_barrier; load another lane's element" has to be an explicit rendezvous
+static inline void __builtin_amdgcn_wave_barrier() {
+    int in = 0; unsigned long long out;
+    hipemu::wave_collective(hipemu::OP_WAVE_BARRIER, &in, &out);
+}
 static inline void __builtin_amdgcn_sched_barrier(int) {}
+static inline int __builtin_amdgcn_readlane(int v, int lane) { return hipemu::shfl_any(v, lane); }
+static inline int __double2loint(double x) { uint64_t u; std::memcpy(&u, &x, 8); return (int)(uint32_t)u; }
+static inline int __double2hiint(double x) { uint64_t u; std::memcpy(&u, &x, 8); return (int)(uint32_t)(u >> 32); }
+static inline double __hiloint2double(int hi, int lo) {
+    uint64_t u = ((uint64_t)(uint32_t)hi << 32) | (uint32_t)lo; double x; std::memcpy(&x, &u, 8); return x;
+}
 static inline long long clock64() { return 0; }
 static inline long long wall_clock64() { return 0; }
 static inline void __threadfence() {}

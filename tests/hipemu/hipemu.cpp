@@ -145,6 +145,8 @@ static void eval_wave(int w) {
         }
         break;
     }
+    case OP_WAVE_BARRIER:
+        break;
     default:
         std::fprintf(stderr, "hipemu: unknown collective %d\n", op);
         std::abort();
@@ -155,7 +157,7 @@ static void eval_wave(int w) {
 }
 
 void wave_collective(Op op, const void* in, void* out) {
-    static const size_t in_bytes[] = {sizeof(ShflIn), 4, 48, 0};
+    static const size_t in_bytes[] = {sizeof(ShflIn), 4, 48, 4};
     static const size_t out_bytes[] = {8, 8, 32, 0};
     Fiber* f = g_cur;
     int w = f->linear >> 6;

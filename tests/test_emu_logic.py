@@ -79,3 +79,22 @@ def test_chunked_workspace_equals_single_pass(emu_ctx, monkeypatch):
     monkeypatch.delenv("ROBO_WS_BYTES")
     _, _, am2, _ = g.acq("ei", 0.0, float(ogp.y.min()), Xc)
     assert am1 == am2
+
+
+def test_multi_panel_factorisation(emu_ctx):
+    """N = 520 -> 5 panels (panel solves on 32-row tiles, trailing updates on the small-tile
+    variant); fit only (the interpreter is slow).  The 64- and 128-row variants run on the GPU."""
+    from oracle import gp_oracle as O
+    rs = np.random.RandomState(12)
+    N, D = 520, 3
+    X = rs.rand(N, D)
+    y = np.sin(4 * X.sum(axis=1))
+    theta = np.array([0.2, np.log(0.4), np.log(0.6), np.log(0.8), np.log(1e-2)])
+    ogp = O.OracleGP("matern52", theta, normalize_input=False)
+    ogp.train(X, y)
+    g = _lib.DeviceGP(emu_ctx, "matern52", N, D)
+    g.set_data(X, y)
+    ll = g.fit(theta, ogp.mean)
+    np.testing.assert_allclose(ll, ogp.loglikelihood(theta), rtol=1e-10)
+    np.testing.assert_allclose(g.factor(), ogp.L, rtol=0, atol=1e-11)
+    g.close()
