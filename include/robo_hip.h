@@ -14,7 +14,7 @@
  *   - handles own all device memory; nothing is allocated per call on the hot path
  *   - a handle is not thread-safe; one HIP stream per context; no callbacks
  *   - theta is the reference's log-space hyper-parameter vector
- *       [log amp, log m_1 .. log m_D, log sigma^2]           (P = D + 2)
+ *       [log amp, log m_1 .. log m_D, log sigma^2]           (P = D + 2; ROBO_KERNEL_FABOLAS: see enum)
  *     (robo/models/gaussian_process.py:110-114,151-152; robo/priors/default_priors.py:28-35)
  */
 #ifndef ROBO_HIP_H
@@ -44,7 +44,11 @@ enum robo_status {
 enum robo_kernel_kind {
     ROBO_KERNEL_MATERN52_ARD = 0, /* amp * george.kernels.Matern52Kernel(metric, ndim=D)
                                      (robo/fmin/bayesian_optimization.py:75-81)              */
-    ROBO_KERNEL_RBF_ARD = 1       /* amp * george.kernels.ExpSquaredKernel(metric, ndim=D)   */
+    ROBO_KERNEL_RBF_ARD = 1,      /* amp * george.kernels.ExpSquaredKernel(metric, ndim=D)   */
+    ROBO_KERNEL_FABOLAS = 2       /* amp * prod_d Matern52Kernel(m_d, axes=d) * BayesianLinearRegressionKernel(
+                                     log_a, log_b, axes=D)   (robo/fmin/fabolas.py:104-117).  dim = D + 1: the
+                                     last input column is the basis-transformed fidelity u (fabolas_gp.py:122-126);
+                                     theta = [log amp, log m_1..m_D, log_a, log_b, log sigma^2]  (P = dim + 3)    */
 };
 
 enum robo_acq_kind {
@@ -88,6 +92,11 @@ int32_t robo_gp_set_data(robo_gp* gp, const double* X, const double* y, int32_t 
 /* un-normalisation applied to predictions: mu*y_std + y_mean, var*y_std^2
  * (gaussian_process.py:282-284).  Default (0, 1).                                          */
 int32_t robo_gp_set_output_transform(robo_gp* gp, double y_mean, double y_std);
+/* 0 (default): covariance entries in fp64.  1: evaluated in fp32 and widened -- the mixed
+ * precision "fp32 K-build + fp64 Cholesky" of BASELINE.json config 5 (applies to K and K*).  */
+int32_t robo_gp_set_precision(robo_gp* gp, int32_t fp32_gram);
+/* number of theta entries for a kernel kind and input dimension                              */
+int32_t robo_theta_size(int32_t kernel_kind, int32_t dim);
 /* K = k_theta(X,X) + (sigma^2 + 1.25e-12) I ; L = chol(K) ; z = L^-1 (y - mean_c);
  * loglik = -1/2 (z.z + 2 sum log L_ii + n log 2pi).  On ROBO_NOT_POSITIVE_DEFINITE
  * *out_fail_col is the 0-based failing column and the GP is left unfitted.
@@ -114,6 +123,11 @@ int32_t robo_cand_get_points(robo_cand* cand, double* out_Xc);
  * transform, exactly gaussian_process.py:282-294.  Either output may be NULL.               */
 int32_t robo_gp_predict_cand(robo_gp* gp, robo_cand* cand, double* out_mean, double* out_var);
 int32_t robo_gp_predict(robo_gp* gp, const double* Xc, int64_t m, double* out_mean, double* out_var);
+/* GaussianProcessMCMC.predict (gaussian_process_mcmc.py:205-249): mixture over S fitted GPs,
+ * m = mean_s mu_s, v = var_s(mu_s) + mean_s(var_s), floored at DBL_EPSILON; NumPy's operation
+ * order along the sample axis.                                                                */
+int32_t robo_gp_predict_mixture_cand(robo_gp* const* gps, int32_t S, robo_cand* cand, double* out_mean,
+                                     double* out_var);
 /* full covariance (m x m), small m only (predict(full_cov=True), predict_variance,
  * sample_functions: gaussian_process.py:221-248,298-332)                                    */
 int32_t robo_gp_predict_cov(robo_gp* gp, const double* Xc, int64_t m, double* out_mean, double* out_cov);

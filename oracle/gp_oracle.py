@@ -81,51 +81,80 @@ def zero_mean_unit_var_unnormalization(Xn, mean, std):
 # theta_k = [log amp, log m_1 .. log m_D]  (m_d = SQUARED length scale)
 # --------------------------------------------------------------------------
 def n_kernel_params(kind, D):
+    """number of kernel parameters (without the noise) for D input columns"""
     if kind in ("matern52", "rbf"):
         return 1 + D
+    if kind == "fabolas":
+        return 1 + (D - 1) + 2
     raise ValueError(kind)
 
 
-def _r2(theta_k, X1, X2):
-    m = np.exp(np.asarray(theta_k[1:], dtype=np.float64))
-    A = X1 / np.sqrt(m)
-    B = X2 / np.sqrt(m)
+def _matern52_unit(r2):
+    s = np.sqrt(r2.dtype.type(5.0) * r2)
+    return (r2.dtype.type(1.0) + s + r2.dtype.type(5.0) * r2 / r2.dtype.type(3.0)) * np.exp(-s)
+
+
+def _r2(metric, X1, X2, dtype):
+    m = np.asarray(metric, dtype=np.float64)
+    # scaling in fp64 (the device pre-scales the inputs once in fp64), differences in `dtype`
+    A = (X1 / np.sqrt(m)).astype(dtype)
+    B = (X2 / np.sqrt(m)).astype(dtype)
     # direct differences (not the |a|^2+|b|^2-2ab expansion): exact zero on the
     # diagonal and no cancellation, like george's metric evaluation.
-    r2 = np.zeros((A.shape[0], B.shape[0]))
+    r2 = np.zeros((A.shape[0], B.shape[0]), dtype=dtype)
     for d in range(A.shape[1]):
         diff = A[:, d][:, None] - B[:, d][None, :]
         r2 += diff * diff
     return r2
 
 
-def kernel_matrix(kind, theta_k, X1, X2=None):
-    """k(X1, X2) for ``amp * Matern52Kernel(metric, ndim=D)`` / ``amp * ExpSquaredKernel``.
+def kernel_matrix(kind, theta_k, X1, X2=None, dtype=np.float64):
+    """k(X1, X2) for ``amp * Matern52Kernel(metric, ndim=D)`` / ``amp * ExpSquaredKernel`` and the
+    Fabolas product kernel (contract: SURVEY.md A.2).
 
     Call sites restated: robo/fmin/bayesian_optimization.py:75-81 (construction),
-    test/test_models/test_gaussian_process.py:44-46 (``kernel.get_value``).
+    robo/fmin/fabolas.py:104-117, test/test_models/test_gaussian_process.py:44-46
+    (``kernel.get_value``).  ``dtype=np.float32`` is the mixed-precision K-build of BASELINE
+    config 5: covariance entries evaluated in fp32, returned widened to fp64.
     """
     X1 = np.asarray(X1, dtype=np.float64)
     X2 = X1 if X2 is None else np.asarray(X2, dtype=np.float64)
-    amp = np.exp(theta_k[0])
-    r2 = _r2(theta_k, X1, X2)
+    T = np.dtype(dtype).type
+    amp = T(np.exp(theta_k[0]))
+    if kind == "fabolas":
+        # theta_k = [log amp, log m_1..m_D, log_a, log_b]; columns 0..D-1 inputs, column D = basis(s)
+        D = X1.shape[1] - 1
+        m = np.exp(np.asarray(theta_k[1:1 + D], dtype=np.float64))
+        a, b = T(np.exp(theta_k[1 + D])), T(np.exp(theta_k[2 + D]))
+        A = (X1[:, :D] / np.sqrt(m)).astype(dtype)
+        B = (X2[:, :D] / np.sqrt(m)).astype(dtype)
+        prod = np.ones((X1.shape[0], X2.shape[0]), dtype=dtype)
+        for d in range(D):
+            diff = A[:, d][:, None] - B[:, d][None, :]
+            prod *= _matern52_unit(diff * diff)
+        uu = X1[:, D].astype(dtype)[:, None] * X2[:, D].astype(dtype)[None, :]
+        return (amp * prod * (a + b * uu)).astype(np.float64)
+    r2 = _r2(np.exp(np.asarray(theta_k[1:], dtype=np.float64)), X1, X2, dtype)
     if kind == "matern52":
-        s = np.sqrt(5.0 * r2)
-        return amp * (1.0 + s + 5.0 * r2 / 3.0) * np.exp(-s)
+        return (amp * _matern52_unit(r2)).astype(np.float64)
     if kind == "rbf":
-        return amp * np.exp(-0.5 * r2)
+        return (amp * np.exp(T(-0.5) * r2)).astype(np.float64)
     raise ValueError(kind)
 
 
 def kernel_diag(kind, theta_k, X):
-    """k(x, x) for stationary kernels = amp."""
-    return np.full(X.shape[0], np.exp(theta_k[0]))
+    """k(x, x): amp for the stationary kernels, amp (a + b u^2) for the Fabolas kernel."""
+    amp = np.exp(theta_k[0])
+    if kind == "fabolas":
+        D = X.shape[1] - 1
+        return amp * (np.exp(theta_k[1 + D]) + np.exp(theta_k[2 + D]) * X[:, D] ** 2)
+    return np.full(X.shape[0], amp)
 
 
 # --------------------------------------------------------------------------
 # george.GP.compute / log_likelihood / predict
 # --------------------------------------------------------------------------
-def gp_compute(kind, theta, X):
+def gp_compute(kind, theta, X, dtype=np.float64):
     """``gp.compute(X, yerr=sqrt(sigma2))``: K + (sigma2 + JITTER) I, Cholesky.
 
     theta = [theta_k..., log sigma2] (robo/models/gaussian_process.py:151-155).
@@ -133,7 +162,7 @@ def gp_compute(kind, theta, X):
     Returns the lower factor L.
     """
     theta = np.asarray(theta, dtype=np.float64)
-    K = kernel_matrix(kind, theta[:-1], X)
+    K = kernel_matrix(kind, theta[:-1], X, dtype=dtype)
     K[np.diag_indices_from(K)] += np.exp(theta[-1]) + JITTER
     return sla.cholesky(K, lower=True, check_finite=False)
 
@@ -161,7 +190,7 @@ def gp_predict(kind, theta, L, X, y, mean, Xs):
     return mu, cov
 
 
-def gp_predict_diag(kind, theta, L, X, y, mean, Xs, chunk=4096):
+def gp_predict_diag(kind, theta, L, X, y, mean, Xs, chunk=4096, dtype=np.float64):
     """Diagonal-only variant of :func:`gp_predict` ("fair" CPU baseline; same math).
 
     var_c = k(x_c,x_c) - |L^{-1} k(X,x_c)|^2 ;  mu_c = k(x_c,X) alpha + mean.
@@ -173,7 +202,7 @@ def gp_predict_diag(kind, theta, L, X, y, mean, Xs, chunk=4096):
     var = np.empty(M)
     for s in range(0, M, chunk):
         e = min(M, s + chunk)
-        Kxs = kernel_matrix(kind, theta[:-1], Xs[s:e], X)
+        Kxs = kernel_matrix(kind, theta[:-1], Xs[s:e], X, dtype=dtype)
         mu[s:e] = Kxs @ alpha + mean
         V = sla.solve_triangular(L, Kxs.T, lower=True, check_finite=False)
         var[s:e] = kernel_diag(kind, theta[:-1], Xs[s:e]) - np.sum(V * V, axis=0)
@@ -187,7 +216,8 @@ class OracleGP(object):
     """Restatement of ``GaussianProcess`` with an explicit (kind, theta)."""
 
     def __init__(self, kind, theta, prior=None, normalize_output=False,
-                 normalize_input=True, lower=None, upper=None):
+                 normalize_input=True, lower=None, upper=None, dtype=np.float64):
+        self.dtype = dtype
         self.kind = kind
         self.theta = np.asarray(theta, dtype=np.float64).copy()
         self.prior = prior
@@ -217,11 +247,11 @@ class OracleGP(object):
             self.y = y
         self.mean = np.mean(self.y, axis=0)
         try:
-            self.L = gp_compute(self.kind, self.theta, self.X)
+            self.L = gp_compute(self.kind, self.theta, self.X, self.dtype)
         except np.linalg.LinAlgError:
             # gaussian_process.py:120-122
             self.theta[-1] = np.log(np.exp(self.theta[-1]) * 10)
-            self.L = gp_compute(self.kind, self.theta, self.X)
+            self.L = gp_compute(self.kind, self.theta, self.X, self.dtype)
         self.is_trained = True
 
     # gaussian_process.py:129-166
@@ -230,7 +260,7 @@ class OracleGP(object):
         if np.any((-20 > theta) + (theta > 20)):
             return 1e25
         try:
-            L = gp_compute(self.kind, theta, self.X)
+            L = gp_compute(self.kind, theta, self.X, self.dtype)
         except np.linalg.LinAlgError:
             return 1e25
         ll = gp_log_likelihood(L, self.y, self.mean)
@@ -244,7 +274,7 @@ class OracleGP(object):
         if np.any((-20 > theta) + (theta > 20)):
             return -np.inf
         try:
-            L = gp_compute(self.kind, theta, self.X)
+            L = gp_compute(self.kind, theta, self.X, self.dtype)
         except Exception:
             return -np.inf
         ll = gp_log_likelihood(L, self.y, self.mean)
@@ -262,7 +292,8 @@ class OracleGP(object):
         else:
             Xt = X_test
         if diag_only and not full_cov:
-            mu, var = gp_predict_diag(self.kind, self.theta, self.L, self.X, self.y, self.mean, Xt)
+            mu, var = gp_predict_diag(self.kind, self.theta, self.L, self.X, self.y, self.mean, Xt,
+                                      dtype=self.dtype)
         else:
             mu, var = gp_predict(self.kind, self.theta, self.L, self.X, self.y, self.mean, Xt)
         if self.normalize_output:

@@ -17,7 +17,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 DEFAULT_LIBRARY = os.path.join(_HERE, "librobo_hip.so")
 
 OK, NOT_POSITIVE_DEFINITE, NOT_FITTED, BAD_SHAPE, RUNTIME_ERROR, BAD_ARGUMENT = range(6)
-KERNEL_KINDS = {"matern52": 0, "rbf": 1}
+KERNEL_KINDS = {"matern52": 0, "rbf": 1, "fabolas": 2}
 ACQ_KINDS = {"ei": 0, "log_ei": 1, "pi": 2, "lcb": 3}
 FLAG_ZERO_SIGMA, FLAG_NEGATIVE_EI, FLAG_NAN = 1, 2, 4
 
@@ -27,9 +27,10 @@ SYMBOLS = [
     "robo_ctx_device_name", "robo_ctx_event_record", "robo_ctx_event_elapsed_ms",
     "robo_last_error_string", "robo_version_string",
     "robo_gp_create", "robo_gp_destroy", "robo_gp_set_data", "robo_gp_set_output_transform",
+    "robo_gp_set_precision", "robo_theta_size",
     "robo_gp_fit", "robo_gp_loglik_batch", "robo_gp_get_factor", "robo_gp_get_gram",
     "robo_cand_create", "robo_cand_destroy", "robo_cand_create_uniform", "robo_cand_get_points",
-    "robo_gp_predict_cand", "robo_gp_predict", "robo_gp_predict_cov",
+    "robo_gp_predict_cand", "robo_gp_predict", "robo_gp_predict_cov", "robo_gp_predict_mixture_cand",
     "robo_acq_eval_cand", "robo_acq_eval", "robo_acq_eval_moments", "robo_acq_eval_marginal_cand", "robo_acq_eval_sum_cand",
     "robo_selftest_mfma_layout", "robo_microbench_mfma_f64", "robo_microbench_mfma_f64_detail",
 ]
@@ -98,6 +99,8 @@ def lib():
         "robo_gp_destroy": [vp],
         "robo_gp_set_data": [vp, _dp, _dp, i32],
         "robo_gp_set_output_transform": [vp, dbl, dbl],
+        "robo_gp_set_precision": [vp, i32],
+        "robo_theta_size": [i32, i32],
         "robo_gp_fit": [vp, _dp, dbl, _dp, C.POINTER(i32)],
         "robo_gp_loglik_batch": [vp, _dp, i32, dbl, _dp, C.POINTER(i32)],
         "robo_gp_get_factor": [vp, _dp],
@@ -109,6 +112,7 @@ def lib():
         "robo_gp_predict_cand": [vp, vp, _dp, _dp],
         "robo_gp_predict": [vp, _dp, i64, _dp, _dp],
         "robo_gp_predict_cov": [vp, _dp, i64, _dp, _dp],
+        "robo_gp_predict_mixture_cand": [pp, i32, vp, _dp, _dp],
         "robo_acq_eval_cand": [vp, i32, dbl, dbl, vp, _dp, _dp, C.POINTER(i64), C.POINTER(C.c_uint32)],
         "robo_acq_eval": [vp, i32, dbl, dbl, _dp, i64, _dp, _dp, C.POINTER(i64), C.POINTER(C.c_uint32)],
         "robo_acq_eval_moments": [vp, i32, dbl, dbl, _dp, _dp, i64, _dp, _dp, C.POINTER(i64), C.POINTER(C.c_uint32)],
@@ -267,6 +271,10 @@ class DeviceGP(object):
         self._h = C.c_void_p()
         check(lib().robo_gp_create(ctx._h, KERNEL_KINDS[kind], self.n_max, self.dim, C.byref(self._h)))
         self.n = 0
+        self.n_theta = lib().robo_theta_size(KERNEL_KINDS[kind], self.dim)
+
+    def set_precision(self, fp32_gram):
+        check(lib().robo_gp_set_precision(self._h, 1 if fp32_gram else 0))
 
     def close(self):
         if getattr(self, "_h", None) is not None and self._h:
@@ -290,14 +298,14 @@ class DeviceGP(object):
 
     def fit(self, theta, mean_c):
         """-> log-likelihood; raises np.linalg.LinAlgError when K is not PD."""
-        theta = _f64(theta, (self.dim + 2,))
+        theta = _f64(theta, (self.n_theta,))
         ll, col = C.c_double(0), C.c_int32(0)
         check(lib().robo_gp_fit(self._h, _arr(theta), float(mean_c), C.byref(ll), C.byref(col)))
         return ll.value
 
     def loglik_batch(self, thetas, mean_c):
         thetas = _f64(thetas)
-        assert thetas.ndim == 2 and thetas.shape[1] == self.dim + 2
+        assert thetas.ndim == 2 and thetas.shape[1] == self.n_theta
         S = thetas.shape[0]
         ll = np.empty(S)
         st = np.empty(S, dtype=np.int32)
@@ -311,7 +319,7 @@ class DeviceGP(object):
         return out
 
     def gram(self, theta):
-        theta = _f64(theta, (self.dim + 2,))
+        theta = _f64(theta, (self.n_theta,))
         out = np.empty((self.n, self.n))
         check(lib().robo_gp_get_gram(self._h, _arr(theta), _arr(out)))
         return out
@@ -352,6 +360,15 @@ class DeviceGP(object):
             check(lib().robo_acq_eval(self._h, ACQ_KINDS[kind], float(par), float(eta), _arr(Xc), m,
                                       _arr(out) if want_values else None, C.byref(mx), C.byref(am), C.byref(fl)))
         return out, mx.value, am.value, fl.value
+
+
+def predict_mixture(gps, cand):
+    """GaussianProcessMCMC.predict over device GPs -> (mean (M,), var (M,))"""
+    S = len(gps)
+    arr = (C.c_void_p * S)(*[g._h for g in gps])
+    mean, var = np.empty(cand.m), np.empty(cand.m)
+    check(lib().robo_gp_predict_mixture_cand(arr, S, cand._h, _arr(mean), _arr(var)))
+    return mean, var
 
 
 def acq_from_moments(ctx, kind, par, eta, mean, var):

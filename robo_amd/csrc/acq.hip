@@ -135,6 +135,43 @@ __global__ __launch_bounds__(256) void best_final_kernel(double* __restrict__ pa
     }
 }
 
+// GaussianProcessMCMC.predict mixture (robo/models/gaussian_process_mcmc.py:235-247):
+//   m = mean_s mu_s ;  v = var_s(mu_s) + mean_s(var_s), floored at eps.
+// Same operation order as NumPy on an (S, M) array reduced along axis 0: sequential sums over s,
+// np.var as the mean of squared deviations from the (already rounded) mean.
+__global__ __launch_bounds__(256) void mixture_kernel(const double* __restrict__ mu_all,
+                                                      const double* __restrict__ var_all, long long stride, int S,
+                                                      long long m, double* __restrict__ out_mean,
+                                                      double* __restrict__ out_var) {
+#pragma clang fp contract(off)   // NumPy rounds d*d before adding; an fma would differ in the last bit
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= m) return;
+    double sm = 0.0, sv = 0.0;
+    for (int s = 0; s < S; ++s) {
+        sm += mu_all[s * stride + i];
+        sv += var_all[s * stride + i];
+    }
+    const double mean = sm / (double)S;
+    double sd = 0.0;
+    for (int s = 0; s < S; ++s) {
+        const double d = mu_all[s * stride + i] - mean;
+        sd += d * d;                      // NumPy: multiply(x, x) then add -- two roundings, no fma
+    }
+    double v = sd / (double)S + sv / (double)S;
+    const double eps = 2.220446049250313e-16;
+    v = v < eps ? eps : v;
+    out_mean[i] = mean;
+    out_var[i] = v;
+}
+
+int launch_mixture(robo_cand* cand, int S) {
+    hipLaunchKernelGGL(mixture_kernel, dim3((unsigned)((cand->m + 255) / 256)), dim3(256), 0, cand->ctx->stream,
+                       (const double*)cand->d_mu_all, (const double*)cand->d_var_all, (long long)cand->m_pad, S,
+                       (long long)cand->m, cand->d_mean, cand->d_var);
+    ROBO_LAUNCH_CHECK();
+    return ROBO_OK;
+}
+
 // ---- Philox-4x32-10 counter-based uniforms (device-side candidate generation; the
 // large-M maximiser row of SURVEY.md section 8f) ---------------------------------------------
 __device__ __forceinline__ void philox_round(unsigned (&c)[4], unsigned k0, unsigned k1) {

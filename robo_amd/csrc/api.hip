@@ -123,11 +123,11 @@ int32_t robo_ctx_event_elapsed_ms(robo_ctx* c, int32_t a, int32_t b, float* out_
 // ---------------------------------------------------------------------------------------
 int32_t robo_gp_create(robo_ctx* ctx, int32_t kind, int32_t n_max, int32_t dim, robo_gp** out) {
     if (!ctx || !out) return ROBO_BAD_ARGUMENT;
-    if (kind != ROBO_KERNEL_MATERN52_ARD && kind != ROBO_KERNEL_RBF_ARD) {
+    if (kind != ROBO_KERNEL_MATERN52_ARD && kind != ROBO_KERNEL_RBF_ARD && kind != ROBO_KERNEL_FABOLAS) {
         set_error("unknown kernel kind %d", kind);
         return ROBO_BAD_ARGUMENT;
     }
-    if (n_max < 1 || dim < 1 || dim > MAX_DIM) {
+    if (n_max < 1 || dim < 1 || dim > MAX_DIM || (kind == ROBO_KERNEL_FABOLAS && dim < 2)) {
         set_error("bad shape n_max=%d dim=%d (dim <= %d)", n_max, dim, MAX_DIM);
         return ROBO_BAD_SHAPE;
     }
@@ -186,6 +186,15 @@ int32_t robo_gp_set_data(robo_gp* g, const double* X, const double* y, int32_t n
     return ROBO_OK;
 }
 
+int32_t robo_theta_size(int32_t kind, int32_t dim) { return kind == ROBO_KERNEL_FABOLAS ? dim + 3 : dim + 2; }
+
+int32_t robo_gp_set_precision(robo_gp* g, int32_t fp32_gram) {
+    if (!g) return ROBO_BAD_ARGUMENT;
+    g->fp32_gram = fp32_gram != 0;
+    g->fitted = false;
+    return ROBO_OK;
+}
+
 int32_t robo_gp_set_output_transform(robo_gp* g, double y_mean, double y_std) {
     if (!g) return ROBO_BAD_ARGUMENT;
     g->y_mean = y_mean;
@@ -196,7 +205,7 @@ int32_t robo_gp_set_output_transform(robo_gp* g, double y_mean, double y_std) {
 // stage theta, scale inputs, build the gram matrix (asynchronous)
 static int gp_build_gram(robo_gp* g, const double* theta, double mean_c) {
     robo_ctx* c = g->ctx;
-    const int D = g->dim, P = D + 2;
+    const int D = g->dim, P = robo_theta_size(g->kind, D);
     for (int p = 0; p < P; ++p)
         if (!std::isfinite(theta[p])) {
             set_error("theta[%d] is not finite", p);
@@ -205,8 +214,16 @@ static int gp_build_gram(robo_gp* g, const double* theta, double mean_c) {
     ROBO_HIP_CHECK(hipSetDevice(c->device));
     // the pinned staging buffer is reused by every fit: the previous upload must have landed
     ROBO_HIP_CHECK(hipStreamSynchronize(c->stream));
-    for (int d = 0; d < D; ++d) g->h_theta[d] = std::exp(-0.5 * theta[1 + d]);   // 1/sqrt(metric_d)
+    const bool fab = g->kind == ROBO_KERNEL_FABOLAS;
+    const int n_metric = fab ? D - 1 : D;
+    for (int d = 0; d < n_metric; ++d) g->h_theta[d] = std::exp(-0.5 * theta[1 + d]);   // 1/sqrt(metric_d)
+    if (fab) g->h_theta[D - 1] = 1.0;   // the fidelity column enters the linear kernel unscaled
     g->amp = std::exp(theta[0]);
+    g->cov.kind = g->kind;
+    g->cov.dim = D;
+    g->cov.amp = g->amp;
+    g->cov.blr_a = fab ? std::exp(theta[D]) : 0.0;
+    g->cov.blr_b = fab ? std::exp(theta[D + 1]) : 0.0;
     g->noise = std::exp(theta[P - 1]) + JITTER;
     g->mean_c = mean_c;
     ROBO_HIP_CHECK(hipMemcpyAsync(g->d_theta, g->h_theta, (size_t)D * sizeof(double), hipMemcpyHostToDevice, c->stream));
@@ -255,7 +272,7 @@ int32_t robo_gp_fit(robo_gp* g, const double* theta, double mean_c, double* out_
 int32_t robo_gp_loglik_batch(robo_gp* g, const double* thetas, int32_t S, double mean_c, double* out_loglik,
                              int32_t* out_status) {
     if (!g || !thetas || S < 0 || !out_loglik) return ROBO_BAD_ARGUMENT;
-    const int P = g->dim + 2;
+    const int P = robo_theta_size(g->kind, g->dim);
     for (int s = 0; s < S; ++s) {
         double ll = -HUGE_VAL;
         const int st = robo_gp_fit(g, thetas + (size_t)s * P, mean_c, &ll, nullptr);
@@ -366,6 +383,8 @@ int32_t robo_cand_destroy(robo_cand* k) {
     hipFree(k->d_var);
     hipFree(k->d_acq);
     hipFree(k->d_acq_sum);
+    hipFree(k->d_mu_all);
+    hipFree(k->d_var_all);
     hipFree(k->d_part_val);
     hipFree(k->d_part_idx);
     hipFree(k->d_flags);
@@ -426,6 +445,37 @@ static int predict_core(robo_gp* g, robo_cand* k, bool single_chunk) {
 int32_t robo_gp_predict_cand(robo_gp* g, robo_cand* k, double* out_mean, double* out_var) {
     ROBO_TRY(predict_core(g, k, false));
     hipStream_t st = g->ctx->stream;
+    if (out_mean)
+        ROBO_HIP_CHECK(hipMemcpyAsync(out_mean, k->d_mean, (size_t)k->m * sizeof(double), hipMemcpyDeviceToHost, st));
+    if (out_var)
+        ROBO_HIP_CHECK(hipMemcpyAsync(out_var, k->d_var, (size_t)k->m * sizeof(double), hipMemcpyDeviceToHost, st));
+    ROBO_HIP_CHECK(hipStreamSynchronize(st));
+    return ROBO_OK;
+}
+
+int32_t robo_gp_predict_mixture_cand(robo_gp* const* gps, int32_t S, robo_cand* k, double* out_mean,
+                                     double* out_var) {
+    if (!gps || S < 1 || !k) return ROBO_BAD_ARGUMENT;
+    ROBO_HIP_CHECK(hipSetDevice(k->ctx->device));
+    const size_t mp = (size_t)k->m_pad;
+    if (k->s_cap < S) {
+        if (k->d_mu_all) ROBO_HIP_CHECK(hipFree(k->d_mu_all));
+        if (k->d_var_all) ROBO_HIP_CHECK(hipFree(k->d_var_all));
+        k->d_mu_all = k->d_var_all = nullptr;
+        k->s_cap = 0;
+        ROBO_TRY(dev_alloc(&k->d_mu_all, (size_t)S * mp));
+        ROBO_TRY(dev_alloc(&k->d_var_all, (size_t)S * mp));
+        k->s_cap = S;
+    }
+    hipStream_t st = k->ctx->stream;
+    for (int s = 0; s < S; ++s) {
+        ROBO_TRY(predict_core(gps[s], k, false));
+        ROBO_HIP_CHECK(hipMemcpyAsync(k->d_mu_all + (size_t)s * mp, k->d_mean, mp * sizeof(double),
+                                      hipMemcpyDeviceToDevice, st));
+        ROBO_HIP_CHECK(hipMemcpyAsync(k->d_var_all + (size_t)s * mp, k->d_var, mp * sizeof(double),
+                                      hipMemcpyDeviceToDevice, st));
+    }
+    ROBO_TRY(launch_mixture(k, S));
     if (out_mean)
         ROBO_HIP_CHECK(hipMemcpyAsync(out_mean, k->d_mean, (size_t)k->m * sizeof(double), hipMemcpyDeviceToHost, st));
     if (out_var)

@@ -25,11 +25,11 @@ __device__ __forceinline__ v4d mfma_f64(double a, double b, v4d c) {
     return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0);
 }
 
-struct KernelParams {
-    int kind;          // robo_kernel_kind
-    int dim;
-    double amp;        // exp(theta[0])
-    double noise;      // exp(theta[P-1]) + JITTER  (added to the diagonal)
+// covariance function of the current theta (see kern_math.h)
+struct CovParams {
+    int kind;   // robo_kernel_kind
+    int dim;    // input dimensions (FABOLAS: the last one is the basis-transformed fidelity u)
+    double amp, blr_a, blr_b;
 };
 
 void set_error(const char* fmt, ...);
@@ -78,6 +78,8 @@ struct robo_gp {
     int n_pad;      // round_up(n + 1, NB): row n is the augmented (y - mean) row, rest identity
     int n_pad_max;
     bool has_data, fitted;
+    bool fp32_gram;     // mixed precision: covariance entries evaluated in fp32 (BASELINE config 5)
+    robo::CovParams cov;   // kind, dim, amp, blr_a, blr_b of the current theta
     double amp, noise, mean_c;
     double y_mean, y_std;
     double loglik;
@@ -107,6 +109,9 @@ struct robo_cand {
     double* d_var;      // (m_pad) transformed, floored variance
     double* d_acq;      // (m_pad)
     double* d_acq_sum;  // (m_pad) marginal accumulator
+    double* d_mu_all;   // (s_cap, m_pad) per-sample means/variances for the GP-MCMC mixture (lazy)
+    double* d_var_all;
+    int s_cap;
     double* d_part_val; // per-block argmax partials
     long long* d_part_idx;
     unsigned* d_flags;
@@ -126,6 +131,7 @@ int launch_post(robo_gp* gp, robo_cand* cand, int64_t c0, int64_t cn);
 int launch_acq(robo_ctx* ctx, robo_cand* cand, int acq_kind, double par, double eta, bool accumulate, bool first);
 int launch_argmax(robo_cand* cand, const double* d_vals, double scale);
 int launch_cov(robo_gp* gp, robo_cand* cand, double* d_cov);
+int launch_mixture(robo_cand* cand, int S);
 int launch_uniform(robo_ctx* ctx, double* d_out, int64_t m, int64_t m_pad, int dim, uint64_t seed);
 int launch_mfma_selftest(robo_ctx* ctx, double* out_err);
 int launch_mfma_microbench(robo_ctx* ctx, int iters, double* out_tflops, double* out_cycles_per_mfma,

@@ -34,14 +34,17 @@ __global__ __launch_bounds__(256) void scale_inputs_kernel(const double* __restr
     }
 }
 
-// r2[a][b] = sum_d (Xi[i0 + ty*4 + a][d] - Xj[j0 + tx*4 + b][d])^2 ; Xi/Xj row-major (rows, dim)
-__device__ __forceinline__ void pair_r2(const double* __restrict__ Xi, const double* __restrict__ Xj, long long i0,
-                                        long long j0, int dim, double* sI, double* sJ, double (&r2)[4][4]) {
-    const int t = threadIdx.x, tx = t & 15, ty = t >> 4;
+// cov[a][b] = k(Xi[i0 + ty*4 + a], Xj[j0 + tx*4 + b]) ; Xi/Xj row-major (rows, dim), pre-scaled
+template <class T, int KIND>
+__device__ __forceinline__ void pair_cov(const CovParams& cp, const double* __restrict__ Xi,
+                                         const double* __restrict__ Xj, long long i0, long long j0, double* sI,
+                                         double* sJ, double (&cov)[4][4]) {
+    const int t = threadIdx.x, tx = t & 15, ty = t >> 4, dim = cp.dim;
+    T acc[4][4], uu[4][4];
 #pragma unroll
     for (int a = 0; a < 4; ++a)
 #pragma unroll
-        for (int b = 0; b < 4; ++b) r2[a][b] = 0.0;
+        for (int b = 0; b < 4; ++b) cov_init<T, KIND>(cp, acc[a][b], uu[a][b]);
     for (int d0 = 0; d0 < dim; d0 += GD) {
         // stage 64 rows x 16 dims of both blocks, transposed to [d][row]
 #pragma unroll
@@ -55,22 +58,23 @@ __device__ __forceinline__ void pair_r2(const double* __restrict__ Xi, const dou
         __syncthreads();
         const int dn = dim - d0 < GD ? dim - d0 : GD;
         for (int d = 0; d < dn; ++d) {
-            double xi[4], xj[4];
+            T xi[4], xj[4];
 #pragma unroll
             for (int a = 0; a < 4; ++a) {
-                xi[a] = sI[d * GLD + ty * 4 + a];
-                xj[a] = sJ[d * GLD + tx * 4 + a];
+                xi[a] = (T)sI[d * GLD + ty * 4 + a];
+                xj[a] = (T)sJ[d * GLD + tx * 4 + a];
             }
 #pragma unroll
             for (int a = 0; a < 4; ++a)
 #pragma unroll
-                for (int b = 0; b < 4; ++b) {
-                    const double df = xi[a] - xj[b];
-                    r2[a][b] = fma(df, df, r2[a][b]);
-                }
+                for (int b = 0; b < 4; ++b) cov_step<T, KIND>(cp, d0 + d, xi[a], xj[b], acc[a][b], uu[a][b]);
         }
         __syncthreads();
     }
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) cov[a][b] = cov_finish<T, KIND>(cp, acc[a][b], uu[a][b]);
 }
 
 // map linear lower-triangular tile index to (bi, bj), bj <= bi
@@ -85,16 +89,17 @@ __device__ __forceinline__ void tri_tile(int t, int& bi, int& bj) {
 // K[i][j] for j-tile <= i-tile.  Rows/cols >= n: row n is the augmented right-hand side
 // (y - mean), the rest identity, so that one Cholesky also yields z = L^-1 (y - mean)
 // as row n of the factor (DESIGN.md "augmented row").
+template <class T, int KIND>
 __global__ __launch_bounds__(256) void gram_kernel(const double* __restrict__ Xs, const double* __restrict__ y,
-                                                   double* __restrict__ K, int n, int n_pad, int dim, int kind,
-                                                   double amp, double noise, double mean_c) {
+                                                   double* __restrict__ K, int n, int n_pad, CovParams cp,
+                                                   double noise, double mean_c) {
     __shared__ double sI[GD * GLD];
     __shared__ double sJ[GD * GLD];
     int bi, bj;
     tri_tile(blockIdx.x, bi, bj);
     const long long i0 = (long long)bi * GT, j0 = (long long)bj * GT;
-    double r2[4][4];
-    pair_r2(Xs, Xs, i0, j0, dim, sI, sJ, r2);
+    double cov[4][4];
+    pair_cov<T, KIND>(cp, Xs, Xs, i0, j0, sI, sJ, cov);
     const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
 #pragma unroll
     for (int a = 0; a < 4; ++a) {
@@ -105,7 +110,7 @@ __global__ __launch_bounds__(256) void gram_kernel(const double* __restrict__ Xs
             const int gj = (int)j0 + tx * 4 + b;
             double val;
             if (gi < n && gj < n) {
-                val = cov_from_r2(kind, amp, r2[a][b]);
+                val = cov[a][b];
                 if (gi == gj) val += noise;
             } else if (gi == gj) {
                 val = 1.0;
@@ -125,16 +130,16 @@ __global__ __launch_bounds__(256) void gram_kernel(const double* __restrict__ Xs
 }
 
 // V[c - c0][j] = k(xc_c, x_j) for j < n, 0 for n <= j < n_pad
+template <class T, int KIND>
 __global__ __launch_bounds__(256) void cross_gram_kernel(const double* __restrict__ Xcs,
                                                          const double* __restrict__ Xs, double* __restrict__ V,
-                                                         long long c0, int n, int n_pad, int dim, int kind,
-                                                         double amp) {
+                                                         long long c0, int n, int n_pad, CovParams cp) {
     __shared__ double sI[GD * GLD];
     __shared__ double sJ[GD * GLD];
     const long long i0 = (long long)blockIdx.y * GT;   // candidate tile (chunk local)
     const long long j0 = (long long)blockIdx.x * GT;   // train tile
-    double r2[4][4];
-    pair_r2(Xcs, Xs, c0 + i0, j0, dim, sI, sJ, r2);
+    double cov[4][4];
+    pair_cov<T, KIND>(cp, Xcs, Xs, c0 + i0, j0, sI, sJ, cov);
     const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
 #pragma unroll
     for (int a = 0; a < 4; ++a) {
@@ -143,7 +148,7 @@ __global__ __launch_bounds__(256) void cross_gram_kernel(const double* __restric
 #pragma unroll
         for (int b = 0; b < 4; ++b) {
             const int gj = (int)j0 + tx * 4 + b;
-            v[b] = gj < n ? cov_from_r2(kind, amp, r2[a][b]) : 0.0;
+            v[b] = gj < n ? cov[a][b] : 0.0;
         }
         double2* dst = reinterpret_cast<double2*>(V + (size_t)ci * n_pad + j0 + tx * 4);
         dst[0] = make_double2(v[0], v[1]);
@@ -163,21 +168,42 @@ int launch_scale_inputs(robo_ctx* ctx, const double* d_in, double* d_out, const 
     return ROBO_OK;
 }
 
+// instantiate per (precision, kind); K is robo_kernel_kind
+#define ROBO_DISPATCH_COV(fp32, kind, CALL)                                        \
+    do {                                                                           \
+        if (fp32) {                                                                \
+            if ((kind) == ROBO_KERNEL_MATERN52_ARD) { CALL(float, ROBO_KERNEL_MATERN52_ARD); }      \
+            else if ((kind) == ROBO_KERNEL_RBF_ARD) { CALL(float, ROBO_KERNEL_RBF_ARD); }           \
+            else { CALL(float, ROBO_KERNEL_FABOLAS); }                             \
+        } else {                                                                   \
+            if ((kind) == ROBO_KERNEL_MATERN52_ARD) { CALL(double, ROBO_KERNEL_MATERN52_ARD); }     \
+            else if ((kind) == ROBO_KERNEL_RBF_ARD) { CALL(double, ROBO_KERNEL_RBF_ARD); }          \
+            else { CALL(double, ROBO_KERNEL_FABOLAS); }                            \
+        }                                                                          \
+    } while (0)
+
 int launch_gram(robo_gp* gp) {
     const int T = gp->n_pad / GT;
     const int tiles = T * (T + 1) / 2;
-    hipLaunchKernelGGL(gram_kernel, dim3(tiles), dim3(256), 0, gp->ctx->stream, (const double*)gp->d_Xs,
-                       (const double*)gp->d_y, gp->d_K, gp->n, gp->n_pad, gp->dim, gp->kind, gp->amp, gp->noise,
-                       gp->mean_c);
+#define ROBO_GRAM_CALL(TYPE, KIND)                                                                              \
+    hipLaunchKernelGGL((gram_kernel<TYPE, KIND>), dim3(tiles), dim3(256), 0, gp->ctx->stream,                   \
+                       (const double*)gp->d_Xs, (const double*)gp->d_y, gp->d_K, gp->n, gp->n_pad, gp->cov,     \
+                       gp->noise, gp->mean_c)
+    ROBO_DISPATCH_COV(gp->fp32_gram, gp->kind, ROBO_GRAM_CALL);
+#undef ROBO_GRAM_CALL
     ROBO_LAUNCH_CHECK();
     return ROBO_OK;
 }
 
 int launch_cross_gram(robo_gp* gp, robo_cand* cand, int64_t c0, int64_t cn) {
     // cn is a multiple of NB (=2*GT)
-    hipLaunchKernelGGL(cross_gram_kernel, dim3(gp->n_pad / GT, (unsigned)(cn / GT)), dim3(256), 0, gp->ctx->stream,
-                       (const double*)cand->d_Xcs, (const double*)gp->d_Xs, cand->d_V, (long long)c0, gp->n,
-                       gp->n_pad, gp->dim, gp->kind, gp->amp);
+    const dim3 grid(gp->n_pad / GT, (unsigned)(cn / GT));
+#define ROBO_CROSS_CALL(TYPE, KIND)                                                                             \
+    hipLaunchKernelGGL((cross_gram_kernel<TYPE, KIND>), grid, dim3(256), 0, gp->ctx->stream,                    \
+                       (const double*)cand->d_Xcs, (const double*)gp->d_Xs, cand->d_V, (long long)c0, gp->n,    \
+                       gp->n_pad, gp->cov)
+    ROBO_DISPATCH_COV(gp->fp32_gram, gp->kind, ROBO_CROSS_CALL);
+#undef ROBO_CROSS_CALL
     ROBO_LAUNCH_CHECK();
     return ROBO_OK;
 }

@@ -5,14 +5,66 @@
 
 namespace robo {
 
-// k(r^2) for amp * Matern52Kernel / amp * ExpSquaredKernel, r^2 = sum_d (x_d - x'_d)^2 / m_d
-// (SURVEY.md A.2).  r2 == 0 gives exactly amp.
-__device__ __forceinline__ double cov_from_r2(int kind, double amp, double r2) {
-    if (kind == ROBO_KERNEL_MATERN52_ARD) {
-        const double s = sqrt(5.0 * r2);
-        return amp * (1.0 + s + 5.0 * r2 / 3.0) * exp(-s);
+// Covariance functions (SURVEY.md A.2 -- the project's stated contract for the un-vendored george):
+//   MATERN52_ARD  amp (1 + sqrt(5 r2) + 5 r2 / 3) exp(-sqrt(5 r2)),  r2 = sum_d (x_d - x'_d)^2 / m_d
+//   RBF_ARD       amp exp(-r2 / 2)
+//   FABOLAS       amp prod_{d < D} matern52((x_d - x'_d)^2 / m_d) * (a + b u u'),  u = last coordinate
+//                 (robo/fmin/fabolas.py:104-117: one 1-D Matern-5/2 per input dimension times the
+//                  Bayesian-linear-regression kernel on the basis-transformed fidelity column)
+// Inputs arrive pre-scaled by 1/sqrt(m_d) (the fidelity column unscaled).  A pair is reduced
+// dimension by dimension: cov_init -> cov_step per dimension -> cov_finish.  T = double, or
+// float for the mixed-precision K-build of BASELINE config 5 (widened to fp64 afterwards).
+template <class T>
+__device__ __forceinline__ T matern52_unit(T r2) {
+    const T s = sqrt(T(5) * r2);
+    return (T(1) + s + T(5) * r2 / T(3)) * exp(-s);
+}
+
+// KIND < 0: decided at run time from p.kind (cold paths); otherwise compiled in (the tiled
+// gram kernels are instantiated per kind: a run-time branch in their inner loop cost 2x)
+template <class T, int KIND = -1>
+__device__ __forceinline__ void cov_init(const CovParams& p, T& acc, T& uu) {
+    const int kind = KIND < 0 ? p.kind : KIND;
+    acc = kind == ROBO_KERNEL_FABOLAS ? T(1) : T(0);
+    uu = T(0);
+}
+
+template <class T, int KIND = -1>
+__device__ __forceinline__ void cov_step(const CovParams& p, int d, T xi, T xj, T& acc, T& uu) {
+    const int kind = KIND < 0 ? p.kind : KIND;
+    if (kind == ROBO_KERNEL_FABOLAS) {
+        if (d == p.dim - 1) {
+            uu = xi * xj;
+        } else {
+            const T df = xi - xj;
+            acc *= matern52_unit(df * df);
+        }
+    } else {
+        const T df = xi - xj;
+        acc = fma(df, df, acc);
     }
-    return amp * exp(-0.5 * r2);
+}
+
+template <class T, int KIND = -1>
+__device__ __forceinline__ double cov_finish(const CovParams& p, T acc, T uu) {
+    const int kind = KIND < 0 ? p.kind : KIND;
+    if (kind == ROBO_KERNEL_MATERN52_ARD) return (double)(T(p.amp) * matern52_unit(acc));
+    if (kind == ROBO_KERNEL_RBF_ARD) return (double)(T(p.amp) * exp(T(-0.5) * acc));
+    return (double)(T(p.amp) * acc * (T(p.blr_a) + T(p.blr_b) * uu));
+}
+
+// prior variance k(x, x) of a (scaled) point whose fidelity coordinate is u
+__device__ __forceinline__ double cov_self(const CovParams& p, double u) {
+    return p.kind == ROBO_KERNEL_FABOLAS ? p.amp * (p.blr_a + p.blr_b * u * u) : p.amp;
+}
+
+// scalar path (cov_kernel): both points given as rows of `dim` scaled coordinates
+__device__ __forceinline__ double cov_rows(const CovParams& p, const double* __restrict__ xi,
+                                           const double* __restrict__ xj) {
+    double acc, uu;
+    cov_init(p, acc, uu);
+    for (int d = 0; d < p.dim; ++d) cov_step(p, d, xi[d], xj[d], acc, uu);
+    return cov_finish(p, acc, uu);
 }
 
 constexpr double SQRT1_2 = 0.70710678118654752440;

@@ -100,13 +100,13 @@ __global__ __launch_bounds__(256) void trsm_step_kernel(double* __restrict__ V, 
 // mean/var from the reductions, with the reference's output transform and variance floor
 // (robo/models/gaussian_process.py:282-294)
 __global__ __launch_bounds__(256) void post_kernel(const double* __restrict__ q, const double* __restrict__ mu,
-                                                   double* __restrict__ mean, double* __restrict__ var, long long c0,
-                                                   long long cn, double amp, double mean_c, double y_mean,
-                                                   double y_std) {
+                                                   const double* __restrict__ Xcs, double* __restrict__ mean,
+                                                   double* __restrict__ var, long long c0, long long cn, CovParams cp,
+                                                   double mean_c, double y_mean, double y_std) {
     const long long i = c0 + (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= c0 + cn) return;
     double m = mu[i] + mean_c;
-    double v = amp - q[i];
+    double v = cov_self(cp, Xcs[i * cp.dim + cp.dim - 1]) - q[i];
     m = m * y_std + y_mean;
     v = v * (y_std * y_std);
     const double eps = 2.220446049250313e-16;
@@ -117,8 +117,8 @@ __global__ __launch_bounds__(256) void post_kernel(const double* __restrict__ q,
 
 // cov[c][c'] = (k(x_c, x_c') - v_c . v_c') * y_std^2   for c, c' < m  (small m)
 __global__ __launch_bounds__(256) void cov_kernel(const double* __restrict__ V, int ldv,
-                                                  const double* __restrict__ Xcs, int dim, int kind, double amp,
-                                                  double y_std, long long m, double* __restrict__ cov) {
+                                                  const double* __restrict__ Xcs, CovParams cp, double y_std,
+                                                  long long m, double* __restrict__ cov) {
     __shared__ double smem[GEMM_SMEM_DOUBLES];
     const long long r0 = (long long)blockIdx.y * NB, q0 = (long long)blockIdx.x * NB;
     Acc acc;
@@ -131,14 +131,9 @@ __global__ __launch_bounds__(256) void cov_kernel(const double* __restrict__ V, 
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const long long a = r0 + acc_row(tm, r), b = q0 + acc_col(tn);
-                if (a < m && b < m) {
-                    double r2 = 0.0;
-                    for (int d = 0; d < dim; ++d) {
-                        const double df = Xcs[a * dim + d] - Xcs[b * dim + d];
-                        r2 = fma(df, df, r2);
-                    }
-                    cov[a * m + b] = (cov_from_r2(kind, amp, r2) - acc.t[tm][tn][r]) * (y_std * y_std);
-                }
+                if (a < m && b < m)
+                    cov[a * m + b] = (cov_rows(cp, Xcs + a * cp.dim, Xcs + b * cp.dim) - acc.t[tm][tn][r]) *
+                                     (y_std * y_std);
             }
 }
 
@@ -158,8 +153,8 @@ int launch_trsm(robo_gp* gp, robo_cand* cand, int64_t c0, int64_t cn) {
 
 int launch_post(robo_gp* gp, robo_cand* cand, int64_t c0, int64_t cn) {
     hipLaunchKernelGGL(post_kernel, dim3((unsigned)((cn + 255) / 256)), dim3(256), 0, gp->ctx->stream,
-                       (const double*)cand->d_q, (const double*)cand->d_mu, cand->d_mean, cand->d_var, (long long)c0,
-                       (long long)cn, gp->amp, gp->mean_c, gp->y_mean, gp->y_std);
+                       (const double*)cand->d_q, (const double*)cand->d_mu, (const double*)cand->d_Xcs, cand->d_mean,
+                       cand->d_var, (long long)c0, (long long)cn, gp->cov, gp->mean_c, gp->y_mean, gp->y_std);
     ROBO_LAUNCH_CHECK();
     return ROBO_OK;
 }
@@ -167,7 +162,7 @@ int launch_post(robo_gp* gp, robo_cand* cand, int64_t c0, int64_t cn) {
 int launch_cov(robo_gp* gp, robo_cand* cand, double* d_cov) {
     const unsigned t = (unsigned)(cand->m_pad / NB);
     hipLaunchKernelGGL(cov_kernel, dim3(t, t), dim3(256), 0, gp->ctx->stream, (const double*)cand->d_V, gp->n_pad,
-                       (const double*)cand->d_Xcs, gp->dim, gp->kind, gp->amp, gp->y_std, (long long)cand->m, d_cov);
+                       (const double*)cand->d_Xcs, gp->cov, gp->y_std, (long long)cand->m, d_cov);
     ROBO_LAUNCH_CHECK();
     return ROBO_OK;
 }

@@ -86,3 +86,34 @@ class Matern52Kernel(Kernel):
 class ExpSquaredKernel(Kernel):
     """k = amp exp(-r2 / 2)"""
     kind = "rbf"
+
+
+class FabolasKernel(Kernel):
+    """amp * prod_d Matern52Kernel(m_d, axes=d) * BayesianLinearRegressionKernel(log_a, log_b, axes=D)
+
+    The kernel robo/fmin/fabolas.py:104-117 builds for the objective and cost models: one 1-D
+    Matern-5/2 per configuration dimension (initial metric 0.01) times a degree-1
+    Bayesian-linear-regression kernel ``e^{log_a} + e^{log_b} u u'`` on the basis-transformed
+    fidelity column (SURVEY.md A.2: the BLR formula is not recoverable from the reference tree;
+    this is the Fabolas paper's kernel, stated as this project's contract).
+    ``ndim`` counts ALL input columns (D + 1).  Parameter vector, in george's product order:
+    [log amp, log m_1 .. log m_D, log_a, log_b].
+    """
+    kind = "fabolas"
+
+    def __init__(self, ndim, metric=0.01, log_a=0.1, log_b=0.1, amp=1.0):
+        assert ndim >= 2
+        self.ndim = int(ndim)
+        metric = np.atleast_1d(np.asarray(metric, dtype=np.float64))
+        if metric.shape[0] == 1:
+            metric = np.full(self.ndim - 1, metric[0])
+        assert metric.shape[0] == self.ndim - 1
+        # cov_amp * kernel: ConstantKernel(log(amp / ndim)) (george __rmul__, SURVEY.md A.2)
+        self._vector = np.concatenate([[np.log(float(amp) / self.ndim)], np.log(metric), [log_a, log_b]])
+
+    def __rmul__(self, b):
+        out = FabolasKernel(self.ndim, np.exp(self._vector[1:-2]), self._vector[-2], self._vector[-1])
+        out._vector[0] = self._vector[0] + np.log(float(b) / self.ndim)
+        return out
+
+    __mul__ = __rmul__

@@ -68,9 +68,22 @@ class GaussianProcessMCMC(BaseModel):
         d["gp"] = None
         return d
 
+    # hooks for FabolasGPMCMC -------------------------------------------------------------------
+    def _model_inputs(self, X):
+        """the inputs the kernel sees (None: standard [0,1] normalisation when enabled)"""
+        return None
+
+    def _make_model(self, kernel, noise):
+        return GaussianProcess(kernel, normalize_output=self.normalize_output, normalize_input=self.normalize_input,
+                               noise=noise, lower=self.lower, upper=self.upper, rng=self.rng, device=self.device)
+
     @BaseModel._check_shapes_train
     def train(self, X, y, do_optimize=True, **kwargs):
-        if self.normalize_input:
+        self.original_X = X
+        mapped = self._model_inputs(X)
+        if mapped is not None:
+            self.X = mapped
+        elif self.normalize_input:
             self.X, self.lower, self.upper = normalization.zero_one_normalization(X, self.lower, self.upper)
         else:
             self.X = X
@@ -97,7 +110,7 @@ class GaussianProcessMCMC(BaseModel):
             pos, _, _ = sampler.run_mcmc(self.p0, self.chain_length, rstate0=self.rng)
             self.p0 = pos
             self.hypers = sampler.chain[:, -1]
-        else:
+        elif getattr(self, "hypers", None) is None or not self._keep_hypers_without_optimize():
             self.hypers = self.kernel[:].tolist()
             self.hypers.append(self.noise)
             self.hypers = [self.hypers]
@@ -116,15 +129,18 @@ class GaussianProcessMCMC(BaseModel):
                 model.noise = np.exp(sample[-1])
                 model.lower, model.upper = self.lower, self.upper
             else:
-                model = GaussianProcess(kernel, normalize_output=self.normalize_output,
-                                        normalize_input=self.normalize_input, noise=np.exp(sample[-1]),
-                                        lower=self.lower, upper=self.upper, rng=self.rng, device=self.device)
+                model = self._make_model(kernel, np.exp(sample[-1]))
             model.train(X, y, do_optimize=False)
             self.models.append(model)
         for m in old[len(self.models):]:
             if getattr(m, "gp", None) is not None:
                 m.gp.close()
         self.is_trained = True
+
+    def _keep_hypers_without_optimize(self):
+        # FabolasGPMCMC keeps the previous samples when do_optimize=False (fabolas_gp.py:80-84);
+        # the plain model resets to the kernel's current vector (gaussian_process_mcmc.py:144-147)
+        return hasattr(self, "basis_func")
 
     # ---- likelihood ------------------------------------------------------------------------------
     def loglikelihood_batch(self, thetas):
@@ -149,6 +165,16 @@ class GaussianProcessMCMC(BaseModel):
     def predict(self, X_test, **kwargs):
         if not self.is_trained:
             raise Exception('Model has to be trained first!')
+        gps = [getattr(m, "gp", None) for m in self.models]
+        if all(isinstance(g, _lib.DeviceGP) for g in gps) and all(m.is_trained for m in self.models):
+            # all samples live on the device: S posteriors on one candidate upload + mixture kernel
+            m0 = self.models[0]
+            Xn = m0.normalize(X_test) if hasattr(m0, "normalize") else m0._normalised(X_test)
+            cand = _lib.Candidates(gps[0].ctx, Xn)
+            try:
+                return _lib.predict_mixture(gps, cand)
+            finally:
+                cand.close()
         mu = np.zeros([len(self.models), X_test.shape[0]])
         var = np.zeros([len(self.models), X_test.shape[0]])
         for i, model in enumerate(self.models):

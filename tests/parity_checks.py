@@ -124,6 +124,15 @@ def check_mcmc_marginal(ctx):
         mu, var = g.predict(cand)
         np.testing.assert_allclose(mu, gold["mu_s"][s], rtol=MU_RTOL, atol=MU_ATOL)
         np.testing.assert_allclose(var, gold["var_s"][s], rtol=0, atol=VAR_ATOL_REL_AMP * np.exp(inp["thetas"][s][0]))
+    # K7 mixture: device == NumPy on the device's own per-sample moments (bit for bit), and == fixture
+    per_mu = np.array([g.predict(cand)[0] for g in gps])
+    per_var = np.array([g.predict(cand)[1] for g in gps])
+    mm, mv = _lib.predict_mixture(gps, cand)
+    rm, rv = O.mcmc_mixture(per_mu, per_var)
+    np.testing.assert_array_equal(mm, rm)
+    np.testing.assert_array_equal(mv, rv)
+    np.testing.assert_allclose(mm, gold["mix_m"], rtol=MU_RTOL, atol=MU_ATOL)
+    np.testing.assert_allclose(mv, gold["mix_v"], rtol=1e-7, atol=1e-10)
     for kind, par in (("ei", 0.0), ("pi", 0.0), ("lcb", 1.0)):
         vals, mx, am, flags = _lib.acq_marginal(gps, kind, par, eta, cand)
         ref = gold["marg_" + kind]
@@ -256,3 +265,75 @@ def check_uniform_generator(ctx):
     np.testing.assert_array_equal(P, c2.points())
     c3 = _lib.Candidates(ctx, m=5000, dim=7, seed=124)
     assert not np.array_equal(P, c3.points())
+
+
+def check_fabolas_kernel(ctx):
+    """ROBO_KERNEL_FABOLAS (config 4's kernel, robo/fmin/fabolas.py:104-117): gram, fit, posterior
+    with the non-stationary prior variance amp (a + b u^2), acquisition."""
+    rs = np.random.RandomState(31)
+    N, D, M = 150, 4, 300
+    s_fid = rs.rand(N) * 0.95 + 0.05
+    X = np.concatenate([rs.rand(N, D), ((1 - s_fid) ** 2)[:, None]], axis=1)      # basis (1-s)^2
+    y = np.sin(3 * X[:, :D].sum(axis=1)) + 0.5 * X[:, D]
+    Xc = np.concatenate([rs.rand(M, D), ((1 - rs.rand(M)) ** 2)[:, None]], axis=1)
+    theta = np.concatenate([[0.1], np.log([0.3, 0.5, 0.8, 1.2]), [0.1, -0.3], [np.log(1e-3)]])
+    ogp = O.OracleGP("fabolas", theta, normalize_input=False)
+    ogp.train(X, y)
+    g = _lib.DeviceGP(ctx, "fabolas", N, D + 1)
+    assert g.n_theta == theta.size
+    g.set_data(X, y)
+    K = g.gram(theta)
+    Ko = O.kernel_matrix("fabolas", theta[:-1], X) + (ogp.noise + O.JITTER) * np.eye(N)
+    np.testing.assert_allclose(K, Ko, rtol=1e-12, atol=1e-14)
+    ll = g.fit(theta, ogp.mean)
+    np.testing.assert_allclose(ll, ogp.loglikelihood(theta), rtol=LOGLIK_RTOL)
+    mu, var = g.predict(Xc)
+    mo, vo = ogp.predict(Xc, diag_only=True)
+    np.testing.assert_allclose(mu, mo, rtol=MU_RTOL, atol=MU_ATOL)
+    np.testing.assert_allclose(var, vo, rtol=0, atol=VAR_ATOL_REL_AMP * Ko.max())
+    eta = float(y.min())
+    vals, mx, am, _ = g.acq("ei", 0.0, eta, Xc)
+    np.testing.assert_allclose(vals, O.ei(mu, var, eta), rtol=1e-10, atol=1e-14)
+    assert am == int(np.argmax(O.ei(mo, vo, eta)))
+    _, cov = g.predict_cov(Xc[:20])
+    covo = O.gp_predict("fabolas", theta, ogp.L, X, y, ogp.mean, Xc[:20])[1]
+    np.testing.assert_allclose(cov, covo, rtol=0, atol=VAR_ATOL_REL_AMP * Ko.max())
+    g.close()
+
+
+def check_fp32_gram(ctx):
+    """mixed precision of BASELINE config 5: covariance entries in fp32, Cholesky/solves in fp64.
+    The device must agree with the oracle's fp32 K-build to fp32 rounding (different libm: a few
+    ulp of fp32), and the effect on the posterior vs the all-fp64 path is REPORTED as bounded by
+    the conditioning of K, not claimed equal."""
+    rs = np.random.RandomState(41)
+    N, D, M = 200, 6, 256
+    X = rs.rand(N, D)
+    y = np.sin(3 * X.sum(axis=1))
+    Xc = rs.rand(M, D)
+    theta = np.concatenate([[0.0], np.full(D, np.log(0.25 * D)), [np.log(1e-2)]])
+    g = _lib.DeviceGP(ctx, "matern52", N, D)
+    g.set_data(X, y)
+    g.set_precision(True)
+    K32 = g.gram(theta)
+    K64 = O.kernel_matrix("matern52", theta[:-1], X) + (np.exp(theta[-1]) + O.JITTER) * np.eye(N)
+    Ko32 = O.kernel_matrix("matern52", theta[:-1], X, dtype=np.float32) + (np.exp(theta[-1]) + O.JITTER) * np.eye(N)
+    assert 1e-9 < np.abs(K32 - K64).max() < 2e-6          # really fp32, and no worse than fp32
+    assert np.abs(K32 - Ko32).max() < 1e-6
+    o32 = O.OracleGP("matern52", theta, normalize_input=False, dtype=np.float32)
+    o32.train(X, y)
+    ll = g.fit(theta, o32.mean)
+    np.testing.assert_allclose(ll, o32.loglikelihood(theta), rtol=1e-4)
+    mu, var = g.predict(Xc)
+    mo, vo = o32.predict(Xc, diag_only=True)
+    np.testing.assert_allclose(mu, mo, rtol=0, atol=2e-3)
+    np.testing.assert_allclose(var, vo, rtol=0, atol=2e-3)
+    g.set_precision(False)      # back to fp64: must match the fp64 oracle tightly again
+    o64 = O.OracleGP("matern52", theta, normalize_input=False)
+    o64.train(X, y)
+    g.fit(theta, o64.mean)
+    mu, var = g.predict(Xc)
+    mo, vo = o64.predict(Xc, diag_only=True)
+    np.testing.assert_allclose(mu, mo, rtol=MU_RTOL, atol=MU_ATOL)
+    np.testing.assert_allclose(var, vo, rtol=0, atol=VAR_ATOL_REL_AMP)
+    g.close()

@@ -61,6 +61,14 @@ def test_uniform_generator(emu_ctx):
     P.check_uniform_generator(emu_ctx)
 
 
+def test_fabolas_kernel(emu_ctx):
+    P.check_fabolas_kernel(emu_ctx)
+
+
+def test_fp32_gram_mixed_precision(emu_ctx):
+    P.check_fp32_gram(emu_ctx)
+
+
 def test_chunked_workspace_equals_single_pass(emu_ctx, monkeypatch):
     """candidate batches larger than the solve workspace are processed in chunks"""
     from make_golden import golden_inputs

@@ -64,6 +64,14 @@ def test_uniform_generator(ctx):
     P.check_uniform_generator(ctx)
 
 
+def test_fabolas_kernel(ctx):
+    P.check_fabolas_kernel(ctx)
+
+
+def test_fp32_gram_mixed_precision(ctx):
+    P.check_fp32_gram(ctx)
+
+
 def _headline_inputs(N, D, M):
     X = np.random.RandomState(0).rand(N, D)
     y = np.sinc(X * 10 - 5).sum(axis=1)
