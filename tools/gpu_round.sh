@@ -12,7 +12,7 @@ echo "== smoke" | tee -a $OUT/summary.txt
 timeout 300 python __graft_entry__.py smoke >> $OUT/summary.txt 2>&1
 echo "smoke rc=$?" | tee -a $OUT/summary.txt
 echo "== pytest -m gpu" | tee -a $OUT/summary.txt
-timeout 1500 python -m pytest tests -m gpu -q -rA --durations=20 > $OUT/pytest_gpu.log 2>&1
+timeout 1500 python -m pytest tests -m gpu -q -rA -s --durations=20 > $OUT/pytest_gpu.log 2>&1
 echo "pytest rc=$?" | tee -a $OUT/summary.txt
 tail -40 $OUT/pytest_gpu.log >> $OUT/summary.txt
 echo "== bench" | tee -a $OUT/summary.txt
