@@ -33,6 +33,7 @@ SYMBOLS = [
     "robo_gp_predict_cand", "robo_gp_predict", "robo_gp_predict_cov", "robo_gp_predict_mixture_cand",
     "robo_acq_eval_cand", "robo_acq_eval", "robo_acq_eval_moments", "robo_acq_eval_marginal_cand", "robo_acq_eval_sum_cand",
     "robo_selftest_mfma_layout", "robo_microbench_mfma_f64", "robo_microbench_mfma_f64_detail",
+    "robo_selftest_diag_timeline",
 ]
 
 
@@ -122,6 +123,7 @@ def lib():
         "robo_selftest_mfma_layout": [vp, _dp],
         "robo_microbench_mfma_f64": [vp, i32, _dp],
         "robo_microbench_mfma_f64_detail": [vp, i32, _dp],
+        "robo_selftest_diag_timeline": [vp, _dp, _dp],
     }
     for name, args in sig.items():
         fn = getattr(L, name)
@@ -322,6 +324,12 @@ class DeviceGP(object):
         theta = _f64(theta, (self.n_theta,))
         out = np.empty((self.n, self.n))
         check(lib().robo_gp_get_gram(self._h, _arr(theta), _arr(out)))
+        return out
+
+    def diag_timeline(self, theta):
+        theta = _f64(theta, (self.n_theta,))
+        out = np.zeros(13)
+        check(lib().robo_selftest_diag_timeline(self._h, _arr(theta), _arr(out)))
         return out
 
     def predict(self, Xc):

@@ -652,6 +652,23 @@ int32_t robo_microbench_mfma_f64(robo_ctx* ctx, int32_t iters, double* out_tflop
     return launch_mfma_microbench(ctx, iters, out_tflops, nullptr, nullptr);
 }
 
+int32_t robo_selftest_diag_timeline(robo_gp* g, const double* theta, double* out13) {
+    if (!g || !theta || !out13) return ROBO_BAD_ARGUMENT;
+    if (!g->has_data) return ROBO_NOT_FITTED;
+    g->fitted = false;
+    ROBO_TRY(gp_build_gram(g, theta, 0.0));
+    long long* d = nullptr;
+    ROBO_HIP_CHECK(hipMalloc((void**)&d, 16 * sizeof(long long)));
+    ROBO_HIP_CHECK(hipMemsetAsync(d, 0, 16 * sizeof(long long), g->ctx->stream));
+    ROBO_TRY(launch_diag_timeline(g, d));
+    long long h[16];
+    ROBO_HIP_CHECK(hipMemcpyAsync(h, d, sizeof(h), hipMemcpyDeviceToHost, g->ctx->stream));
+    ROBO_HIP_CHECK(hipStreamSynchronize(g->ctx->stream));
+    ROBO_HIP_CHECK(hipFree(d));
+    for (int i = 0; i < 13; ++i) out13[i] = (double)(h[i] - h[0]);
+    return ROBO_OK;
+}
+
 int32_t robo_microbench_mfma_f64_detail(robo_ctx* ctx, int32_t iters, double* out3) {
     if (!ctx || !out3 || iters < 1) return ROBO_BAD_ARGUMENT;
     ROBO_HIP_CHECK(hipSetDevice(ctx->device));

@@ -125,6 +125,7 @@ int launch_scale_inputs(robo_ctx* ctx, const double* d_in, double* d_out, const 
 int launch_gram(robo_gp* gp);
 int launch_potrf(robo_gp* gp);
 int launch_loglik(robo_gp* gp);
+int launch_diag_timeline(robo_gp* gp, long long* d_stamps);
 int launch_cross_gram(robo_gp* gp, robo_cand* cand, int64_t c0, int64_t cn);
 int launch_trsm(robo_gp* gp, robo_cand* cand, int64_t c0, int64_t cn);
 int launch_post(robo_gp* gp, robo_cand* cand, int64_t c0, int64_t cn);

@@ -74,32 +74,36 @@ __device__ __forceinline__ v4d blk_mma_nn(const double* A, const double* B, int 
 }
 
 // broadcast lane `src`'s double to the whole wave through SGPRs (v_readlane_b32 x2; `src` is a
-// compile-time constant after unrolling) -- no LDS round trip, unlike ds_bpermute
+// compile-time constant after unrolling)
 __device__ __forceinline__ double bcast_lane(double x, int src) {
     const int lo = __builtin_amdgcn_readlane(__double2loint(x), src);
     const int hi = __builtin_amdgcn_readlane(__double2hiint(x), src);
     return __hiloint2double(hi, lo);
 }
 
-// One wave: unblocked Cholesky of the 16x16 block Ld (lower part valid) fused with its
-// inverse.  Lane i (mod 16) owns row i of L and column i of W = L^-1 in registers; columns
-// are exchanged with readlane broadcasts.  The inverse rides in the same unrolled loop
-// (row k of W only needs row k of L, complete after step k), so its broadcasts fill the
-// latency gaps of the pivot chain (rsqrt -> scale -> rank-1 update -> next pivot).
-// g0 = global index of the block's first row; rows >= n_real have their pivot forced to 1
-// (augmented row and identity padding).  Writes L (upper zeroed) to Ld, L^-1 (upper
-// zeroed) to Wd.  Returns the first failing global column + 1, or 0.
-__device__ __forceinline__ int potf2_inv_16(double* Ld, double* Wd, int lane, int g0, int n_real) {
+// ---- 16x16 building blocks ------------------------------------------------------------
+// Everything in the diagonal kernel is latency-bound on one pivot chain (128 sequential
+// rsqrt -> scale -> update steps), so the blocks below are written for few instructions on that
+// chain and for everything else to run on the other three waves meanwhile (measured with
+// robo_selftest_diag_timeline: the first version spent 11.5k cycles per 16x16 potf2+inverse).
+
+// One wave: unblocked Cholesky of the 16x16 block Ld (lower part valid), in place.
+// Lane i (mod 16) owns row i in registers.  Per column: the pivot comes through one readlane
+// pair, the scaled column goes through a 16-double LDS buffer that every lane then reads back
+// uniformly (broadcast reads, two values per ds_read_b128).  1/L_kk is kept in rd[] for the
+// forward substitutions.  g0 = global index of the block's first row; rows >= n_real have their
+// pivot forced to 1 (augmented row and identity padding).  Returns the first failing global
+// column + 1, or 0.
+__device__ __forceinline__ int potf2_16(double* Ld, double* rd, double* colbuf, int lane, int g0, int n_real) {
     const int row = lane & 15;
-    double a[SB], x[SB];
+    double a[SB];
 #pragma unroll
     for (int j = 0; j < SB; ++j) a[j] = j <= row ? Ld[row * SB + j] : 0.0;
     int fail = 0;
 #pragma unroll
     for (int k = 0; k < SB; ++k) {
         double p = bcast_lane(a[k], k);   // pivot after the previous rank-1 updates
-        const bool forced = g0 + k >= n_real;
-        if (forced) p = 1.0;
+        if (g0 + k >= n_real) p = 1.0;
         if (!(p > 0.0)) {                 // also catches NaN
             if (fail == 0) fail = g0 + k + 1;
             p = 1.0;
@@ -107,104 +111,153 @@ __device__ __forceinline__ int potf2_inv_16(double* Ld, double* Wd, int lane, in
         const double ri = rsqrt(p);
         const double lik = row == k ? p * ri : a[k] * ri;   // rows < k hold garbage here, never read
         a[k] = lik;
-#pragma unroll
-        for (int j = k + 1; j < SB; ++j) {
-            const double ljk = bcast_lane(lik, j);
-            a[j] = fma(-lik, ljk, a[j]);
+        double* cb = colbuf + (k & 1) * SB;
+        if (lane < SB) {
+            cb[row] = lik;
+            if (row == k) rd[k] = ri;
         }
-        // W[k][c] for this lane's column c = row:  (delta_kc - sum_{j<k} L[k][j] W[j][c]) / L[k][k]
-        double acc = row == k ? 1.0 : 0.0;
+        wave_lds_fence();
 #pragma unroll
-        for (int j = 0; j < k; ++j) {
-            const double lkj = bcast_lane(a[j], k);         // L[k][j]: lane k, register j
-            acc = fma(-lkj, x[j], acc);
-        }
-        x[k] = k < row ? 0.0 : acc * ri;
+        for (int j = k + 1; j < SB; ++j) a[j] = fma(-lik, cb[j], a[j]);
     }
     if (lane < SB) {
 #pragma unroll
-        for (int j = 0; j < SB; ++j) {
-            Ld[row * SB + j] = j <= row ? a[j] : 0.0;
-            Wd[j * SB + row] = x[j];          // W[j][row]; zero for j < row
-        }
+        for (int j = 0; j < SB; ++j) Ld[row * SB + j] = j <= row ? a[j] : 0.0;
     }
     return fail;
 }
 
+// Solve L y = b for one right-hand side per lane: L = 16x16 lower block in LDS (read uniformly:
+// every lane the same address), rd = 1 / diag(L), b/y in registers.  Right-looking, so the
+// dependent chain is 16 x (mul + fma), the 120 updates are independent.
+__device__ __forceinline__ void fwd_subst_16(const double* Ls, const double* rd, double (&b)[SB]) {
+#pragma unroll
+    for (int k = 0; k < SB; ++k) {
+        b[k] *= rd[k];
+#pragma unroll
+        for (int i = k + 1; i < SB; ++i) b[i] = fma(-Ls[i * SB + k], b[k], b[i]);
+    }
+}
+
+constexpr int TLD = SB + 2;   // padded leading dimension of the per-wave transposition scratch
+
+// ---- the 128x128 diagonal block, block-packed in LDS -------------------------------------
+// sL: 36 lower 16x16 blocks of A -> L in place; sW: 36 blocks of W = L^-1; sT: per-wave 16 x TLD
+// scratch; sRd: 128 reciprocal pivots; sCol: 2 x 16 column exchange buffer (wave 0).
+// Schedule per 16-column step s (two barriers):
+//   A  all waves : sub-panel  L_is = A_is L_ss^-T  by forward substitution, one row per lane
+//   B  wave 0    : trailing tile (s+1,s+1), then potf2(s+1)             <- the critical path
+//      waves 1-3 : block row s of W = L^-1 (s+1 tiles) and the other trailing tiles
+// so the inverse and the MFMA updates ride in the shadow of the pivot chain.
+__device__ __forceinline__ void diag128_factor_invert(double* sL, double* sW, double* sT, double* sRd, double* sCol,
+                                                      int kbase, int n_real, int* fail, long long* dbg) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (wave == 0) {
+        const int f = potf2_16(sL + blk_off(0, 0), sRd, sCol, lane, kbase, n_real);
+        if (f != 0 && lane == 0 && *fail == 0) *fail = f;
+    }
+    __syncthreads();
+    if (dbg && tid == 0) dbg[2] = clock64();
+    for (int s = 0; s < NSB; ++s) {
+        // ---- phase A: sub-panel rows.  16-lane group g of wave w takes block s+1 + 4w + g
+        {
+            const int bi = s + 1 + 4 * wave + (lane >> 4);
+            if (s + 1 + 4 * wave < NSB) {      // wave-uniform
+                const bool live = bi < NSB;
+                double* A = sL + blk_off(live ? bi : NSB - 1, s) + (lane & 15) * SB;
+                double b[SB];
+#pragma unroll
+                for (int j = 0; j < SB; ++j) b[j] = A[j];
+                fwd_subst_16(sL + blk_off(s, s), sRd + s * SB, b);
+                if (live) {
+#pragma unroll
+                    for (int j = 0; j < SB; ++j) A[j] = b[j];
+                }
+            }
+        }
+        __syncthreads();
+        if (dbg && tid == 0 && s == 0) dbg[3] = clock64();
+        // ---- phase B
+        const int rem = NSB - 1 - s;
+        const int cnt = rem * (rem + 1) / 2;          // trailing tiles; tile 0 is (s+1, s+1)
+        if (wave == 0 && s + 1 < NSB) {
+            double* C = sL + blk_off(s + 1, s + 1);
+            v4d acc = blk_load_c(C, lane);
+            acc = blk_mma_nt<true>(sL + blk_off(s + 1, s), sL + blk_off(s + 1, s), lane, acc);
+            blk_store_c(C, lane, acc);
+            wave_lds_fence();
+            const int f = potf2_16(C, sRd + (s + 1) * SB, sCol, lane, kbase + (s + 1) * SB, n_real);
+            if (f != 0 && lane == 0 && *fail == 0) *fail = f;
+        } else {
+            // tasks: W tiles (s, j), j = 0..s  first (longer), then trailing tiles 1..cnt-1
+            const int nw = s + 1 < NSB ? 3 : 4;       // last step: wave 0 has no pivot work left
+            const int me = s + 1 < NSB ? wave - 1 : wave;
+            const int ntask = (s + 1) + (cnt > 0 ? cnt - 1 : 0);
+            double* T = sT + wave * SB * TLD;
+            for (int t = me; t < ntask; t += nw) {
+                if (t <= s) {
+                    const int j = t;
+                    double b[SB];
+                    if (j == s) {
+#pragma unroll
+                        for (int i = 0; i < SB; ++i) b[i] = i == (lane & 15) ? 1.0 : 0.0;
+                    } else {
+                        v4d acc = {0.0, 0.0, 0.0, 0.0};
+                        for (int kb = j; kb < s; ++kb)
+                            acc = blk_mma_nn<true>(sL + blk_off(s, kb), sW + blk_off(kb, j), lane, acc);
+                        // store -T transposed: lane c then reads column c as one padded row
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) T[(lane & 15) * TLD + (lane >> 4) + 4 * r] = acc[r];
+                        wave_lds_fence();
+#pragma unroll
+                        for (int i = 0; i < SB; ++i) b[i] = T[(lane & 15) * TLD + i];
+                        wave_lds_fence();   // T is rewritten by this wave's next task
+                    }
+                    fwd_subst_16(sL + blk_off(s, s), sRd + s * SB, b);
+                    if (lane < SB) {
+                        double* W = sW + blk_off(s, j);
+#pragma unroll
+                        for (int i = 0; i < SB; ++i) W[i * SB + lane] = b[i];
+                    }
+                } else {
+                    const int tt = t - s;              // 1 .. cnt-1
+                    int ii = 0;
+                    while ((ii + 1) * (ii + 2) / 2 <= tt) ++ii;
+                    const int jj = tt - ii * (ii + 1) / 2;
+                    const int bi = s + 1 + ii, bj = s + 1 + jj;
+                    double* C = sL + blk_off(bi, bj);
+                    v4d acc = blk_load_c(C, lane);
+                    acc = blk_mma_nt<true>(sL + blk_off(bi, s), sL + blk_off(bj, s), lane, acc);
+                    blk_store_c(C, lane, acc);
+                }
+            }
+        }
+        __syncthreads();
+        if (dbg && tid == 0 && s < NSB - 1) dbg[4 + s] = clock64();
+    }
+    if (dbg && tid == 0) dbg[11] = clock64();
+}
+
 __global__ __launch_bounds__(256) void potrf_diag_kernel(double* __restrict__ K, int ld, int k, int n_real,
-                                                         double* __restrict__ Linv, int* __restrict__ fail) {
+                                                         double* __restrict__ Linv, int* __restrict__ fail,
+                                                         long long* __restrict__ dbg) {
     __shared__ double sL[NBLK * BLK];
     __shared__ double sW[NBLK * BLK];
-    __shared__ double sT[4 * BLK];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    __shared__ double sT[4 * SB * TLD];
+    __shared__ double sRd[NB];
+    __shared__ double sCol[2 * SB];
+    const int tid = threadIdx.x;
     double* Kd = K + ((size_t)k * NB) * ld + (size_t)k * NB;
+    if (dbg && tid == 0) dbg[0] = clock64();
 
     // ---- load the 36 lower sub-blocks ------------------------------------------------
     for (int bi = 0; bi < NSB; ++bi)
         for (int bj = 0; bj <= bi; ++bj)
             sL[blk_off(bi, bj) + tid] = Kd[(size_t)(bi * SB + (tid >> 4)) * ld + bj * SB + (tid & 15)];
     __syncthreads();
+    if (dbg && tid == 0) dbg[1] = clock64();
 
-    // ---- right-looking factorisation over 16-wide sub-panels, with look-ahead: after the
-    // sub-panel solve of step s, wave 0 updates the next diagonal block and factors it while
-    // waves 1-3 apply the rest of the trailing update (the pivot chain is the critical path).
-    if (wave == 0) {
-        const int f = potf2_inv_16(sL + blk_off(0, 0), sW + blk_off(0, 0), lane, k * NB, n_real);
-        if (f != 0 && lane == 0 && *fail == 0) *fail = f;
-    }
-    __syncthreads();
-    for (int s = 0; s < NSB - 1; ++s) {
-        // sub-panel: L_is = A_is * W_ss^T
-        for (int bi = s + 1 + wave; bi < NSB; bi += 4) {
-            double* A = sL + blk_off(bi, s);
-            v4d acc = {0.0, 0.0, 0.0, 0.0};
-            acc = blk_mma_nt<false>(A, sW + blk_off(s, s), lane, acc);
-            blk_store_c(A, lane, acc);   // in place: every operand read precedes the MFMA result
-        }
-        __syncthreads();
-        // trailing: A_ij -= L_is * L_js^T  for s < j <= i
-        const int rem = NSB - 1 - s;
-        const int cnt = rem * (rem + 1) / 2;     // tile 0 is (s+1, s+1)
-        if (wave == 0) {
-            double* C = sL + blk_off(s + 1, s + 1);
-            v4d acc = blk_load_c(C, lane);
-            acc = blk_mma_nt<true>(sL + blk_off(s + 1, s), sL + blk_off(s + 1, s), lane, acc);
-            blk_store_c(C, lane, acc);
-            wave_lds_fence();
-            const int f = potf2_inv_16(C, sW + blk_off(s + 1, s + 1), lane, k * NB + (s + 1) * SB, n_real);
-            if (f != 0 && lane == 0 && *fail == 0) *fail = f;
-        } else {
-            for (int t = wave; t < cnt; t += 3) {      // t = 1 .. cnt-1 over waves 1..3
-                int ii = 0;
-                while ((ii + 1) * (ii + 2) / 2 <= t) ++ii;
-                const int jj = t - ii * (ii + 1) / 2;
-                const int bi = s + 1 + ii, bj = s + 1 + jj;
-                double* C = sL + blk_off(bi, bj);
-                v4d acc = blk_load_c(C, lane);
-                acc = blk_mma_nt<true>(sL + blk_off(bi, s), sL + blk_off(bj, s), lane, acc);
-                blk_store_c(C, lane, acc);
-            }
-        }
-        __syncthreads();
-    }
-
-    // ---- W = L^-1 block column by block column (columns are independent) -----------------
-    // W_ij = -W_ii * sum_{k=j}^{i-1} L_ik W_kj ;  wave w handles columns w and 7 - w
-    for (int pass = 0; pass < 2; ++pass) {
-        const int j = pass == 0 ? wave : NSB - 1 - wave;
-        double* T = sT + wave * BLK;
-        for (int i = j + 1; i < NSB; ++i) {
-            v4d acc = {0.0, 0.0, 0.0, 0.0};
-            for (int kb = j; kb < i; ++kb) acc = blk_mma_nn<false>(sL + blk_off(i, kb), sW + blk_off(kb, j), lane, acc);
-            blk_store_c(T, lane, acc);
-            wave_lds_fence();
-            v4d w = {0.0, 0.0, 0.0, 0.0};
-            w = blk_mma_nn<true>(sW + blk_off(i, i), T, lane, w);
-            blk_store_c(sW + blk_off(i, j), lane, w);
-            wave_lds_fence();
-        }
-    }
-    __syncthreads();
+    diag128_factor_invert(sL, sW, sT, sRd, sCol, k * NB, n_real, fail, dbg);
 
     // ---- write back: L into K (lower blocks), W as a dense 128x128 row-major block --------
     double* Wg = Linv + (size_t)k * NB * NB;
@@ -218,6 +271,7 @@ __global__ __launch_bounds__(256) void potrf_diag_kernel(double* __restrict__ K,
                 Wg[r * NB + c] = 0.0;
             }
         }
+    if (dbg && tid == 0) dbg[12] = clock64();
 }
 
 // A_ik <- A_ik * W_k^T for the rows below the diagonal block of panel k, 32 rows per workgroup
@@ -309,7 +363,7 @@ int launch_potrf(robo_gp* gp) {
     ROBO_HIP_CHECK(hipMemsetAsync(ctx->d_fail, 0, sizeof(int), ctx->stream));
     for (int k = 0; k < nb; ++k) {
         hipLaunchKernelGGL(potrf_diag_kernel, dim3(1), dim3(256), 0, ctx->stream, gp->d_K, ld, k, gp->n, gp->d_Linv,
-                           ctx->d_fail);
+                           ctx->d_fail, (long long*)nullptr);
         const int rem = nb - k - 1;
         if (rem > 0) {
             hipLaunchKernelGGL(potrf_panel_kernel, dim3(rem * 4), dim3(256), 0, ctx->stream, gp->d_K, ld, k,
@@ -323,6 +377,14 @@ int launch_potrf(robo_gp* gp) {
                 hipLaunchKernelGGL(potrf_syrk_kernel<1>, dim3(blocks * 4), dim3(256), 0, ctx->stream, gp->d_K, ld, k);
         }
     }
+    ROBO_LAUNCH_CHECK();
+    return ROBO_OK;
+}
+
+// one instrumented diagonal-block kernel on panel 0 of the current gram matrix
+int launch_diag_timeline(robo_gp* gp, long long* d_stamps) {
+    hipLaunchKernelGGL(potrf_diag_kernel, dim3(1), dim3(256), 0, gp->ctx->stream, gp->d_K, gp->n_pad, 0, gp->n,
+                       gp->d_Linv, gp->ctx->d_fail, d_stamps);
     ROBO_LAUNCH_CHECK();
     return ROBO_OK;
 }
