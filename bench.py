@@ -112,6 +112,16 @@ def main():
         fit_ms.append((time.perf_counter() - t0) * 1e3)
         fit_chol_ms.append((ctx.elapsed_ms(20, 21), ctx.elapsed_ms(21, 22), ctx.elapsed_ms(22, 23)))
     gram_ms, chol_ms, ll_ms = fit_chol_ms[int(np.argmin(fit_ms))]
+    # the MCMC inner loop evaluates half an ensemble of thetas at once (n_hypers = 3 (D + 2) made
+    # even = 54 at D = 16 -> 27 per half-step; robo/fmin/bayesian_optimization.py:85-87):
+    # robo_gp_loglik_batch runs them through ONE sequence of launches
+    S_half = max(1, (3 * (D + 2) + (3 * (D + 2)) % 2) // 2)
+    thetas = theta[None, :] + 0.1 * np.random.RandomState(7).randn(S_half, theta.size)
+    gp.loglik_batch(thetas, mean_c)
+    t0 = time.perf_counter()
+    gp.loglik_batch(thetas, mean_c)
+    batch_ms = (time.perf_counter() - t0) * 1e3
+    gp.fit(theta, mean_c)          # the batch call leaves the GP unfitted
 
     def barrier():
         ctx.synchronize()
@@ -174,6 +184,7 @@ def main():
                        "parallelism": "candidate-shard x%d, replicated fit" % world},
             "gp_fit_ms": float(np.min(fit_ms)),
             "gp_fit_phases_ms": {"gram": gram_ms, "cholesky": chol_ms, "loglik": ll_ms},
+            "gp_fit_batched": {"thetas": S_half, "ms_total": batch_ms, "ms_per_theta": batch_ms / S_half},
             "ei_eval_phases_ms_per_step": {"cross_gram": cross_ms / args.steps, "trsm": trsm_ms / args.steps},
             "argmax": list(best),
             "roofline": {"bound": "mfma", "kernel": "trsm_step_kernel", "achieved": achieved,

@@ -102,8 +102,9 @@ int32_t robo_theta_size(int32_t kernel_kind, int32_t dim);
  * *out_fail_col is the 0-based failing column and the GP is left unfitted.
  * out_loglik / out_fail_col may be NULL.                                                   */
 int32_t robo_gp_fit(robo_gp* gp, const double* theta, double mean_c, double* out_loglik, int32_t* out_fail_col);
-/* S independent fits on the same data; out_status[s] is a robo_status.  The GP is left in
- * the state of the LAST fit of the batch (fitted iff out_status[S-1] == ROBO_OK).           */
+/* S independent likelihood evaluations on the same data in ONE batched pass (every kernel of
+ * the fit runs with S x the workgroups); out_status[s] is a robo_status.  Works on a separate
+ * batch workspace; the GP itself is left UNFITTED (call robo_gp_fit for the theta to keep).    */
 int32_t robo_gp_loglik_batch(robo_gp* gp, const double* thetas, int32_t S, double mean_c, double* out_loglik,
                              int32_t* out_status);
 /* copy the lower Cholesky factor (n x n, row-major, upper zeroed) back -- diagnostics/tests */

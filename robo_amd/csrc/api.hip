@@ -147,8 +147,9 @@ int32_t robo_gp_create(robo_ctx* ctx, int32_t kind, int32_t n_max, int32_t dim, 
     ROBO_TRY(dev_alloc(&g->d_y, (size_t)n_max));
     ROBO_TRY(dev_alloc(&g->d_K, np * np));
     ROBO_TRY(dev_alloc(&g->d_Linv, np * NB));
-    ROBO_TRY(dev_alloc(&g->d_theta, (size_t)2 * dim + 8));
-    ROBO_HIP_CHECK(hipHostMalloc((void**)&g->h_theta, ((size_t)2 * dim + 8) * sizeof(double), 0));
+    ROBO_TRY(dev_alloc(&g->d_theta, (size_t)dim + 8 + sizeof(FitSample) / sizeof(double)));
+    g->d_sp = reinterpret_cast<FitSample*>(g->d_theta + dim + 8);
+    ROBO_HIP_CHECK(hipHostMalloc((void**)&g->h_theta, ((size_t)dim + 8) * sizeof(double) + sizeof(FitSample), 0));
     *out = g;
     return ROBO_OK;
 }
@@ -164,6 +165,14 @@ int32_t robo_gp_destroy(robo_gp* g) {
     hipFree(g->d_Linv);
     hipFree(g->d_theta);
     hipHostFree(g->h_theta);
+    hipFree(g->d_bK);
+    hipFree(g->d_bLinv);
+    hipFree(g->d_bXs);
+    hipFree(g->d_bism);
+    hipFree(g->d_bout);
+    hipFree(g->d_bsp);
+    hipFree(g->d_bfail);
+    if (g->h_bstage) hipHostFree(g->h_bstage);
     delete g;
     return ROBO_OK;
 }
@@ -202,33 +211,57 @@ int32_t robo_gp_set_output_transform(robo_gp* g, double y_mean, double y_std) {
     return ROBO_OK;
 }
 
-// stage theta, scale inputs, build the gram matrix (asynchronous)
-static int gp_build_gram(robo_gp* g, const double* theta, double mean_c) {
-    robo_ctx* c = g->ctx;
+// theta -> (FitSample, 1/sqrt(metric_d)); returns BAD_ARGUMENT for non-finite entries
+static int theta_to_sample(const robo_gp* g, const double* theta, double mean_c, FitSample* sp, double* ism) {
     const int D = g->dim, P = robo_theta_size(g->kind, D);
     for (int p = 0; p < P; ++p)
         if (!std::isfinite(theta[p])) {
             set_error("theta[%d] is not finite", p);
             return ROBO_BAD_ARGUMENT;
         }
+    const bool fab = g->kind == ROBO_KERNEL_FABOLAS;
+    const int n_metric = fab ? D - 1 : D;
+    for (int d = 0; d < n_metric; ++d) ism[d] = std::exp(-0.5 * theta[1 + d]);   // 1/sqrt(metric_d)
+    if (fab) ism[D - 1] = 1.0;   // the fidelity column enters the linear kernel unscaled
+    sp->cov.kind = g->kind;
+    sp->cov.dim = D;
+    sp->cov.amp = std::exp(theta[0]);
+    sp->cov.blr_a = fab ? std::exp(theta[D]) : 0.0;
+    sp->cov.blr_b = fab ? std::exp(theta[D + 1]) : 0.0;
+    sp->noise = std::exp(theta[P - 1]) + JITTER;
+    sp->mean_c = mean_c;
+    return ROBO_OK;
+}
+
+static FitBuffers own_buffers(robo_gp* g) {
+    FitBuffers fb;
+    fb.K = g->d_K; fb.k_stride = 0;
+    fb.Linv = g->d_Linv; fb.linv_stride = 0;
+    fb.Xs = g->d_Xs; fb.xs_stride = 0;
+    fb.sp = g->d_sp;
+    fb.fail = g->ctx->d_fail;
+    fb.out = g->ctx->d_scalars;
+    fb.S = 1;
+    return fb;
+}
+
+// stage theta, scale inputs, build the gram matrix into the GP's own buffers (asynchronous)
+static int gp_build_gram(robo_gp* g, const double* theta, double mean_c) {
+    robo_ctx* c = g->ctx;
+    const int D = g->dim;
     ROBO_HIP_CHECK(hipSetDevice(c->device));
     // the pinned staging buffer is reused by every fit: the previous upload must have landed
     ROBO_HIP_CHECK(hipStreamSynchronize(c->stream));
-    const bool fab = g->kind == ROBO_KERNEL_FABOLAS;
-    const int n_metric = fab ? D - 1 : D;
-    for (int d = 0; d < n_metric; ++d) g->h_theta[d] = std::exp(-0.5 * theta[1 + d]);   // 1/sqrt(metric_d)
-    if (fab) g->h_theta[D - 1] = 1.0;   // the fidelity column enters the linear kernel unscaled
-    g->amp = std::exp(theta[0]);
-    g->cov.kind = g->kind;
-    g->cov.dim = D;
-    g->cov.amp = g->amp;
-    g->cov.blr_a = fab ? std::exp(theta[D]) : 0.0;
-    g->cov.blr_b = fab ? std::exp(theta[D + 1]) : 0.0;
-    g->noise = std::exp(theta[P - 1]) + JITTER;
+    FitSample* hsp = reinterpret_cast<FitSample*>(g->h_theta + D + 8);
+    ROBO_TRY(theta_to_sample(g, theta, mean_c, hsp, g->h_theta));
+    g->cov = hsp->cov;
+    g->amp = hsp->cov.amp;
+    g->noise = hsp->noise;
     g->mean_c = mean_c;
-    ROBO_HIP_CHECK(hipMemcpyAsync(g->d_theta, g->h_theta, (size_t)D * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    ROBO_HIP_CHECK(hipMemcpyAsync(g->d_theta, g->h_theta, ((size_t)D + 8) * sizeof(double) + sizeof(FitSample),
+                                  hipMemcpyHostToDevice, c->stream));
     ROBO_TRY(launch_scale_inputs(c, g->d_X, g->d_Xs, g->d_theta, g->n, g->n_pad, D));
-    ROBO_TRY(launch_gram(g));
+    ROBO_TRY(launch_gram(g, own_buffers(g)));
     return ROBO_OK;
 }
 
@@ -245,9 +278,9 @@ int32_t robo_gp_fit(robo_gp* g, const double* theta, double mean_c, double* out_
     ROBO_HIP_CHECK(hipEventRecord(c->events[20], c->stream));
     ROBO_TRY(gp_build_gram(g, theta, mean_c));
     ROBO_HIP_CHECK(hipEventRecord(c->events[21], c->stream));
-    ROBO_TRY(launch_potrf(g));
+    ROBO_TRY(launch_potrf(g, own_buffers(g)));
     ROBO_HIP_CHECK(hipEventRecord(c->events[22], c->stream));
-    ROBO_TRY(launch_loglik(g));
+    ROBO_TRY(launch_loglik(g, own_buffers(g)));
     ROBO_HIP_CHECK(hipEventRecord(c->events[23], c->stream));
     double* hp = c->h_pinned;
     ROBO_HIP_CHECK(hipMemcpyAsync(hp, c->d_scalars, 2 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
@@ -269,16 +302,93 @@ int32_t robo_gp_fit(robo_gp* g, const double* theta, double mean_c, double* out_
     return ROBO_OK;
 }
 
+// grow the batch workspace to hold S samples at the current n_pad
+static int batch_ensure(robo_gp* g, int S) {
+    if (g->b_cap >= S && g->b_npad == g->n_pad) return ROBO_OK;
+    hipFree(g->d_bK); hipFree(g->d_bLinv); hipFree(g->d_bXs); hipFree(g->d_bism); hipFree(g->d_bout);
+    hipFree(g->d_bsp); hipFree(g->d_bfail);
+    if (g->h_bstage) hipHostFree(g->h_bstage);
+    g->d_bK = g->d_bLinv = g->d_bXs = g->d_bism = g->d_bout = g->h_bstage = nullptr;
+    g->d_bsp = nullptr; g->d_bfail = nullptr;
+    g->b_cap = 0;
+    const size_t np = (size_t)g->n_pad, D = (size_t)g->dim;
+    ROBO_TRY(dev_alloc(&g->d_bK, (size_t)S * np * np));
+    ROBO_TRY(dev_alloc(&g->d_bLinv, (size_t)S * np * NB));
+    ROBO_TRY(dev_alloc(&g->d_bXs, (size_t)S * np * D));
+    ROBO_TRY(dev_alloc(&g->d_bism, (size_t)S * D));
+    ROBO_TRY(dev_alloc(&g->d_bout, (size_t)S * 2));
+    ROBO_TRY(dev_alloc(&g->d_bsp, (size_t)S));
+    ROBO_TRY(dev_alloc(&g->d_bfail, (size_t)S));
+    // pinned staging: [S x FitSample | S x D ism] up, [S x 2 doubles | S ints] down
+    const size_t bytes = (size_t)S * (sizeof(FitSample) + D * sizeof(double) + 2 * sizeof(double) + sizeof(int)) + 64;
+    ROBO_HIP_CHECK(hipHostMalloc((void**)&g->h_bstage, bytes, 0));
+    g->b_cap = S;
+    g->b_npad = g->n_pad;
+    return ROBO_OK;
+}
+
 int32_t robo_gp_loglik_batch(robo_gp* g, const double* thetas, int32_t S, double mean_c, double* out_loglik,
                              int32_t* out_status) {
     if (!g || !thetas || S < 0 || !out_loglik) return ROBO_BAD_ARGUMENT;
-    const int P = robo_theta_size(g->kind, g->dim);
-    for (int s = 0; s < S; ++s) {
-        double ll = -HUGE_VAL;
-        const int st = robo_gp_fit(g, thetas + (size_t)s * P, mean_c, &ll, nullptr);
-        if (st == ROBO_RUNTIME_ERROR) return st;
-        out_loglik[s] = ll;
-        if (out_status) out_status[s] = st;
+    if (!g->has_data) {
+        set_error("robo_gp_loglik_batch before robo_gp_set_data");
+        return ROBO_NOT_FITTED;
+    }
+    if (S == 0) return ROBO_OK;
+    robo_ctx* c = g->ctx;
+    const int P = robo_theta_size(g->kind, g->dim), D = g->dim;
+    const size_t np = (size_t)g->n_pad;
+    ROBO_HIP_CHECK(hipSetDevice(c->device));
+    // bound the workspace: sub-batches of at most `chunk` samples (S * n_pad^2 doubles each)
+    size_t per = np * np * sizeof(double) + np * (NB + (size_t)D) * sizeof(double);
+    int chunk = (int)(workspace_bytes() / per);
+    if (chunk < 1) chunk = 1;
+    if (chunk > S) chunk = S;
+    ROBO_TRY(batch_ensure(g, chunk));
+    g->fitted = false;   // the GP's own factor is not touched, but the call documents "unfitted after"
+    for (int s0 = 0; s0 < S; s0 += chunk) {
+        const int ns = S - s0 < chunk ? S - s0 : chunk;
+        ROBO_HIP_CHECK(hipStreamSynchronize(c->stream));   // staging buffer reuse
+        FitSample* hsp = reinterpret_cast<FitSample*>(g->h_bstage);
+        double* hism = reinterpret_cast<double*>(hsp + chunk);
+        std::vector<int> bad(ns, ROBO_OK);
+        for (int s = 0; s < ns; ++s) {
+            const int st = theta_to_sample(g, thetas + (size_t)(s0 + s) * P, mean_c, hsp + s, hism + (size_t)s * D);
+            bad[s] = st;
+            if (st != ROBO_OK) {   // keep the slot numerically harmless: unit kernel
+                static const double zeros[MAX_DIM + 8] = {0};
+                theta_to_sample(g, zeros, mean_c, hsp + s, hism + (size_t)s * D);
+            }
+        }
+        ROBO_HIP_CHECK(hipMemcpyAsync(g->d_bsp, hsp, (size_t)ns * sizeof(FitSample), hipMemcpyHostToDevice, c->stream));
+        ROBO_HIP_CHECK(hipMemcpyAsync(g->d_bism, hism, (size_t)ns * D * sizeof(double), hipMemcpyHostToDevice, c->stream));
+        FitBuffers fb;
+        fb.K = g->d_bK; fb.k_stride = np * np;
+        fb.Linv = g->d_bLinv; fb.linv_stride = np * NB;
+        fb.Xs = g->d_bXs; fb.xs_stride = np * D;
+        fb.sp = g->d_bsp;
+        fb.fail = g->d_bfail;
+        fb.out = g->d_bout;
+        fb.S = ns;
+        ROBO_TRY(launch_scale_inputs(c, g->d_X, g->d_bXs, g->d_bism, g->n, g->n_pad, D, ns, np * D, (size_t)D));
+        ROBO_TRY(launch_gram(g, fb));
+        ROBO_TRY(launch_potrf(g, fb));
+        ROBO_TRY(launch_loglik(g, fb));
+        double* hout = hism + (size_t)chunk * D;
+        int* hfail = reinterpret_cast<int*>(hout + 2 * (size_t)chunk);
+        ROBO_HIP_CHECK(hipMemcpyAsync(hout, g->d_bout, (size_t)ns * 2 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+        ROBO_HIP_CHECK(hipMemcpyAsync(hfail, g->d_bfail, (size_t)ns * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+        ROBO_HIP_CHECK(hipStreamSynchronize(c->stream));
+        for (int s = 0; s < ns; ++s) {
+            int st = bad[s];
+            double ll = -HUGE_VAL;
+            if (st == ROBO_OK) {
+                if (hfail[s] != 0) st = ROBO_NOT_POSITIVE_DEFINITE;
+                else ll = -0.5 * (hout[2 * s] + hout[2 * s + 1] + (double)g->n * std::log(2.0 * M_PI));
+            }
+            out_loglik[s0 + s] = ll;
+            if (out_status) out_status[s0 + s] = st;
+        }
     }
     return ROBO_OK;
 }

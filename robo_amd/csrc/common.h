@@ -32,6 +32,16 @@ struct CovParams {
     double amp, blr_a, blr_b;
 };
 
+// per-theta inputs of one fit; the fit kernels take an array of these and index it with the
+// batch coordinate of the grid, so S hyper-parameter samples are factorised by ONE sequence of
+// launches (S x more workgroups per launch: the MCMC inner loop of the reference evaluates
+// n_hypers/2 independent likelihoods per ensemble half-step)
+struct FitSample {
+    CovParams cov;
+    double noise;    // exp(theta[P-1]) + JITTER, added to the diagonal
+    double mean_c;   // constant prior mean
+};
+
 void set_error(const char* fmt, ...);
 
 #define ROBO_HIP_CHECK(expr)                                                                       \
@@ -88,8 +98,14 @@ struct robo_gp {
     double* d_y;        // (n_max)
     double* d_K;        // (n_pad_max, n_pad_max) gram -> Cholesky factor in place (lower)
     double* d_Linv;     // (n_pad_max / NB) x NB x NB inverses of the diagonal blocks
-    double* d_theta;    // (dim + 2) + inverse sqrt metric (dim)
-    double* h_theta;    // host copy
+    double* d_theta;    // inverse sqrt metric (dim) of the current theta
+    double* h_theta;    // pinned staging: [FitSample | inverse sqrt metric (dim)]
+    robo::FitSample* d_sp;   // device copy of the current FitSample
+    // batch workspace for robo_gp_loglik_batch (lazy, b_cap samples)
+    int b_cap, b_npad;
+    double *d_bK, *d_bLinv, *d_bXs, *d_bism, *d_bout, *h_bstage;
+    robo::FitSample* d_bsp;
+    int* d_bfail;
 };
 
 struct robo_cand {
@@ -121,10 +137,21 @@ struct robo_cand {
 // ---- launchers implemented in the .hip files (all asynchronous on ctx->stream) ------------
 namespace robo {
 int launch_scale_inputs(robo_ctx* ctx, const double* d_in, double* d_out, const double* d_inv_sqrt_metric,
-                        int64_t rows_real, int64_t rows_pad, int dim);
-int launch_gram(robo_gp* gp);
-int launch_potrf(robo_gp* gp);
-int launch_loglik(robo_gp* gp);
+                        int64_t rows_real, int64_t rows_pad, int dim, int S = 1, size_t out_stride = 0,
+                        size_t ism_stride = 0);
+// the fit pipeline on S matrices at once (S = 1: the GP's own buffers)
+struct FitBuffers {
+    double* K; size_t k_stride;          // (n_pad x n_pad) per sample
+    double* Linv; size_t linv_stride;    // (n_pad/128 x 128 x 128) per sample
+    const double* Xs; size_t xs_stride;  // (n_pad x dim) per sample
+    const FitSample* sp;                 // [S]
+    int* fail;                           // [S]
+    double* out;                         // [S][2]: z.z, 2 sum log diag
+    int S;
+};
+int launch_gram(robo_gp* gp, const FitBuffers& fb);
+int launch_potrf(robo_gp* gp, const FitBuffers& fb);
+int launch_loglik(robo_gp* gp, const FitBuffers& fb);
 int launch_diag_timeline(robo_gp* gp, long long* d_stamps);
 int launch_cross_gram(robo_gp* gp, robo_cand* cand, int64_t c0, int64_t cn);
 int launch_trsm(robo_gp* gp, robo_cand* cand, int64_t c0, int64_t cn);

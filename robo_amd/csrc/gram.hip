@@ -22,7 +22,10 @@ constexpr int GLD = GT + 2; // LDS leading dimension (doubles)
 
 __global__ __launch_bounds__(256) void scale_inputs_kernel(const double* __restrict__ in, double* __restrict__ out,
                                                            const double* __restrict__ inv_sqrt_m, long long rows_real,
-                                                           long long rows_pad, int dim) {
+                                                           long long rows_pad, int dim, size_t out_stride,
+                                                           size_t ism_stride) {
+    out += (size_t)blockIdx.y * out_stride;          // batch coordinate: one scaling per theta
+    inv_sqrt_m += (size_t)blockIdx.y * ism_stride;
     const long long total = rows_pad * dim;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
          i += (long long)gridDim.x * blockDim.x) {
@@ -90,11 +93,16 @@ __device__ __forceinline__ void tri_tile(int t, int& bi, int& bj) {
 // (y - mean), the rest identity, so that one Cholesky also yields z = L^-1 (y - mean)
 // as row n of the factor (DESIGN.md "augmented row").
 template <class T, int KIND>
-__global__ __launch_bounds__(256) void gram_kernel(const double* __restrict__ Xs, const double* __restrict__ y,
-                                                   double* __restrict__ K, int n, int n_pad, CovParams cp,
-                                                   double noise, double mean_c) {
+__global__ __launch_bounds__(256) void gram_kernel(const double* __restrict__ Xs, size_t xs_stride,
+                                                   const double* __restrict__ y, double* __restrict__ K,
+                                                   size_t k_stride, int n, int n_pad,
+                                                   const FitSample* __restrict__ sp) {
     __shared__ double sI[GD * GLD];
     __shared__ double sJ[GD * GLD];
+    Xs += (size_t)blockIdx.y * xs_stride;
+    K += (size_t)blockIdx.y * k_stride;
+    const CovParams cp = sp[blockIdx.y].cov;
+    const double noise = sp[blockIdx.y].noise, mean_c = sp[blockIdx.y].mean_c;
     int bi, bj;
     tri_tile(blockIdx.x, bi, bj);
     const long long i0 = (long long)bi * GT, j0 = (long long)bj * GT;
@@ -157,13 +165,13 @@ __global__ __launch_bounds__(256) void cross_gram_kernel(const double* __restric
 }
 
 int launch_scale_inputs(robo_ctx* ctx, const double* d_in, double* d_out, const double* d_inv_sqrt_metric,
-                        int64_t rows_real, int64_t rows_pad, int dim) {
+                        int64_t rows_real, int64_t rows_pad, int dim, int S, size_t out_stride, size_t ism_stride) {
     const long long total = (long long)rows_pad * dim;
     int blocks = (int)((total + 255) / 256);
     if (blocks > 4096) blocks = 4096;
     if (blocks < 1) blocks = 1;
-    hipLaunchKernelGGL(scale_inputs_kernel, dim3(blocks), dim3(256), 0, ctx->stream, d_in, d_out, d_inv_sqrt_metric,
-                       (long long)rows_real, (long long)rows_pad, dim);
+    hipLaunchKernelGGL(scale_inputs_kernel, dim3(blocks, S), dim3(256), 0, ctx->stream, d_in, d_out,
+                       d_inv_sqrt_metric, (long long)rows_real, (long long)rows_pad, dim, out_stride, ism_stride);
     ROBO_LAUNCH_CHECK();
     return ROBO_OK;
 }
@@ -182,13 +190,12 @@ int launch_scale_inputs(robo_ctx* ctx, const double* d_in, double* d_out, const 
         }                                                                          \
     } while (0)
 
-int launch_gram(robo_gp* gp) {
+int launch_gram(robo_gp* gp, const FitBuffers& fb) {
     const int T = gp->n_pad / GT;
     const int tiles = T * (T + 1) / 2;
 #define ROBO_GRAM_CALL(TYPE, KIND)                                                                              \
-    hipLaunchKernelGGL((gram_kernel<TYPE, KIND>), dim3(tiles), dim3(256), 0, gp->ctx->stream,                   \
-                       (const double*)gp->d_Xs, (const double*)gp->d_y, gp->d_K, gp->n, gp->n_pad, gp->cov,     \
-                       gp->noise, gp->mean_c)
+    hipLaunchKernelGGL((gram_kernel<TYPE, KIND>), dim3(tiles, fb.S), dim3(256), 0, gp->ctx->stream, fb.Xs,      \
+                       fb.xs_stride, (const double*)gp->d_y, fb.K, fb.k_stride, gp->n, gp->n_pad, fb.sp)
     ROBO_DISPATCH_COV(gp->fp32_gram, gp->kind, ROBO_GRAM_CALL);
 #undef ROBO_GRAM_CALL
     ROBO_LAUNCH_CHECK();

@@ -238,15 +238,18 @@ __device__ __forceinline__ void diag128_factor_invert(double* sL, double* sW, do
     if (dbg && tid == 0) dbg[11] = clock64();
 }
 
-__global__ __launch_bounds__(256) void potrf_diag_kernel(double* __restrict__ K, int ld, int k, int n_real,
-                                                         double* __restrict__ Linv, int* __restrict__ fail,
-                                                         long long* __restrict__ dbg) {
+__global__ __launch_bounds__(256) void potrf_diag_kernel(double* __restrict__ K, size_t k_stride, int ld, int k,
+                                                         int n_real, double* __restrict__ Linv, size_t linv_stride,
+                                                         int* __restrict__ fail, long long* __restrict__ dbg) {
     __shared__ double sL[NBLK * BLK];
     __shared__ double sW[NBLK * BLK];
     __shared__ double sT[4 * SB * TLD];
     __shared__ double sRd[NB];
     __shared__ double sCol[2 * SB];
     const int tid = threadIdx.x;
+    K += (size_t)blockIdx.x * k_stride;           // batch coordinate
+    Linv += (size_t)blockIdx.x * linv_stride;
+    fail += blockIdx.x;
     double* Kd = K + ((size_t)k * NB) * ld + (size_t)k * NB;
     if (dbg && tid == 0) dbg[0] = clock64();
 
@@ -277,9 +280,11 @@ __global__ __launch_bounds__(256) void potrf_diag_kernel(double* __restrict__ K,
 // A_ik <- A_ik * W_k^T for the rows below the diagonal block of panel k, 32 rows per workgroup
 // (4x more workgroups than 128-row tiles: with <= 32 block rows the panel would otherwise
 // occupy an eighth of the chip for a full 512-MFMA-deep tile)
-__global__ __launch_bounds__(256) void potrf_panel_kernel(double* __restrict__ K, int ld, int k,
-                                                          const double* __restrict__ Linv) {
+__global__ __launch_bounds__(256) void potrf_panel_kernel(double* __restrict__ K, size_t k_stride, int ld, int k,
+                                                          const double* __restrict__ Linv, size_t linv_stride) {
     __shared__ double smem[gemm_smem_doubles<1>()];
+    K += (size_t)blockIdx.y * k_stride;
+    Linv += (size_t)blockIdx.y * linv_stride;
     const size_t row0 = (size_t)(k + 1) * NB + (size_t)blockIdx.x * 32;
     double* A = K + row0 * ld + (size_t)k * NB;
     const double* W = Linv + (size_t)k * NB * NB;
@@ -298,8 +303,9 @@ __global__ __launch_bounds__(256) void potrf_panel_kernel(double* __restrict__ K
 // (A two-level variant with 512-deep updates was measured slower: its strip updates put
 // <= 32 workgroups on the critical path.)
 template <int TM>
-__global__ __launch_bounds__(256) void potrf_syrk_kernel(double* __restrict__ K, int ld, int k) {
+__global__ __launch_bounds__(256) void potrf_syrk_kernel(double* __restrict__ K, size_t k_stride, int ld, int k) {
     __shared__ double smem[gemm_smem_doubles<TM>()];
+    K += (size_t)blockIdx.y * k_stride;
     constexpr int SPLIT = 4 / TM;                    // row sub-tiles per 128-row block
     int ii, jj;
     {
@@ -332,9 +338,11 @@ __global__ __launch_bounds__(256) void potrf_syrk_kernel(double* __restrict__ K,
 }
 
 // out[0] = z.z, out[1] = 2 sum_{i<n} log L_ii   (z = row n of the factor); fixed summation order
-__global__ __launch_bounds__(256) void loglik_kernel(const double* __restrict__ K, int ld, int n,
+__global__ __launch_bounds__(256) void loglik_kernel(const double* __restrict__ K, size_t k_stride, int ld, int n,
                                                      double* __restrict__ out) {
     __shared__ double sq[4], sl[4];
+    K += (size_t)blockIdx.x * k_stride;
+    out += 2 * blockIdx.x;
     double q = 0.0, l = 0.0;
     const double* z = K + (size_t)n * ld;
     for (int i = threadIdx.x; i < n; i += 256) {
@@ -357,24 +365,26 @@ __global__ __launch_bounds__(256) void loglik_kernel(const double* __restrict__ 
     }
 }
 
-int launch_potrf(robo_gp* gp) {
+int launch_potrf(robo_gp* gp, const FitBuffers& fb) {
     robo_ctx* ctx = gp->ctx;
-    const int ld = gp->n_pad, nb = gp->n_pad / NB;
-    ROBO_HIP_CHECK(hipMemsetAsync(ctx->d_fail, 0, sizeof(int), ctx->stream));
+    const int ld = gp->n_pad, nb = gp->n_pad / NB, S = fb.S;
+    ROBO_HIP_CHECK(hipMemsetAsync(fb.fail, 0, (size_t)S * sizeof(int), ctx->stream));
     for (int k = 0; k < nb; ++k) {
-        hipLaunchKernelGGL(potrf_diag_kernel, dim3(1), dim3(256), 0, ctx->stream, gp->d_K, ld, k, gp->n, gp->d_Linv,
-                           ctx->d_fail, (long long*)nullptr);
+        hipLaunchKernelGGL(potrf_diag_kernel, dim3(S), dim3(256), 0, ctx->stream, fb.K, fb.k_stride, ld, k, gp->n,
+                           fb.Linv, fb.linv_stride, fb.fail, (long long*)nullptr);
         const int rem = nb - k - 1;
         if (rem > 0) {
-            hipLaunchKernelGGL(potrf_panel_kernel, dim3(rem * 4), dim3(256), 0, ctx->stream, gp->d_K, ld, k,
-                               (const double*)gp->d_Linv);
+            hipLaunchKernelGGL(potrf_panel_kernel, dim3(rem * 4, S), dim3(256), 0, ctx->stream, fb.K, fb.k_stride, ld,
+                               k, (const double*)fb.Linv, fb.linv_stride);
             const int blocks = rem * (rem + 1) / 2;
-            // measured (N = 4096): 128-row tiles 43 us/step at 384..528 blocks, 64-row tiles slower
-            // (55 us: B panel re-read twice), 32-row tiles 16 us vs 21 us once blocks < 96
-            if (blocks >= 96)
-                hipLaunchKernelGGL(potrf_syrk_kernel<4>, dim3(blocks), dim3(256), 0, ctx->stream, gp->d_K, ld, k);
+            // measured (N = 4096, S = 1): 128-row tiles 43 us/step at 384..528 blocks, 64-row tiles
+            // slower (55 us: B panel re-read twice), 32-row tiles 16 us vs 21 us once blocks < 96
+            if (blocks * S >= 96)
+                hipLaunchKernelGGL(potrf_syrk_kernel<4>, dim3(blocks, S), dim3(256), 0, ctx->stream, fb.K, fb.k_stride,
+                                   ld, k);
             else
-                hipLaunchKernelGGL(potrf_syrk_kernel<1>, dim3(blocks * 4), dim3(256), 0, ctx->stream, gp->d_K, ld, k);
+                hipLaunchKernelGGL(potrf_syrk_kernel<1>, dim3(blocks * 4, S), dim3(256), 0, ctx->stream, fb.K,
+                                   fb.k_stride, ld, k);
         }
     }
     ROBO_LAUNCH_CHECK();
@@ -383,15 +393,15 @@ int launch_potrf(robo_gp* gp) {
 
 // one instrumented diagonal-block kernel on panel 0 of the current gram matrix
 int launch_diag_timeline(robo_gp* gp, long long* d_stamps) {
-    hipLaunchKernelGGL(potrf_diag_kernel, dim3(1), dim3(256), 0, gp->ctx->stream, gp->d_K, gp->n_pad, 0, gp->n,
-                       gp->d_Linv, gp->ctx->d_fail, d_stamps);
+    hipLaunchKernelGGL(potrf_diag_kernel, dim3(1), dim3(256), 0, gp->ctx->stream, gp->d_K, (size_t)0, gp->n_pad, 0,
+                       gp->n, gp->d_Linv, (size_t)0, gp->ctx->d_fail, d_stamps);
     ROBO_LAUNCH_CHECK();
     return ROBO_OK;
 }
 
-int launch_loglik(robo_gp* gp) {
-    hipLaunchKernelGGL(loglik_kernel, dim3(1), dim3(256), 0, gp->ctx->stream, (const double*)gp->d_K, gp->n_pad,
-                       gp->n, gp->ctx->d_scalars);
+int launch_loglik(robo_gp* gp, const FitBuffers& fb) {
+    hipLaunchKernelGGL(loglik_kernel, dim3(fb.S), dim3(256), 0, gp->ctx->stream, (const double*)fb.K, fb.k_stride,
+                       gp->n_pad, gp->n, fb.out);
     ROBO_LAUNCH_CHECK();
     return ROBO_OK;
 }

@@ -117,7 +117,7 @@ def check_mcmc_marginal(ctx):
     ll, st = gps[0].loglik_batch(inp["thetas"], float(np.mean(y)))
     assert np.all(st == _lib.OK)
     np.testing.assert_allclose(ll, gold["loglik_s"], rtol=LOGLIK_RTOL)
-    gps[0].fit(inp["thetas"][0], float(np.mean(y)))     # loglik_batch leaves the last theta fitted
+    gps[0].fit(inp["thetas"][0], float(np.mean(y)))     # loglik_batch leaves the GP unfitted
     cand = _lib.Candidates(ctx, Xcn)
     eta = float(y.min())
     for s, g in enumerate(gps):
@@ -337,3 +337,35 @@ def check_fp32_gram(ctx):
     np.testing.assert_allclose(mu, mo, rtol=MU_RTOL, atol=MU_ATOL)
     np.testing.assert_allclose(var, vo, rtol=0, atol=VAR_ATOL_REL_AMP)
     g.close()
+
+
+def check_batched_likelihoods(ctx, sizes=((60, 3), (300, 4))):
+    """robo_gp_loglik_batch (one batched pass over S thetas) == S sequential robo_gp_fit calls, bit for
+    bit, including a non-finite theta in the middle of the batch; and == the oracle."""
+    rs = np.random.RandomState(17)
+    for N, D in sizes:
+        X = rs.rand(N, D)
+        y = np.sin(3 * X.sum(axis=1))
+        base = np.concatenate([[0.0], np.full(D, np.log(0.3 * D)), [np.log(1e-2)]])
+        S = 7
+        thetas = base[None, :] + 0.4 * rs.randn(S, base.size)
+        thetas[3, 1] = np.nan
+        g = _lib.DeviceGP(ctx, "matern52", N, D)
+        g.set_data(X, y)
+        mean_c = float(y.mean())
+        seq = np.full(S, -np.inf)
+        for s in range(S):
+            if np.all(np.isfinite(thetas[s])):
+                seq[s] = g.fit(thetas[s], mean_c)
+        ll, st = g.loglik_batch(thetas, mean_c)
+        assert st[3] == _lib.BAD_ARGUMENT and ll[3] == -np.inf
+        ok = np.arange(S) != 3
+        assert np.all(st[ok] == _lib.OK)
+        np.testing.assert_array_equal(ll[ok], seq[ok])
+        ogp = O.OracleGP("matern52", thetas[0], normalize_input=False)
+        ogp.train(X, y)
+        np.testing.assert_allclose(ll[0], ogp.loglikelihood(thetas[0]), rtol=LOGLIK_RTOL)
+        import pytest
+        with pytest.raises(Exception, match="trained first"):
+            g.predict(X[:2])          # the batch call leaves the GP unfitted
+        g.close()

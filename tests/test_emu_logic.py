@@ -61,6 +61,10 @@ def test_uniform_generator(emu_ctx):
     P.check_uniform_generator(emu_ctx)
 
 
+def test_batched_likelihoods(emu_ctx):
+    P.check_batched_likelihoods(emu_ctx)
+
+
 def test_fabolas_kernel(emu_ctx):
     P.check_fabolas_kernel(emu_ctx)
 

@@ -64,6 +64,10 @@ def test_uniform_generator(ctx):
     P.check_uniform_generator(ctx)
 
 
+def test_batched_likelihoods(ctx):
+    P.check_batched_likelihoods(ctx, sizes=((60, 3), (300, 4), (1500, 8)))
+
+
 def test_fabolas_kernel(ctx):
     P.check_fabolas_kernel(ctx)
 
