@@ -155,7 +155,7 @@ def main():
         nb = (N + 127) // 128     # trsm_step_kernel launches per step (block rows holding training points)
         ms_per_step = elapsed / args.steps * 1e3
         value = world * M * args.steps / elapsed
-        # dominant kernel: trsm_step_kernel (nb launches per step).  Algorithmic flops of one
+        # dominant kernel: trsm_step_gen_kernel (nb launches per step; cross-gram tile generated in registers).  Algorithmic flops of one
         # step's launches: M * N^2 (the lower-triangular solve term of flops_ei);
         # per launch = M N^2 / nb; avg launch duration = trsm time / nb (HIP events on the
         # library's stream, slots 25->26).
@@ -187,7 +187,7 @@ def main():
             "gp_fit_batched": {"thetas": S_half, "ms_total": batch_ms, "ms_per_theta": batch_ms / S_half},
             "ei_eval_phases_ms_per_step": {"cross_gram": cross_ms / args.steps, "trsm": trsm_ms / args.steps},
             "argmax": list(best),
-            "roofline": {"bound": "mfma", "kernel": "trsm_step_kernel", "achieved": achieved,
+            "roofline": {"bound": "mfma", "kernel": "trsm_step_gen_kernel", "achieved": achieved,
                          "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / FP64_MFMA_PEAK_TFLOPS,
                          "traffic": traffic, "traffic_unit": "bytes per launch (PMC, profiles/trsm_traffic.json)",
                          "algorithmic_flops_per_launch": float(M) * N * N / nb, "launches_per_step": nb, "avg_launch_ms": trsm_avg_launch_ms,

@@ -28,6 +28,12 @@ static size_t workspace_bytes() {
     return (size_t)6 << 30;
 }
 
+// ROBO_PREDICT_STEPWISE=1 selects the step-wise (one launch per block row) posterior for A/B runs
+static bool stepwise_predict() {
+    const char* e = getenv("ROBO_PREDICT_STEPWISE");
+    return e && *e == '1';
+}
+
 template <class T>
 static int dev_alloc(T** p, size_t count) {
     ROBO_HIP_CHECK(hipMalloc((void**)p, (count ? count : 1) * sizeof(T)));
@@ -542,9 +548,15 @@ static int predict_core(robo_gp* g, robo_cand* k, bool single_chunk) {
     for (int64_t c0 = 0; c0 < k->m_pad; c0 += k->chunk) {
         const int64_t cn = k->m_pad - c0 < k->chunk ? k->m_pad - c0 : k->chunk;
         ROBO_HIP_CHECK(hipEventRecord(g->ctx->events[24], st));
-        ROBO_TRY(launch_cross_gram(g, k, c0, cn));
-        ROBO_HIP_CHECK(hipEventRecord(g->ctx->events[25], st));
-        ROBO_TRY(launch_trsm(g, k, c0, cn));
+        if (g->fp32_gram || stepwise_predict()) {
+            // mixed precision (fp32 covariance entries) keeps the two-pass form
+            ROBO_TRY(launch_cross_gram(g, k, c0, cn));
+            ROBO_HIP_CHECK(hipEventRecord(g->ctx->events[25], st));
+            ROBO_TRY(launch_trsm(g, k, c0, cn));
+        } else {
+            ROBO_HIP_CHECK(hipEventRecord(g->ctx->events[25], st));
+            ROBO_TRY(launch_predict_fused(g, k, c0, cn));
+        }
         ROBO_HIP_CHECK(hipEventRecord(g->ctx->events[26], st));
     }
     ROBO_TRY(launch_post(g, k, 0, k->m_pad));

@@ -155,6 +155,7 @@ int launch_loglik(robo_gp* gp, const FitBuffers& fb);
 int launch_diag_timeline(robo_gp* gp, long long* d_stamps);
 int launch_cross_gram(robo_gp* gp, robo_cand* cand, int64_t c0, int64_t cn);
 int launch_trsm(robo_gp* gp, robo_cand* cand, int64_t c0, int64_t cn);
+int launch_predict_fused(robo_gp* gp, robo_cand* cand, int64_t c0, int64_t cn);
 int launch_post(robo_gp* gp, robo_cand* cand, int64_t c0, int64_t cn);
 int launch_acq(robo_ctx* ctx, robo_cand* cand, int acq_kind, double par, double eta, bool accumulate, bool first);
 int launch_argmax(robo_cand* cand, const double* d_vals, double scale);

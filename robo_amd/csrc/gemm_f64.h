@@ -61,23 +61,37 @@ __device__ __forceinline__ int acc_col(int tn) {
 }
 
 // rows x 16 doubles of a row-major operand -> registers: thread t takes row t/2, half t%2
+// 64 bytes of one operand row in flight between global memory and LDS (plain scalars, passed by
+// value: as an array passed by reference the compiler kept it in scratch memory once the kernel
+// around the k-loop grew, r01k)
+struct Tile4 {
+    double2 a, b, c, d;
+};
+
 template <int ROWS>
-__device__ __forceinline__ void tile_load_regs(const double* __restrict__ G, int ld, int k0, double2 (&r)[4]) {
+__device__ __forceinline__ Tile4 tile_load_regs(const double* __restrict__ G, int ld, int k0) {
     const int row = threadIdx.x >> 1, kh = (threadIdx.x & 1) * 8;
+    Tile4 t;
+    if (ROWS != 128) t.a = t.b = t.c = t.d = make_double2(0.0, 0.0);   // rows beyond the tile: defined, unused
     if (ROWS == 128 || row < ROWS) {
         const double2* p = reinterpret_cast<const double2*>(G + (size_t)row * ld + k0 + kh);
-#pragma unroll
-        for (int i = 0; i < 4; ++i) r[i] = p[i];
+        t.a = p[0];
+        t.b = p[1];
+        t.c = p[2];
+        t.d = p[3];
     }
+    return t;
 }
 
 template <int ROWS>
-__device__ __forceinline__ void tile_store_lds(double* S, const double2 (&r)[4]) {
+__device__ __forceinline__ void tile_store_lds(double* S, const Tile4 t) {
     const int row = threadIdx.x >> 1, kh = (threadIdx.x & 1) * 8;
     if (ROWS == 128 || row < ROWS) {
         double2* p = reinterpret_cast<double2*>(S + row * LDS_LD + kh);
-#pragma unroll
-        for (int i = 0; i < 4; ++i) p[i] = r[i];
+        p[0] = t.a;
+        p[1] = t.b;
+        p[2] = t.c;
+        p[3] = t.d;
     }
 }
 
@@ -113,9 +127,8 @@ __device__ __forceinline__ void gemm_nt(const double* __restrict__ A, int lda, c
     constexpr int SA = stage_a<TM>(), ST = SA + STAGE_B;
     const int nk = (kend - kbeg) / BK;
     if (nk <= 0) return;
-    double2 ra[4], rb[4];
-    tile_load_regs<32 * TM>(A, lda, kbeg, ra);
-    tile_load_regs<128>(B, ldb, kbeg, rb);
+    Tile4 ra = tile_load_regs<32 * TM>(A, lda, kbeg);
+    Tile4 rb = tile_load_regs<128>(B, ldb, kbeg);
     tile_store_lds<32 * TM>(smem, ra);
     tile_store_lds<128>(smem + SA, rb);
     __syncthreads();
@@ -124,8 +137,8 @@ __device__ __forceinline__ void gemm_nt(const double* __restrict__ A, int lda, c
         double* nxt = smem + ((kt + 1) & 1) * ST;
         const bool more = kt + 1 < nk;
         if (more) {
-            tile_load_regs<32 * TM>(A, lda, kbeg + (kt + 1) * BK, ra);
-            tile_load_regs<128>(B, ldb, kbeg + (kt + 1) * BK, rb);
+            ra = tile_load_regs<32 * TM>(A, lda, kbeg + (kt + 1) * BK);
+            rb = tile_load_regs<128>(B, ldb, kbeg + (kt + 1) * BK);
         }
         tile_mfma<TM, NEG>(cur, cur + SA, acc);
         if (more) {

@@ -21,36 +21,12 @@
 
 namespace robo {
 
-__global__ __launch_bounds__(256) void trsm_step_kernel(double* __restrict__ V, int ldv, const double* __restrict__ L,
-                                                        int ld, const double* __restrict__ Linv, int i, int n,
-                                                        double* __restrict__ q, double* __restrict__ mu,
-                                                        long long c0) {
-    __shared__ double smem[GEMM_SMEM_DOUBLES];
-    double* Vrow = V + (size_t)blockIdx.x * NB * ldv;
-    double* Vt = Vrow + (size_t)i * NB;   // the tile being solved
-    Acc acc;
-    if (i > 0) {
-#pragma unroll
-        for (int tm = 0; tm < 4; ++tm)
-#pragma unroll
-            for (int tn = 0; tn < 4; ++tn)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) acc.t[tm][tn][r] = Vt[(size_t)acc_row(tm, r) * ldv + acc_col(tn)];
-        gemm_nt_128<true>(Vrow, ldv, L + (size_t)i * NB * ld, ld, 0, i * NB, acc, smem);
-#pragma unroll
-        for (int tm = 0; tm < 4; ++tm)
-#pragma unroll
-            for (int tn = 0; tn < 4; ++tn)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) Vt[(size_t)acc_row(tm, r) * ldv + acc_col(tn)] = acc.t[tm][tn][r];
-        __syncthreads();   // T visible to the whole workgroup (global memory, workgroup scope)
-    }
-    acc_zero(acc);
-    gemm_nt_128<false>(Vt, ldv, Linv + (size_t)i * NB * NB, NB, 0, NB, acc, smem);
-
-    // epilogue: store V_i (columns >= n zeroed: augmented row + padding), reduce |v|^2 and v.z
+// epilogue of a block-row step: store V_i (columns >= n zeroed: augmented row + padding), reduce
+// |v|^2 and v.z per candidate with wavefront shuffles in a fixed order, accumulate into q / mu
+__device__ __forceinline__ void trsm_epilogue(Acc& acc, double* __restrict__ Vt, int ldv,
+                                              const double* __restrict__ z, int i, int n, double* smem,
+                                              double* __restrict__ q, double* __restrict__ mu, long long c0) {
     const int lane = threadIdx.x & 63, wx = (threadIdx.x >> 6) & 1;
-    const double* z = L + (size_t)n * ld;
     double zc[4];
     bool live[4];
 #pragma unroll
@@ -97,6 +73,141 @@ __global__ __launch_bounds__(256) void trsm_step_kernel(double* __restrict__ V, 
     }
 }
 
+__global__ __launch_bounds__(256) void trsm_step_kernel(double* __restrict__ V, int ldv, const double* __restrict__ L,
+                                                        int ld, const double* __restrict__ Linv, int i, int n,
+                                                        double* __restrict__ q, double* __restrict__ mu,
+                                                        long long c0) {
+    __shared__ double smem[GEMM_SMEM_DOUBLES];
+    double* Vrow = V + (size_t)blockIdx.x * NB * ldv;
+    double* Vt = Vrow + (size_t)i * NB;   // the tile being solved
+    Acc acc;
+    if (i > 0) {
+#pragma unroll
+        for (int tm = 0; tm < 4; ++tm)
+#pragma unroll
+            for (int tn = 0; tn < 4; ++tn)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) acc.t[tm][tn][r] = Vt[(size_t)acc_row(tm, r) * ldv + acc_col(tn)];
+        gemm_nt_128<true>(Vrow, ldv, L + (size_t)i * NB * ld, ld, 0, i * NB, acc, smem);
+#pragma unroll
+        for (int tm = 0; tm < 4; ++tm)
+#pragma unroll
+            for (int tn = 0; tn < 4; ++tn)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) Vt[(size_t)acc_row(tm, r) * ldv + acc_col(tn)] = acc.t[tm][tn][r];
+        __syncthreads();   // T visible to the whole workgroup (global memory, workgroup scope)
+    }
+    acc_zero(acc);
+    gemm_nt_128<false>(Vt, ldv, Linv + (size_t)i * NB * NB, NB, 0, NB, acc, smem);
+
+    trsm_epilogue(acc, Vt, ldv, L + (size_t)n * ld, i, n, smem, q, mu, c0);
+}
+
+// ---- cross-gram tile in registers ----------------------------------------------------------
+// The tile K*_i (128 candidates x 128 training points) is generated straight into the
+// accumulator registers (C-layout) from LDS-staged coordinates instead of being written to and
+// re-read from HBM by a separate pass (4.6 % of the step at N = 4096, 2.2 GB written + read); its
+// fp64 VALU work (sqrt/exp) overlaps the other resident workgroup's MFMAs.
+template <int KIND>
+__device__ __forceinline__ void gen_cross_tile(const CovParams& cp, const double* __restrict__ Xc,
+                                               const double* __restrict__ Xt, int n_valid, double* smem, Acc& acc) {
+    // Xc: 128 scaled candidates (rows of the tile), Xt: 128 scaled training points (columns);
+    // columns >= n_valid are written as 0.  smem: [GD][GXL] for each operand.
+    constexpr int GD = 16, GXL = NB + 2;
+    double* sC = smem;
+    double* sX = smem + GD * GXL;
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6, wy = wave >> 1, wx = wave & 1, dim = cp.dim;
+    const bool fab = KIND == ROBO_KERNEL_FABOLAS;
+#pragma unroll
+    for (int tm = 0; tm < 4; ++tm)
+#pragma unroll
+        for (int tn = 0; tn < 4; ++tn) acc.t[tm][tn] = fab ? v4d{1.0, 1.0, 1.0, 1.0} : v4d{0.0, 0.0, 0.0, 0.0};
+    const int rbase = wy * 64 + (lane >> 4), cbase = wx * 64 + (lane & 15);
+    for (int d0 = 0; d0 < dim; d0 += GD) {
+        __syncthreads();   // previous chunk (or previous user of smem) fully consumed
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int idx = t + e * 256;          // 128 rows x 16 dims
+            const int row = idx >> 4, d = idx & 15;
+            const bool ok = d0 + d < dim;
+            sC[d * GXL + row] = ok ? Xc[(size_t)row * dim + d0 + d] : 0.0;
+            sX[d * GXL + row] = ok ? Xt[(size_t)row * dim + d0 + d] : 0.0;
+        }
+        __syncthreads();
+        const int dn = dim - d0 < GD ? dim - d0 : GD;
+        for (int d = 0; d < dn; ++d) {
+            if (fab && d0 + d == dim - 1) break;   // fidelity column: handled in the finish
+            double xj[4];
+#pragma unroll
+            for (int tn = 0; tn < 4; ++tn) xj[tn] = sX[d * GXL + cbase + tn * 16];
+#pragma unroll
+            for (int tm = 0; tm < 4; ++tm)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const double xi = sC[d * GXL + rbase + tm * 16 + 4 * r];
+#pragma unroll
+                    for (int tn = 0; tn < 4; ++tn) {
+                        const double df = xi - xj[tn];
+                        if (fab) acc.t[tm][tn][r] *= matern52_unit(df * df);
+                        else acc.t[tm][tn][r] = fma(df, df, acc.t[tm][tn][r]);
+                    }
+                }
+        }
+    }
+    // finish: covariance function of the accumulated distances; the last staged chunk still holds
+    // the fidelity column (dim - 1) for the Fabolas kernel
+    const int dl = (dim - 1) % GD;
+#pragma unroll
+    for (int tm = 0; tm < 4; ++tm)
+#pragma unroll
+        for (int tn = 0; tn < 4; ++tn) {
+            const int col = cbase + tn * 16;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                double uu = 0.0;
+                if (fab) uu = sC[dl * GXL + rbase + tm * 16 + 4 * r] * sX[dl * GXL + col];
+                const double v = cov_finish<double, KIND>(cp, acc.t[tm][tn][r], uu);
+                acc.t[tm][tn][r] = col < n_valid ? v : 0.0;
+            }
+        }
+    __syncthreads();   // smem free for the GEMM stages
+}
+
+// Step kernel with the cross-gram tile generated in registers: block row i of
+//     V = L^-1 K*^T   for 128 candidates per workgroup,
+// identical to trsm_step_kernel except that K*_i never exists in HBM.  One launch per block row
+// is kept on purpose: a fully fused (persistent, all block rows per workgroup) variant was
+// measured 2x SLOWER -- the launch boundary keeps the 512 workgroups in lock-step on the same
+// L block row, which is what makes L an L2 hit; free-running workgroups drift apart and stream L
+// from the Infinity Cache instead (r01k: 36 ms vs 18.4 ms per 65 536 candidates).
+template <int KIND>
+__global__ __launch_bounds__(256, 2) void trsm_step_gen_kernel(const double* __restrict__ Xcs,
+                                                               const double* __restrict__ Xs, double* __restrict__ V,
+                                                               int ldv, const double* __restrict__ L, int ld,
+                                                               const double* __restrict__ Linv, int i, int n,
+                                                               double* __restrict__ q, double* __restrict__ mu,
+                                                               long long c0, CovParams cp) {
+    __shared__ double smem[GEMM_SMEM_DOUBLES];
+    double* Vrow = V + (size_t)blockIdx.x * NB * ldv;
+    double* Vt = Vrow + (size_t)i * NB;
+    Acc acc;
+    gen_cross_tile<KIND>(cp, Xcs + (size_t)(c0 + (long long)blockIdx.x * NB) * cp.dim, Xs + (size_t)i * NB * cp.dim,
+                         n - i * NB, smem, acc);
+    if (i > 0) {
+        gemm_nt<4, true>(Vrow, ldv, L + (size_t)i * NB * ld, ld, 0, i * NB, acc, smem);
+    }
+#pragma unroll
+    for (int tm = 0; tm < 4; ++tm)
+#pragma unroll
+        for (int tn = 0; tn < 4; ++tn)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) Vt[(size_t)acc_row(tm, r) * ldv + acc_col(tn)] = acc.t[tm][tn][r];
+    __syncthreads();   // T visible to the whole workgroup (global memory, workgroup scope)
+    acc_zero(acc);
+    gemm_nt<4, false>(Vt, ldv, Linv + (size_t)i * NB * NB, NB, 0, NB, acc, smem);
+    trsm_epilogue(acc, Vt, ldv, L + (size_t)n * ld, i, n, smem, q, mu, c0);
+}
+
 // mean/var from the reductions, with the reference's output transform and variance floor
 // (robo/models/gaussian_process.py:282-294)
 __global__ __launch_bounds__(256) void post_kernel(const double* __restrict__ q, const double* __restrict__ mu,
@@ -116,14 +227,14 @@ __global__ __launch_bounds__(256) void post_kernel(const double* __restrict__ q,
 }
 
 // cov[c][c'] = (k(x_c, x_c') - v_c . v_c') * y_std^2   for c, c' < m  (small m)
-__global__ __launch_bounds__(256) void cov_kernel(const double* __restrict__ V, int ldv,
+__global__ __launch_bounds__(256) void cov_kernel(const double* __restrict__ V, int ldv, int kend,
                                                   const double* __restrict__ Xcs, CovParams cp, double y_std,
                                                   long long m, double* __restrict__ cov) {
     __shared__ double smem[GEMM_SMEM_DOUBLES];
     const long long r0 = (long long)blockIdx.y * NB, q0 = (long long)blockIdx.x * NB;
     Acc acc;
     acc_zero(acc);
-    gemm_nt_128<false>(V + (size_t)r0 * ldv, ldv, V + (size_t)q0 * ldv, ldv, 0, ldv, acc, smem);
+    gemm_nt_128<false>(V + (size_t)r0 * ldv, ldv, V + (size_t)q0 * ldv, ldv, 0, kend, acc, smem);
 #pragma unroll
     for (int tm = 0; tm < 4; ++tm)
 #pragma unroll
@@ -151,6 +262,25 @@ int launch_trsm(robo_gp* gp, robo_cand* cand, int64_t c0, int64_t cn) {
     return ROBO_OK;
 }
 
+// block-row steps with the cross-gram tile generated in registers (fp64 covariance entries)
+int launch_predict_fused(robo_gp* gp, robo_cand* cand, int64_t c0, int64_t cn) {
+    const int nbk = (gp->n + NB - 1) / NB;
+    const dim3 grid((unsigned)(cn / NB));
+#define ROBO_STEP_CALL(KIND)                                                                                   \
+    hipLaunchKernelGGL(trsm_step_gen_kernel<KIND>, grid, dim3(256), 0, gp->ctx->stream,                        \
+                       (const double*)cand->d_Xcs, (const double*)gp->d_Xs, cand->d_V, gp->n_pad,             \
+                       (const double*)gp->d_K, gp->n_pad, (const double*)gp->d_Linv, i, gp->n, cand->d_q,      \
+                       cand->d_mu, (long long)c0, gp->cov)
+    for (int i = 0; i < nbk; ++i) {
+        if (gp->kind == ROBO_KERNEL_MATERN52_ARD) ROBO_STEP_CALL(ROBO_KERNEL_MATERN52_ARD);
+        else if (gp->kind == ROBO_KERNEL_RBF_ARD) ROBO_STEP_CALL(ROBO_KERNEL_RBF_ARD);
+        else ROBO_STEP_CALL(ROBO_KERNEL_FABOLAS);
+    }
+#undef ROBO_STEP_CALL
+    ROBO_LAUNCH_CHECK();
+    return ROBO_OK;
+}
+
 int launch_post(robo_gp* gp, robo_cand* cand, int64_t c0, int64_t cn) {
     hipLaunchKernelGGL(post_kernel, dim3((unsigned)((cn + 255) / 256)), dim3(256), 0, gp->ctx->stream,
                        (const double*)cand->d_q, (const double*)cand->d_mu, (const double*)cand->d_Xcs, cand->d_mean,
@@ -161,8 +291,9 @@ int launch_post(robo_gp* gp, robo_cand* cand, int64_t c0, int64_t cn) {
 
 int launch_cov(robo_gp* gp, robo_cand* cand, double* d_cov) {
     const unsigned t = (unsigned)(cand->m_pad / NB);
+    // only the block rows that were solved hold data (the fused kernel never touches the rest)
     hipLaunchKernelGGL(cov_kernel, dim3(t, t), dim3(256), 0, gp->ctx->stream, (const double*)cand->d_V, gp->n_pad,
-                       (const double*)cand->d_Xcs, gp->cov, gp->y_std, (long long)cand->m, d_cov);
+                       (gp->n + NB - 1) / NB * NB, (const double*)cand->d_Xcs, gp->cov, gp->y_std, (long long)cand->m, d_cov);
     ROBO_LAUNCH_CHECK();
     return ROBO_OK;
 }
