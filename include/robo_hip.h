@@ -117,7 +117,13 @@ int32_t robo_cand_create(robo_ctx* ctx, const double* Xc, int64_t m, int32_t dim
 int32_t robo_cand_destroy(robo_cand* cand);
 /* device-side generation, no H2D: uniform [0,1)^dim, counter-based (Philox-4x32-10)         */
 int32_t robo_cand_create_uniform(robo_ctx* ctx, int64_t m, int32_t dim, uint64_t seed, robo_cand** out);
+/* RandomSampling.maximize's candidate recipe on the device (random_sampling.py:38-47), in the
+ * normalised space: rows < n_uniform uniform, the rest N(loc, scale) clipped to [0,1]
+ * (loc = normalised incumbent, scale_d = 0.1 / (upper_d - lower_d)).                           */
+int32_t robo_cand_create_random(robo_ctx* ctx, int64_t m, int32_t dim, uint64_t seed, int64_t n_uniform,
+                                const double* loc, const double* scale, robo_cand** out);
 int32_t robo_cand_get_points(robo_cand* cand, double* out_Xc);
+int32_t robo_cand_get_point(robo_cand* cand, int64_t index, double* out_x); /* one row: the winner */
 
 /* ---- posterior: replaces george.GP.predict (gaussian_process.py:280-294) ------------ */
 /* mean (m,), var (m,): diagonal only; var floored at DBL_EPSILON after the output

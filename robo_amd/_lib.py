@@ -30,6 +30,7 @@ SYMBOLS = [
     "robo_gp_set_precision", "robo_theta_size",
     "robo_gp_fit", "robo_gp_loglik_batch", "robo_gp_get_factor", "robo_gp_get_gram",
     "robo_cand_create", "robo_cand_destroy", "robo_cand_create_uniform", "robo_cand_get_points",
+    "robo_cand_create_random", "robo_cand_get_point",
     "robo_gp_predict_cand", "robo_gp_predict", "robo_gp_predict_cov", "robo_gp_predict_mixture_cand",
     "robo_acq_eval_cand", "robo_acq_eval", "robo_acq_eval_moments", "robo_acq_eval_marginal_cand", "robo_acq_eval_sum_cand",
     "robo_selftest_mfma_layout", "robo_microbench_mfma_f64", "robo_microbench_mfma_f64_detail",
@@ -110,6 +111,8 @@ def lib():
         "robo_cand_destroy": [vp],
         "robo_cand_create_uniform": [vp, i64, i32, C.c_uint64, pp],
         "robo_cand_get_points": [vp, _dp],
+        "robo_cand_create_random": [vp, i64, i32, C.c_uint64, i64, _dp, _dp, pp],
+        "robo_cand_get_point": [vp, i64, _dp],
         "robo_gp_predict_cand": [vp, vp, _dp, _dp],
         "robo_gp_predict": [vp, _dp, i64, _dp, _dp],
         "robo_gp_predict_cov": [vp, _dp, i64, _dp, _dp],
@@ -236,10 +239,17 @@ def default_context(device=None):
 class Candidates(object):
     """robo_cand: a device-resident candidate batch (normalised input space) + workspace."""
 
-    def __init__(self, ctx, Xc=None, m=None, dim=None, seed=None):
+    def __init__(self, ctx, Xc=None, m=None, dim=None, seed=None, n_uniform=None, loc=None, scale=None):
         self.ctx = ctx
         self._h = C.c_void_p()
-        if Xc is not None:
+        if loc is not None:
+            loc, scale = _f64(loc), _f64(scale)
+            self.m, self.dim = int(m), int(loc.shape[0])
+            assert scale.shape == loc.shape
+            check(lib().robo_cand_create_random(ctx._h, self.m, self.dim, int(seed or 0),
+                                                self.m if n_uniform is None else int(n_uniform), _arr(loc),
+                                                _arr(scale), C.byref(self._h)))
+        elif Xc is not None:
             Xc = _f64(Xc)
             assert Xc.ndim == 2
             self.m, self.dim = Xc.shape
@@ -247,6 +257,11 @@ class Candidates(object):
         else:
             self.m, self.dim = int(m), int(dim)
             check(lib().robo_cand_create_uniform(ctx._h, self.m, self.dim, int(seed or 0), C.byref(self._h)))
+
+    def point(self, index):
+        out = np.empty(self.dim)
+        check(lib().robo_cand_get_point(self._h, int(index), _arr(out)))
+        return out
 
     def points(self):
         out = np.empty((self.m, self.dim))

@@ -205,6 +205,59 @@ __global__ __launch_bounds__(256) void uniform_kernel(double* __restrict__ out, 
     (void)m;
 }
 
+// RandomSampling's candidate recipe generated on the device, in the GP's normalised input space
+// (robo/maximizers/random_sampling.py:38-47): rows < n_uniform uniform in [0,1)^dim, the rest
+// N(loc, scale) clipped to [0,1] (loc = normalised incumbent, scale = 0.1 / (upper - lower): the
+// reference's absolute sigma of 0.1 in raw units).  Box-Muller on the Philox stream.
+__global__ __launch_bounds__(256) void random_candidates_kernel(double* __restrict__ out, long long m_pad, int dim,
+                                                                unsigned long long seed, long long n_uniform,
+                                                                const double* __restrict__ loc,
+                                                                const double* __restrict__ scale) {
+    const long long total = m_pad * dim;
+    for (long long p = (long long)blockIdx.x * blockDim.x + threadIdx.x; p * 2 < total;
+         p += (long long)gridDim.x * blockDim.x) {
+        unsigned c[4] = {(unsigned)p, (unsigned)(p >> 32), 0x52425321u, 0u};
+        unsigned k0 = (unsigned)seed, k1 = (unsigned)(seed >> 32);
+#pragma unroll
+        for (int r = 0; r < 10; ++r) {
+            philox_round(c, k0, k1);
+            k0 += 0x9E3779B9u;
+            k1 += 0xBB67AE85u;
+        }
+        const unsigned long long a = ((unsigned long long)c[0] << 32 | c[1]) >> 11;
+        const unsigned long long b = ((unsigned long long)c[2] << 32 | c[3]) >> 11;
+        const double ua = (double)a * (1.0 / 9007199254740992.0), ub = (double)b * (1.0 / 9007199254740992.0);
+        // one Box-Muller pair from (ua, ub): used for elements that fall in the local cloud
+        const double rad = sqrt(-2.0 * log(1.0 - ua)), ang = 6.283185307179586476925 * ub;
+        const double g0 = rad * cos(ang), g1 = rad * sin(ang);
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const long long e = p * 2 + h;
+            if (e >= total) break;
+            const long long row = e / dim;
+            const int d = (int)(e - row * dim);
+            double v = h == 0 ? ua : ub;
+            if (row >= n_uniform) {
+                v = loc[d] + scale[d] * (h == 0 ? g0 : g1);
+                v = v < 0.0 ? 0.0 : (v > 1.0 ? 1.0 : v);
+            }
+            out[e] = v;
+        }
+    }
+}
+
+int launch_random_candidates(robo_ctx* ctx, double* d_out, int64_t m_pad, int dim, uint64_t seed, int64_t n_uniform,
+                             const double* d_loc, const double* d_scale) {
+    const long long pairs = ((long long)m_pad * dim + 1) / 2;
+    int blocks = (int)((pairs + 255) / 256);
+    if (blocks > 8192) blocks = 8192;
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(random_candidates_kernel, dim3(blocks), dim3(256), 0, ctx->stream, d_out, (long long)m_pad,
+                       dim, (unsigned long long)seed, (long long)n_uniform, d_loc, d_scale);
+    ROBO_LAUNCH_CHECK();
+    return ROBO_OK;
+}
+
 int launch_acq(robo_ctx* ctx, robo_cand* cand, int acq_kind, double par, double eta, bool accumulate, bool first) {
     const int blocks = (int)((cand->m + 255) / 256);
     const int mode = accumulate ? (first ? 1 : 2) : 0;

@@ -478,6 +478,32 @@ int32_t robo_cand_create_uniform(robo_ctx* ctx, int64_t m, int32_t dim, uint64_t
     return ROBO_OK;
 }
 
+int32_t robo_cand_create_random(robo_ctx* ctx, int64_t m, int32_t dim, uint64_t seed, int64_t n_uniform,
+                                const double* loc, const double* scale, robo_cand** out) {
+    if (!loc || !scale || n_uniform < 0 || n_uniform > m) return ROBO_BAD_ARGUMENT;
+    robo_cand* k = nullptr;
+    ROBO_TRY(cand_alloc(ctx, m, dim, &k));
+    // loc/scale ride in the (still unused) scaled-candidate buffer
+    ROBO_HIP_CHECK(hipMemcpyAsync(k->d_Xcs, loc, (size_t)dim * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    ROBO_HIP_CHECK(hipMemcpyAsync(k->d_Xcs + dim, scale, (size_t)dim * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    ROBO_TRY(launch_random_candidates(ctx, k->d_Xc, k->m_pad, dim, seed, n_uniform, k->d_Xcs, k->d_Xcs + dim));
+    ROBO_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    *out = k;
+    return ROBO_OK;
+}
+
+int32_t robo_cand_get_point(robo_cand* k, int64_t index, double* out_x) {
+    if (!k || !out_x) return ROBO_BAD_ARGUMENT;
+    if (index < 0 || index >= k->m) {
+        set_error("candidate index %lld outside [0, %lld)", (long long)index, (long long)k->m);
+        return ROBO_BAD_SHAPE;
+    }
+    ROBO_HIP_CHECK(hipMemcpyAsync(out_x, k->d_Xc + (size_t)index * k->dim, (size_t)k->dim * sizeof(double),
+                                  hipMemcpyDeviceToHost, k->ctx->stream));
+    ROBO_HIP_CHECK(hipStreamSynchronize(k->ctx->stream));
+    return ROBO_OK;
+}
+
 int32_t robo_cand_get_points(robo_cand* k, double* out_Xc) {
     if (!k || !out_Xc) return ROBO_BAD_ARGUMENT;
     ROBO_HIP_CHECK(hipMemcpyAsync(out_Xc, k->d_Xc, (size_t)k->m * k->dim * sizeof(double), hipMemcpyDeviceToHost,

@@ -161,6 +161,8 @@ int launch_acq(robo_ctx* ctx, robo_cand* cand, int acq_kind, double par, double 
 int launch_argmax(robo_cand* cand, const double* d_vals, double scale);
 int launch_cov(robo_gp* gp, robo_cand* cand, double* d_cov);
 int launch_mixture(robo_cand* cand, int S);
+int launch_random_candidates(robo_ctx* ctx, double* d_out, int64_t m_pad, int dim, uint64_t seed, int64_t n_uniform,
+                             const double* d_loc, const double* d_scale);
 int launch_uniform(robo_ctx* ctx, double* d_out, int64_t m, int64_t m_pad, int dim, uint64_t seed);
 int launch_mfma_selftest(robo_ctx* ctx, double* out_err);
 int launch_mfma_microbench(robo_ctx* ctx, int iters, double* out_tflops, double* out_cycles_per_mfma,

@@ -20,7 +20,7 @@ import numpy as np
 from robo_amd.acquisition_functions import EI, LCB, PI, LogEI, MarginalizationGPMCMC
 from robo_amd.initial_design import init_latin_hypercube_sampling
 from robo_amd.kernels import Matern52Kernel
-from robo_amd.maximizers import RandomSampling
+from robo_amd.maximizers import DeviceRandomSampling, RandomSampling
 from robo_amd.models import GaussianProcess, GaussianProcessMCMC
 from robo_amd.priors import DefaultPrior
 from robo_amd.solver import BayesianOptimization
@@ -69,9 +69,12 @@ def bayesian_optimization(objective_function, lower, upper, num_iterations=30, X
 
     if maximizer == "random":
         max_func = RandomSampling(acq, lower, upper, n_samples=n_candidates, rng=rng)
+    elif maximizer == "device_random":
+        # same recipe, candidates generated and scored on the device, only x* comes back
+        max_func = DeviceRandomSampling(acq, lower, upper, n_samples=n_candidates, rng=rng)
     else:
         raise ValueError("'{}' is not a valid function to maximize the acquisition function "
-                         "(robo_amd provides 'random')".format(maximizer))
+                         "(robo_amd provides 'random' and 'device_random')".format(maximizer))
 
     bo = BayesianOptimization(objective_function, lower, upper, acq, model, max_func, initial_points=n_init, rng=rng,
                               initial_design=init_latin_hypercube_sampling, output_path=output_path)

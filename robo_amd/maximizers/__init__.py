@@ -1,1 +1,1 @@
-from robo_amd.maximizers.random_sampling import BaseMaximizer, RandomSampling  # noqa: F401
+from robo_amd.maximizers.random_sampling import BaseMaximizer, DeviceRandomSampling, RandomSampling  # noqa: F401

@@ -50,3 +50,39 @@ class RandomSampling(BaseMaximizer):
             return X[self.objective_func.argmax(X)]
         y = self.objective_func(X)
         return X[y.argmax()]
+
+
+class DeviceRandomSampling(BaseMaximizer):
+    """Large-M variant of :class:`RandomSampling` whose candidates never exist on the host.
+
+    Same recipe (70 % uniform over the box, 30 % N(incumbent, 0.1) clipped,
+    robo/maximizers/random_sampling.py:38-47) generated ON THE DEVICE with a counter-based
+    generator, evaluated by one fused acquisition call, and only the winning row is copied back
+    (SURVEY.md section 8f rank 2).  Needs a robo_amd model (GaussianProcess or a
+    MarginalizationGPMCMC over them) because the candidates live in the model's normalised input
+    space; the random stream is Philox, so the sequence differs from the reference's NumPy one.
+    """
+
+    def __init__(self, objective_function, lower, upper, n_samples=65536, rng=None):
+        super(DeviceRandomSampling, self).__init__(objective_function, lower, upper, rng)
+        self.n_samples = int(n_samples)
+
+    def maximize(self):
+        from robo_amd import _lib
+        acq = self.objective_func
+        model = acq.model
+        sub = model.models[0] if hasattr(model, "models") and len(model.models) > 0 else model
+        if not getattr(sub, "normalize_input", False) or not hasattr(sub, "gp"):
+            raise TypeError("DeviceRandomSampling needs a robo_amd GP model with normalize_input=True")
+        lower, upper = np.asarray(sub.lower, dtype=np.float64), np.asarray(sub.upper, dtype=np.float64)
+        inc = np.asarray(model.get_incumbent()[0], dtype=np.float64)
+        loc = (inc - lower) / (upper - lower)
+        scale = 0.1 / (upper - lower)
+        seed = int(self.rng.randint(0, 2 ** 31 - 1))
+        cand = _lib.Candidates(sub.gp.ctx, m=self.n_samples, seed=seed, n_uniform=int(self.n_samples * .7), loc=loc,
+                               scale=scale)
+        try:
+            best = acq.argmax(cand)
+            return lower + (upper - lower) * cand.point(best)
+        finally:
+            cand.close()

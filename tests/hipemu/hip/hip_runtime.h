@@ -194,7 +194,7 @@ static inline double rsqrt(double x) { return 1.0 / std::sqrt(x); }
 double erfcx(double x);
 using std::erfc; using std::erf; using std::exp; using std::log; using std::log1p; using std::sqrt;
 using std::fabs; using std::fma; using std::isnan; using std::isinf; using std::fmax; using std::fmin;
-using std::isfinite;
+using std::isfinite; using std::cos; using std::sin;
 
 // ---- atomics (single-threaded fibers: plain RMW) --------------------------------------
 template <class T> static inline T atomicAdd(T* p, T v) { T o = *p; *p = o + v; return o; }

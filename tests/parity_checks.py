@@ -369,3 +369,20 @@ def check_batched_likelihoods(ctx, sizes=((60, 3), (300, 4))):
         with pytest.raises(Exception, match="trained first"):
             g.predict(X[:2])          # the batch call leaves the GP unfitted
         g.close()
+
+
+def check_device_random_candidates(ctx):
+    """device-generated RandomSampling recipe: bounds, split, moments; winner row read-back"""
+    loc = np.array([0.2, 0.9, 0.5])
+    scale = np.array([0.1, 0.05, 0.02])
+    m, nu = 20000, 14000
+    c = _lib.Candidates(ctx, m=m, seed=5, n_uniform=nu, loc=loc, scale=scale)
+    P_ = c.points()
+    assert P_.shape == (m, 3) and P_.min() >= 0.0 and P_.max() <= 1.0
+    U, G = P_[:nu], P_[nu:]
+    assert abs(U.mean() - 0.5) < 0.01 and abs(U.var() - 1 / 12.0) < 0.005
+    assert np.all(np.abs(G[:, 2].mean() - 0.5) < 0.002) and abs(G[:, 2].std() - 0.02) < 0.002
+    assert abs(G[:, 0].mean() - 0.2) < 0.01                   # mildly clipped at 0
+    assert (G[:, 1] == 1.0).mean() > 0.01                     # clipping at the upper bound happens
+    np.testing.assert_array_equal(c.point(nu + 7), P_[nu + 7])
+    np.testing.assert_array_equal(_lib.Candidates(ctx, m=m, seed=5, n_uniform=nu, loc=loc, scale=scale).points(), P_)

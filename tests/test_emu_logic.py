@@ -65,6 +65,10 @@ def test_batched_likelihoods(emu_ctx):
     P.check_batched_likelihoods(emu_ctx)
 
 
+def test_device_random_candidates(emu_ctx):
+    P.check_device_random_candidates(emu_ctx)
+
+
 def test_fabolas_kernel(emu_ctx):
     P.check_fabolas_kernel(emu_ctx)
 

@@ -68,6 +68,10 @@ def test_batched_likelihoods(ctx):
     P.check_batched_likelihoods(ctx, sizes=((60, 3), (300, 4), (1500, 8)))
 
 
+def test_device_random_candidates(ctx):
+    P.check_device_random_candidates(ctx)
+
+
 def test_fabolas_kernel(ctx):
     P.check_fabolas_kernel(ctx)
 
@@ -274,6 +278,14 @@ def test_host_classes_on_gpu(ctx):
                               n_candidates=20000)
     assert r["f_opt"] < 5.0 and len(r["X"]) == 25           # global minimum 0.3979; smoke-level bound
     assert np.all(np.diff(r["incumbent_values"]) <= 0)
+    r = bayesian_optimization(branin, np.array([-5., 0.]), np.array([10., 15.]), num_iterations=20,
+                              model_type="gp", acquisition_func="ei", rng=np.random.RandomState(1),
+                              maximizer="device_random", n_candidates=2 ** 18)
+    assert r["f_opt"] < 5.0 and np.all(np.array(r["X"]) >= [-5, 0]) and np.all(np.array(r["X"]) <= [10, 15])
+    r = bayesian_optimization(branin, np.array([-5., 0.]), np.array([10., 15.]), num_iterations=8,
+                              model_type="gp_mcmc", acquisition_func="log_ei", rng=np.random.RandomState(1),
+                              chain_length=20, burnin_steps=20, maximizer="device_random", n_candidates=4096)
+    assert np.all(np.array(r["x_opt"]) >= [-5, 0]) and np.all(np.array(r["x_opt"]) <= [10, 15])
     r = bayesian_optimization(branin, np.array([-5., 0.]), np.array([10., 15.]), num_iterations=8,
                               model_type="gp_mcmc", acquisition_func="log_ei", rng=np.random.RandomState(1),
                               chain_length=20, burnin_steps=20)
