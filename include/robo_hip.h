@@ -162,6 +162,27 @@ int32_t robo_acq_eval_marginal_cand(robo_gp* const* gps, int32_t S, int32_t acq_
 int32_t robo_acq_eval_sum_cand(robo_gp* const* gps, int32_t S, int32_t acq_kind, double par, double eta,
                                robo_cand* cand, double* out_acq_sum, uint32_t* out_flags);
 
+/* ---- entropy search: replaces InformationGain.innovations/_dh_fun/compute ---------------
+ * (robo/acquisition_functions/information_gain.py:87-125,169-203,253-272), batched over candidates.
+ * rep: the Nb <= 64 representer points as a candidate batch (same normalised space).  The EP
+ * state (log p_min and its derivatives, robo/util/epmgp.py:11-81) is host input:
+ *   logP (Nb), lmb (Nb) log proposal values, W (Np <= 512) standard-normal quantiles,
+ *   dlogPdMu (Nb,Nb), dlogPdSigma (Nb, Nb(Nb+1)/2) lower-triangle packed, dlogPdMudMu (Nb,Nb,Nb).
+ * sn2 = model noise (get_noise()).  out_dh (m,) may be NULL; argmax as robo_acq_eval.         */
+int32_t robo_ig_eval_cand(robo_gp* gp, robo_cand* cand, robo_cand* rep, int32_t n_outcomes, double sn2,
+                          const double* logP, const double* lmb, const double* W, const double* dlogPdMu,
+                          const double* dlogPdSigma, const double* dlogPdMudMu, double* out_dh, double* out_max,
+                          int64_t* out_argmax);
+/* the same from innovations inputs supplied by any other model: s (m, nb) covariances between each
+ * candidate and the representer points, v (m,) predictive variances                              */
+int32_t robo_ig_eval_moments(robo_ctx* ctx, int64_t m, int32_t nb, int32_t n_outcomes, double sn2, const double* s,
+                             const double* v, const double* logP, const double* lmb, const double* W,
+                             const double* dlogPdMu, const double* dlogPdSigma, const double* dlogPdMudMu,
+                             double* out_dh);
+/* posterior covariances cov(x_c, z_b) (m, nref <= 64), floored at DBL_EPSILON like the reference's
+ * predict(full_cov=True) -> predict_variance path (gaussian_process.py:243-246,290-294)            */
+int32_t robo_gp_cross_cov(robo_gp* gp, robo_cand* cand, robo_cand* ref, double* out_cov);
+
 /* ---- self tests / micro benchmarks (used by tests and bench.py, not by the product) --- */
 /* runs one v_mfma_f64_16x16x4_f64 with asymmetric operands, returns max |D - A*B|          */
 int32_t robo_selftest_mfma_layout(robo_ctx* ctx, double* out_max_err);

@@ -33,6 +33,7 @@ SYMBOLS = [
     "robo_cand_create_random", "robo_cand_get_point",
     "robo_gp_predict_cand", "robo_gp_predict", "robo_gp_predict_cov", "robo_gp_predict_mixture_cand",
     "robo_acq_eval_cand", "robo_acq_eval", "robo_acq_eval_moments", "robo_acq_eval_marginal_cand", "robo_acq_eval_sum_cand",
+    "robo_ig_eval_cand", "robo_ig_eval_moments", "robo_gp_cross_cov",
     "robo_selftest_mfma_layout", "robo_microbench_mfma_f64", "robo_microbench_mfma_f64_detail",
     "robo_selftest_diag_timeline",
 ]
@@ -123,6 +124,9 @@ def lib():
         "robo_acq_eval_marginal_cand": [pp, i32, i32, dbl, dbl, vp, _dp, _dp, C.POINTER(i64),
                                         C.POINTER(C.c_uint32)],
         "robo_acq_eval_sum_cand": [pp, i32, i32, dbl, dbl, vp, _dp, C.POINTER(C.c_uint32)],
+        "robo_ig_eval_cand": [vp, vp, vp, i32, dbl, _dp, _dp, _dp, _dp, _dp, _dp, _dp, _dp, C.POINTER(i64)],
+        "robo_ig_eval_moments": [vp, i64, i32, i32, dbl, _dp, _dp, _dp, _dp, _dp, _dp, _dp, _dp, _dp],
+        "robo_gp_cross_cov": [vp, vp, vp, _dp],
         "robo_selftest_mfma_layout": [vp, _dp],
         "robo_microbench_mfma_f64": [vp, i32, _dp],
         "robo_microbench_mfma_f64_detail": [vp, i32, _dp],
@@ -403,6 +407,47 @@ def acq_from_moments(ctx, kind, par, eta, mean, var):
     check(lib().robo_acq_eval_moments(ctx._h, ACQ_KINDS[kind], float(par), float(eta), _arr(mean), _arr(var),
                                       mean.shape[0], _arr(out), C.byref(mx), C.byref(am), C.byref(fl)))
     return out, mx.value, am.value, fl.value
+
+
+class EPState(object):
+    """the host-side EP tensors of entropy search, contiguous fp64"""
+
+    def __init__(self, logP, lmb, W, dlogPdMu, dlogPdSigma, dlogPdMudMu):
+        self.nb = int(np.asarray(logP).size)
+        self.logP = _f64(np.asarray(logP).reshape(-1))
+        self.lmb = _f64(np.asarray(lmb).reshape(-1))
+        self.W = _f64(np.asarray(W).reshape(-1))
+        self.dMu = _f64(dlogPdMu, (self.nb, self.nb))
+        self.dSigma = _f64(dlogPdSigma, (self.nb, self.nb * (self.nb + 1) // 2))
+        self.dMuMu = _f64(dlogPdMudMu, (self.nb, self.nb, self.nb))
+
+    def args(self):
+        return [_arr(a) for a in (self.logP, self.lmb, self.W, self.dMu, self.dSigma, self.dMuMu)]
+
+
+def ig_eval(gp, cand, rep, ep, sn2, want_values=True):
+    """information gain of every candidate -> (values, max, argmax)"""
+    assert rep.m == ep.nb
+    out = np.empty(cand.m) if want_values else None
+    mx, am = C.c_double(0), C.c_int64(0)
+    check(lib().robo_ig_eval_cand(gp._h, cand._h, rep._h, ep.W.size, float(sn2), *ep.args(),
+                                  _arr(out) if want_values else None, C.byref(mx), C.byref(am)))
+    return out, mx.value, am.value
+
+
+def ig_from_moments(ctx, s, v, ep, sn2):
+    s, v = _f64(s), _f64(v)
+    assert s.ndim == 2 and s.shape[1] == ep.nb and v.shape == (s.shape[0],)
+    out = np.empty(s.shape[0])
+    check(lib().robo_ig_eval_moments(ctx._h, s.shape[0], ep.nb, ep.W.size, float(sn2), _arr(s), _arr(v), *ep.args(),
+                                     _arr(out)))
+    return out
+
+
+def cross_cov(gp, cand, ref):
+    out = np.empty((cand.m, ref.m))
+    check(lib().robo_gp_cross_cov(gp._h, cand._h, ref._h, _arr(out)))
+    return out
 
 
 def acq_marginal(gps, kind, par, eta, cand, want_values=True, reduce="mean"):

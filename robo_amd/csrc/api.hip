@@ -4,6 +4,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdlib>
+#include <functional>
 #include <vector>
 
 #include "common.h"
@@ -527,6 +528,11 @@ int32_t robo_cand_destroy(robo_cand* k) {
     hipFree(k->d_acq_sum);
     hipFree(k->d_mu_all);
     hipFree(k->d_var_all);
+    hipFree(k->d_S);
+    hipFree(k->d_F);
+    hipFree(k->d_Q);
+    hipFree(k->d_G);
+    hipFree(k->d_igc);
     hipFree(k->d_part_val);
     hipFree(k->d_part_idx);
     hipFree(k->d_flags);
@@ -553,8 +559,10 @@ static int cand_ensure_workspace(robo_cand* k, int n_pad, bool single_chunk) {
     return ROBO_OK;
 }
 
-// K4 + K5: fills cand->d_mean / d_var (asynchronous)
-static int predict_core(robo_gp* g, robo_cand* k, bool single_chunk) {
+// K4 + K5: fills cand->d_mean / d_var (asynchronous).  after_chunk(c0, cn), if given, runs while
+// the chunk's V = L^-1 K*^T is still in the workspace (cross-covariances for entropy search).
+static int predict_core(robo_gp* g, robo_cand* k, bool single_chunk,
+                        const std::function<int(int64_t, int64_t)>& after_chunk = nullptr) {
     if (!g || !k) return ROBO_BAD_ARGUMENT;
     if (!g->fitted) {
         set_error("Model has to be trained first!");
@@ -584,6 +592,7 @@ static int predict_core(robo_gp* g, robo_cand* k, bool single_chunk) {
             ROBO_TRY(launch_predict_fused(g, k, c0, cn));
         }
         ROBO_HIP_CHECK(hipEventRecord(g->ctx->events[26], st));
+        if (after_chunk) ROBO_TRY(after_chunk(c0, cn));
     }
     ROBO_TRY(launch_post(g, k, 0, k->m_pad));
     ROBO_HIP_CHECK(hipEventRecord(g->ctx->events[27], st));
@@ -783,6 +792,154 @@ int32_t robo_acq_eval_moments(robo_ctx* ctx, int32_t acq_kind, double par, doubl
     }
     if (st == ROBO_OK) st = launch_acq(ctx, k, acq_kind, par, eta, false, false);
     if (st == ROBO_OK) st = acq_read_back(k, k->d_acq, out_acq, out_max, out_argmax, out_flags);
+    robo_cand_destroy(k);
+    return st;
+}
+
+// ---------------------------------------------------------------------------------------
+// entropy search: information gain of a candidate batch
+// ---------------------------------------------------------------------------------------
+static int ig_ensure(robo_cand* k, int kf) {
+    const size_t mp = (size_t)k->m_pad;
+    if (!k->d_S) ROBO_TRY(dev_alloc(&k->d_S, mp * NB));
+    const size_t need_f = (size_t)k->chunk * kf;
+    if (k->f_cap < need_f) {
+        hipFree(k->d_F);
+        k->d_F = nullptr;
+        k->f_cap = 0;
+        ROBO_TRY(dev_alloc(&k->d_F, need_f));
+        k->f_cap = need_f;
+    }
+    if (k->q_cap < (size_t)k->chunk) {
+        hipFree(k->d_Q);
+        k->d_Q = nullptr;
+        ROBO_TRY(dev_alloc(&k->d_Q, (size_t)k->chunk * NB));
+        k->q_cap = (size_t)k->chunk;
+    }
+    if (k->g_cap < (size_t)kf) {
+        hipFree(k->d_G);
+        hipFree(k->d_igc);
+        k->d_G = k->d_igc = nullptr;
+        ROBO_TRY(dev_alloc(&k->d_G, (size_t)NB * kf));
+        ROBO_TRY(dev_alloc(&k->d_igc, (size_t)128 + 512 + 64 * 64));
+        k->g_cap = (size_t)kf;
+    }
+    return ROBO_OK;
+}
+
+// upload the EP state: consts = [logP (64) | lmb (64) | W (npts) | dlogPdMu (nb x nb)], G (128 x kf)
+static int ig_upload(robo_cand* k, int nb, int npts, int kf, const double* logP, const double* lmb, const double* W,
+                     const double* dlogPdMu, const double* dlogPdSigma, const double* dlogPdMudMu) {
+    std::vector<double> hc((size_t)128 + npts + (size_t)nb * nb, 0.0), hg((size_t)NB * kf, 0.0);
+    for (int i = 0; i < nb; ++i) {
+        hc[i] = logP[i];
+        hc[64 + i] = lmb[i];
+    }
+    for (int p = 0; p < npts; ++p) hc[128 + p] = W[p];
+    for (int i = 0; i < nb * nb; ++i) hc[128 + npts + i] = dlogPdMu[i];
+    const int ntri = nb * (nb + 1) / 2;
+    for (int i = 0; i < nb; ++i) {
+        double* g1 = hg.data() + (size_t)i * kf;            // q1_i = s^T dlogPdMudMu_i s
+        double* g2 = hg.data() + (size_t)(64 + i) * kf;     // q2_i = sum_{a>=b} dlogPdSigma_i[ab] s_a s_b
+        for (int e = 0; e < nb * nb; ++e) g1[e] = dlogPdMudMu[(size_t)i * nb * nb + e];
+        int idx = 0;
+        for (int a = 0; a < nb; ++a)
+            for (int b = 0; b <= a; ++b) g2[a * nb + b] = dlogPdSigma[(size_t)i * ntri + idx++];
+    }
+    hipStream_t st = k->ctx->stream;
+    ROBO_HIP_CHECK(hipMemcpyAsync(k->d_igc, hc.data(), hc.size() * sizeof(double), hipMemcpyHostToDevice, st));
+    ROBO_HIP_CHECK(hipMemcpyAsync(k->d_G, hg.data(), hg.size() * sizeof(double), hipMemcpyHostToDevice, st));
+    ROBO_HIP_CHECK(hipStreamSynchronize(st));   // the staging vectors die with this scope
+    return ROBO_OK;
+}
+
+static int ig_check(int nb, int npts) {
+    if (nb < 2 || nb > 64 || npts < 1 || npts > 512) {
+        set_error("information gain: Nb=%d must be in [2, 64], Np=%d in [1, 512]", nb, npts);
+        return ROBO_BAD_SHAPE;
+    }
+    return ROBO_OK;
+}
+
+static double ig_entropy(int nb, const double* logP, const double* lmb) {
+    double H = 0.0;
+    for (int i = 0; i < nb; ++i) H -= std::exp(logP[i]) * (logP[i] + lmb[i]);
+    return H;
+}
+
+int32_t robo_gp_cross_cov(robo_gp* g, robo_cand* k, robo_cand* rep, double* out_cov) {
+    if (!g || !k || !rep || !out_cov) return ROBO_BAD_ARGUMENT;
+    if (rep->m > 64) {
+        set_error("cross-covariance reference set limited to 64 points (got %lld)", (long long)rep->m);
+        return ROBO_BAD_SHAPE;
+    }
+    ROBO_TRY(predict_core(g, rep, true));
+    ROBO_TRY(cand_ensure_workspace(k, g->n_pad, false));
+    ROBO_TRY(ig_ensure(k, 16));
+    ROBO_TRY(predict_core(g, k, false, [&](int64_t c0, int64_t cn) { return launch_cross_cov(g, k, rep, c0, cn, k->d_S); }));
+    std::vector<double> h((size_t)k->m * NB);
+    ROBO_HIP_CHECK(hipMemcpyAsync(h.data(), k->d_S, h.size() * sizeof(double), hipMemcpyDeviceToHost, g->ctx->stream));
+    ROBO_HIP_CHECK(hipStreamSynchronize(g->ctx->stream));
+    for (int64_t c = 0; c < k->m; ++c)
+        for (int64_t b = 0; b < rep->m; ++b) out_cov[c * rep->m + b] = h[(size_t)c * NB + b];
+    return ROBO_OK;
+}
+
+int32_t robo_ig_eval_cand(robo_gp* g, robo_cand* k, robo_cand* rep, int32_t npts, double sn2, const double* logP,
+                          const double* lmb, const double* W, const double* dlogPdMu, const double* dlogPdSigma,
+                          const double* dlogPdMudMu, double* out_dh, double* out_max, int64_t* out_argmax) {
+    if (!g || !k || !rep || !logP || !lmb || !W || !dlogPdMu || !dlogPdSigma || !dlogPdMudMu) return ROBO_BAD_ARGUMENT;
+    const int nb = (int)rep->m;
+    ROBO_TRY(ig_check(nb, npts));
+    const int kf = round_up(nb * nb, 16);
+    ROBO_TRY(predict_core(g, rep, true));                       // V of the representer points
+    ROBO_TRY(cand_ensure_workspace(k, g->n_pad, false));
+    ROBO_TRY(ig_ensure(k, kf));
+    ROBO_TRY(ig_upload(k, nb, npts, kf, logP, lmb, W, dlogPdMu, dlogPdSigma, dlogPdMudMu));
+    ROBO_TRY(predict_core(g, k, false, [&](int64_t c0, int64_t cn) { return launch_cross_cov(g, k, rep, c0, cn, k->d_S); }));
+    const double H = ig_entropy(nb, logP, lmb);
+    for (int64_t c0 = 0; c0 < k->m_pad; c0 += k->chunk) {
+        const int64_t cn = k->m_pad - c0 < k->chunk ? k->m_pad - c0 : k->chunk;
+        ROBO_TRY(launch_ig_dh(g->ctx, k->d_S, k->d_var, k->d_F, k->d_Q, k->d_G, k->d_igc, c0, cn, k->m, nb, npts, kf,
+                              sn2, H, k->d_acq_sum));
+    }
+    ROBO_HIP_CHECK(hipMemsetAsync(k->d_flags, 0, sizeof(unsigned), g->ctx->stream));
+    ROBO_TRY(launch_argmax(k, k->d_acq_sum, 1.0));
+    return acq_read_back(k, k->d_acq, out_dh, out_max, out_argmax, nullptr);
+}
+
+int32_t robo_ig_eval_moments(robo_ctx* ctx, int64_t m, int32_t nb, int32_t npts, double sn2, const double* s,
+                             const double* v, const double* logP, const double* lmb, const double* W,
+                             const double* dlogPdMu, const double* dlogPdSigma, const double* dlogPdMudMu,
+                             double* out_dh) {
+    if (!ctx || !s || !v || !out_dh) return ROBO_BAD_ARGUMENT;
+    ROBO_TRY(ig_check(nb, npts));
+    const int kf = round_up(nb * nb, 16);
+    robo_cand* k = nullptr;
+    ROBO_TRY(cand_alloc(ctx, m, 1, &k));
+    k->chunk = k->m_pad;
+    int st = ig_ensure(k, kf);
+    if (st == ROBO_OK) st = ig_upload(k, nb, npts, kf, logP, lmb, W, dlogPdMu, dlogPdSigma, dlogPdMudMu);
+    if (st == ROBO_OK) {
+        std::vector<double> hs((size_t)k->m_pad * NB, 0.0);
+        for (int64_t c = 0; c < m; ++c)
+            for (int b = 0; b < nb; ++b) hs[(size_t)c * NB + b] = s[c * nb + b];
+        hipError_t e = hipMemcpyAsync(k->d_S, hs.data(), hs.size() * sizeof(double), hipMemcpyHostToDevice, ctx->stream);
+        if (e == hipSuccess) e = hipMemcpyAsync(k->d_var, v, (size_t)m * sizeof(double), hipMemcpyHostToDevice, ctx->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+        if (e != hipSuccess) {
+            set_error("robo_ig_eval_moments upload failed: %s", hipGetErrorString(e));
+            st = ROBO_RUNTIME_ERROR;
+        }
+    }
+    if (st == ROBO_OK)
+        st = launch_ig_dh(ctx, k->d_S, k->d_var, k->d_F, k->d_Q, k->d_G, k->d_igc, 0, k->m_pad, m, nb, npts, kf, sn2,
+                          ig_entropy(nb, logP, lmb), k->d_acq_sum);
+    if (st == ROBO_OK) {
+        hipError_t e = hipMemcpyAsync(out_dh, k->d_acq_sum, (size_t)m * sizeof(double), hipMemcpyDeviceToHost, ctx->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+        if (e != hipSuccess) st = ROBO_RUNTIME_ERROR;
+    }
     robo_cand_destroy(k);
     return st;
 }

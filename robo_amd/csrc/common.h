@@ -125,6 +125,10 @@ struct robo_cand {
     double* d_var;      // (m_pad) transformed, floored variance
     double* d_acq;      // (m_pad)
     double* d_acq_sum;  // (m_pad) marginal accumulator
+    // entropy search (lazy): cross-covariances with the representer points, quadratic-form
+    // features / outputs, EP tensors
+    double *d_S, *d_F, *d_Q, *d_G, *d_igc;
+    size_t f_cap, q_cap, g_cap;
     double* d_mu_all;   // (s_cap, m_pad) per-sample means/variances for the GP-MCMC mixture (lazy)
     double* d_var_all;
     int s_cap;
@@ -161,6 +165,10 @@ int launch_acq(robo_ctx* ctx, robo_cand* cand, int acq_kind, double par, double 
 int launch_argmax(robo_cand* cand, const double* d_vals, double scale);
 int launch_cov(robo_gp* gp, robo_cand* cand, double* d_cov);
 int launch_mixture(robo_cand* cand, int S);
+int launch_cross_cov(robo_gp* gp, robo_cand* cand, robo_cand* rep, int64_t c0, int64_t cn, double* d_S);
+int launch_ig_dh(robo_ctx* ctx, const double* d_S, const double* d_var, double* d_F, double* d_Q, const double* d_G,
+                 const double* d_consts, int64_t c0, int64_t cn, int64_t m, int nb, int npts, int kf, double sn2,
+                 double H, double* d_out);
 int launch_random_candidates(robo_ctx* ctx, double* d_out, int64_t m_pad, int dim, uint64_t seed, int64_t n_uniform,
                              const double* d_loc, const double* d_scale);
 int launch_uniform(robo_ctx* ctx, double* d_out, int64_t m, int64_t m_pad, int dim, uint64_t seed);

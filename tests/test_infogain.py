@@ -1,0 +1,137 @@
+"""Entropy search: EP vs the reference's own epmgp (importable), device information gain vs the
+NumPy restatement (oracle/ig_oracle.py), through the interpreter on CPU and on the GPU."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+from oracle import gp_oracle as O
+from oracle import ig_oracle as IG
+from robo_amd import _lib
+from robo_amd.util import epmgp
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+HAVE_REF = os.path.isdir("/root/reference/robo")
+
+
+@pytest.mark.skipif(not HAVE_REF, reason="reference tree not on this box")
+def test_ep_matches_reference_epmgp():
+    if not hasattr(np, "Infinity"):
+        np.Infinity = np.inf
+    if not hasattr(np, "NAN"):
+        np.NAN = np.nan
+    sys.path.insert(0, "/root/reference")
+    from robo.util import epmgp as ref
+    rs = np.random.RandomState(0)
+    for n in (3, 8, 20):
+        A = rs.randn(n, n)
+        S = A @ A.T / n + 0.1 * np.eye(n)
+        mu = rs.randn(n)
+        r = ref.joint_min(mu, S, with_derivatives=True)
+        m = epmgp.joint_min(mu, S, with_derivatives=True)
+        for a, b in zip(r, m):
+            np.testing.assert_allclose(b, a, rtol=1e-10, atol=1e-13)
+        np.testing.assert_allclose(epmgp.joint_min(mu, S), ref.joint_min(mu, S), rtol=1e-10, atol=1e-13)
+
+
+def test_pmin_pins():
+    """test/test_acquisition_functions/test_information_gain.py:33-56: uniform and Dirac beliefs"""
+    n = 10
+    p = np.exp(epmgp.joint_min(np.zeros(n), np.eye(n)))
+    assert np.all(np.abs(p - 1.0 / n) < 0.03)
+    mu = np.ones(n) * 1e4
+    mu[0] = -1e4
+    assert np.exp(epmgp.joint_min(mu, np.eye(n) * 1e-3))[0] == 1.0
+
+
+def _setup(ctx, N=60, D=3, M=150, Nb=12, Np=40, seed=0):
+    rs = np.random.RandomState(seed)
+    X = rs.rand(N, D)
+    y = np.sin(3 * X.sum(axis=1)) + 0.1 * rs.randn(N)
+    theta = np.concatenate([[0.0], np.log([0.3, 0.5, 0.8])[:D], [np.log(1e-2)]])
+    Xc = rs.rand(M, D)
+    zb = rs.rand(Nb, D)
+    lmb = rs.randn(Nb)
+    ogp = O.OracleGP("matern52", theta, normalize_input=False)
+    ogp.train(X, y)
+    mu_b, var_b = ogp.predict(zb, full_cov=True)
+    logP, dMu, dSig, dMM = epmgp.joint_min(mu_b, var_b, with_derivatives=True)
+    W = IG.outcome_quantiles(Np)
+    g = _lib.DeviceGP(ctx, "matern52", N, D)
+    g.set_data(X, y)
+    g.fit(theta, ogp.mean)
+    return dict(ogp=ogp, g=g, Xc=Xc, zb=zb, lmb=lmb, logP=logP, dMu=dMu, dSig=dSig, dMM=dMM, W=W,
+                sn2=np.exp(theta[-1]), ep=_lib.EPState(logP, lmb, W, dMu, dSig, dMM))
+
+
+def _check_ig(ctx, **kw):
+    d = _setup(ctx, **kw)
+    cand = _lib.Candidates(ctx, d["Xc"])
+    rep = _lib.Candidates(ctx, d["zb"])
+    # (1) cross-covariances vs the oracle's full covariance (clipped at eps like the reference)
+    S = _lib.cross_cov(d["g"], cand, rep)
+    both = np.concatenate([d["zb"], d["Xc"][:20]])
+    _, cov = d["ogp"].predict(both, full_cov=True)
+    Nb = d["zb"].shape[0]
+    np.testing.assert_allclose(S[:20], cov[Nb:, :Nb], rtol=0, atol=1e-9)
+    # (2) information gain vs the NumPy restatement fed with the device's own (v, s)
+    vals, mx, am = _lib.ig_eval(d["g"], cand, rep, d["ep"], d["sn2"])
+    _, var = d["g"].predict(cand)
+    ref = np.array([IG.dh_fun(var[c], S[c][:, None], d["sn2"], d["logP"], d["lmb"], d["dMu"], d["dSig"], d["dMM"],
+                              d["W"]) for c in range(d["Xc"].shape[0])])
+    np.testing.assert_allclose(vals, ref, rtol=1e-8, atol=1e-10)
+    assert am == int(np.argmax(vals)) and am == int(np.argmax(ref))
+    # (3) the moments entry point (any model) gives the same numbers
+    vals2 = _lib.ig_from_moments(ctx, S, var, d["ep"], d["sn2"])
+    np.testing.assert_allclose(vals2, vals, rtol=1e-12, atol=1e-14)
+    cand.close()
+    rep.close()
+    d["g"].close()
+
+
+@pytest.fixture(scope="module")
+def emu_ctx():
+    sys.path.insert(0, os.path.join(HERE, "hipemu"))
+    import build_emu
+    _lib.use_library(build_emu.build())
+    ctx = _lib.Context(0)
+    yield ctx
+    ctx.close()
+    _lib.use_library(None)
+
+
+def test_information_gain_logic_emulated(emu_ctx):
+    _check_ig(emu_ctx, N=60, D=3, M=150, Nb=12, Np=40)
+
+
+def test_information_gain_class_emulated(emu_ctx):
+    """the assertions of the reference's test_information_gain.py:21-31,58-72 on the RoBO-surface class"""
+    from robo_amd.acquisition_functions import InformationGain
+    from robo_amd.kernels import Matern52Kernel
+    from robo_amd.models import GaussianProcess
+    rs = np.random.RandomState(2)
+    lo, hi = np.zeros(1), np.ones(1)
+    X = rs.rand(10, 1)
+    y = np.sinc(X * 10 - 5).sum(axis=1)
+    model = GaussianProcess(2 * Matern52Kernel(np.array([0.1]), ndim=1), noise=1e-3, lower=lo, upper=hi,
+                            rng=np.random.RandomState(3))
+    model.train(X, y, do_optimize=False)
+    a = InformationGain(model, lo, hi, Nb=10, Np=30, rng=np.random.RandomState(4))
+    a.update(model)
+    assert a.zb.shape == (10, 1) and np.all(a.zb >= lo) and np.all(a.zb <= hi)
+    Xt = rs.rand(5, 1)
+    v = a.compute(Xt)
+    assert v.shape == (5,) and np.all(np.isfinite(v))
+    out = a.compute(np.array([[1.5]]))
+    assert out[0] == np.spacing(1)
+    assert a.argmax(Xt) == int(np.argmax(v))
+
+
+@pytest.mark.gpu
+def test_information_gain_gpu():
+    _lib.use_library(None)
+    ctx = _lib.Context(0)
+    _check_ig(ctx, N=60, D=3, M=150, Nb=12, Np=40)
+    _check_ig(ctx, N=700, D=3, M=3000, Nb=50, Np=400, seed=3)
+    ctx.close()
