@@ -1,2 +1,2 @@
 from robo_amd.priors.priors import (BasePrior, TophatPrior, HorseshoePrior, LognormalPrior,  # noqa: F401
-                                    NormalPrior, DefaultPrior)
+                                    NormalPrior, DefaultPrior, EnvPrior)

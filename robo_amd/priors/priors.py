@@ -129,3 +129,38 @@ class DefaultPrior(BasePrior):
 
     def gradient(self, theta):
         return np.zeros([theta.shape[0]])
+
+
+class EnvPrior(BasePrior):
+    """Prior of the Fabolas kernels (robo/priors/env_priors.py:8-80): theta = [log amp,
+    log metric_1..n_ls, n_lr Bayesian-linear-regression parameters, log noise] with
+    lognormal(mean=-2, sigma=1) on the amplitude, tophat [-10, 2] on the length scales,
+    NormalPrior(sigma=1) on the regression parameters (whose ``lnprob`` is a pdf, see NormalPrior)
+    and horseshoe(0.001) on the noise."""
+
+    def __init__(self, n_dims, n_ls, n_lr, rng=None):
+        super(EnvPrior, self).__init__(rng)
+        self.n_dims, self.n_ls, self.n_lr = n_dims, n_ls, n_lr
+        self.bayes_lin_prior = NormalPrior(sigma=1, mean=0, rng=self.rng)
+        self.tophat = TophatPrior(-10, 2, rng=self.rng)
+        self.ln_prior = LognormalPrior(mean=-2, sigma=1.0, rng=self.rng)
+        self.horseshoe = HorseshoePrior(scale=0.001, rng=self.rng)
+
+    def lnprob(self, theta):
+        lp = self.ln_prior.lnprob(theta[0]) + self.tophat.lnprob(theta[1:self.n_ls + 1])
+        for t in theta[self.n_ls + 1:self.n_ls + self.n_lr + 1]:
+            lp += self.bayes_lin_prior.lnprob(t)
+        return lp + self.horseshoe.lnprob(theta[-1])
+
+    def sample_from_prior(self, n_samples):
+        p0 = np.zeros([n_samples, self.n_dims])
+        p0[:, 0] = self.ln_prior.sample_from_prior(n_samples)[:, 0]
+        for col in range(1, self.n_ls + 1):
+            p0[:, col] = self.tophat.sample_from_prior(n_samples)[:, 0]
+        for col in range(self.n_ls + 1, self.n_ls + self.n_lr + 1):
+            p0[:, col] = self.bayes_lin_prior.sample_from_prior(n_samples)[:, 0]
+        p0[:, -1] = self.horseshoe.sample_from_prior(n_samples)[:, 0]
+        return p0
+
+    def gradient(self, theta):
+        return np.zeros([theta.shape[0]])

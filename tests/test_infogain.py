@@ -135,3 +135,31 @@ def test_information_gain_gpu():
     _check_ig(ctx, N=60, D=3, M=150, Nb=12, Np=40)
     _check_ig(ctx, N=700, D=3, M=3000, Nb=50, Np=400, seed=3)
     ctx.close()
+
+
+def test_entropy_search_front_end_emulated(emu_ctx):
+    """robo_amd.fmin.entropy_search, the assertions of the reference's test_fmin_interface.py (x_opt in bounds)"""
+    from robo_amd.fmin import entropy_search
+    r = entropy_search(lambda x: float((x[0] - 0.3) ** 2), np.zeros(1), np.ones(1), num_iterations=4, model="gp",
+                       rng=np.random.RandomState(0), n_candidates=40, n_representer=6, n_outcomes=12)
+    assert 0.0 <= r["x_opt"][0] <= 1.0 and len(r["X"]) == 4
+
+
+@pytest.mark.gpu
+def test_entropy_search_and_fabolas_front_ends_gpu():
+    """the reference's test/test_fmin: x_opt inside the bounds for entropy_search (gp, gp_mcmc) and fabolas
+    (test_fmin_interface.py:18-91, test_fabolas.py:24-36), at the reference's Nb=50 / Np=400"""
+    _lib.use_library(None)
+    from robo_amd.fmin import entropy_search, fabolas
+    f = lambda x: float((x[0] - 0.3) ** 2)
+    for model in ("gp", "gp_mcmc"):
+        r = entropy_search(f, np.zeros(1), np.ones(1), num_iterations=6, model=model, rng=np.random.RandomState(0),
+                           n_candidates=2000, chain_length=10, burnin_steps=10)
+        assert 0.0 <= r["x_opt"][0] <= 1.0 and len(r["X"]) == 6
+
+    def obj(x, s):
+        return float((x[0] - 0.5) ** 2 + 1.0 / s + 0.05), float(s) / 100.0
+
+    r = fabolas(obj, np.zeros(1), np.ones(1), s_min=10, s_max=1000, n_init=3, num_iterations=10, subsets=[64, 16],
+                burnin=5, chain_length=5, n_hypers=10, rng=np.random.RandomState(1), n_candidates=1000)
+    assert 0.0 <= r["x_opt"][0] <= 1.0 and len(r["X"]) == 10 and len(r["c"]) == 10
