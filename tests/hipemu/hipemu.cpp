@@ -192,17 +192,12 @@ void launch(std::function<void()> body, dim3 grid, dim3 block, size_t shmem) {
     g_body = std::move(body);
     g_bdim = block; g_gdim = grid;
     g_dyn.assign(shmem + 64, 0);
-    std::vector<Fiber> saved;  // keep stacks of fibers beyond nt
-    size_t total = g_fibers.size();
-    (void)total;
     for (unsigned bz = 0; bz < grid.z; ++bz)
     for (unsigned by = 0; by < grid.y; ++by)
     for (unsigned bx = 0; bx < grid.x; ++bx) {
         g_block = dim3(bx, by, bz);
         // only the first nt fibers take part
         std::vector<Fiber>& F = g_fibers;
-        size_t keep = F.size();
-        (void)keep;
         for (size_t i = 0; i < nt; ++i) {
             F[i].linear = (int)i;
             F[i].lane.tid = dim3((unsigned)(i % block.x), (unsigned)((i / block.x) % block.y), (unsigned)(i / ((size_t)block.x * block.y)));
