@@ -386,3 +386,46 @@ def check_device_random_candidates(ctx):
     assert (G[:, 1] == 1.0).mean() > 0.01                     # clipping at the upper bound happens
     np.testing.assert_array_equal(c.point(nu + 7), P_[nu + 7])
     np.testing.assert_array_equal(_lib.Candidates(ctx, m=m, seed=5, n_uniform=nu, loc=loc, scale=scale).points(), P_)
+
+
+def check_shape_sweep(ctx, n_cases=40, seed=123, max_n=700):
+    """randomised shapes: N, D (incl. D > 16: several LDS coordinate chunks), M, kernel kind, output
+    normalisation; fit + posterior + EI argmax against the oracle."""
+    rs = np.random.RandomState(seed)
+    dims = [1, 2, 3, 5, 8, 15, 16, 17, 31, 33, 64, 100]
+    for case in range(n_cases):
+        N = int(rs.choice([1, 2, 3, 17, 100, 127, 128, 129, 255, 256, 257, 300, 511, max_n]))
+        D = int(rs.choice(dims))
+        M = int(rs.choice([1, 5, 64, 127, 128, 129, 300, 700]))
+        kind = str(rs.choice(["matern52", "rbf", "fabolas"])) if D >= 2 else str(rs.choice(["matern52", "rbf"]))
+        nout = bool(rs.rand() < 0.3) and N > 1
+        X = rs.rand(N, D)
+        y = np.sin(3 * X.sum(axis=1) / np.sqrt(D)) + 0.05 * rs.randn(N)
+        Xc = rs.rand(M, D)
+        if kind == "fabolas":
+            theta = np.concatenate([[0.1], np.log(0.3 + rs.rand(D - 1)), [0.1, -0.3], [np.log(1e-2)]])
+        else:
+            theta = np.concatenate([[0.2], np.log((0.2 + rs.rand(D)) * D), [np.log(1e-2)]])
+        ogp = O.OracleGP(kind, theta, normalize_input=False, normalize_output=nout)
+        ogp.train(X, y)
+        g = _lib.DeviceGP(ctx, kind, N, D)
+        g.set_data(ogp.X, ogp.y)
+        if nout:
+            g.set_output_transform(ogp.y_mean, ogp.y_std)
+        tag = "case %d: N=%d D=%d M=%d %s nout=%s" % (case, N, D, M, kind, nout)
+        ll = g.fit(theta, ogp.mean)
+        np.testing.assert_allclose(ll, ogp.loglikelihood(theta), rtol=LOGLIK_RTOL, atol=1e-9, err_msg=tag)
+        mu, var = g.predict(Xc)
+        mo, vo = ogp.predict(Xc, diag_only=True)
+        scale = max(1.0, np.abs(mo).max())
+        amp = O.kernel_diag(kind, theta[:-1], Xc).max() * (ogp.y_std ** 2 if nout else 1.0)
+        np.testing.assert_allclose(mu, mo, rtol=MU_RTOL, atol=MU_ATOL * scale, err_msg=tag)
+        np.testing.assert_allclose(var, vo, rtol=0, atol=VAR_ATOL_REL_AMP * max(amp, 1.0), err_msg=tag)
+        _, eta = ogp.get_incumbent()
+        vals, mx, am, _ = g.acq("ei", 0.0, float(eta), Xc)
+        eo = O.ei(mo, vo, eta)
+        want = int(np.argmax(eo))
+        srt = np.sort(eo)
+        gap = srt[-1] - srt[-2] if M > 1 else 1.0
+        assert am == want or gap <= 1e-7 * max(abs(eo[want]), 1e-300), tag
+        g.close()

@@ -69,6 +69,10 @@ def test_device_random_candidates(emu_ctx):
     P.check_device_random_candidates(emu_ctx)
 
 
+def test_shape_sweep(emu_ctx):
+    P.check_shape_sweep(emu_ctx, n_cases=6, seed=5, max_n=200)
+
+
 def test_fabolas_kernel(emu_ctx):
     P.check_fabolas_kernel(emu_ctx)
 

@@ -72,6 +72,10 @@ def test_device_random_candidates(ctx):
     P.check_device_random_candidates(ctx)
 
 
+def test_shape_sweep(ctx):
+    P.check_shape_sweep(ctx, n_cases=60)
+
+
 def test_fabolas_kernel(ctx):
     P.check_fabolas_kernel(ctx)
 
