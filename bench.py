@@ -79,6 +79,7 @@ def main():
     ap.add_argument("--m", type=int, default=65536, help="candidates per GPU")
     ap.add_argument("--acq", default="ei")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--lib", default=None, help="alternative build of librobo_hip.so (A/B runs of kernel variants)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -93,6 +94,8 @@ def main():
         dist.init_process_group(backend="nccl", rank=rank, world_size=world)
 
     from robo_amd import _lib, sharding
+    if args.lib:
+        _lib.use_library(os.path.abspath(args.lib))
 
     ctx = _lib.Context(local_rank if world > 1 else int(os.environ.get("ROBO_DEVICE", "0")))
     N, D, M = args.n, args.d, args.m

@@ -95,8 +95,15 @@ __device__ __forceinline__ void tile_store_lds(double* S, const Tile4 t) {
     }
 }
 
+// s_setprio(1) around each MFMA cluster: with two independent workgroups per CU the wave that has
+// its operands ready keeps the matrix pipe while the other issues LDS/global traffic
+// (A/B on MI355X, r01m: 18.45 -> 18.05 ms per 65 536 candidates, +2.5 %)
+#ifndef ROBO_SETPRIO
+#define ROBO_SETPRIO 1
+#endif
 template <int TM, bool NEG>
 __device__ __forceinline__ void tile_mfma(const double* sA, const double* sB, AccT<TM>& acc) {
+    constexpr bool SETPRIO = ROBO_SETPRIO != 0;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int wy = wave >> 1, wx = wave & 1;
     const double* pa = sA + (wy * (16 * TM) + (lane & 15)) * LDS_LD + (lane >> 4);
@@ -111,10 +118,12 @@ __device__ __forceinline__ void tile_mfma(const double* sA, const double* sB, Ac
         }
 #pragma unroll
         for (int t = 0; t < 4; ++t) b[t] = pb[t * 16 * LDS_LD + kk * 4];
+        if (SETPRIO) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int tm = 0; tm < TM; ++tm)
 #pragma unroll
             for (int tn = 0; tn < 4; ++tn) acc.t[tm][tn] = mfma_f64(a[tm], b[tn], acc.t[tm][tn]);
+        if (SETPRIO) __builtin_amdgcn_s_setprio(0);
     }
 }
 
