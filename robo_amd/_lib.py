@@ -217,9 +217,10 @@ class Context(object):
 
     def microbench_mfma_f64_detail(self, iters=2000):
         """-> dict(full-chip tflops, issue interval of one lone wave in shader cycles, MHz under load)"""
-        out = np.zeros(3)
+        out = np.zeros(4)
         check(lib().robo_microbench_mfma_f64_detail(self._h, int(iters), _arr(out)))
-        return {"tflops": out[0], "cycles_per_mfma_single_wave": out[1], "shader_mhz": out[2]}
+        return {"tflops": out[0], "cycles_per_mfma_single_wave": out[1], "shader_mhz": out[2],
+                "cycles_per_mfma_dependent_chain": out[3]}
 
     def microbench_mfma_f64(self, iters=2000):
         t = C.c_double(0)

@@ -954,7 +954,7 @@ int32_t robo_selftest_mfma_layout(robo_ctx* ctx, double* out_max_err) {
 int32_t robo_microbench_mfma_f64(robo_ctx* ctx, int32_t iters, double* out_tflops) {
     if (!ctx || !out_tflops || iters < 1) return ROBO_BAD_ARGUMENT;
     ROBO_HIP_CHECK(hipSetDevice(ctx->device));
-    return launch_mfma_microbench(ctx, iters, out_tflops, nullptr, nullptr);
+    return launch_mfma_microbench(ctx, iters, out_tflops, nullptr, nullptr, nullptr);
 }
 
 int32_t robo_selftest_diag_timeline(robo_gp* g, const double* theta, double* out13) {
@@ -977,7 +977,7 @@ int32_t robo_selftest_diag_timeline(robo_gp* g, const double* theta, double* out
 int32_t robo_microbench_mfma_f64_detail(robo_ctx* ctx, int32_t iters, double* out3) {
     if (!ctx || !out3 || iters < 1) return ROBO_BAD_ARGUMENT;
     ROBO_HIP_CHECK(hipSetDevice(ctx->device));
-    return launch_mfma_microbench(ctx, iters, out3, out3 + 1, out3 + 2);
+    return launch_mfma_microbench(ctx, iters, out3, out3 + 1, out3 + 2, out3 + 3);
 }
 
 }  // extern "C"

@@ -174,5 +174,5 @@ int launch_random_candidates(robo_ctx* ctx, double* d_out, int64_t m_pad, int di
 int launch_uniform(robo_ctx* ctx, double* d_out, int64_t m, int64_t m_pad, int dim, uint64_t seed);
 int launch_mfma_selftest(robo_ctx* ctx, double* out_err);
 int launch_mfma_microbench(robo_ctx* ctx, int iters, double* out_tflops, double* out_cycles_per_mfma,
-                           double* out_shader_mhz);
+                           double* out_shader_mhz, double* out_chain);
 }  // namespace robo

@@ -44,6 +44,25 @@ __global__ __launch_bounds__(256) void mfma_bench_kernel(double* __restrict__ si
     }
 }
 
+// one accumulator: every MFMA depends on the previous one (the shape of the small products in the
+// diagonal-block kernel)
+__global__ __launch_bounds__(64) void mfma_chain_kernel(double* __restrict__ sink, int iters, double seed,
+                                                        long long* __restrict__ clocks) {
+    const int l = threadIdx.x & 63;
+    const double a = seed + 1e-3 * l, b = seed - 1e-3 * l;
+    v4d c0 = {0, 0, 0, 0};
+    const long long t0 = clock64();
+    for (int i = 0; i < iters; ++i) {
+        c0 = mfma_f64(a, b, c0);
+        c0 = mfma_f64(a, b, c0);
+        c0 = mfma_f64(a, b, c0);
+        c0 = mfma_f64(a, b, c0);
+    }
+    if (c0[0] + c0[1] == 12345.678) sink[threadIdx.x] = c0[0];
+    const long long t1 = clock64();
+    if (threadIdx.x == 0) clocks[0] = t1 - t0;
+}
+
 int launch_mfma_selftest(robo_ctx* ctx, double* out_err) {
     double hA[64], hB[64], hC[256];
     for (int i = 0; i < 64; ++i) {
@@ -72,7 +91,7 @@ int launch_mfma_selftest(robo_ctx* ctx, double* out_err) {
 }
 
 int launch_mfma_microbench(robo_ctx* ctx, int iters, double* out_tflops, double* out_cycles_per_mfma,
-                           double* out_shader_mhz) {
+                           double* out_shader_mhz, double* out_chain) {
     const int blocks = 4096;
     double* sink = nullptr;
     ROBO_HIP_CHECK(hipMalloc(&sink, (256 + 4) * sizeof(double)));
@@ -98,8 +117,12 @@ int launch_mfma_microbench(robo_ctx* ctx, int iters, double* out_tflops, double*
     hipLaunchKernelGGL(mfma_bench_kernel, dim3(1), dim3(64), 0, ctx->stream, sink, iters, 0.5, clocks);
     ROBO_HIP_CHECK(hipStreamSynchronize(ctx->stream));
     ROBO_HIP_CHECK(hipMemcpy(hclk, clocks, sizeof(hclk), hipMemcpyDeviceToHost));
-    ROBO_HIP_CHECK(hipFree(sink));
     if (out_cycles_per_mfma) *out_cycles_per_mfma = (double)hclk[0] / ((double)iters * 8.0);
+    hipLaunchKernelGGL(mfma_chain_kernel, dim3(1), dim3(64), 0, ctx->stream, sink, iters, 0.5, clocks);
+    ROBO_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    ROBO_HIP_CHECK(hipMemcpy(hclk, clocks, sizeof(hclk), hipMemcpyDeviceToHost));
+    ROBO_HIP_CHECK(hipFree(sink));
+    if (out_chain) *out_chain = (double)hclk[0] / ((double)iters * 4.0);
     const double flops = (double)blocks * 4.0 * (double)iters * 8.0 * 2048.0;
     *out_tflops = flops / ((double)ms * 1e-3) / 1e12;
     return ROBO_OK;

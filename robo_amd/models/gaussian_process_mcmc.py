@@ -153,7 +153,10 @@ class GaussianProcessMCMC(BaseModel):
             ll, st = self.gp.loglik_batch(thetas[ok], self.mean)
             ll = np.where(st == _lib.OK, ll, -np.inf)
             if self.prior is not None:
-                ll = ll + np.array([self.prior.lnprob(t) for t in thetas[ok]])
+                if hasattr(self.prior, "lnprob_batch"):
+                    ll = ll + self.prior.lnprob_batch(thetas[ok])
+                else:
+                    ll = ll + np.array([self.prior.lnprob(t) for t in thetas[ok]])
             out[ok] = ll
         return out
 

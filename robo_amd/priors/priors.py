@@ -118,6 +118,18 @@ class DefaultPrior(BasePrior):
         return (self.ln_prior.lnprob(theta[0]) + self.tophat.lnprob(theta[1:-1])
                 + self.horseshoe.lnprob(theta[-1]))
 
+    def lnprob_batch(self, thetas):
+        """lnprob for a (k, P) batch of thetas in one vectorised evaluation (the ensemble sampler asks
+        for half an ensemble at a time); identical values to k calls of lnprob."""
+        thetas = np.atleast_2d(thetas)
+        ls = thetas[:, 1:-1]
+        top = np.where(np.any(ls < self.tophat.min, axis=1) | np.any(ls > self.tophat.max, axis=1), -np.inf, 0.0)
+        noise = thetas[:, -1]
+        with np.errstate(divide="ignore", over="ignore"):
+            hs = np.log(np.log(1 + 3.0 * (self.horseshoe.scale / np.exp(noise)) ** 2))
+        hs = np.where(noise == 0.0, np.inf, hs)
+        return sps.lognorm.logpdf(thetas[:, 0], self.ln_prior.sigma, loc=self.ln_prior.mean) + top + hs
+
     def sample_from_prior(self, n_samples):
         p0 = np.zeros([n_samples, self.n_dims])
         p0[:, 0] = self.ln_prior.sample_from_prior(n_samples)[:, 0]

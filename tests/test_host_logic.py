@@ -67,6 +67,17 @@ def test_initial_designs_match_reference_draw_order():
                                   ref_lhs(lo, hi, 7, rng=np.random.RandomState(3)))
 
 
+def test_default_prior_batch_equals_scalar():
+    pr = DefaultPrior(6, rng=np.random.RandomState(0))
+    th = np.random.RandomState(1).randn(40, 6) * 3
+    th[3, 2] = 5.0          # outside the tophat
+    th[7, -1] = 0.0         # the horseshoe's +inf point
+    with np.errstate(all="ignore"):
+        want = np.array([pr.lnprob(t) for t in th])
+        got = pr.lnprob_batch(th)
+    np.testing.assert_array_equal(got, want)
+
+
 def test_initial_designs_properties():
     lo, hi = np.array([-5.0, 0.0]), np.array([10.0, 15.0])
     P = init_latin_hypercube_sampling(lo, hi, 10, rng=np.random.RandomState(0))

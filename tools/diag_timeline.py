@@ -1,6 +1,9 @@
 import sys, os, numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from robo_amd import _lib
+if len(sys.argv) > 1:
+    _lib.use_library(os.path.abspath(sys.argv[1]))
+    print("== library", sys.argv[1])
 ctx = _lib.Context(0)
 N, D = 1000, 8
 X = np.random.RandomState(0).rand(N, D); y = np.sin(X.sum(axis=1))
