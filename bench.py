@@ -86,7 +86,7 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     dist = None
-    if world > 1:
+    if world > 1 or os.environ.get("ROBO_BENCH_FORCE_DIST") == "1":   # the latter: exercise the RCCL path on one rank
         import torch
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
