@@ -169,6 +169,15 @@ def main():
             mfma_ceiling = mb["tflops"]
         except Exception:
             mb, mfma_ceiling = None, None
+        # shader clock under an operand-streaming fp64 MFMA load (GEMM in the step kernel's shape): the
+        # datasheet peak assumes 2.4 GHz, the chip holds 2.0-2.2 GHz on this kind of kernel
+        try:
+            g_tf, g_mhz = ctx.microbench_gemm_f64(0, 512, 2048, 3)
+            clock_peak = FP64_MFMA_PEAK_TFLOPS * g_mhz / 2400.0
+            gemm_mb = {"lds_core_tflops": g_tf, "shader_mhz_under_load": g_mhz,
+                       "peak_at_that_clock_tflops": clock_peak, "frac_of_peak_at_that_clock": achieved / clock_peak}
+        except Exception:
+            gemm_mb = None
         traffic = None
         try:   # PMC-measured HBM bytes per launch for this exact workload (collected by tools/gpu_pmc.sh)
             tj = json.load(open(os.path.join(ROOT, "profiles", "trsm_traffic.json")))
@@ -194,7 +203,8 @@ def main():
                          "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / FP64_MFMA_PEAK_TFLOPS,
                          "traffic": traffic, "traffic_unit": "bytes per launch (PMC, profiles/trsm_traffic.json)",
                          "algorithmic_flops_per_launch": float(M) * N * N / nb, "launches_per_step": nb, "avg_launch_ms": trsm_avg_launch_ms,
-                         "mfma_f64_microbench_tflops": mfma_ceiling, "mfma_f64_microbench": mb},
+                         "mfma_f64_microbench_tflops": mfma_ceiling, "mfma_f64_microbench": mb,
+                         "gemm_f64_microbench": gemm_mb},
             "device": ctx.name,
         }
         if world == 1 and not args.no_cpu_baseline:

@@ -194,6 +194,11 @@ int32_t robo_selftest_diag_timeline(robo_gp* gp, const double* theta, double* ou
 /* out3[4] = {full-chip TFLOP/s, shader cycles per MFMA of one wave alone (8 independent
  * accumulators), shader MHz under load, cycles per MFMA in a fully dependent chain}            */
 int32_t robo_microbench_mfma_f64_detail(robo_ctx* ctx, int32_t iters, double* out3);
+/* GEMM-core microbenchmark in the shape of one posterior block-row step: wgs workgroups, each
+ * C(128x128) = A_wg(128xK) B(128xK)^T.  variant 0 = LDS-staged core (gemm_f64.h), 1 = barrier-free
+ * fragment streaming from a packed operand layout.  out2 = {TFLOP/s, shader MHz}.  Measurement only. */
+int32_t robo_microbench_gemm_f64(robo_ctx* ctx, int32_t variant, int32_t wgs, int32_t k, int32_t reps,
+                                 double* out2);
 
 #ifdef __cplusplus
 }

@@ -34,7 +34,7 @@ SYMBOLS = [
     "robo_gp_predict_cand", "robo_gp_predict", "robo_gp_predict_cov", "robo_gp_predict_mixture_cand",
     "robo_acq_eval_cand", "robo_acq_eval", "robo_acq_eval_moments", "robo_acq_eval_marginal_cand", "robo_acq_eval_sum_cand",
     "robo_ig_eval_cand", "robo_ig_eval_moments", "robo_gp_cross_cov",
-    "robo_selftest_mfma_layout", "robo_microbench_mfma_f64", "robo_microbench_mfma_f64_detail",
+    "robo_selftest_mfma_layout", "robo_microbench_mfma_f64", "robo_microbench_mfma_f64_detail", "robo_microbench_gemm_f64",
     "robo_selftest_diag_timeline",
 ]
 
@@ -130,6 +130,7 @@ def lib():
         "robo_selftest_mfma_layout": [vp, _dp],
         "robo_microbench_mfma_f64": [vp, i32, _dp],
         "robo_microbench_mfma_f64_detail": [vp, i32, _dp],
+        "robo_microbench_gemm_f64": [vp, i32, i32, i32, i32, _dp],
         "robo_selftest_diag_timeline": [vp, _dp, _dp],
     }
     for name, args in sig.items():
@@ -221,6 +222,11 @@ class Context(object):
         check(lib().robo_microbench_mfma_f64_detail(self._h, int(iters), _arr(out)))
         return {"tflops": out[0], "cycles_per_mfma_single_wave": out[1], "shader_mhz": out[2],
                 "cycles_per_mfma_dependent_chain": out[3]}
+
+    def microbench_gemm_f64(self, variant, wgs=512, k=4096, reps=5):
+        out = np.zeros(2)
+        check(lib().robo_microbench_gemm_f64(self._h, int(variant), int(wgs), int(k), int(reps), _arr(out)))
+        return float(out[0]), float(out[1])    # TFLOP/s, shader MHz
 
     def microbench_mfma_f64(self, iters=2000):
         t = C.c_double(0)

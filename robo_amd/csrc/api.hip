@@ -974,6 +974,13 @@ int32_t robo_selftest_diag_timeline(robo_gp* g, const double* theta, double* out
     return ROBO_OK;
 }
 
+int32_t robo_microbench_gemm_f64(robo_ctx* ctx, int32_t variant, int32_t wgs, int32_t k, int32_t reps,
+                                 double* out_tflops) {
+    if (!ctx || !out_tflops) return ROBO_BAD_ARGUMENT;
+    ROBO_HIP_CHECK(hipSetDevice(ctx->device));
+    return launch_gemm_microbench(ctx, variant, wgs, k, reps, out_tflops);
+}
+
 int32_t robo_microbench_mfma_f64_detail(robo_ctx* ctx, int32_t iters, double* out3) {
     if (!ctx || !out3 || iters < 1) return ROBO_BAD_ARGUMENT;
     ROBO_HIP_CHECK(hipSetDevice(ctx->device));

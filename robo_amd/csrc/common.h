@@ -173,6 +173,7 @@ int launch_random_candidates(robo_ctx* ctx, double* d_out, int64_t m_pad, int di
                              const double* d_loc, const double* d_scale);
 int launch_uniform(robo_ctx* ctx, double* d_out, int64_t m, int64_t m_pad, int dim, uint64_t seed);
 int launch_mfma_selftest(robo_ctx* ctx, double* out_err);
+int launch_gemm_microbench(robo_ctx* ctx, int variant, int wgs, int K, int reps, double* out_tflops);
 int launch_mfma_microbench(robo_ctx* ctx, int iters, double* out_tflops, double* out_cycles_per_mfma,
                            double* out_shader_mhz, double* out_chain);
 }  // namespace robo
