@@ -124,6 +124,12 @@ def main():
     t0 = time.perf_counter()
     gp.loglik_batch(thetas, mean_c)
     batch_ms = (time.perf_counter() - t0) * 1e3
+    # analytic likelihood gradient (fit + W^T + A + reductions)
+    gp.grad_loglik(theta, mean_c)
+    t0 = time.perf_counter()
+    gp.grad_loglik(theta, mean_c)
+    grad_ms = (time.perf_counter() - t0) * 1e3
+    grad_dev_ms = ctx.elapsed_ms(28, 29)
     gp.fit(theta, mean_c)          # the batch call leaves the GP unfitted
 
     def barrier():
@@ -197,6 +203,7 @@ def main():
             "gp_fit_ms": float(np.min(fit_ms)),
             "gp_fit_phases_ms": {"gram": gram_ms, "cholesky": chol_ms, "loglik": ll_ms},
             "gp_fit_batched": {"thetas": S_half, "ms_total": batch_ms, "ms_per_theta": batch_ms / S_half},
+            "gp_grad_loglik_ms": {"total_incl_fit": grad_ms, "after_factorisation": grad_dev_ms},
             "ei_eval_phases_ms_per_step": {"cross_gram": cross_ms / args.steps, "trsm": trsm_ms / args.steps},
             "argmax": list(best),
             "roofline": {"bound": "mfma", "kernel": "trsm_step_gen_kernel", "achieved": achieved,

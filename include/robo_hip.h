@@ -102,6 +102,17 @@ int32_t robo_theta_size(int32_t kernel_kind, int32_t dim);
  * *out_fail_col is the 0-based failing column and the GP is left unfitted.
  * out_loglik / out_fail_col may be NULL.                                                   */
 int32_t robo_gp_fit(robo_gp* gp, const double* theta, double mean_c, double* out_loglik, int32_t* out_fail_col);
+/* Analytic gradient of the log marginal likelihood w.r.t. theta (log-space), fitted at theta on
+ * return like robo_gp_fit.  Replaces the body of GaussianProcess.grad_nll
+ * (robo/models/gaussian_process.py:168-191: K^-1 via solver.apply_inverse, kernel.gradient (N,N,P),
+ * 0.5 einsum('ijk,ij', Kg, alpha alpha^T - K^-1)) without forming K^-1 or the gradient tensor on
+ * the host.  out_grad[theta_size]: d loglik / d theta_p for the kernel parameters; the LAST entry is
+ * 0.5 tr(alpha alpha^T - K^-1) = d loglik / d sigma^2 (not d / d log sigma^2) exactly as the
+ * reference computes it (:178-182 use the identity as the noise "gradient").  Prior gradients and
+ * the sign flip of grad_nll stay with the caller.                                               */
+int32_t robo_gp_grad_loglik(robo_gp* gp, const double* theta, double mean_c, double* out_loglik,
+                            double* out_grad, int32_t* out_fail_col);
+
 /* S independent likelihood evaluations on the same data in ONE batched pass (every kernel of
  * the fit runs with S x the workgroups); out_status[s] is a robo_status.  Works on a separate
  * batch workspace; the GP itself is left UNFITTED (call robo_gp_fit for the theta to keep).    */

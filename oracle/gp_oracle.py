@@ -19,6 +19,9 @@ What is restated, and from where (paths relative to /root/reference):
 * ``GaussianProcess.train/nll/predict/get_incumbent``
   (robo/models/gaussian_process.py:70-124,129-166,251-296,334-352) ->
   :class:`OracleGP`.
+* ``GaussianProcess.grad_nll`` (robo/models/gaussian_process.py:168-191) ->
+  :func:`gp_grad_log_likelihood` (+ :func:`kernel_gradient` for george's
+  ``kernel.gradient``, PARITY UNPINNED like the kernel values).
 * ``GaussianProcessMCMC.predict`` mixture (robo/models/gaussian_process_mcmc.py:230-247)
   -> :func:`mcmc_mixture`.
 * ``EI/LogEI/PI/LCB.compute`` (robo/acquisition_functions/ei.py:65-88,
@@ -36,7 +39,7 @@ from scipy.special import erfc, erfcx
 
 __all__ = [
     "JITTER", "EPS", "kernel_matrix", "kernel_diag", "n_kernel_params", "gp_compute",
-    "gp_log_likelihood", "gp_predict", "gp_predict_diag", "OracleGP", "mcmc_mixture",
+    "gp_log_likelihood", "gp_grad_log_likelihood", "kernel_gradient", "gp_predict", "gp_predict_diag", "OracleGP", "mcmc_mixture",
     "norm_cdf", "norm_pdf", "norm_logpdf", "norm_logcdf",
     "ei", "log_ei", "pi", "lcb", "marginalize", "np_argmax",
     "zero_one_normalization", "zero_one_unnormalization",
@@ -165,6 +168,65 @@ def gp_compute(kind, theta, X, dtype=np.float64):
     K = kernel_matrix(kind, theta[:-1], X, dtype=dtype)
     K[np.diag_indices_from(K)] += np.exp(theta[-1]) + JITTER
     return sla.cholesky(K, lower=True, check_finite=False)
+
+
+def kernel_gradient(kind, theta_k, X):
+    """``kernel.gradient(X)`` -> (N, N, P_k): derivative of k(X, X) w.r.t. every entry of the
+    LOG-space parameter vector (call site robo/models/gaussian_process.py:181).  george's own
+    formulas are not in the tree (PARITY UNPINNED, like the kernel values); these are the exact
+    derivatives of :func:`kernel_matrix`, checked against central differences of it in
+    tests/test_oracle.py.
+    """
+    X = np.asarray(X, dtype=np.float64)
+    K = kernel_matrix(kind, theta_k, X)
+    N = X.shape[0]
+    G = np.zeros((N, N, len(theta_k)))
+    G[:, :, 0] = K                                        # d/d log amp
+    if kind == "fabolas":
+        D = X.shape[1] - 1
+        m = np.exp(np.asarray(theta_k[1:1 + D], dtype=np.float64))
+        a, b = np.exp(theta_k[1 + D]), np.exp(theta_k[2 + D])
+        for d in range(D):
+            diff = (X[:, d][:, None] - X[:, d][None, :]) / np.sqrt(m[d])
+            s = diff * diff
+            t = np.sqrt(5.0 * s)
+            # d log matern52(s) / d log m = -(f'/f) s,  f'/f = -(5/6)(1 + t) / (1 + t + 5 s / 3)
+            G[:, :, 1 + d] = K * (5.0 / 6.0) * (1.0 + t) * s / (1.0 + t + 5.0 * s / 3.0)
+        uu = X[:, D][:, None] * X[:, D][None, :]
+        B = a + b * uu
+        G[:, :, 1 + D] = K * a / B
+        G[:, :, 2 + D] = K * b * uu / B
+        return G
+    amp = np.exp(theta_k[0])
+    m = np.exp(np.asarray(theta_k[1:], dtype=np.float64))
+    r2 = _r2(m, X, X, np.float64)
+    if kind == "matern52":
+        t = np.sqrt(5.0 * r2)
+        dk = -amp * (5.0 / 6.0) * (1.0 + t) * np.exp(-t)   # amp f'(r2)
+    elif kind == "rbf":
+        dk = -0.5 * K
+    else:
+        raise ValueError(kind)
+    for d in range(X.shape[1]):
+        diff = (X[:, d][:, None] - X[:, d][None, :]) / np.sqrt(m[d])
+        G[:, :, 1 + d] = dk * (-(diff * diff))             # d r2 / d log m_d = -diff^2
+    return G
+
+
+def gp_grad_log_likelihood(kind, theta, X, y, mean):
+    """The likelihood part of ``GaussianProcess.grad_nll`` (robo/models/gaussian_process.py:168-191)
+    with its sign flipped: 0.5 einsum('ijk,ij', Kg, alpha alpha^T - K^-1).  As in the reference
+    (:178-182) the 'gradient' of the Gram matrix w.r.t. the last entry (log sigma^2) is the IDENTITY,
+    not sigma^2 I -- mirrored, see DESIGN.md "Mirrored quirks"."""
+    theta = np.asarray(theta, dtype=np.float64)
+    L = gp_compute(kind, theta, X)
+    r = np.asarray(y, dtype=np.float64) - mean
+    alpha = sla.cho_solve((L, True), r, check_finite=False)
+    K_inv = sla.cho_solve((L, True), np.eye(L.shape[0]), check_finite=False)
+    Kg = kernel_gradient(kind, theta[:-1], X)
+    Kg = np.concatenate((Kg, np.eye(L.shape[0])[:, :, None]), axis=2)
+    A = np.outer(alpha, alpha) - K_inv
+    return 0.5 * np.einsum('ijk,ij', Kg, A)
 
 
 def gp_log_likelihood(L, y, mean):

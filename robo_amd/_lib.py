@@ -28,7 +28,7 @@ SYMBOLS = [
     "robo_last_error_string", "robo_version_string",
     "robo_gp_create", "robo_gp_destroy", "robo_gp_set_data", "robo_gp_set_output_transform",
     "robo_gp_set_precision", "robo_theta_size",
-    "robo_gp_fit", "robo_gp_loglik_batch", "robo_gp_get_factor", "robo_gp_get_gram",
+    "robo_gp_fit", "robo_gp_loglik_batch", "robo_gp_grad_loglik", "robo_gp_get_factor", "robo_gp_get_gram",
     "robo_cand_create", "robo_cand_destroy", "robo_cand_create_uniform", "robo_cand_get_points",
     "robo_cand_create_random", "robo_cand_get_point",
     "robo_gp_predict_cand", "robo_gp_predict", "robo_gp_predict_cov", "robo_gp_predict_mixture_cand",
@@ -106,6 +106,7 @@ def lib():
         "robo_theta_size": [i32, i32],
         "robo_gp_fit": [vp, _dp, dbl, _dp, C.POINTER(i32)],
         "robo_gp_loglik_batch": [vp, _dp, i32, dbl, _dp, C.POINTER(i32)],
+        "robo_gp_grad_loglik": [vp, _dp, dbl, _dp, _dp, C.POINTER(i32)],
         "robo_gp_get_factor": [vp, _dp],
         "robo_gp_get_gram": [vp, _dp, _dp],
         "robo_cand_create": [vp, _dp, i64, i32, pp],
@@ -330,6 +331,16 @@ class DeviceGP(object):
         ll, col = C.c_double(0), C.c_int32(0)
         check(lib().robo_gp_fit(self._h, _arr(theta), float(mean_c), C.byref(ll), C.byref(col)))
         return ll.value
+
+    def grad_loglik(self, theta, mean_c):
+        """(log likelihood, d loglik / d theta) at theta; the GP is fitted at theta afterwards.  The last
+        gradient entry is d / d sigma^2, as in the reference's grad_nll (include/robo_hip.h)."""
+        theta = _f64(theta, (self.n_theta,))
+        ll = C.c_double()
+        col = C.c_int32()
+        grad = np.empty(self.n_theta)
+        check(lib().robo_gp_grad_loglik(self._h, _arr(theta), float(mean_c), C.byref(ll), _arr(grad), C.byref(col)))
+        return ll.value, grad
 
     def loglik_batch(self, thetas, mean_c):
         thetas = _f64(thetas)

@@ -172,6 +172,11 @@ int32_t robo_gp_destroy(robo_gp* g) {
     hipFree(g->d_Linv);
     hipFree(g->d_theta);
     hipHostFree(g->h_theta);
+    hipFree(g->d_gV);
+    hipFree(g->d_gA);
+    hipFree(g->d_galpha);
+    hipFree(g->d_gpart);
+    hipFree(g->d_gout);
     hipFree(g->d_bK);
     hipFree(g->d_bLinv);
     hipFree(g->d_bXs);
@@ -306,6 +311,29 @@ int32_t robo_gp_fit(robo_gp* g, const double* theta, double mean_c, double* out_
     g->fitted = true;
     if (out_loglik) *out_loglik = g->loglik;
     if (out_fail_col) *out_fail_col = -1;
+    return ROBO_OK;
+}
+
+int32_t robo_gp_grad_loglik(robo_gp* g, const double* theta, double mean_c, double* out_loglik, double* out_grad,
+                            int32_t* out_fail_col) {
+    if (!g || !theta || !out_grad) return ROBO_BAD_ARGUMENT;
+    ROBO_TRY(robo_gp_fit(g, theta, mean_c, out_loglik, out_fail_col));
+    robo_ctx* c = g->ctx;
+    const int P = robo_theta_size(g->kind, g->dim);
+    if (!g->d_gV) {
+        const size_t np = (size_t)g->n_pad_max, t64 = (np + 63) / 64;
+        ROBO_TRY(dev_alloc(&g->d_gV, np * np));
+        ROBO_TRY(dev_alloc(&g->d_gA, np * np));
+        ROBO_TRY(dev_alloc(&g->d_galpha, np));
+        ROBO_TRY(dev_alloc(&g->d_gpart, (size_t)P * (t64 * (t64 + 1) / 2)));
+        ROBO_TRY(dev_alloc(&g->d_gout, (size_t)P));
+    }
+    // event slots 28 -> 29: everything after the factorisation (W^T, A, the reductions)
+    ROBO_HIP_CHECK(hipEventRecord(c->events[28], c->stream));
+    ROBO_TRY(launch_grad_loglik(g, g->d_gV, g->d_gA, g->d_galpha, g->d_gpart, g->d_gout));
+    ROBO_HIP_CHECK(hipEventRecord(c->events[29], c->stream));
+    ROBO_HIP_CHECK(hipMemcpyAsync(out_grad, g->d_gout, (size_t)P * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    ROBO_HIP_CHECK(hipStreamSynchronize(c->stream));
     return ROBO_OK;
 }
 

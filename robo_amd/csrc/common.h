@@ -106,6 +106,8 @@ struct robo_gp {
     double *d_bK, *d_bLinv, *d_bXs, *d_bism, *d_bout, *h_bstage;
     robo::FitSample* d_bsp;
     int* d_bfail;
+    // workspace of robo_gp_grad_loglik (lazy, sized for n_pad_max): W^T, A = alpha alpha^T - K^-1, ...
+    double *d_gV, *d_gA, *d_galpha, *d_gpart, *d_gout;
 };
 
 struct robo_cand {
@@ -160,6 +162,7 @@ int launch_diag_timeline(robo_gp* gp, long long* d_stamps);
 int launch_cross_gram(robo_gp* gp, robo_cand* cand, int64_t c0, int64_t cn);
 int launch_trsm(robo_gp* gp, robo_cand* cand, int64_t c0, int64_t cn);
 int launch_predict_fused(robo_gp* gp, robo_cand* cand, int64_t c0, int64_t cn);
+int launch_grad_loglik(robo_gp* gp, double* d_V, double* d_A, double* d_alpha, double* d_part, double* d_out);
 int launch_post(robo_gp* gp, robo_cand* cand, int64_t c0, int64_t cn);
 int launch_acq(robo_ctx* ctx, robo_cand* cand, int acq_kind, double par, double eta, bool accumulate, bool first);
 int launch_argmax(robo_cand* cand, const double* d_vals, double scale);

@@ -80,15 +80,6 @@ __device__ __forceinline__ void pair_cov(const CovParams& cp, const double* __re
         for (int b = 0; b < 4; ++b) cov[a][b] = cov_finish<T, KIND>(cp, acc[a][b], uu[a][b]);
 }
 
-// map linear lower-triangular tile index to (bi, bj), bj <= bi
-__device__ __forceinline__ void tri_tile(int t, int& bi, int& bj) {
-    int i = (int)((sqrt(8.0 * (double)t + 1.0) - 1.0) * 0.5);
-    while ((i + 1) * (i + 2) / 2 <= t) ++i;
-    while (i * (i + 1) / 2 > t) --i;
-    bi = i;
-    bj = t - i * (i + 1) / 2;
-}
-
 // K[i][j] for j-tile <= i-tile.  Rows/cols >= n: row n is the augmented right-hand side
 // (y - mean), the rest identity, so that one Cholesky also yields z = L^-1 (y - mean)
 // as row n of the factor (DESIGN.md "augmented row").

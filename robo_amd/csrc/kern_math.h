@@ -67,6 +67,15 @@ __device__ __forceinline__ double cov_rows(const CovParams& p, const double* __r
     return cov_finish(p, acc, uu);
 }
 
+// map linear lower-triangular tile index to (bi, bj), bj <= bi
+__device__ __forceinline__ void tri_tile(int t, int& bi, int& bj) {
+    int i = (int)((sqrt(8.0 * (double)t + 1.0) - 1.0) * 0.5);
+    while ((i + 1) * (i + 2) / 2 <= t) ++i;
+    while (i * (i + 1) / 2 > t) --i;
+    bi = i;
+    bj = t - i * (i + 1) / 2;
+}
+
 constexpr double SQRT1_2 = 0.70710678118654752440;
 constexpr double SQRT_2PI = 2.50662827463100050242;
 constexpr double LOG_SQRT_2PI = 0.91893853320467274178;

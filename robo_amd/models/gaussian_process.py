@@ -148,11 +148,53 @@ class GaussianProcess(BaseModel):
         return -ll if np.isfinite(ll) else 1e25
 
     def grad_nll(self, theta):
-        raise NotImplementedError("analytic grad_nll is a 'next' row (SURVEY.md 8f rank 1); "
-                                  "optimize() uses finite differences like the reference default")
+        """Gradient of :meth:`nll` as the reference computes it (gaussian_process.py:168-191):
+        ``-(0.5 einsum('ijk,ij', Kg, alpha alpha^T - K^-1) + prior.gradient(theta))`` -- on the
+        device, without K^-1 or the (N, N, P) kernel-gradient tensor on the host.  Mirrored quirks:
+        the noise entry is the derivative w.r.t. sigma^2 (the reference stacks an identity matrix as the
+        noise "gradient", :178-182), and the prior term is whatever ``prior.gradient`` returns
+        (zeros for DefaultPrior, default_priors.py:51-53)."""
+        theta = np.asarray(theta, dtype=np.float64)
+        _, g = self.gp.grad_loglik(theta, self.mean)
+        if self.prior is not None:
+            g = g + self.prior.gradient(theta)
+        return -g
+
+    def _nll_with_gradient(self, theta):
+        """(nll, d nll / d theta) with a CONSISTENT gradient for the optimiser: chain rule on the noise
+        entry (d / d log sigma^2 = sigma^2 d / d sigma^2) and a central difference of the prior's
+        lnprob (host scalar work) instead of ``prior.gradient`` -- one device pass for both."""
+        theta = np.asarray(theta, dtype=np.float64)
+        if np.any((-20 > theta) + (theta > 20)):
+            return 1e25, np.zeros_like(theta)
+        try:
+            ll, g = self.gp.grad_loglik(theta, self.mean)
+        except np.linalg.LinAlgError:
+            return 1e25, np.zeros_like(theta)
+        g = g.copy()
+        g[-1] *= np.exp(theta[-1])
+        if self.prior is not None:
+            ll += self.prior.lnprob(theta)
+            h = 1e-6
+            for p in range(theta.size):
+                e = np.zeros_like(theta)
+                e[p] = h
+                with np.errstate(invalid="ignore"):     # -inf - -inf outside a tophat's support
+                    d = (self.prior.lnprob(theta + e) - self.prior.lnprob(theta - e)) / (2 * h)
+                if np.isfinite(d):
+                    g[p] += d
+        if not np.isfinite(ll) or not np.all(np.isfinite(g)):
+            return 1e25, np.zeros_like(theta)
+        return -ll, -g
 
     def optimize(self):
         p0 = np.append(self.kernel.get_parameter_vector(), np.log(self.noise))
+        if self.use_gradients:
+            # reference: optimize.minimize(self.nll, p0, method="BFGS", jac=self.grad_nll), whose
+            # 3-tuple unpacking of the OptimizeResult cannot succeed (gaussian_process.py:207-210);
+            # here the result's .x, with the consistent gradient above (DESIGN.md deviations)
+            results = optimize.minimize(self._nll_with_gradient, p0, method="BFGS", jac=True)
+            return results.x
         try:
             results = optimize.minimize(self.nll, p0, method='L-BFGS-B')
             theta = results.x

@@ -371,6 +371,75 @@ def check_batched_likelihoods(ctx, sizes=((60, 3), (300, 4))):
         g.close()
 
 
+def check_grad_loglik(ctx, cases=(("matern52", 70, 3), ("rbf", 200, 5), ("fabolas", 150, 4), ("matern52", 300, 20),
+                                  ("matern52", 650, 2))):
+    """robo_gp_grad_loglik == the oracle's restatement of GaussianProcess.grad_nll
+    (robo/models/gaussian_process.py:168-191) for every kernel kind, several block counts (N below,
+    across and well above one 128 block) and D above one 16-dimension staging pass; the GP is left
+    fitted at theta; the call is deterministic (bitwise repeatable)."""
+    rs = np.random.RandomState(23)
+    for kind, N, D in cases:
+        X = rs.rand(N, D)
+        y = np.sin(3 * X.sum(axis=1)) + 0.1 * rs.randn(N)
+        P = O.n_kernel_params(kind, D) + 1
+        theta = 0.3 * rs.randn(P)
+        theta[1:P - 1] += np.log(0.3 * D) if kind != "fabolas" else 0.0
+        theta[-1] = np.log(1e-2)
+        mean_c = float(y.mean())
+        g = _lib.DeviceGP(ctx, kind, N, D)
+        g.set_data(X, y)
+        ll, grad = g.grad_loglik(theta, mean_c)
+        ref = O.gp_grad_log_likelihood(kind, theta, X, y, mean_c)
+        L = O.gp_compute(kind, theta, X)
+        np.testing.assert_allclose(ll, O.gp_log_likelihood(L, y, mean_c), rtol=LOGLIK_RTOL)
+        scale = np.max(np.abs(ref))
+        np.testing.assert_allclose(grad, ref, rtol=1e-8, atol=1e-9 * scale, err_msg="%s N=%d D=%d" % (kind, N, D))
+        ll2, grad2 = g.grad_loglik(theta, mean_c)
+        assert ll2 == ll
+        np.testing.assert_array_equal(grad2, grad)
+        mu, var = g.predict(X[:5])          # fitted at theta afterwards
+        assert np.all(np.isfinite(mu)) and np.all(var > 0)
+        g.close()
+
+
+def check_model_gradients(ctx):
+    """GaussianProcess.grad_nll (host mirror) == the oracle restatement of the reference's grad_nll
+    incl. the prior term and the noise quirk; the gradient-based optimize() (use_gradients=True,
+    BFGS on the consistent gradient) ends at an nll no worse than the finite-difference L-BFGS-B
+    default, from the same start."""
+    from robo_amd.kernels import Matern52Kernel
+    from robo_amd.models import GaussianProcess
+    from robo_amd.priors import DefaultPrior
+    rs = np.random.RandomState(5)
+    N, D = 90, 3
+    X = rs.rand(N, D)
+    y = np.sinc(X * 10 - 5).sum(axis=1)
+    lower, upper = np.zeros(D), np.ones(D)
+    models = {}
+    for ug in (False, True):
+        kernel = 2.0 * Matern52Kernel(np.ones(D), ndim=D)
+        prior = DefaultPrior(len(kernel) + 1, rng=np.random.RandomState(0))
+        m = GaussianProcess(kernel, prior=prior, use_gradients=ug, lower=lower, upper=upper,
+                            rng=np.random.RandomState(1))
+        m.train(X, y, do_optimize=True)
+        models[ug] = m
+    m = models[True]
+    theta = m.hypers + 0.05
+    ref = -(O.gp_grad_log_likelihood("matern52", theta, m.X, m.y, m.mean) + m.prior.gradient(theta))
+    np.testing.assert_allclose(m.grad_nll(theta), ref, rtol=1e-7, atol=1e-8 * np.max(np.abs(ref)))
+    # consistent objective/gradient pair: central differences of the objective itself
+    f0, g0 = m._nll_with_gradient(theta)
+    for p in range(theta.size):
+        e = np.zeros_like(theta)
+        e[p] = 1e-5
+        fd = (m._nll_with_gradient(theta + e)[0] - m._nll_with_gradient(theta - e)[0]) / 2e-5
+        assert abs(fd - g0[p]) <= 1e-4 * max(1.0, abs(fd)), (p, fd, g0[p])
+    assert models[True].nll(models[True].hypers) <= models[False].nll(models[False].hypers) + 1e-3 * abs(
+        models[False].nll(models[False].hypers))
+    mu, var = models[True].predict(X[:4])
+    assert np.all(np.isfinite(mu)) and np.all(var > 0)
+
+
 def check_device_random_candidates(ctx):
     """device-generated RandomSampling recipe: bounds, split, moments; winner row read-back"""
     loc = np.array([0.2, 0.9, 0.5])

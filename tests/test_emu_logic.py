@@ -65,6 +65,14 @@ def test_batched_likelihoods(emu_ctx):
     P.check_batched_likelihoods(emu_ctx)
 
 
+def test_grad_loglik(emu_ctx):
+    P.check_grad_loglik(emu_ctx)
+
+
+def test_model_gradients(emu_ctx):
+    P.check_model_gradients(emu_ctx)
+
+
 def test_device_random_candidates(emu_ctx):
     P.check_device_random_candidates(emu_ctx)
 

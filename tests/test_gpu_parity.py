@@ -68,6 +68,15 @@ def test_batched_likelihoods(ctx):
     P.check_batched_likelihoods(ctx, sizes=((60, 3), (300, 4), (1500, 8)))
 
 
+def test_grad_loglik(ctx):
+    P.check_grad_loglik(ctx)
+    P.check_grad_loglik(ctx, cases=(("matern52", 1500, 8), ("rbf", 1100, 40)))
+
+
+def test_model_gradients(ctx):
+    P.check_model_gradients(ctx)
+
+
 def test_device_random_candidates(ctx):
     P.check_device_random_candidates(ctx)
 
