@@ -202,6 +202,15 @@ def main():
                        "parallelism": "candidate-shard x%d, replicated fit" % world},
             "gp_fit_ms": float(np.min(fit_ms)),
             "gp_fit_phases_ms": {"gram": gram_ms, "cholesky": chol_ms, "loglik": ll_ms},
+            # north_star's two side figures: K-assembly against the HBM roofline (lower
+            # triangle written once + X read once) and the factorisation against the fp64 MFMA peak
+            "k_assembly": {"bytes": 8.0 * N * (N + 1) / 2 + 8.0 * N * D, "ms": gram_ms,
+                           "GB_per_s": (8.0 * N * (N + 1) / 2 + 8.0 * N * D) / (gram_ms * 1e-3) / 1e9,
+                           "frac_of_8TBps": (8.0 * N * (N + 1) / 2 + 8.0 * N * D) / (gram_ms * 1e-3) / 8.0e12},
+            "cholesky": {"flops": N ** 3 / 3.0, "ms": chol_ms, "TFLOP_per_s": N ** 3 / 3.0 / (chol_ms * 1e-3) / 1e12,
+                         "frac_of_mfma_peak": N ** 3 / 3.0 / (chol_ms * 1e-3) / 1e12 / FP64_MFMA_PEAK_TFLOPS,
+                         "note": "latency-bound by the 128 sequential pivots of each diagonal block; the trailing "
+                                 "MFMA updates alone run at ~27 TFLOP/s (profiles/*_kernel_stats.csv)"},
             "gp_fit_batched": {"thetas": S_half, "ms_total": batch_ms, "ms_per_theta": batch_ms / S_half},
             "gp_grad_loglik_ms": {"total_incl_fit": grad_ms, "after_factorisation": grad_dev_ms},
             "ei_eval_phases_ms_per_step": {"cross_gram": cross_ms / args.steps, "trsm": trsm_ms / args.steps},

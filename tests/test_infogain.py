@@ -45,20 +45,26 @@ def test_pmin_pins():
     assert np.exp(epmgp.joint_min(mu, np.eye(n) * 1e-3))[0] == 1.0
 
 
-def _setup(ctx, N=60, D=3, M=150, Nb=12, Np=40, seed=0):
+def _setup(ctx, N=60, D=3, M=150, Nb=12, Np=40, seed=0, kind="matern52"):
     rs = np.random.RandomState(seed)
     X = rs.rand(N, D)
     y = np.sin(3 * X.sum(axis=1)) + 0.1 * rs.randn(N)
-    theta = np.concatenate([[0.0], np.log([0.3, 0.5, 0.8])[:D], [np.log(1e-2)]])
+    if kind == "fabolas":   # BASELINE config 4: D-1 inputs + the basis-transformed fidelity column
+        X[:, -1] = (1.0 - X[:, -1]) ** 2
+        theta = np.concatenate([[0.0], np.log(0.3 * (D - 1)) + 0.2 * rs.randn(D - 1), [-0.5, 0.3], [np.log(1e-2)]])
+    else:
+        theta = np.concatenate([[0.0], np.log([0.3, 0.5, 0.8])[:D], [np.log(1e-2)]])
     Xc = rs.rand(M, D)
     zb = rs.rand(Nb, D)
+    if kind == "fabolas":   # representers live on the s = 1 subspace (information_gain_per_unit_cost.py:125-138)
+        zb[:, -1] = 0.0
     lmb = rs.randn(Nb)
-    ogp = O.OracleGP("matern52", theta, normalize_input=False)
+    ogp = O.OracleGP(kind, theta, normalize_input=False)
     ogp.train(X, y)
     mu_b, var_b = ogp.predict(zb, full_cov=True)
     logP, dMu, dSig, dMM = epmgp.joint_min(mu_b, var_b, with_derivatives=True)
     W = IG.outcome_quantiles(Np)
-    g = _lib.DeviceGP(ctx, "matern52", N, D)
+    g = _lib.DeviceGP(ctx, kind, N, D)
     g.set_data(X, y)
     g.fit(theta, ogp.mean)
     return dict(ogp=ogp, g=g, Xc=Xc, zb=zb, lmb=lmb, logP=logP, dMu=dMu, dSig=dSig, dMM=dMM, W=W,
@@ -103,6 +109,7 @@ def emu_ctx():
 
 def test_information_gain_logic_emulated(emu_ctx):
     _check_ig(emu_ctx, N=60, D=3, M=150, Nb=12, Np=40)
+    _check_ig(emu_ctx, N=70, D=4, M=130, Nb=10, Np=30, seed=4, kind="fabolas")
 
 
 def test_information_gain_class_emulated(emu_ctx):
@@ -134,6 +141,17 @@ def test_information_gain_gpu():
     ctx = _lib.Context(0)
     _check_ig(ctx, N=60, D=3, M=150, Nb=12, Np=40)
     _check_ig(ctx, N=700, D=3, M=3000, Nb=50, Np=400, seed=3)
+    ctx.close()
+
+
+@pytest.mark.gpu
+def test_information_gain_config4_shard():
+    """BASELINE config 4 at its per-GPU size: Fabolas product kernel, N = 4096, D = 10 + 1, Nb = 50,
+    Np = 400, 65 536 / 8 = 8192 candidates -- cross-covariances against the oracle, information gain of
+    every candidate against the NumPy restatement, argmax index equal."""
+    _lib.use_library(None)
+    ctx = _lib.Context(0)
+    _check_ig(ctx, N=4096, D=11, M=8192, Nb=50, Np=400, seed=4, kind="fabolas")
     ctx.close()
 
 
