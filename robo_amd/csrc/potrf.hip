@@ -7,7 +7,8 @@
 // Per panel k (block column k of the n_pad x n_pad lower matrix, in place):
 //   potrf_diag_kernel   1 workgroup : L_kk = chol(A_kk), W_k = L_kk^-1            (LDS resident)
 //   potrf_panel_kernel  nb-k-1 WGs  : A_ik <- A_ik * W_k^T          (fp64 MFMA, gemm_f64.h)
-//   potrf_syrk_kernel   tri tiles   : A_ij <- A_ij - A_ik * A_jk^T  (fp64 MFMA, gemm_f64.h)
+//   potrf_step_kernel   tri tiles   : A_ij <- A_ij - A_ik * A_jk^T  (fp64 MFMA, gemm_f64.h); the
+//                                     workgroup of tile (k+1, k+1) then factors it (next diagonal block)
 // Because row n of the matrix is the augmented right-hand side (gram.hip), the finished
 // factor holds z = L^-1 (y - mean) in row n: loglik_kernel only reduces z.z and log diag.
 //
@@ -238,14 +239,42 @@ __device__ __forceinline__ void diag128_factor_invert(double* sL, double* sW, do
     if (dbg && tid == 0) dbg[11] = clock64();
 }
 
+constexpr int DIAG_SMEM_DOUBLES = 2 * NBLK * BLK + 4 * SB * TLD + NB + 2 * SB;   // 150 KB
+
+struct DiagSmem {
+    double *sL, *sW, *sT, *sRd, *sCol;
+};
+__device__ __forceinline__ DiagSmem diag_carve(double* base) {
+    DiagSmem m;
+    m.sL = base;
+    m.sW = m.sL + NBLK * BLK;
+    m.sT = m.sW + NBLK * BLK;
+    m.sRd = m.sT + 4 * SB * TLD;
+    m.sCol = m.sRd + NB;
+    return m;
+}
+
+// L into K (lower sub-blocks), W as a dense 128x128 row-major block
+__device__ __forceinline__ void diag_writeback(const DiagSmem& m, double* __restrict__ Kd, int ld,
+                                               double* __restrict__ Wg) {
+    const int tid = threadIdx.x;
+    for (int bi = 0; bi < NSB; ++bi)
+        for (int bj = 0; bj < NSB; ++bj) {
+            const int r = bi * SB + (tid >> 4), c = bj * SB + (tid & 15);
+            if (bj <= bi) {
+                Kd[(size_t)r * ld + c] = m.sL[blk_off(bi, bj) + tid];
+                Wg[r * NB + c] = m.sW[blk_off(bi, bj) + tid];
+            } else {
+                Wg[r * NB + c] = 0.0;
+            }
+        }
+}
+
 __global__ __launch_bounds__(256) void potrf_diag_kernel(double* __restrict__ K, size_t k_stride, int ld, int k,
                                                          int n_real, double* __restrict__ Linv, size_t linv_stride,
                                                          int* __restrict__ fail, long long* __restrict__ dbg) {
-    __shared__ double sL[NBLK * BLK];
-    __shared__ double sW[NBLK * BLK];
-    __shared__ double sT[4 * SB * TLD];
-    __shared__ double sRd[NB];
-    __shared__ double sCol[2 * SB];
+    __shared__ double smem[DIAG_SMEM_DOUBLES];
+    const DiagSmem m = diag_carve(smem);
     const int tid = threadIdx.x;
     K += (size_t)blockIdx.x * k_stride;           // batch coordinate
     Linv += (size_t)blockIdx.x * linv_stride;
@@ -256,24 +285,13 @@ __global__ __launch_bounds__(256) void potrf_diag_kernel(double* __restrict__ K,
     // ---- load the 36 lower sub-blocks ------------------------------------------------
     for (int bi = 0; bi < NSB; ++bi)
         for (int bj = 0; bj <= bi; ++bj)
-            sL[blk_off(bi, bj) + tid] = Kd[(size_t)(bi * SB + (tid >> 4)) * ld + bj * SB + (tid & 15)];
+            m.sL[blk_off(bi, bj) + tid] = Kd[(size_t)(bi * SB + (tid >> 4)) * ld + bj * SB + (tid & 15)];
     __syncthreads();
     if (dbg && tid == 0) dbg[1] = clock64();
 
-    diag128_factor_invert(sL, sW, sT, sRd, sCol, k * NB, n_real, fail, dbg);
+    diag128_factor_invert(m.sL, m.sW, m.sT, m.sRd, m.sCol, k * NB, n_real, fail, dbg);
 
-    // ---- write back: L into K (lower blocks), W as a dense 128x128 row-major block --------
-    double* Wg = Linv + (size_t)k * NB * NB;
-    for (int bi = 0; bi < NSB; ++bi)
-        for (int bj = 0; bj < NSB; ++bj) {
-            const int r = bi * SB + (tid >> 4), c = bj * SB + (tid & 15);
-            if (bj <= bi) {
-                Kd[(size_t)r * ld + c] = sL[blk_off(bi, bj) + tid];
-                Wg[r * NB + c] = sW[blk_off(bi, bj) + tid];
-            } else {
-                Wg[r * NB + c] = 0.0;
-            }
-        }
+    diag_writeback(m, Kd, ld, Linv + (size_t)k * NB * NB);
     if (dbg && tid == 0) dbg[12] = clock64();
 }
 
@@ -297,26 +315,68 @@ __global__ __launch_bounds__(256) void potrf_panel_kernel(double* __restrict__ K
         for (int r = 0; r < 4; ++r) A[(size_t)acc_row<1>(0, r) * ld + acc_col(tn)] = acc.t[0][tn][r];
 }
 
-// A_ij <- A_ij - A_ik * A_jk^T   for k < j <= i (right-looking trailing update, K = 128).
+// Trailing update of step k fused with the NEXT diagonal block:
+//   A_ij <- A_ij - A_ik * A_jk^T   for k < j <= i (right-looking, K = 128), and workgroup 0 -- which
+//   owns tile (k+1, k+1) -- goes on to factor and invert it (diag128_factor_invert) while the other
+//   workgroups are still updating: the 66 us single-workgroup diagonal kernel, the fit's bottleneck,
+//   runs in the shadow of the chip-wide update instead of after it.  (Doing the same with two
+//   streams was slower: cross-queue event waits cost more than they hid, r01q.)
 // Tile height 32*TM is chosen per step by the launcher: a 128x128x128 tile is 512 MFMAs deep
 // (>= 13.6 us per wave), so late steps with few blocks use shorter tiles to cover the chip.
 // (A two-level variant with 512-deep updates was measured slower: its strip updates put
-// <= 32 workgroups on the critical path.)
-template <int TM>
-__global__ __launch_bounds__(256) void potrf_syrk_kernel(double* __restrict__ K, size_t k_stride, int ld, int k) {
-    __shared__ double smem[gemm_smem_doubles<TM>()];
+// <= 32 workgroups on the critical path.)  Every workgroup is sized for the diagonal block's 150 KB
+// of LDS, i.e. one per CU.
+// FUSED = false is the plain trailing update (diagonal blocks by potrf_diag_kernel): used for batched
+// fits, where S diagonal workgroups already run side by side and two update workgroups per CU matter
+// more (measured, 27 thetas at N = 4096: 0.69 ms per theta unfused, 0.78 fused).
+template <int TM, bool FUSED>
+__global__ __launch_bounds__(256) void potrf_step_kernel(double* __restrict__ K, size_t k_stride, int ld, int k,
+                                                         int n_real, double* __restrict__ Linv, size_t linv_stride,
+                                                         int* __restrict__ fail) {
+    __shared__ double smem[FUSED ? DIAG_SMEM_DOUBLES : gemm_smem_doubles<TM>()];
     K += (size_t)blockIdx.y * k_stride;
+    if (FUSED && blockIdx.x == 0) {
+        // ---- tile (k+1, k+1): update, then straight into the block-packed LDS image of the diagonal kernel
+        const size_t d0 = (size_t)(k + 1) * NB;
+        const double* A = K + d0 * ld + (size_t)k * NB;
+        double* C = K + d0 * ld + d0;
+        Acc acc;
+#pragma unroll
+        for (int tm = 0; tm < 4; ++tm)
+#pragma unroll
+            for (int tn = 0; tn < 4; ++tn)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) acc.t[tm][tn][r] = C[(size_t)acc_row(tm, r) * ld + acc_col(tn)];
+        gemm_nt<4, true>(A, ld, A, ld, 0, NB, acc, smem);     // ends on a barrier: smem is free
+        const DiagSmem m = diag_carve(smem);
+#pragma unroll
+        for (int tm = 0; tm < 4; ++tm)
+#pragma unroll
+            for (int tn = 0; tn < 4; ++tn)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int row = acc_row(tm, r), col = acc_col(tn);
+                    if ((col >> 4) <= (row >> 4))
+                        m.sL[blk_off(row >> 4, col >> 4) + (row & 15) * SB + (col & 15)] = acc.t[tm][tn][r];
+                }
+        __syncthreads();
+        diag128_factor_invert(m.sL, m.sW, m.sT, m.sRd, m.sCol, (k + 1) * NB, n_real, fail + blockIdx.y, nullptr);
+        diag_writeback(m, C, ld, Linv + (size_t)blockIdx.y * linv_stride + (size_t)(k + 1) * NB * NB);
+        return;
+    }
     constexpr int SPLIT = 4 / TM;                    // row sub-tiles per 128-row block
+    // sub-tile index; when fused, tile 0's sub-tiles belong to workgroup 0
+    const int b = FUSED ? (int)blockIdx.x - 1 + SPLIT : (int)blockIdx.x;
     int ii, jj;
     {
-        const int t = blockIdx.x / SPLIT;
+        const int t = b / SPLIT;
         int q = (int)((sqrt(8.0 * (double)t + 1.0) - 1.0) * 0.5);
         while ((q + 1) * (q + 2) / 2 <= t) ++q;
         while (q * (q + 1) / 2 > t) --q;
         ii = q;
         jj = t - q * (q + 1) / 2;
     }
-    const int i = k + 1 + ii, j = k + 1 + jj, h = blockIdx.x % SPLIT;
+    const int i = k + 1 + ii, j = k + 1 + jj, h = b % SPLIT;
     const size_t row0 = (size_t)i * NB + (size_t)h * (32 * TM);
     const double* A = K + row0 * ld + (size_t)k * NB;
     const double* B = K + ((size_t)j * NB) * ld + (size_t)k * NB;
@@ -369,23 +429,30 @@ int launch_potrf(robo_gp* gp, const FitBuffers& fb) {
     robo_ctx* ctx = gp->ctx;
     const int ld = gp->n_pad, nb = gp->n_pad / NB, S = fb.S;
     ROBO_HIP_CHECK(hipMemsetAsync(fb.fail, 0, (size_t)S * sizeof(int), ctx->stream));
+    const bool fused = S <= 2;
     for (int k = 0; k < nb; ++k) {
-        hipLaunchKernelGGL(potrf_diag_kernel, dim3(S), dim3(256), 0, ctx->stream, fb.K, fb.k_stride, ld, k, gp->n,
-                           fb.Linv, fb.linv_stride, fb.fail, (long long*)nullptr);
+        if (k == 0 || !fused)
+            hipLaunchKernelGGL(potrf_diag_kernel, dim3(S), dim3(256), 0, ctx->stream, fb.K, fb.k_stride, ld, k, gp->n,
+                               fb.Linv, fb.linv_stride, fb.fail, (long long*)nullptr);
         const int rem = nb - k - 1;
-        if (rem > 0) {
-            hipLaunchKernelGGL(potrf_panel_kernel, dim3(rem * 4, S), dim3(256), 0, ctx->stream, fb.K, fb.k_stride, ld,
-                               k, (const double*)fb.Linv, fb.linv_stride);
-            const int blocks = rem * (rem + 1) / 2;
-            // measured (N = 4096, S = 1): 128-row tiles 43 us/step at 384..528 blocks, 64-row tiles
-            // slower (55 us: B panel re-read twice), 32-row tiles 16 us vs 21 us once blocks < 96
-            if (blocks * S >= 96)
-                hipLaunchKernelGGL(potrf_syrk_kernel<4>, dim3(blocks, S), dim3(256), 0, ctx->stream, fb.K, fb.k_stride,
-                                   ld, k);
-            else
-                hipLaunchKernelGGL(potrf_syrk_kernel<1>, dim3(blocks * 4, S), dim3(256), 0, ctx->stream, fb.K,
-                                   fb.k_stride, ld, k);
+        if (rem <= 0) break;
+        hipLaunchKernelGGL(potrf_panel_kernel, dim3(rem * 4, S), dim3(256), 0, ctx->stream, fb.K, fb.k_stride, ld, k,
+                           (const double*)fb.Linv, fb.linv_stride);
+        const int tiles = rem * (rem + 1) / 2;
+        // trailing update of step k (+ diagonal block k+1 in workgroup 0 when fused).  Tile height, measured
+        // (N = 4096, S = 1): 128-row tiles 43 us/step at 384..528 blocks, 64-row tiles slower (55 us: B
+        // panel re-read twice), 32-row tiles 16 us vs 21 us once blocks < 96
+#define ROBO_STEP(TM, F, GRID)                                                                                  \
+    hipLaunchKernelGGL((potrf_step_kernel<TM, F>), dim3((GRID), S), dim3(256), 0, ctx->stream, fb.K, fb.k_stride, \
+                       ld, k, gp->n, fb.Linv, fb.linv_stride, fb.fail)
+        if (tiles * S >= 96) {
+            if (fused) ROBO_STEP(4, true, tiles);
+            else ROBO_STEP(4, false, tiles);
+        } else {
+            if (fused) ROBO_STEP(1, true, 1 + (tiles - 1) * 4);
+            else ROBO_STEP(1, false, tiles * 4);
         }
+#undef ROBO_STEP
     }
     ROBO_LAUNCH_CHECK();
     return ROBO_OK;
