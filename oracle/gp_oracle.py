@@ -15,7 +15,10 @@ What is restated, and from where (paths relative to /root/reference):
   definitions in ``kernel_matrix``/``JITTER`` are this project's contract
   (SURVEY.md A.2).  The posterior *algebra* is pinned by the reference's own
   test identity (test/test_models/test_gaussian_process.py:44-49), re-checked
-  in tests/test_oracle.py.
+  in tests/test_oracle.py.  As an independent third-party check (not a pin to
+  george) the same test file compares kernel matrix, posterior, log-likelihood
+  and likelihood gradient with scikit-learn's Matern(nu=2.5)/RBF +
+  GaussianProcessRegressor: equal to rounding.
 * ``GaussianProcess.train/nll/predict/get_incumbent``
   (robo/models/gaussian_process.py:70-124,129-166,251-296,334-352) ->
   :class:`OracleGP`.

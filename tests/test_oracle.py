@@ -147,3 +147,55 @@ def test_mcmc_marginal_regression(golden_dir):
     m, v = O.mcmc_mixture(g["mu_s"], g["var_s"])
     np.testing.assert_array_equal(m, g["mix_m"])
     np.testing.assert_array_equal(v, g["mix_v"])
+
+
+@pytest.mark.parametrize("kind", ["matern52", "rbf"])
+def test_oracle_agrees_with_scikit_learn(kind):
+    """Independent third-party cross-check of everything the oracle DEFINES rather than restates
+    (george is absent, so its kernel values are 'parity unpinned'): scikit-learn's Matern(nu=2.5) / RBF
+    with length_scale = sqrt(metric), ConstantKernel(amp), WhiteKernel(sigma^2 + jitter) and its
+    GaussianProcessRegressor give the same kernel matrix, posterior mean / variance, log marginal
+    likelihood and likelihood gradient (d/d log ell = 2 d/d log m; the noise entry differs by the factor
+    sigma^2 the reference's grad_nll drops, gaussian_process.py:178-182)."""
+    sk = pytest.importorskip("sklearn.gaussian_process")
+    from sklearn.gaussian_process.kernels import RBF, ConstantKernel, Matern, WhiteKernel
+    rs = np.random.RandomState(0)
+    N, D = 60, 3
+    X = rs.rand(N, D)
+    y = np.sin(3 * X.sum(axis=1))
+    theta = np.concatenate([[0.3], np.log([0.2, 0.5, 0.9]), [np.log(1e-2)]])
+    amp, m, s2 = np.exp(theta[0]), np.exp(theta[1:-1]), np.exp(theta[-1]) + O.JITTER
+    base = Matern(length_scale=np.sqrt(m), nu=2.5) if kind == "matern52" else RBF(length_scale=np.sqrt(m))
+    k = ConstantKernel(amp) * base
+    np.testing.assert_allclose(O.kernel_matrix(kind, theta[:-1], X), k(X), rtol=0, atol=1e-14)
+    gpr = sk.GaussianProcessRegressor(kernel=k + WhiteKernel(s2), alpha=0.0, optimizer=None)
+    c = y.mean()
+    gpr.fit(X, y - c)
+    Xs = rs.rand(9, D)
+    mu, std = gpr.predict(Xs, return_std=True)
+    L = O.gp_compute(kind, theta, X)
+    mu_o, var_o = O.gp_predict_diag(kind, theta, L, X, y, c, Xs)
+    np.testing.assert_allclose(mu_o, mu + c, rtol=0, atol=1e-12)
+    np.testing.assert_allclose(var_o, std ** 2 - s2, rtol=0, atol=1e-12)   # sklearn adds the white noise
+    lml, grad = gpr.log_marginal_likelihood(gpr.kernel_.theta, eval_gradient=True)
+    np.testing.assert_allclose(O.gp_log_likelihood(L, y, c), lml, rtol=1e-13)
+    g = O.gp_grad_log_likelihood(kind, theta, X, y, c)
+    np.testing.assert_allclose(g[0], grad[0], rtol=1e-9)
+    np.testing.assert_allclose(2.0 * g[1:-1], grad[1:-1], rtol=1e-9, atol=1e-10)
+    np.testing.assert_allclose(g[-1] * s2, grad[-1], rtol=1e-9)
+
+
+def test_kernel_gradient_matches_central_differences():
+    """kernel_gradient (george's kernel.gradient, gaussian_process.py:181) is the exact derivative of
+    kernel_matrix for every kind, Fabolas product kernel included"""
+    rs = np.random.RandomState(1)
+    for kind, D in (("matern52", 3), ("rbf", 2), ("fabolas", 4)):
+        X = rs.rand(25, D)
+        P = O.n_kernel_params(kind, D)
+        th = 0.3 * rs.randn(P)
+        G = O.kernel_gradient(kind, th, X)
+        for p in range(P):
+            e = np.zeros(P)
+            e[p] = 1e-6
+            fd = (O.kernel_matrix(kind, th + e, X) - O.kernel_matrix(kind, th - e, X)) / 2e-6
+            np.testing.assert_allclose(G[:, :, p], fd, rtol=0, atol=2e-8 * max(1.0, np.abs(fd).max()))
