@@ -75,7 +75,9 @@ def test_default_prior_batch_equals_scalar():
     with np.errstate(all="ignore"):
         want = np.array([pr.lnprob(t) for t in th])
         got = pr.lnprob_batch(th)
-    np.testing.assert_array_equal(got, want)
+    fin = np.isfinite(want)
+    np.testing.assert_array_equal(got[~fin], want[~fin])          # same -inf / +inf pattern
+    np.testing.assert_allclose(got[fin], want[fin], rtol=1e-13, atol=1e-13)   # closed-form lognormal vs scipy
 
 
 def test_initial_designs_properties():
