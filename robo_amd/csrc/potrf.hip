@@ -89,43 +89,61 @@ __device__ __forceinline__ double bcast_lane(double x, int src) {
 // robo_selftest_diag_timeline: the first version spent 11.5k cycles per 16x16 potf2+inverse).
 
 // One wave: unblocked Cholesky of the 16x16 block Ld (lower part valid), in place.
-// Lane i (mod 16) owns row i in registers.  Per column: the pivot comes through one readlane
-// pair, the scaled column goes through a 16-double LDS buffer that every lane then reads back
-// uniformly (broadcast reads, two values per ds_read_b128).  1/L_kk is kept in rd[] for the
-// forward substitutions.  g0 = global index of the block's first row; rows >= n_real have their
+// Lane i (mod 16) owns row i in registers.  The dependent chain per column is kept to
+//   pivot (readlane) -> rsqrt -> scale -> one FMA on the NEXT column (its multiplier comes through a
+//   second readlane, not through LDS),
+// so the next pivot never waits for the LDS exchange: the scaled column goes through a 16-double
+// LDS buffer that every lane reads back uniformly (broadcast ds_read_b128) for the bulk rank-1
+// update of columns >= k+2, which is issued one iteration later, in the shadow of the following
+// column's rsqrt chain (r01s: 7.8k -> 6.4k cycles per 16x16; the lone wave is issue-bound).  1/L_kk is kept in rd[] for
+// the forward substitutions.  g0 = global index of the block's first row; rows >= n_real have their
 // pivot forced to 1 (augmented row and identity padding).  Returns the first failing global
 // column + 1, or 0.
-__device__ __forceinline__ int potf2_16(double* Ld, double* rd, double* colbuf, int lane, int g0, int n_real) {
+template <bool GUARD>
+__device__ __forceinline__ int potf2_16_impl(double* Ld, double* rd, double* colbuf, int lane, int g0, int n_real) {
     const int row = lane & 15;
     double a[SB];
 #pragma unroll
     for (int j = 0; j < SB; ++j) a[j] = j <= row ? Ld[row * SB + j] : 0.0;
     int fail = 0;
+    double lprev = 0.0;   // this lane's entry of the previous column (multiplier of the deferred bulk update)
 #pragma unroll
     for (int k = 0; k < SB; ++k) {
-        double p = bcast_lane(a[k], k);   // pivot after the previous rank-1 updates
-        if (g0 + k >= n_real) p = 1.0;
+        double p = bcast_lane(a[k], k);   // pivot: complete (bulk updates <= k-2, fast path k-1)
+        if (GUARD && g0 + k >= n_real) p = 1.0;
         if (!(p > 0.0)) {                 // also catches NaN
             if (fail == 0) fail = g0 + k + 1;
             p = 1.0;
         }
         const double ri = rsqrt(p);
+        if (k > 0) {
+            // deferred bulk update by column k-1 (independent of the rsqrt chain above)
+            const double* cbp = colbuf + ((k - 1) & 1) * SB;
+#pragma unroll
+            for (int j = k + 1; j < SB; ++j) a[j] = fma(-lprev, cbp[j], a[j]);
+        }
         const double lik = row == k ? p * ri : a[k] * ri;   // rows < k hold garbage here, never read
         a[k] = lik;
-        double* cb = colbuf + (k & 1) * SB;
-        if (lane < SB) {
-            cb[row] = lik;
-            if (row == k) rd[k] = ri;
+        // every lane stores (the four 16-lane groups hold identical rows; same value to the same
+        // address): no exec masking or branches on the chain
+        colbuf[(k & 1) * SB + row] = lik;
+        rd[k] = ri;
+        if (k + 1 < SB) {
+            const double l1 = bcast_lane(lik, k + 1);        // L[k+1][k]
+            a[k + 1] = fma(-lik, l1, a[k + 1]);              // fast path: column k+1 is complete
         }
+        lprev = lik;
         wave_lds_fence();
-#pragma unroll
-        for (int j = k + 1; j < SB; ++j) a[j] = fma(-lik, cb[j], a[j]);
     }
-    if (lane < SB) {
 #pragma unroll
-        for (int j = 0; j < SB; ++j) Ld[row * SB + j] = j <= row ? a[j] : 0.0;
-    }
+    for (int j = 0; j < SB; ++j) Ld[row * SB + j] = j <= row ? a[j] : 0.0;
     return fail;
+}
+
+// the pivot guard for rows >= n_real only exists in the block(s) that hold the augmented row / padding
+__device__ __forceinline__ int potf2_16(double* Ld, double* rd, double* colbuf, int lane, int g0, int n_real) {
+    if (g0 + SB <= n_real) return potf2_16_impl<false>(Ld, rd, colbuf, lane, g0, n_real);
+    return potf2_16_impl<true>(Ld, rd, colbuf, lane, g0, n_real);
 }
 
 // Solve L y = b for one right-hand side per lane: L = 16x16 lower block in LDS (read uniformly:
@@ -176,6 +194,21 @@ __device__ __forceinline__ void diag128_factor_invert(double* sL, double* sW, do
                 }
             }
         }
+        // wave 3 never has sub-panel rows (8 block rows): it inverts the diagonal sub-block meanwhile,
+        // W_ss = L_ss^-1 (forward substitution on the identity, one column per lane), which phase B
+        // then applies to the other tiles of block row s as one MFMA product instead of 16-step
+        // substitutions
+        if (wave == 3) {
+            double b[SB];
+#pragma unroll
+            for (int i = 0; i < SB; ++i) b[i] = i == (lane & 15) ? 1.0 : 0.0;
+            fwd_subst_16(sL + blk_off(s, s), sRd + s * SB, b);
+            if (lane < SB) {
+                double* W = sW + blk_off(s, s);
+#pragma unroll
+                for (int i = 0; i < SB; ++i) W[i * SB + lane] = b[i];
+            }
+        }
         __syncthreads();
         if (dbg && tid == 0 && s == 0) dbg[3] = clock64();
         // ---- phase B
@@ -190,38 +223,26 @@ __device__ __forceinline__ void diag128_factor_invert(double* sL, double* sW, do
             const int f = potf2_16(C, sRd + (s + 1) * SB, sCol, lane, kbase + (s + 1) * SB, n_real);
             if (f != 0 && lane == 0 && *fail == 0) *fail = f;
         } else {
-            // tasks: W tiles (s, j), j = 0..s  first (longer), then trailing tiles 1..cnt-1
+            // tasks: W tiles (s, j), j = 0..s-1  first (longer), then trailing tiles 1..cnt-1
             const int nw = s + 1 < NSB ? 3 : 4;       // last step: wave 0 has no pivot work left
             const int me = s + 1 < NSB ? wave - 1 : wave;
-            const int ntask = (s + 1) + (cnt > 0 ? cnt - 1 : 0);
+            const int ntask = s + (cnt > 0 ? cnt - 1 : 0);
             double* T = sT + wave * SB * TLD;
             for (int t = me; t < ntask; t += nw) {
-                if (t <= s) {
+                if (t < s) {
+                    // W_sj = -W_ss (sum_{j <= kb < s} L_s,kb W_kb,j)
                     const int j = t;
-                    double b[SB];
-                    if (j == s) {
-#pragma unroll
-                        for (int i = 0; i < SB; ++i) b[i] = i == (lane & 15) ? 1.0 : 0.0;
-                    } else {
-                        v4d acc = {0.0, 0.0, 0.0, 0.0};
-                        for (int kb = j; kb < s; ++kb)
-                            acc = blk_mma_nn<true>(sL + blk_off(s, kb), sW + blk_off(kb, j), lane, acc);
-                        // store -T transposed: lane c then reads column c as one padded row
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) T[(lane & 15) * TLD + (lane >> 4) + 4 * r] = acc[r];
-                        wave_lds_fence();
-#pragma unroll
-                        for (int i = 0; i < SB; ++i) b[i] = T[(lane & 15) * TLD + i];
-                        wave_lds_fence();   // T is rewritten by this wave's next task
-                    }
-                    fwd_subst_16(sL + blk_off(s, s), sRd + s * SB, b);
-                    if (lane < SB) {
-                        double* W = sW + blk_off(s, j);
-#pragma unroll
-                        for (int i = 0; i < SB; ++i) W[i * SB + lane] = b[i];
-                    }
+                    v4d acc = {0.0, 0.0, 0.0, 0.0};
+                    for (int kb = j; kb < s; ++kb)
+                        acc = blk_mma_nn<true>(sL + blk_off(s, kb), sW + blk_off(kb, j), lane, acc);
+                    blk_store_c(T, lane, acc);
+                    wave_lds_fence();
+                    v4d w = {0.0, 0.0, 0.0, 0.0};
+                    w = blk_mma_nn<false>(sW + blk_off(s, s), T, lane, w);
+                    wave_lds_fence();   // T is rewritten by this wave's next task
+                    blk_store_c(sW + blk_off(s, j), lane, w);
                 } else {
-                    const int tt = t - s;              // 1 .. cnt-1
+                    const int tt = t - s + 1;          // 1 .. cnt-1
                     int ii = 0;
                     while ((ii + 1) * (ii + 2) / 2 <= tt) ++ii;
                     const int jj = tt - ii * (ii + 1) / 2;
