@@ -154,6 +154,8 @@ int32_t robo_gp_create(robo_ctx* ctx, int32_t kind, int32_t n_max, int32_t dim, 
     ROBO_TRY(dev_alloc(&g->d_y, (size_t)n_max));
     ROBO_TRY(dev_alloc(&g->d_K, np * np));
     ROBO_TRY(dev_alloc(&g->d_Linv, np * NB));
+    // the strictly upper 16x16 sub-blocks of every inverted diagonal block are zero and never written
+    ROBO_HIP_CHECK(hipMemset(g->d_Linv, 0, np * NB * sizeof(double)));
     ROBO_TRY(dev_alloc(&g->d_theta, (size_t)dim + 8 + sizeof(FitSample) / sizeof(double)));
     g->d_sp = reinterpret_cast<FitSample*>(g->d_theta + dim + 8);
     ROBO_HIP_CHECK(hipHostMalloc((void**)&g->h_theta, ((size_t)dim + 8) * sizeof(double) + sizeof(FitSample), 0));
@@ -349,6 +351,7 @@ static int batch_ensure(robo_gp* g, int S) {
     const size_t np = (size_t)g->n_pad, D = (size_t)g->dim;
     ROBO_TRY(dev_alloc(&g->d_bK, (size_t)S * np * np));
     ROBO_TRY(dev_alloc(&g->d_bLinv, (size_t)S * np * NB));
+    ROBO_HIP_CHECK(hipMemset(g->d_bLinv, 0, (size_t)S * np * NB * sizeof(double)));
     ROBO_TRY(dev_alloc(&g->d_bXs, (size_t)S * np * D));
     ROBO_TRY(dev_alloc(&g->d_bism, (size_t)S * D));
     ROBO_TRY(dev_alloc(&g->d_bout, (size_t)S * 2));

@@ -30,6 +30,15 @@ constexpr int BLK = SB * SB;           // 256 doubles
 
 __device__ __forceinline__ int blk_off(int bi, int bj) { return (bi * (bi + 1) / 2 + bj) * BLK; }
 
+// Element (r, c) of a 16x16 LDS block.  Rows are 16 doubles apart, so a plain row-major block puts
+// the 16 rows of an MFMA A-fragment read (lane l -> row l & 15, column 4 kk + (l >> 4)) on only two
+// 8-byte bank groups: an 8-way conflict on every fragment read (r01s: 1.4k cycles per 16x16x16
+// product).  XOR-ing the column with (r & 14) spreads the 64 lanes of an A-fragment read, a
+// B-fragment read and a C-layout access evenly over the 32 bank groups (2 lanes each = the minimum
+// for a 512-byte wave access), at no cost in space -- the two images of the diagonal block already
+// take 147 of the 160 KB.
+__device__ __forceinline__ int bidx(int r, int c) { return r * SB + (c ^ (r & 14)); }
+
 // LDS ops of one wave execute in order; this only stops the compiler from moving a
 // cross-lane LDS read above the write it depends on (no instruction is emitted).
 __device__ __forceinline__ void wave_lds_fence() {
@@ -42,20 +51,20 @@ __device__ __forceinline__ void wave_lds_fence() {
 __device__ __forceinline__ v4d blk_load_c(const double* b, int lane) {
     v4d c;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) c[r] = b[((lane >> 4) + 4 * r) * SB + (lane & 15)];
+    for (int r = 0; r < 4; ++r) c[r] = b[bidx((lane >> 4) + 4 * r, lane & 15)];
     return c;
 }
 __device__ __forceinline__ void blk_store_c(double* b, int lane, v4d c) {
 #pragma unroll
-    for (int r = 0; r < 4; ++r) b[((lane >> 4) + 4 * r) * SB + (lane & 15)] = c[r];
+    for (int r = 0; r < 4; ++r) b[bidx((lane >> 4) + 4 * r, lane & 15)] = c[r];
 }
 // acc += sgn * A(16x16) * B^T(16x16)   ("NT": both blocks indexed [row][k])
 template <bool NEG>
 __device__ __forceinline__ v4d blk_mma_nt(const double* A, const double* B, int lane, v4d acc) {
 #pragma unroll
     for (int kk = 0; kk < 4; ++kk) {
-        double a = A[(lane & 15) * SB + kk * 4 + (lane >> 4)];
-        const double b = B[(lane & 15) * SB + kk * 4 + (lane >> 4)];
+        double a = A[bidx(lane & 15, kk * 4 + (lane >> 4))];
+        const double b = B[bidx(lane & 15, kk * 4 + (lane >> 4))];
         if (NEG) a = -a;
         acc = mfma_f64(a, b, acc);
     }
@@ -66,8 +75,8 @@ template <bool NEG>
 __device__ __forceinline__ v4d blk_mma_nn(const double* A, const double* B, int lane, v4d acc) {
 #pragma unroll
     for (int kk = 0; kk < 4; ++kk) {
-        double a = A[(lane & 15) * SB + kk * 4 + (lane >> 4)];
-        const double b = B[(kk * 4 + (lane >> 4)) * SB + (lane & 15)];
+        double a = A[bidx(lane & 15, kk * 4 + (lane >> 4))];
+        const double b = B[bidx(kk * 4 + (lane >> 4), lane & 15)];
         if (NEG) a = -a;
         acc = mfma_f64(a, b, acc);
     }
@@ -100,13 +109,24 @@ __device__ __forceinline__ double bcast_lane(double x, int src) {
 // pivot forced to 1 (augmented row and identity padding).  Returns the first failing global
 // column + 1, or 0.
 template <bool GUARD>
-__device__ __forceinline__ int potf2_16_impl(double* Ld, double* rd, double* colbuf, int lane, int g0, int n_real) {
-    const int row = lane & 15;
+__device__ __forceinline__ int potf2_16_impl(double* Ld, double* Wd, double* rd, double* colbuf, int lane, int g0,
+                                             int n_real) {
+    const int row = lane & 15, grp = lane >> 4;
+    // lanes 16..31 run the SAME instruction stream on different data: instead of row `row` of the block
+    // they hold column `row` of W = L^-1, started as a unit vector -- the forward substitution
+    // L w = e_c is exactly "scale entry k by 1/L_kk, subtract column k of L times it from the entries
+    // below", i.e. the scale / fast-path / bulk-update instructions below with this lane's own
+    // multiplier.  The inverse of the diagonal sub-block costs no instruction of its own.
+    const bool isW = grp == 1;
     double a[SB];
 #pragma unroll
-    for (int j = 0; j < SB; ++j) a[j] = j <= row ? Ld[row * SB + j] : 0.0;
+    for (int j = 0; j < SB; ++j) {
+        const double l = j <= row ? Ld[bidx(row, j)] : 0.0;
+        a[j] = isW ? (j == row ? 1.0 : 0.0) : l;
+    }
     int fail = 0;
     double lprev = 0.0;   // this lane's entry of the previous column (multiplier of the deferred bulk update)
+    double* cbw = colbuf + grp * 2 * SB;   // every 16-lane group stores to its own copy; group 0's is read
 #pragma unroll
     for (int k = 0; k < SB; ++k) {
         double p = bcast_lane(a[k], k);   // pivot: complete (bulk updates <= k-2, fast path k-1)
@@ -122,11 +142,10 @@ __device__ __forceinline__ int potf2_16_impl(double* Ld, double* rd, double* col
 #pragma unroll
             for (int j = k + 1; j < SB; ++j) a[j] = fma(-lprev, cbp[j], a[j]);
         }
-        const double lik = row == k ? p * ri : a[k] * ri;   // rows < k hold garbage here, never read
+        // rows < k (columns > k of W) hold garbage (zeros) here, never read
+        const double lik = (row == k && !isW) ? p * ri : a[k] * ri;
         a[k] = lik;
-        // every lane stores (the four 16-lane groups hold identical rows; same value to the same
-        // address): no exec masking or branches on the chain
-        colbuf[(k & 1) * SB + row] = lik;
+        cbw[(k & 1) * SB + row] = lik;    // no exec masking or branches on the chain
         rd[k] = ri;
         if (k + 1 < SB) {
             const double l1 = bcast_lane(lik, k + 1);        // L[k+1][k]
@@ -136,78 +155,48 @@ __device__ __forceinline__ int potf2_16_impl(double* Ld, double* rd, double* col
         wave_lds_fence();
     }
 #pragma unroll
-    for (int j = 0; j < SB; ++j) Ld[row * SB + j] = j <= row ? a[j] : 0.0;
+    for (int j = 0; j < SB; ++j) {
+        if (isW) Wd[bidx(j, row)] = a[j];                     // W[j][c], zero above the diagonal
+        else Ld[bidx(row, j)] = j <= row ? a[j] : 0.0;
+    }
     return fail;
 }
 
 // the pivot guard for rows >= n_real only exists in the block(s) that hold the augmented row / padding
-__device__ __forceinline__ int potf2_16(double* Ld, double* rd, double* colbuf, int lane, int g0, int n_real) {
-    if (g0 + SB <= n_real) return potf2_16_impl<false>(Ld, rd, colbuf, lane, g0, n_real);
-    return potf2_16_impl<true>(Ld, rd, colbuf, lane, g0, n_real);
-}
-
-// Solve L y = b for one right-hand side per lane: L = 16x16 lower block in LDS (read uniformly:
-// every lane the same address), rd = 1 / diag(L), b/y in registers.  Right-looking, so the
-// dependent chain is 16 x (mul + fma), the 120 updates are independent.
-__device__ __forceinline__ void fwd_subst_16(const double* Ls, const double* rd, double (&b)[SB]) {
-#pragma unroll
-    for (int k = 0; k < SB; ++k) {
-        b[k] *= rd[k];
-#pragma unroll
-        for (int i = k + 1; i < SB; ++i) b[i] = fma(-Ls[i * SB + k], b[k], b[i]);
-    }
+__device__ __forceinline__ int potf2_16(double* Ld, double* Wd, double* rd, double* colbuf, int lane, int g0,
+                                        int n_real) {
+    if (g0 + SB <= n_real) return potf2_16_impl<false>(Ld, Wd, rd, colbuf, lane, g0, n_real);
+    return potf2_16_impl<true>(Ld, Wd, rd, colbuf, lane, g0, n_real);
 }
 
 constexpr int TLD = SB + 2;   // padded leading dimension of the per-wave transposition scratch
 
 // ---- the 128x128 diagonal block, block-packed in LDS -------------------------------------
 // sL: 36 lower 16x16 blocks of A -> L in place; sW: 36 blocks of W = L^-1; sT: per-wave 16 x TLD
-// scratch; sRd: 128 reciprocal pivots; sCol: 2 x 16 column exchange buffer (wave 0).
+// scratch; sRd: 128 reciprocal pivots; sCol: 4 x 2 x 16 column exchange buffers (wave 0).
 // Schedule per 16-column step s (two barriers):
-//   A  all waves : sub-panel  L_is = A_is L_ss^-T  by forward substitution, one row per lane
-//   B  wave 0    : trailing tile (s+1,s+1), then potf2(s+1)             <- the critical path
-//      waves 1-3 : block row s of W = L^-1 (s+1 tiles) and the other trailing tiles
+//   A  all waves : sub-panel  L_is = A_is W_ss^T  (one 16x16x16 MFMA product per block, W_ss = L_ss^-1)
+//   B  wave 0    : trailing tile (s+1,s+1), potf2(s+1) -- which also yields W_s+1,s+1 on lanes
+//                  16..31 of the same instruction stream --             <- the critical path
+//      waves 1-3 : block row s of W = L^-1 (s tiles) and the other trailing tiles
 // so the inverse and the MFMA updates ride in the shadow of the pivot chain.
 __device__ __forceinline__ void diag128_factor_invert(double* sL, double* sW, double* sT, double* sRd, double* sCol,
                                                       int kbase, int n_real, int* fail, long long* dbg) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     if (wave == 0) {
-        const int f = potf2_16(sL + blk_off(0, 0), sRd, sCol, lane, kbase, n_real);
+        const int f = potf2_16(sL + blk_off(0, 0), sW + blk_off(0, 0), sRd, sCol, lane, kbase, n_real);
         if (f != 0 && lane == 0 && *fail == 0) *fail = f;
     }
     __syncthreads();
     if (dbg && tid == 0) dbg[2] = clock64();
     for (int s = 0; s < NSB; ++s) {
-        // ---- phase A: sub-panel rows.  16-lane group g of wave w takes block s+1 + 4w + g
-        {
-            const int bi = s + 1 + 4 * wave + (lane >> 4);
-            if (s + 1 + 4 * wave < NSB) {      // wave-uniform
-                const bool live = bi < NSB;
-                double* A = sL + blk_off(live ? bi : NSB - 1, s) + (lane & 15) * SB;
-                double b[SB];
-#pragma unroll
-                for (int j = 0; j < SB; ++j) b[j] = A[j];
-                fwd_subst_16(sL + blk_off(s, s), sRd + s * SB, b);
-                if (live) {
-#pragma unroll
-                    for (int j = 0; j < SB; ++j) A[j] = b[j];
-                }
-            }
-        }
-        // wave 3 never has sub-panel rows (8 block rows): it inverts the diagonal sub-block meanwhile,
-        // W_ss = L_ss^-1 (forward substitution on the identity, one column per lane), which phase B
-        // then applies to the other tiles of block row s as one MFMA product instead of 16-step
-        // substitutions
-        if (wave == 3) {
-            double b[SB];
-#pragma unroll
-            for (int i = 0; i < SB; ++i) b[i] = i == (lane & 15) ? 1.0 : 0.0;
-            fwd_subst_16(sL + blk_off(s, s), sRd + s * SB, b);
-            if (lane < SB) {
-                double* W = sW + blk_off(s, s);
-#pragma unroll
-                for (int i = 0; i < SB; ++i) W[i * SB + lane] = b[i];
-            }
+        // ---- phase A: sub-panel blocks L_is = A_is W_ss^T, wave w takes blocks s+1+w, s+5+w
+        for (int bi = s + 1 + wave; bi < NSB; bi += 4) {
+            double* A = sL + blk_off(bi, s);
+            v4d acc = {0.0, 0.0, 0.0, 0.0};
+            acc = blk_mma_nt<false>(A, sW + blk_off(s, s), lane, acc);
+            wave_lds_fence();   // all fragment reads of A before it is overwritten
+            blk_store_c(A, lane, acc);
         }
         __syncthreads();
         if (dbg && tid == 0 && s == 0) dbg[3] = clock64();
@@ -220,7 +209,8 @@ __device__ __forceinline__ void diag128_factor_invert(double* sL, double* sW, do
             acc = blk_mma_nt<true>(sL + blk_off(s + 1, s), sL + blk_off(s + 1, s), lane, acc);
             blk_store_c(C, lane, acc);
             wave_lds_fence();
-            const int f = potf2_16(C, sRd + (s + 1) * SB, sCol, lane, kbase + (s + 1) * SB, n_real);
+            const int f = potf2_16(C, sW + blk_off(s + 1, s + 1), sRd + (s + 1) * SB, sCol, lane,
+                                   kbase + (s + 1) * SB, n_real);
             if (f != 0 && lane == 0 && *fail == 0) *fail = f;
         } else {
             // tasks: W tiles (s, j), j = 0..s-1  first (longer), then trailing tiles 1..cnt-1
@@ -260,7 +250,7 @@ __device__ __forceinline__ void diag128_factor_invert(double* sL, double* sW, do
     if (dbg && tid == 0) dbg[11] = clock64();
 }
 
-constexpr int DIAG_SMEM_DOUBLES = 2 * NBLK * BLK + 4 * SB * TLD + NB + 2 * SB;   // 150 KB
+constexpr int DIAG_SMEM_DOUBLES = 2 * NBLK * BLK + 4 * SB * TLD + NB + 8 * SB;   // 150 KB
 
 struct DiagSmem {
     double *sL, *sW, *sT, *sRd, *sCol;
@@ -275,19 +265,16 @@ __device__ __forceinline__ DiagSmem diag_carve(double* base) {
     return m;
 }
 
-// L into K (lower sub-blocks), W as a dense 128x128 row-major block
+// L into K (lower sub-blocks), W into its 128x128 row-major block (lower sub-blocks; the strictly upper
+// ones were zeroed when the buffer was allocated and are never written)
 __device__ __forceinline__ void diag_writeback(const DiagSmem& m, double* __restrict__ Kd, int ld,
                                                double* __restrict__ Wg) {
     const int tid = threadIdx.x;
     for (int bi = 0; bi < NSB; ++bi)
-        for (int bj = 0; bj < NSB; ++bj) {
+        for (int bj = 0; bj <= bi; ++bj) {
             const int r = bi * SB + (tid >> 4), c = bj * SB + (tid & 15);
-            if (bj <= bi) {
-                Kd[(size_t)r * ld + c] = m.sL[blk_off(bi, bj) + tid];
-                Wg[r * NB + c] = m.sW[blk_off(bi, bj) + tid];
-            } else {
-                Wg[r * NB + c] = 0.0;
-            }
+            Kd[(size_t)r * ld + c] = m.sL[blk_off(bi, bj) + bidx(tid >> 4, tid & 15)];
+            Wg[r * NB + c] = m.sW[blk_off(bi, bj) + bidx(tid >> 4, tid & 15)];
         }
 }
 
@@ -306,7 +293,8 @@ __global__ __launch_bounds__(256) void potrf_diag_kernel(double* __restrict__ K,
     // ---- load the 36 lower sub-blocks ------------------------------------------------
     for (int bi = 0; bi < NSB; ++bi)
         for (int bj = 0; bj <= bi; ++bj)
-            m.sL[blk_off(bi, bj) + tid] = Kd[(size_t)(bi * SB + (tid >> 4)) * ld + bj * SB + (tid & 15)];
+            m.sL[blk_off(bi, bj) + bidx(tid >> 4, tid & 15)] =
+                Kd[(size_t)(bi * SB + (tid >> 4)) * ld + bj * SB + (tid & 15)];
     __syncthreads();
     if (dbg && tid == 0) dbg[1] = clock64();
 
@@ -378,7 +366,7 @@ __global__ __launch_bounds__(256) void potrf_step_kernel(double* __restrict__ K,
                 for (int r = 0; r < 4; ++r) {
                     const int row = acc_row(tm, r), col = acc_col(tn);
                     if ((col >> 4) <= (row >> 4))
-                        m.sL[blk_off(row >> 4, col >> 4) + (row & 15) * SB + (col & 15)] = acc.t[tm][tn][r];
+                        m.sL[blk_off(row >> 4, col >> 4) + bidx(row & 15, col & 15)] = acc.t[tm][tn][r];
                 }
         __syncthreads();
         diag128_factor_invert(m.sL, m.sW, m.sT, m.sRd, m.sCol, (k + 1) * NB, n_real, fail + blockIdx.y, nullptr);
