@@ -324,6 +324,51 @@ __global__ __launch_bounds__(256) void potrf_panel_kernel(double* __restrict__ K
         for (int r = 0; r < 4; ++r) A[(size_t)acc_row<1>(0, r) * ld + acc_col(tn)] = acc.t[0][tn][r];
 }
 
+// Tile (k+1, k+1) of the trailing update for the fused diagonal workgroup:  C_lower - P P^T  straight
+// into the block-packed LDS image sL (P = A_{k+1,k}, 128 x 128).  Only the 36 lower 16x16 tiles are
+// formed and both factors are the same panel (one staged operand): wave w owns block rows 7-w and w
+// (8-w + w+1 = 9 tiles each), 288 MFMAs per wave against the 512 of a full 128 x 128 tile -- the
+// lone-workgroup update in front of the pivot chain drops from 13.6 to ~8 us.
+__device__ __forceinline__ void diag_tile_update(const double* __restrict__ P, const double* __restrict__ C, int ld,
+                                                 double* stage, double* sL) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int rA = 7 - wave, rB = wave;
+    v4d acc[9];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) {
+        const int br = i <= rA ? rA : rB, bj = i <= rA ? i : i - rA - 1;
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+            acc[i][r] = C[(size_t)(br * SB + (lane >> 4) + 4 * r) * ld + bj * SB + (lane & 15)];
+    }
+    Tile4 rp = tile_load_regs<128>(P, ld, 0);
+    tile_store_lds<128>(stage, rp);
+    __syncthreads();
+    for (int kt = 0; kt < NB / BK; ++kt) {
+        const double* cur = stage + (kt & 1) * STAGE_B;
+        double* nxt = stage + ((kt + 1) & 1) * STAGE_B;
+        const bool more = kt + 1 < NB / BK;
+        if (more) rp = tile_load_regs<128>(P, ld, (kt + 1) * BK);
+        const double* f = cur + (lane & 15) * LDS_LD + (lane >> 4);
+#pragma unroll
+        for (int kk = 0; kk < BK / 4; ++kk) {
+            const double aA = -f[rA * SB * LDS_LD + kk * 4], aB = -f[rB * SB * LDS_LD + kk * 4];
+#pragma unroll
+            for (int i = 0; i < 9; ++i) {
+                const int bj = i <= rA ? i : i - rA - 1;
+                acc[i] = mfma_f64(i <= rA ? aA : aB, f[bj * SB * LDS_LD + kk * 4], acc[i]);
+            }
+        }
+        if (more) tile_store_lds<128>(nxt, rp);
+        __syncthreads();
+    }
+#pragma unroll
+    for (int i = 0; i < 9; ++i) {
+        const int br = i <= rA ? rA : rB, bj = i <= rA ? i : i - rA - 1;
+        blk_store_c(sL + blk_off(br, bj), lane, acc[i]);
+    }
+}
+
 // Trailing update of step k fused with the NEXT diagonal block:
 //   A_ij <- A_ij - A_ik * A_jk^T   for k < j <= i (right-looking, K = 128), and workgroup 0 -- which
 //   owns tile (k+1, k+1) -- goes on to factor and invert it (diag128_factor_invert) while the other
@@ -349,25 +394,8 @@ __global__ __launch_bounds__(256) void potrf_step_kernel(double* __restrict__ K,
         const size_t d0 = (size_t)(k + 1) * NB;
         const double* A = K + d0 * ld + (size_t)k * NB;
         double* C = K + d0 * ld + d0;
-        Acc acc;
-#pragma unroll
-        for (int tm = 0; tm < 4; ++tm)
-#pragma unroll
-            for (int tn = 0; tn < 4; ++tn)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) acc.t[tm][tn][r] = C[(size_t)acc_row(tm, r) * ld + acc_col(tn)];
-        gemm_nt<4, true>(A, ld, A, ld, 0, NB, acc, smem);     // ends on a barrier: smem is free
         const DiagSmem m = diag_carve(smem);
-#pragma unroll
-        for (int tm = 0; tm < 4; ++tm)
-#pragma unroll
-            for (int tn = 0; tn < 4; ++tn)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int row = acc_row(tm, r), col = acc_col(tn);
-                    if ((col >> 4) <= (row >> 4))
-                        m.sL[blk_off(row >> 4, col >> 4) + bidx(row & 15, col & 15)] = acc.t[tm][tn][r];
-                }
+        diag_tile_update(A, C, ld, m.sW, m.sL);   // staging in the (still unused) W image
         __syncthreads();
         diag128_factor_invert(m.sL, m.sW, m.sT, m.sRd, m.sCol, (k + 1) * NB, n_real, fail + blockIdx.y, nullptr);
         diag_writeback(m, C, ld, Linv + (size_t)blockIdx.y * linv_stride + (size_t)(k + 1) * NB * NB);
