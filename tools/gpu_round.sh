@@ -21,7 +21,7 @@ echo "bench rc=$?" | tee -a $OUT/summary.txt
 cat $OUT/bench.json >> $OUT/summary.txt
 tail -5 $OUT/bench.err >> $OUT/summary.txt
 echo "== rocprofv3 kernel trace" | tee -a $OUT/summary.txt
-timeout 900 rocprofv3 --kernel-trace --stats -d $OUT/prof -o bench -- python bench.py --gpus 1 --steps 3 --warmup 1 --no-cpu-baseline > $OUT/prof_bench.json 2> $OUT/prof.err
+timeout 900 rocprofv3 --kernel-trace --stats -d $OUT/prof -o bench -- python bench.py --gpus 1 --steps 5 --warmup 2 --no-cpu-baseline > $OUT/prof_bench.json 2> $OUT/prof.err
 echo "rocprof rc=$?" | tee -a $OUT/summary.txt
 find $OUT/prof -name "*stats*" | head >> $OUT/summary.txt
 for f in $(find $OUT/prof -name "*kernel_stats.csv"); do head -30 $f >> $OUT/summary.txt; done
