@@ -73,6 +73,10 @@ def test_model_gradients(emu_ctx):
     P.check_model_gradients(emu_ctx)
 
 
+def test_ill_conditioned(emu_ctx):
+    P.check_ill_conditioned(emu_ctx)
+
+
 def test_device_random_candidates(emu_ctx):
     P.check_device_random_candidates(emu_ctx)
 

@@ -77,6 +77,11 @@ def test_model_gradients(ctx):
     P.check_model_gradients(ctx)
 
 
+def test_ill_conditioned(ctx):
+    P.check_ill_conditioned(ctx)
+    P.check_ill_conditioned(ctx, cases=((1500, 2, 1e-8, 0.5), (3000, 3, 1e-4, 0.5), (1000, 1, 1e-6, 0.2)))
+
+
 def test_device_random_candidates(ctx):
     P.check_device_random_candidates(ctx)
 
