@@ -386,7 +386,10 @@ __device__ __forceinline__ void diag_tile_update(const double* __restrict__ P, c
 template <int TM, bool FUSED>
 __global__ __launch_bounds__(256) void potrf_step_kernel(double* __restrict__ K, size_t k_stride, int ld, int k,
                                                          int n_real, double* __restrict__ Linv, size_t linv_stride,
-                                                         int* __restrict__ fail) {
+                                                         int* __restrict__ fail, int kop, int depth, int first_col) {
+    // k: trailing base (tiles cover block rows/columns > k); kop: first block column of the panel
+    // operand(s); depth: contraction length (128, or 256 = two panels at once, see launch_potrf);
+    // first_col != 0: block column k+1 only
     __shared__ double smem[FUSED ? DIAG_SMEM_DOUBLES : gemm_smem_doubles<TM>()];
     K += (size_t)blockIdx.y * k_stride;
     if (FUSED && blockIdx.x == 0) {
@@ -407,16 +410,21 @@ __global__ __launch_bounds__(256) void potrf_step_kernel(double* __restrict__ K,
     int ii, jj;
     {
         const int t = b / SPLIT;
-        int q = (int)((sqrt(8.0 * (double)t + 1.0) - 1.0) * 0.5);
-        while ((q + 1) * (q + 2) / 2 <= t) ++q;
-        while (q * (q + 1) / 2 > t) --q;
-        ii = q;
-        jj = t - q * (q + 1) / 2;
+        if (first_col) {
+            ii = t;
+            jj = 0;
+        } else {
+            int q = (int)((sqrt(8.0 * (double)t + 1.0) - 1.0) * 0.5);
+            while ((q + 1) * (q + 2) / 2 <= t) ++q;
+            while (q * (q + 1) / 2 > t) --q;
+            ii = q;
+            jj = t - q * (q + 1) / 2;
+        }
     }
     const int i = k + 1 + ii, j = k + 1 + jj, h = b % SPLIT;
     const size_t row0 = (size_t)i * NB + (size_t)h * (32 * TM);
-    const double* A = K + row0 * ld + (size_t)k * NB;
-    const double* B = K + ((size_t)j * NB) * ld + (size_t)k * NB;
+    const double* A = K + row0 * ld + (size_t)kop * NB;
+    const double* B = K + ((size_t)j * NB) * ld + (size_t)kop * NB;
     double* C = K + row0 * ld + (size_t)j * NB;
     AccT<TM> acc;
 #pragma unroll
@@ -425,7 +433,7 @@ __global__ __launch_bounds__(256) void potrf_step_kernel(double* __restrict__ K,
         for (int tn = 0; tn < 4; ++tn)
 #pragma unroll
             for (int r = 0; r < 4; ++r) acc.t[tm][tn][r] = C[(size_t)acc_row<TM>(tm, r) * ld + acc_col(tn)];
-    gemm_nt<TM, true>(A, ld, B, ld, 0, NB, acc, smem);
+    gemm_nt<TM, true>(A, ld, B, ld, 0, depth, acc, smem);
 #pragma unroll
     for (int tm = 0; tm < TM; ++tm)
 #pragma unroll
@@ -467,30 +475,59 @@ int launch_potrf(robo_gp* gp, const FitBuffers& fb) {
     const int ld = gp->n_pad, nb = gp->n_pad / NB, S = fb.S;
     ROBO_HIP_CHECK(hipMemsetAsync(fb.fail, 0, (size_t)S * sizeof(int), ctx->stream));
     const bool fused = S <= 2;
-    for (int k = 0; k < nb; ++k) {
-        if (k == 0 || !fused)
-            hipLaunchKernelGGL(potrf_diag_kernel, dim3(S), dim3(256), 0, ctx->stream, fb.K, fb.k_stride, ld, k, gp->n,
-                               fb.Linv, fb.linv_stride, fb.fail, (long long*)nullptr);
-        const int rem = nb - k - 1;
-        if (rem <= 0) break;
-        hipLaunchKernelGGL(potrf_panel_kernel, dim3(rem * 4, S), dim3(256), 0, ctx->stream, fb.K, fb.k_stride, ld, k,
-                           (const double*)fb.Linv, fb.linv_stride);
-        const int tiles = rem * (rem + 1) / 2;
-        // trailing update of step k (+ diagonal block k+1 in workgroup 0 when fused).  Tile height, measured
-        // (N = 4096, S = 1): 128-row tiles 43 us/step at 384..528 blocks, 64-row tiles slower (55 us: B
-        // panel re-read twice), 32-row tiles 16 us vs 21 us once blocks < 96
-#define ROBO_STEP(TM, F, GRID)                                                                                  \
+#define ROBO_DIAG(KK)                                                                                          \
+    hipLaunchKernelGGL(potrf_diag_kernel, dim3(S), dim3(256), 0, ctx->stream, fb.K, fb.k_stride, ld, (KK), gp->n, \
+                       fb.Linv, fb.linv_stride, fb.fail, (long long*)nullptr)
+#define ROBO_PANEL(KK)                                                                                         \
+    hipLaunchKernelGGL(potrf_panel_kernel, dim3((nb - (KK)-1) * 4, S), dim3(256), 0, ctx->stream, fb.K,        \
+                       fb.k_stride, ld, (KK), (const double*)fb.Linv, fb.linv_stride)
+#define ROBO_STEP(TM, F, GRID, BASE, KOP, DEPTH, FIRST)                                                        \
     hipLaunchKernelGGL((potrf_step_kernel<TM, F>), dim3((GRID), S), dim3(256), 0, ctx->stream, fb.K, fb.k_stride, \
-                       ld, k, gp->n, fb.Linv, fb.linv_stride, fb.fail)
-        if (tiles * S >= 96) {
-            if (fused) ROBO_STEP(4, true, tiles);
-            else ROBO_STEP(4, false, tiles);
-        } else {
-            if (fused) ROBO_STEP(1, true, 1 + (tiles - 1) * 4);
-            else ROBO_STEP(1, false, tiles * 4);
+                       ld, (BASE), gp->n, fb.Linv, fb.linv_stride, fb.fail, (KOP), (DEPTH), (FIRST))
+    // tile height, measured (N = 4096, S = 1): 128-row tiles 43 us/step at 384..528 blocks, 64-row tiles
+    // slower (55 us: B panel re-read twice), 32-row tiles 16 us vs 21 us once blocks < 96
+#define ROBO_UPDATE(TILES, BASE, KOP, DEPTH, FIRST)                                                            \
+    do {                                                                                                       \
+        if ((TILES) * S >= 96) ROBO_STEP(4, false, (TILES), BASE, KOP, DEPTH, FIRST);                          \
+        else if ((TILES) > 0) ROBO_STEP(1, false, (TILES)*4, BASE, KOP, DEPTH, FIRST);                         \
+    } while (0)
+    if (fused) {
+        // single theta: trailing update of step k + diagonal block k+1 (workgroup 0) in one launch
+        ROBO_DIAG(0);
+        for (int k = 0; k + 1 < nb; ++k) {
+            const int rem = nb - k - 1, tiles = rem * (rem + 1) / 2;
+            ROBO_PANEL(k);
+            if (tiles * S >= 96) ROBO_STEP(4, true, tiles, k, k, NB, 0);
+            else ROBO_STEP(1, true, 1 + (tiles - 1) * 4, k, k, NB, 0);
         }
-#undef ROBO_STEP
+    } else {
+        // batched thetas: the chip is full, and a 128-deep update is bound by reading and writing its C
+        // tile (16 flop per byte), not by the MFMA pipe.  Panels are therefore taken in groups of G:
+        // inside a group a block column only receives the group's earlier panels right before it is
+        // factored (left-looking, one update of growing depth), and the rest of the trailing matrix
+        // receives all G panels in ONE (128 G)-deep update -- 1/G of the C traffic.  Bitwise the same
+        // factor: every element still accumulates its products in ascending k on top of the stored value.
+        static const int G = [] {
+            const char* e = getenv("ROBO_POTRF_GROUP");
+            const int g = e ? atoi(e) : 4;   // measured, 27 thetas at N = 4096 (ms per theta): G=1 0.668, 2 0.596, 4 0.574, 6 0.566
+            return g < 1 ? 1 : (g > 8 ? 8 : g);
+        }();
+        for (int k0 = 0; k0 < nb; k0 += G) {
+            const int g = nb - k0 < G ? nb - k0 : G;          // panels in this group
+            for (int kk = k0; kk < k0 + g; ++kk) {
+                // left-looking inside the group: block column kk <- panels k0 .. kk-1, all rows >= kk
+                if (kk > k0) ROBO_UPDATE(nb - kk, kk - 1, k0, (kk - k0) * NB, 1);
+                ROBO_DIAG(kk);
+                if (kk + 1 < nb) ROBO_PANEL(kk);
+            }
+            const int rem = nb - (k0 + g);                    // block rows/columns beyond the group
+            if (rem > 0) ROBO_UPDATE(rem * (rem + 1) / 2, k0 + g - 1, k0, g * NB, 0);
+        }
     }
+#undef ROBO_UPDATE
+#undef ROBO_STEP
+#undef ROBO_PANEL
+#undef ROBO_DIAG
     ROBO_LAUNCH_CHECK();
     return ROBO_OK;
 }
