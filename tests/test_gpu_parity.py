@@ -82,6 +82,27 @@ def test_ill_conditioned(ctx):
     P.check_ill_conditioned(ctx, cases=((1500, 2, 1e-8, 0.5), (3000, 3, 1e-4, 0.5), (1000, 1, 1e-6, 0.2)))
 
 
+def test_grad_loglik_headline_size_fd(ctx):
+    """the analytic gradient at the headline size (N = 4096, 32 block rows, five merge levels of the
+    triangular inverse) against central differences of the device's own log-likelihood (the oracle's
+    (N, N, P) gradient tensor would take 2.3 GB)"""
+    import bench
+    X, y, theta, _ = bench.synthetic(4096, 16, 128, 0)
+    g = _lib.DeviceGP(ctx, "matern52", 4096, 16)
+    g.set_data(X, y)
+    c = float(y.mean())
+    ll, grad = g.grad_loglik(theta, c)
+    h = 1e-5
+    for p in (0, 1, 7, 16, 17):
+        e = np.zeros_like(theta)
+        e[p] = h
+        fd = (g.fit(theta + e, c) - g.fit(theta - e, c)) / (2 * h)
+        if p == theta.size - 1:
+            fd /= np.exp(theta[-1])          # the reference's noise entry is d / d sigma^2
+        assert abs(grad[p] - fd) <= 2e-5 * max(1.0, abs(fd)), (p, grad[p], fd)
+    g.close()
+
+
 def test_device_random_candidates(ctx):
     P.check_device_random_candidates(ctx)
 
