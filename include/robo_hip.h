@@ -165,12 +165,15 @@ int32_t robo_acq_eval_moments(robo_ctx* ctx, int32_t acq_kind, double par, doubl
                               const double* var, int64_t m, double* out_acq, double* out_max, int64_t* out_argmax,
                               uint32_t* out_flags);
 /* MarginalizationGPMCMC.compute (marginalization.py:115-121): mean over S fitted GPs of
- * the per-sample acquisition, accumulated in sample order (= NumPy's axis-0 mean).           */
-int32_t robo_acq_eval_marginal_cand(robo_gp* const* gps, int32_t S, int32_t acq_kind, double par, double eta,
+ * the per-sample acquisition, accumulated in sample order (= NumPy's axis-0 mean).
+ * etas (S): the incumbent value of every sample -- each estimator asks ITS OWN sub-model
+ * (marginalization.py:40, ei.py:68): equal entries for plain GPs (observed minimum), different
+ * ones for FabolasGP sub-models (predicted minimum of the projected points, fabolas_gp.py:141-164). */
+int32_t robo_acq_eval_marginal_cand(robo_gp* const* gps, int32_t S, int32_t acq_kind, double par, const double* etas,
                                     robo_cand* cand, double* out_acq, double* out_max, int64_t* out_argmax,
                                     uint32_t* out_flags);
 /* partial form for sample-sharded multi-GPU runs: returns sum_s acq_s (no division)          */
-int32_t robo_acq_eval_sum_cand(robo_gp* const* gps, int32_t S, int32_t acq_kind, double par, double eta,
+int32_t robo_acq_eval_sum_cand(robo_gp* const* gps, int32_t S, int32_t acq_kind, double par, const double* etas,
                                robo_cand* cand, double* out_acq_sum, uint32_t* out_flags);
 
 /* ---- entropy search: replaces InformationGain.innovations/_dh_fun/compute ---------------

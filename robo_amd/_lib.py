@@ -122,9 +122,9 @@ def lib():
         "robo_acq_eval_cand": [vp, i32, dbl, dbl, vp, _dp, _dp, C.POINTER(i64), C.POINTER(C.c_uint32)],
         "robo_acq_eval": [vp, i32, dbl, dbl, _dp, i64, _dp, _dp, C.POINTER(i64), C.POINTER(C.c_uint32)],
         "robo_acq_eval_moments": [vp, i32, dbl, dbl, _dp, _dp, i64, _dp, _dp, C.POINTER(i64), C.POINTER(C.c_uint32)],
-        "robo_acq_eval_marginal_cand": [pp, i32, i32, dbl, dbl, vp, _dp, _dp, C.POINTER(i64),
+        "robo_acq_eval_marginal_cand": [pp, i32, i32, dbl, _dp, vp, _dp, _dp, C.POINTER(i64),
                                         C.POINTER(C.c_uint32)],
-        "robo_acq_eval_sum_cand": [pp, i32, i32, dbl, dbl, vp, _dp, C.POINTER(C.c_uint32)],
+        "robo_acq_eval_sum_cand": [pp, i32, i32, dbl, _dp, vp, _dp, C.POINTER(C.c_uint32)],
         "robo_ig_eval_cand": [vp, vp, vp, i32, dbl, _dp, _dp, _dp, _dp, _dp, _dp, _dp, _dp, C.POINTER(i64)],
         "robo_ig_eval_moments": [vp, i64, i32, i32, dbl, _dp, _dp, _dp, _dp, _dp, _dp, _dp, _dp, _dp],
         "robo_gp_cross_cov": [vp, vp, vp, _dp],
@@ -469,16 +469,18 @@ def cross_cov(gp, cand, ref):
 
 
 def acq_marginal(gps, kind, par, eta, cand, want_values=True, reduce="mean"):
-    """MarginalizationGPMCMC.compute over device GPs -> (values, max, argmax, flags)."""
+    """MarginalizationGPMCMC.compute over device GPs -> (values, max, argmax, flags).
+    eta: one incumbent value for all samples, or one per sample (S,)."""
     S = len(gps)
     arr = (C.c_void_p * S)(*[g._h for g in gps])
+    etas = _f64(np.broadcast_to(np.asarray(eta, dtype=np.float64), (S,)))
     mx, am, fl = C.c_double(0), C.c_int64(0), C.c_uint32(0)
     out = np.empty(cand.m) if (want_values or reduce == "sum") else None
     if reduce == "sum":
-        check(lib().robo_acq_eval_sum_cand(arr, S, ACQ_KINDS[kind], float(par), float(eta), cand._h, _arr(out),
+        check(lib().robo_acq_eval_sum_cand(arr, S, ACQ_KINDS[kind], float(par), _arr(etas), cand._h, _arr(out),
                                            C.byref(fl)))
         return out, None, None, fl.value
-    check(lib().robo_acq_eval_marginal_cand(arr, S, ACQ_KINDS[kind], float(par), float(eta), cand._h,
+    check(lib().robo_acq_eval_marginal_cand(arr, S, ACQ_KINDS[kind], float(par), _arr(etas), cand._h,
                                             _arr(out) if want_values else None, C.byref(mx), C.byref(am),
                                             C.byref(fl)))
     return out, mx.value, am.value, fl.value

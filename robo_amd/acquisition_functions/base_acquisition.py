@@ -80,8 +80,15 @@ class ClosedFormAcquisition(BaseAcquisitionFunction):
         """Index of the best candidate without copying the values back (large-M maximisers)."""
         eta = self._eta(eta)
         if self._is_native():
-            _, mx, am, _ = self.model.acquisition(self.kind, self.par, eta, X, want_values=False)
+            _, mx, am, flags = self.model.acquisition(self.kind, self.par, eta, X, want_values=False)
             self.last_max, self.last_argmax = mx, am
+            if self.kind == "ei":
+                # the reference's guards apply when maximising too (ei.py:72-74,86-88): any zero sigma
+                # collapses the batch to [[0]] (argmax 0), any negative EI raises
+                if flags & _lib.FLAG_ZERO_SIGMA:
+                    return 0
+                if flags & _lib.FLAG_NEGATIVE_EI:
+                    raise ValueError
             return int(am)
         return int(np.argmax(self.compute(X, eta=eta)))
 

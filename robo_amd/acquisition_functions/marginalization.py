@@ -71,9 +71,13 @@ class MarginalizationGPMCMC(BaseAcquisitionFunction):
         est = self.estimators
         models = [e.model for e in est]
         gps = [m.gp for m in models]
-        eta = est[0]._eta(None)
-        cand = X_test if isinstance(X_test, _lib.Candidates) else \
-            _lib.Candidates(gps[0].ctx, models[0]._normalised(X_test))
+        # every estimator asks its own sub-model for the incumbent (marginalization.py:40, ei.py:68)
+        eta = np.array([e._eta(None) for e in est])
+        # FabolasGP sub-models map their inputs through normalize() ([0,1] scaling of the configuration
+        # columns + basis function on the fidelity column, fabolas_gp.py:122-126); plain GPs through the
+        # [0,1] normalisation
+        norm = models[0].normalize if hasattr(models[0], "normalize") else models[0]._normalised
+        cand = X_test if isinstance(X_test, _lib.Candidates) else _lib.Candidates(gps[0].ctx, norm(X_test))
         try:
             vals, mx, am, flags = _lib.acq_marginal(gps, est[0].kind, est[0].par, eta, cand, want_values)
         finally:
@@ -103,6 +107,8 @@ class MarginalizationGPMCMC(BaseAcquisitionFunction):
 
     def argmax(self, X_test):
         if self._native():
-            self._native_eval(X_test, False)
-            return int(self.last_argmax)
+            _, flags = self._native_eval(X_test, False)
+            if self.estimators[0].kind != "ei" or not flags & (_lib.FLAG_ZERO_SIGMA | _lib.FLAG_NEGATIVE_EI):
+                return int(self.last_argmax)
+            # an estimator would have collapsed to [[0]] / raised (ei.py:72-74,86-88): same path as compute()
         return int(np.argmax(self.compute(X_test)))

@@ -779,29 +779,30 @@ int32_t robo_acq_eval(robo_gp* g, int32_t acq_kind, double par, double eta, cons
     return st;
 }
 
-static int acq_accumulate(robo_gp* const* gps, int32_t S, int32_t acq_kind, double par, double eta, robo_cand* k) {
-    if (!gps || S < 1 || !k) return ROBO_BAD_ARGUMENT;
+static int acq_accumulate(robo_gp* const* gps, int32_t S, int32_t acq_kind, double par, const double* etas,
+                          robo_cand* k) {
+    if (!gps || S < 1 || !k || !etas) return ROBO_BAD_ARGUMENT;
     ROBO_TRY(check_acq_kind(acq_kind));
     ROBO_HIP_CHECK(hipSetDevice(k->ctx->device));
     ROBO_HIP_CHECK(hipMemsetAsync(k->d_flags, 0, sizeof(unsigned), k->ctx->stream));
     for (int s = 0; s < S; ++s) {
         ROBO_TRY(predict_core(gps[s], k, false));
-        ROBO_TRY(launch_acq(k->ctx, k, acq_kind, par, eta, true, s == 0));
+        ROBO_TRY(launch_acq(k->ctx, k, acq_kind, par, etas[s], true, s == 0));
     }
     return ROBO_OK;
 }
 
-int32_t robo_acq_eval_marginal_cand(robo_gp* const* gps, int32_t S, int32_t acq_kind, double par, double eta,
+int32_t robo_acq_eval_marginal_cand(robo_gp* const* gps, int32_t S, int32_t acq_kind, double par, const double* etas,
                                     robo_cand* k, double* out_acq, double* out_max, int64_t* out_argmax,
                                     uint32_t* out_flags) {
-    ROBO_TRY(acq_accumulate(gps, S, acq_kind, par, eta, k));
+    ROBO_TRY(acq_accumulate(gps, S, acq_kind, par, etas, k));
     ROBO_TRY(launch_argmax(k, k->d_acq_sum, (double)S));
     return acq_read_back(k, k->d_acq, out_acq, out_max, out_argmax, out_flags);
 }
 
-int32_t robo_acq_eval_sum_cand(robo_gp* const* gps, int32_t S, int32_t acq_kind, double par, double eta,
+int32_t robo_acq_eval_sum_cand(robo_gp* const* gps, int32_t S, int32_t acq_kind, double par, const double* etas,
                                robo_cand* k, double* out_acq_sum, uint32_t* out_flags) {
-    ROBO_TRY(acq_accumulate(gps, S, acq_kind, par, eta, k));
+    ROBO_TRY(acq_accumulate(gps, S, acq_kind, par, etas, k));
     ROBO_TRY(launch_argmax(k, k->d_acq_sum, 1.0));
     return acq_read_back(k, k->d_acq_sum, out_acq_sum, nullptr, nullptr, out_flags);
 }

@@ -63,15 +63,17 @@ class Kernel(object):
         from robo_amd import _lib
         X1 = np.ascontiguousarray(X1, dtype=np.float64)
         ctx = _lib.default_context()
+        if X2 is not None:
+            raise NotImplementedError("get_value(X1, X2) is only provided for X2=None")
         gp = _lib.DeviceGP(ctx, self.kind, X1.shape[0], self.ndim)
-        gp.set_data(X1, np.zeros(X1.shape[0]))
-        theta = np.concatenate([self._vector, [-700.0]])   # exp(-700) = 0 noise
-        K = gp.gram(theta) if X2 is None else None
-        if X2 is None:
-            K[np.diag_indices_from(K)] -= 1.25e-12
+        try:
+            gp.set_data(X1, np.zeros(X1.shape[0]))
+            theta = np.concatenate([self._vector, [-700.0]])   # exp(-700) = 0 noise
+            K = gp.gram(theta)
+        finally:
             gp.close()
-            return K
-        raise NotImplementedError("get_value(X1, X2) is only provided for X2=None")
+        K[np.diag_indices_from(K)] -= 1.25e-12
+        return K
 
     def __repr__(self):
         return "%s(amp=%g, metric=%s)" % (self.__class__.__name__, np.exp(self._vector[0]),

@@ -47,10 +47,11 @@ class FabolasGP(GaussianProcess):
     def get_incumbent(self):
         """(configuration projected to s = 1, its predicted mean there)"""
         proj = np.concatenate((self.original_X[:, :-1], np.ones([self.original_X.shape[0], 1])), axis=1)
-        # the reference normalises the projected points twice here (predict() normalises again,
-        # fabolas_gp.py:156-157); with the fmin bounds (s-column basis applied to an already
-        # transformed value) that is a reference quirk we do not reproduce: predict once.
-        m, _ = self.predict(proj)
+        # MIRRORED QUIRK: the reference normalises the projected points and then calls predict(), which
+        # normalises them AGAIN (fabolas_gp.py:156-157): the configuration columns are scaled twice and the
+        # basis function is applied to basis(1).  Kept as is so that the incumbent equals the reference's
+        # (fixture tests/golden/ref_fabolas.npz, produced by the reference class).
+        m, _ = self.predict(self.normalize(proj))
         best = np.argmin(m)
         return proj[best], m[best]
 
@@ -72,10 +73,7 @@ class FabolasGPMCMC(GaussianProcessMCMC):
     def _model_inputs(self, X):
         return _fabolas_normalize(X, self.lower, self.upper, self.basis_func)
 
-    def get_incumbent(self):
-        """average over the hyper-parameter samples of the projected predictions (each sample's
-        FabolasGP supplies the projection; fabolas.py:254 uses projected_incumbent_estimation)"""
-        proj = np.concatenate((self.original_X[:, :-1], np.ones([self.original_X.shape[0], 1])), axis=1)
-        m, _ = self.predict(proj)
-        best = np.argmin(m)
-        return proj[best], m[best]
+    # get_incumbent is NOT overridden, as in the reference (fabolas_gp.py:12-102): it is
+    # GaussianProcessMCMC's -- argmin of the observed y, returned in the model's own input space (configuration
+    # columns in [0,1], basis-transformed fidelity column; normalize_input is False so nothing is mapped
+    # back).  The Fabolas loop itself asks projected_incumbent_estimation (fmin/fabolas.py:254).

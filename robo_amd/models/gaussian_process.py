@@ -86,6 +86,18 @@ class GaussianProcess(BaseModel):
             self._set_transform()
             gp.fit(self._fitted_theta, self.mean)
 
+    def _device(self):
+        """the device GP holding this model's data (re-created after deepcopy / unpickling)"""
+        if self.gp is None:
+            if self.X is None:
+                raise Exception('Model has to be trained first!')
+            self._materialise()
+            if self.gp is None:                       # data set but never fitted (optimize() before train)
+                gp = self._ensure_gp(self.X.shape[0], self.X.shape[1])
+                gp.set_data(self.X, self.y)
+                self._set_transform()
+        return self.gp
+
     def _set_transform(self):
         if self.normalize_output:
             self.gp.set_output_transform(self.y_mean, self.y_std)
@@ -140,7 +152,7 @@ class GaussianProcess(BaseModel):
         if np.any((-20 > theta) + (theta > 20)):
             return 1e25
         try:
-            ll = self.gp.fit(theta, self.mean)
+            ll = self._device().fit(theta, self.mean)
         except np.linalg.LinAlgError:
             return 1e25
         if self.prior is not None:
@@ -155,7 +167,7 @@ class GaussianProcess(BaseModel):
         noise "gradient", :178-182), and the prior term is whatever ``prior.gradient`` returns
         (zeros for DefaultPrior, default_priors.py:51-53)."""
         theta = np.asarray(theta, dtype=np.float64)
-        _, g = self.gp.grad_loglik(theta, self.mean)
+        _, g = self._device().grad_loglik(theta, self.mean)
         if self.prior is not None:
             g = g + self.prior.gradient(theta)
         return -g
@@ -168,7 +180,7 @@ class GaussianProcess(BaseModel):
         if np.any((-20 > theta) + (theta > 20)):
             return 1e25, np.zeros_like(theta)
         try:
-            ll, g = self.gp.grad_loglik(theta, self.mean)
+            ll, g = self._device().grad_loglik(theta, self.mean)
         except np.linalg.LinAlgError:
             return 1e25, np.zeros_like(theta)
         g = g.copy()

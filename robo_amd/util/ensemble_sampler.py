@@ -20,8 +20,10 @@ Algorithm (emcee 2.x ``EnsembleSampler._propose_stretch``, restated from the pap
 the walkers into two halves; for each half S (complement C), for every walker x_k in S draw
 a partner c_j from C uniformly and z ~ g(z) ∝ 1/sqrt(z) on [1/a, a] (a = 2) via
 z = ((a - 1) u + 1)^2 / a; propose q = c_j - z (c_j - x_k); accept with probability
-min(1, z^(ndim-1) exp(lnp(q) - lnp(x_k))).  Random streams are NOT bit-compatible with
-emcee's (sample sequences differ; the stationary distribution is the same).
+min(1, z^(ndim-1) exp(lnp(q) - lnp(x_k))).  The draw order per half-step (rand for z, randint for the
+partners, rand for the accept test) is emcee 2's, so with equal log-probabilities the chain equals the
+one the reference produces (checked against a fixture made by the reference's GaussianProcessMCMC.train,
+tests/ref_checks.py::check_ref_mcmc).
 """
 import numpy as np
 
@@ -76,8 +78,11 @@ class EnsembleSampler(object):
     def run_mcmc(self, pos0, N, rstate0=None, lnprob0=None):
         """-> (pos (k, dim), lnprob (k,), random state)"""
         if rstate0 is not None:
-            # the reference passes its RandomState object (gaussian_process_mcmc.py:126-135)
-            self.random_state = rstate0.get_state() if hasattr(rstate0, "get_state") else rstate0
+            # emcee 2 hands rstate0 to RandomState.set_state inside a try/except: a state TUPLE is applied, the
+            # RandomState OBJECT the reference passes (gaussian_process_mcmc.py:126-135) is silently ignored, so
+            # the stream set through ``sampler.random_state = rng.get_state()`` (:117) simply continues from
+            # the burn-in run into the chain run.  Same here.
+            self.random_state = rstate0
         p = np.array(pos0, dtype=np.float64)
         assert p.shape == (self.k, self.dim)
         lnp = self._eval(p) if lnprob0 is None else np.array(lnprob0, dtype=np.float64)

@@ -1,0 +1,410 @@
+#!/usr/bin/env python
+"""Golden fixtures produced by the REFERENCE'S OWN GP-side classes (run in the BUILD container only).
+
+    python tests/golden/make_golden_ref.py [case ...]
+
+``robo.models.{gaussian_process,gaussian_process_mcmc,fabolas_gp}``,
+``robo.acquisition_functions.{information_gain,information_gain_per_unit_cost,marginalization}``,
+``robo.maximizers.random_sampling``, ``robo.solver.bayesian_optimization`` and
+``robo.fmin.bayesian_optimization`` are imported from /root/reference and executed UNCHANGED; the two
+third-party packages they need and this image lacks are served by the test-only stand-ins under
+oracle/refstub (``george``: the API slice of SURVEY.md A.1 on the stated kernel contract;
+``emcee``: the 2.x ensemble sampler restated with its draw order).  What these fixtures pin is
+therefore everything the reference's Python does -- normalisation, mean, noise retry, clipping,
+mixtures, the Fabolas basis/projection (incl. its double normalisation), innovations, entropy
+change, cost division, the solver loop -- on top of the george kernel formulas, which stay the
+project's stated contract (george's source is not in the tree).
+
+Only outputs and seeds are stored; ``ref_inputs`` below regenerates the inputs (imported by the tests).
+/root/reference does not exist on the GPU box: tests read the committed .npz files only.
+"""
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+from tests.golden.make_golden import objective, default_theta  # noqa: E402
+
+
+def branin(x):
+    x1, x2 = x
+    return (x2 - 5.1 * x1 ** 2 / (4 * np.pi ** 2) + 5 * x1 / np.pi - 6) ** 2 + \
+        10 * (1 - 1 / (8 * np.pi)) * np.cos(x1) + 10
+
+
+# ------------------------------------------------------------------------------------------------
+# inputs (shared with the tests)
+# ------------------------------------------------------------------------------------------------
+GP_CASES = {
+    # name: kind, N, D, M, lo, hi, normalize_output, seed
+    "ref_gp_matern": dict(kind="matern52", N=90, D=4, M=300, lo=-2.0, hi=3.0, nout=False, seed=31),
+    "ref_gp_rbf_nout": dict(kind="rbf", N=140, D=3, M=260, lo=0.0, hi=1.0, nout=True, seed=32),
+    "ref_gp_headline_shape": dict(kind="matern52", N=1500, D=16, M=2048, lo=0.0, hi=1.0, nout=False, seed=33),
+}
+
+
+def ref_inputs(case):
+    c = GP_CASES[case]
+    rng = np.random.RandomState(c["seed"])
+    X01 = rng.rand(c["N"], c["D"])
+    y = objective(X01)
+    y = (y - y.mean()) / y.std() * 1.7 + 0.4          # not standardised: exercises mean / output normalisation
+    lower, upper = np.full(c["D"], c["lo"]), np.full(c["D"], c["hi"])
+    X = lower + (upper - lower) * X01
+    Xc = lower + (upper - lower) * np.random.RandomState(c["seed"] + 1000).rand(c["M"], c["D"])
+    theta = default_theta(c["kind"], c["D"])
+    theta[1:-1] += 0.25 * np.random.RandomState(c["seed"] + 2000).randn(c["D"])
+    theta[0] = 0.3
+    return dict(X=X, y=y, Xc=Xc, theta=theta, lower=lower, upper=upper, kind=c["kind"], nout=c["nout"])
+
+
+def mcmc_ref_inputs():
+    rng = np.random.RandomState(41)
+    N, D, M = 40, 3, 200
+    lower, upper = np.array([-1.0, 0.0, 2.0]), np.array([1.0, 5.0, 3.0])
+    X = lower + (upper - lower) * rng.rand(N, D)
+    y = objective((X - lower) / (upper - lower))
+    Xc = lower + (upper - lower) * np.random.RandomState(42).rand(M, D)
+    X2 = lower + (upper - lower) * np.random.RandomState(43).rand(3, D)
+    y2 = objective((X2 - lower) / (upper - lower))
+    return dict(X=X, y=y, Xc=Xc, X2=X2, y2=y2, lower=lower, upper=upper, n_hypers=10, chain_length=12,
+                burnin_steps=14, seed=44)
+
+
+def fabolas_inputs(N=60, D=3, M=150, S=4, seed=51):
+    """config-4 shaped: D configuration columns + the dataset-size column s in (0, 1]"""
+    rng = np.random.RandomState(seed)
+    lower, upper = np.full(D, -1.0), np.full(D, 2.0)
+    Xcfg = lower + (upper - lower) * rng.rand(N, D)
+    s = rng.rand(N) * 0.95 + 0.05
+    X = np.concatenate((Xcfg, s[:, None]), axis=1)
+    y = objective((Xcfg - lower) / (upper - lower)) / D + 0.5 * (1 - s) ** 2 + 0.05 * rng.randn(N)
+    cost = np.log(0.2 + 3.0 * s) + 0.02 * rng.randn(N)                       # the cost model sees LOG cost
+    rc = np.random.RandomState(seed + 1)
+    Xc = np.concatenate((lower + (upper - lower) * rc.rand(M, D), rc.rand(M, 1) * 0.95 + 0.05), axis=1)
+    P = 1 + D + 2 + 1
+    base = np.concatenate([[np.log(1.0 / (D + 1))], np.full(D, np.log(0.4)), [0.1, 0.1], [np.log(1e-3)]])
+    thetas = base[None, :] + 0.25 * np.random.RandomState(seed + 2).randn(S, P)
+    thetas_cost = base[None, :] + 0.25 * np.random.RandomState(seed + 3).randn(S, P)
+    return dict(X=X, y=y, cost=cost, Xc=Xc, lower=lower, upper=upper, thetas=thetas, thetas_cost=thetas_cost, D=D)
+
+
+def infogain_inputs(N=80, D=2, M=400, seed=61):
+    rng = np.random.RandomState(seed)
+    lower, upper = np.array([-5.0, 0.0])[:D], np.array([10.0, 15.0])[:D]
+    X = lower + (upper - lower) * rng.rand(N, D)
+    y = np.array([branin(x) for x in X]) / 50.0
+    Xc = lower + (upper - lower) * np.random.RandomState(seed + 1).rand(M, D)
+    theta = np.array([0.5, np.log(0.1), np.log(0.15), np.log(1e-3)])
+    return dict(X=X, y=y, Xc=Xc, lower=lower, upper=upper, theta=theta)
+
+
+# ------------------------------------------------------------------------------------------------
+# the reference, importable through the stand-ins
+# ------------------------------------------------------------------------------------------------
+def reference():
+    for attr, val in (("Infinity", np.inf), ("NAN", np.nan)):
+        if not hasattr(np, attr):
+            setattr(np, attr, val)          # NumPy-2 hazards in log_ei.py / epmgp.py
+    stub = os.path.join(ROOT, "oracle", "refstub")
+    for p in (stub, "/root/reference"):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    import types
+    import george                                    # noqa: F401  (the stand-in)
+    import emcee                                     # noqa: F401  (the stand-in)
+    assert "refstub" in george.__file__ and "refstub" in emcee.__file__
+    ns = types.SimpleNamespace()
+    ns.george = george
+    from robo.models.gaussian_process import GaussianProcess
+    from robo.models.gaussian_process_mcmc import GaussianProcessMCMC
+    from robo.models.fabolas_gp import FabolasGP, FabolasGPMCMC
+    from robo.acquisition_functions.ei import EI
+    from robo.acquisition_functions.log_ei import LogEI
+    from robo.acquisition_functions.pi import PI
+    from robo.acquisition_functions.lcb import LCB
+    from robo.acquisition_functions.marginalization import MarginalizationGPMCMC
+    from robo.acquisition_functions.information_gain import InformationGain
+    from robo.acquisition_functions.information_gain_per_unit_cost import InformationGainPerUnitCost
+    from robo.priors.default_priors import DefaultPrior
+    from robo.priors.env_priors import EnvPrior
+    ns.__dict__.update(locals())
+    return ns
+
+
+def george_kernel(R, kind, D, theta_k):
+    K = {"matern52": R.george.kernels.Matern52Kernel, "rbf": R.george.kernels.ExpSquaredKernel}[kind]
+    k = 1.0 * K(np.ones(D), ndim=D)
+    k.set_parameter_vector(theta_k)
+    return k
+
+
+def george_fabolas_kernel(R, D, theta_k=None):
+    """robo/fmin/fabolas.py:103-117, verbatim construction"""
+    kernel = 1
+    for d in range(D):
+        kernel *= R.george.kernels.Matern52Kernel(np.ones([1]) * 0.01, ndim=D + 1, axes=d)
+    kernel *= R.george.kernels.BayesianLinearRegressionKernel(log_a=0.1, log_b=0.1, ndim=D + 1, axes=D)
+    if theta_k is not None:
+        kernel.set_parameter_vector(theta_k)
+    return kernel
+
+
+def _save(name, **out):
+    np.savez(os.path.join(HERE, name + ".npz"), **out)
+    print("wrote", name, sorted(out))
+
+
+# ------------------------------------------------------------------------------------------------
+# (1) GaussianProcess.train / predict / nll / grad_nll / predict_variance / get_incumbent
+# ------------------------------------------------------------------------------------------------
+def make_gp(R):
+    for name, c in GP_CASES.items():
+        inp = ref_inputs(name)
+        D = c["D"]
+        kernel = george_kernel(R, c["kind"], D, inp["theta"][:-1])
+        gp = R.GaussianProcess(kernel, noise=np.exp(inp["theta"][-1]), normalize_output=c["nout"],
+                               lower=inp["lower"], upper=inp["upper"], rng=np.random.RandomState(1))
+        gp.train(inp["X"], inp["y"], do_optimize=False)
+        mu, var = gp.predict(inp["Xc"])
+        out = dict(mu=mu, var=var, hypers=np.array(gp.hypers), noise=gp.noise)
+        inc, inc_val = gp.get_incumbent()
+        out.update(inc=inc, inc_val=inc_val)
+        _, cov = gp.predict(inp["Xc"][:33], full_cov=True)
+        out["cov33"] = cov
+        out["pv"] = gp.predict_variance(inp["Xc"][:1], inp["Xc"][1:20])
+        for nm, cls in (("ei", R.EI), ("log_ei", R.LogEI), ("pi", R.PI), ("lcb", R.LCB)):
+            out[nm] = cls(gp).compute(inp["Xc"])
+            out["argmax_" + nm] = int(np.argmax(out[nm]))
+        if c["N"] <= 256:
+            thetas = inp["theta"][None, :] + 0.4 * np.random.RandomState(c["seed"] + 3000).randn(4, D + 2)
+            thetas[3, 1] = 25.0                      # out of the |theta| <= 20 box -> 1e25
+            out["nll_thetas"] = thetas
+            out["nll"] = np.array([gp.nll(t) for t in thetas])
+            out["grad_nll"] = np.array([gp.grad_nll(t) for t in thetas[:3]])
+        _save(name, **out)
+
+    # noise * 10 retry (gaussian_process.py:118-122).  A numerically rank-deficient K (smooth RBF, long length
+    # scales, 200 points, amplitude e^8) with noise 1e-18: gp.compute fails, the retry at 1e-17 fails as well and
+    # the LinAlgError of the SECOND compute escapes train(); noise has been multiplied by 10 exactly once.
+    rng = np.random.RandomState(35)
+    X = rng.rand(200, 2)
+    y = objective(X)
+    theta = np.array([8.0, np.log(30.0), np.log(30.0), np.log(1e-18)])
+    gp = R.GaussianProcess(george_kernel(R, "rbf", 2, theta[:-1]), noise=np.exp(theta[-1]), lower=np.zeros(2),
+                           upper=np.ones(2), rng=np.random.RandomState(1))
+    status = "ok"
+    try:
+        gp.train(X, y, do_optimize=False)
+    except np.linalg.LinAlgError:
+        status = "LinAlgError"
+    _save("ref_gp_retry", status=status, noise=gp.noise, is_trained=gp.is_trained, theta=theta)
+
+    # do_optimize=True without a prior (L-BFGS-B on nll, finite differences, gaussian_process.py:193-219)
+    inp = ref_inputs("ref_gp_matern")
+    D = 4
+    kernel = george_kernel(R, "matern52", D, inp["theta"][:-1])
+    gp = R.GaussianProcess(kernel, noise=np.exp(inp["theta"][-1]), lower=inp["lower"], upper=inp["upper"],
+                           rng=np.random.RandomState(1))
+    gp.train(inp["X"], inp["y"], do_optimize=True)
+    _save("ref_gp_optimize", hypers=gp.hypers, nll_opt=gp.nll(gp.hypers), nll_start=gp.nll(inp["theta"]))
+
+
+# ------------------------------------------------------------------------------------------------
+# (2) GaussianProcessMCMC.train (emcee draw order) / predict + MarginalizationGPMCMC
+# ------------------------------------------------------------------------------------------------
+def make_mcmc(R):
+    inp = mcmc_ref_inputs()
+    D = inp["X"].shape[1]
+    kernel = 2 * R.george.kernels.Matern52Kernel(np.ones(D), ndim=D)     # fmin/bayesian_optimization.py:75-81
+    prior = R.DefaultPrior(len(kernel) + 1, rng=np.random.RandomState(inp["seed"] + 1))
+    m = R.GaussianProcessMCMC(kernel, prior=prior, n_hypers=inp["n_hypers"], chain_length=inp["chain_length"],
+                              burnin_steps=inp["burnin_steps"], lower=inp["lower"], upper=inp["upper"],
+                              rng=np.random.RandomState(inp["seed"]))
+    m.train(inp["X"], inp["y"], do_optimize=True)
+    out = dict(hypers=np.array(m.hypers), p0=np.array(m.p0))
+    out["mix_m"], out["mix_v"] = m.predict(inp["Xc"])
+    out["mu_s"] = np.array([mm.predict(inp["Xc"])[0] for mm in m.models])
+    out["var_s"] = np.array([mm.predict(inp["Xc"])[1] for mm in m.models])
+    out["loglik"] = np.array([m.loglikelihood(h) for h in m.hypers])
+    out["inc"], out["inc_val"] = m.get_incumbent()
+    for nm, cls in (("ei", R.EI), ("log_ei", R.LogEI), ("pi", R.PI), ("lcb", R.LCB)):
+        out["marg_" + nm] = R.MarginalizationGPMCMC(cls(m)).compute(inp["Xc"])
+    # second BO iteration: burned, walkers continue from p0, RNG streams continue
+    m.train(np.concatenate((inp["X"], inp["X2"])), np.concatenate((inp["y"], inp["y2"])), do_optimize=True)
+    out["hypers2"] = np.array(m.hypers)
+    out["mix_m2"], out["mix_v2"] = m.predict(inp["Xc"])
+    # do_optimize=False: single model at the kernel's current vector + raw log-noise -8 (:144-147)
+    m2 = R.GaussianProcessMCMC(2 * R.george.kernels.Matern52Kernel(np.ones(D), ndim=D), lower=inp["lower"],
+                               upper=inp["upper"], rng=np.random.RandomState(3))
+    m2.train(inp["X"], inp["y"], do_optimize=False)
+    out["noopt_hypers"] = np.array(m2.hypers)
+    out["noopt_m"], out["noopt_v"] = m2.predict(inp["Xc"])
+    _save("ref_gpmcmc", **out)
+
+
+# ------------------------------------------------------------------------------------------------
+# (3) FabolasGP / FabolasGPMCMC (+ marginalised EI over it)
+# ------------------------------------------------------------------------------------------------
+def _fabolas_models(R, inp, which="obj"):
+    D = inp["D"]
+    basis = (lambda x: (1 - x) ** 2) if which == "obj" else (lambda x: x)
+    target = inp["y"] if which == "obj" else inp["cost"]
+    thetas = inp["thetas"] if which == "obj" else inp["thetas_cost"]
+    mc = R.FabolasGPMCMC(george_fabolas_kernel(R, D), basis_func=basis, n_hypers=len(thetas), lower=inp["lower"],
+                         upper=inp["upper"], rng=np.random.RandomState(5))
+    mc.hypers = [t for t in thetas]
+    mc.train(inp["X"], target, do_optimize=False)
+    return mc, basis, target
+
+
+def make_fabolas(R):
+    inp = fabolas_inputs()
+    D = inp["D"]
+    th = inp["thetas"][0]
+    gp = R.FabolasGP(george_fabolas_kernel(R, D, th[:-1]), basis_function=lambda x: (1 - x) ** 2,
+                     noise=np.exp(th[-1]), lower=inp["lower"], upper=inp["upper"], rng=np.random.RandomState(1))
+    gp.train(inp["X"], inp["y"], do_optimize=False)
+    out = dict()
+    out["mu"], out["var"] = gp.predict(inp["Xc"])
+    out["inc"], out["inc_val"] = gp.get_incumbent()
+    _, out["cov17"] = gp.predict(inp["Xc"][:17], full_cov=True)
+    out["ei"] = R.EI(gp).compute(inp["Xc"])
+    # last: the reference's nll() leaves theta in the SHARED kernel object (gaussian_process.py:151), i.e. it
+    # changes what a later train(do_optimize=False) fits -- not mirrored, so nothing may follow it here
+    out["nll"] = gp.nll(inp["thetas"][1])
+    mc, _, _ = _fabolas_models(R, inp)
+    out["mix_m"], out["mix_v"] = mc.predict(inp["Xc"])
+    out["mcmc_inc"], out["mcmc_inc_val"] = mc.get_incumbent()
+    for nm, cls in (("ei", R.EI), ("log_ei", R.LogEI), ("lcb", R.LCB)):
+        out["marg_" + nm] = R.MarginalizationGPMCMC(cls(mc)).compute(inp["Xc"])
+    _save("ref_fabolas", **out)
+
+
+# ------------------------------------------------------------------------------------------------
+# (4) InformationGain / InformationGainPerUnitCost, every candidate through the reference's loop
+# ------------------------------------------------------------------------------------------------
+def _ig_state(ig):
+    return dict(zb=np.array(ig.zb), lmb=np.array(ig.lmb), logP=ig.logP, dlogPdMu=ig.dlogPdMu,
+                dlogPdSigma=ig.dlogPdSigma, dlogPdMudMu=ig.dlogPdMudMu, sn2=ig.sn2)
+
+
+def make_infogain(R):
+    inp = infogain_inputs()
+    D = inp["X"].shape[1]
+    gp = R.GaussianProcess(george_kernel(R, "matern52", D, inp["theta"][:-1]), noise=np.exp(inp["theta"][-1]),
+                           lower=inp["lower"], upper=inp["upper"], rng=np.random.RandomState(1))
+    gp.train(inp["X"], inp["y"], do_optimize=False)
+    np.random.seed(7)
+    ig = R.InformationGain(gp, inp["lower"], inp["upper"], Nb=50, Np=400, rng=np.random.RandomState(8))
+    ig.update(gp)
+    out = _ig_state(ig)
+    out["ig"] = ig.compute(inp["Xc"])
+    out["argmax"] = int(np.argmax(out["ig"]))
+    _save("ref_infogain", **out)
+
+    # per unit cost on Fabolas models, marginalised over S hyper-parameter samples as fmin/fabolas.py:190-198 does
+    finp = fabolas_inputs(M=120)
+    D = finp["D"]
+    mc_obj, _, _ = _fabolas_models(R, finp, "obj")
+    mc_cost, _, _ = _fabolas_models(R, finp, "cost")
+    lower, upper = np.append(finp["lower"], 0), np.append(finp["upper"], 1)
+    is_env = np.zeros(D + 1)
+    is_env[-1] = 1
+    np.random.seed(9)
+    igc = R.InformationGainPerUnitCost(mc_obj, mc_cost, lower, upper, sampling_acquisition=R.EI,
+                                       is_env_variable=is_env, n_representer=20)
+    marg = R.MarginalizationGPMCMC(igc)
+    # NOTE marginalization.py:41-45 points every estimator's *model* at the COST sub-model when a cost model
+    # exists; update() (called by the solver before every maximisation, fabolas.py:245) repairs that.
+    marg.update(mc_obj, mc_cost, overhead=0.35)
+    out = dict(S=len(marg.estimators), overhead=0.35)
+    for i, e in enumerate(marg.estimators):
+        for k, v in _ig_state(e).items():
+            out["%s_%d" % (k, i)] = v
+        out["ig_%d" % i] = e.compute(finp["Xc"])
+        out["log_cost_%d" % i] = mc_cost.models[i].predict(finp["Xc"])[0]
+    out["marg"] = marg.compute(finp["Xc"])
+    _save("ref_infogain_cost", **out)
+
+
+def make_infogain_config4(R, N=2048, D=10, M=256):
+    """BASELINE config 4's shape (Fabolas kernel, D = 10 + 1, Nb = 50, Np = 400) at half its N through the
+    reference's own per-candidate loop: representer sampling costs 2500+ single-point posteriors and every
+    candidate a 51-RHS N x N solve, ~15 min of CPU at N = 2048 (N = 4096 did not finish in 50 min here)."""
+    inp = fabolas_inputs(N=N, D=D, M=M, S=1, seed=71)
+    th = inp["thetas"][0]
+    gp = R.FabolasGP(george_fabolas_kernel(R, D, th[:-1]), basis_function=lambda x: (1 - x) ** 2,
+                     noise=np.exp(th[-1]), lower=inp["lower"], upper=inp["upper"], rng=np.random.RandomState(1))
+    gp.train(inp["X"], inp["y"], do_optimize=False)
+    lower, upper = np.append(inp["lower"], 0), np.append(inp["upper"], 1)
+    np.random.seed(11)
+    ig = R.InformationGain(gp, lower, upper, Nb=50, Np=400, sampling_acquisition=R.EI,
+                           rng=np.random.RandomState(12))
+    ig.update(gp)
+    out = _ig_state(ig)
+    out["ig"] = ig.compute(inp["Xc"])
+    _save("ref_infogain_config4", **out)
+
+
+# ------------------------------------------------------------------------------------------------
+# (5) BASELINE config 1: Branin through robo.fmin.bayesian_optimization, 30 iterations
+# ------------------------------------------------------------------------------------------------
+def _placeholder_optional_models():
+    """robo/fmin/__init__.py imports every front end, and those import the optional model back ends
+    (pybnn: DNGO/Bohamiann, pyrfr: random forests) at module level.  None of them is on the GP path or
+    installed here; empty placeholder modules let ``robo.fmin`` import, any use would raise."""
+    import types
+    for mod, names in (("pybnn", ()), ("pybnn.dngo", ("DNGO",)), ("pybnn.bohamiann", ("Bohamiann",)),
+                       ("pybnn.multi_task_bohamiann", ("MultiTaskBohamiann",)), ("pyrfr", ()),
+                       ("pyrfr.regression", ())):
+        if mod not in sys.modules:
+            m = types.ModuleType(mod)
+            for n in names:
+                setattr(m, n, None)
+            sys.modules[mod] = m
+
+
+def make_branin(R, seed=3, n_iter=30):
+    _placeholder_optional_models()
+    from robo.fmin import bayesian_optimization as fmin_bo
+    GP = R.GaussianProcess
+    log = []
+    orig_train = GP.train
+
+    def train(self, X, y, do_optimize=True):
+        orig_train(self, X, y, do_optimize)
+        st = np.random.get_state()
+        log.append(dict(n=X.shape[0], hypers=np.array(self.hypers, dtype=np.float64), noise=float(self.noise),
+                        keys=st[1].copy(), pos=st[2], has_gauss=st[3], cached=st[4]))
+
+    GP.train = train
+    try:
+        lo, hi = np.array([-5.0, 0.0]), np.array([10.0, 15.0])
+        np.random.seed(seed)
+        res = fmin_bo(branin, lo, hi, num_iterations=n_iter, n_init=3, model_type="gp", acquisition_func="ei",
+                      maximizer="random", rng=np.random.RandomState(seed))
+    finally:
+        GP.train = orig_train
+    out = dict(X=np.array(res["X"]), y=np.array(res["y"]), x_opt=np.array(res["x_opt"]), f_opt=res["f_opt"],
+               incumbent_values=np.array(res["incumbent_values"]), seed=seed,
+               n=np.array([l["n"] for l in log]), hypers=np.array([l["hypers"] for l in log]),
+               noise=np.array([l["noise"] for l in log]), rng_keys=np.array([l["keys"] for l in log]),
+               rng_pos=np.array([l["pos"] for l in log]), rng_has_gauss=np.array([l["has_gauss"] for l in log]),
+               rng_cached=np.array([l["cached"] for l in log]))
+    print("branin f_opt", res["f_opt"], "regret", res["f_opt"] - 0.397887)
+    _save("ref_branin", **out)
+
+
+MAKERS = dict(gp=make_gp, mcmc=make_mcmc, fabolas=make_fabolas, infogain=make_infogain,
+              infogain_config4=make_infogain_config4, branin=make_branin)
+
+if __name__ == "__main__":
+    R = reference()
+    for nm in (sys.argv[1:] or list(MAKERS)):
+        MAKERS[nm](R)

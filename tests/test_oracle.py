@@ -199,3 +199,82 @@ def test_kernel_gradient_matches_central_differences():
             e[p] = 1e-6
             fd = (O.kernel_matrix(kind, th + e, X) - O.kernel_matrix(kind, th - e, X)) / 2e-6
             np.testing.assert_allclose(G[:, :, p], fd, rtol=0, atol=2e-8 * max(1.0, np.abs(fd).max()))
+
+
+# ------------------------------------------------------------------------------------------------
+# GP half against the REFERENCE'S OWN classes (tests/golden/make_golden_ref.py: robo.models.* and
+# robo.acquisition_functions.information_gain* executed unchanged on the george/emcee stand-ins)
+# ------------------------------------------------------------------------------------------------
+def test_oracle_gp_matches_reference_class_fixtures(golden_dir):
+    """OracleGP (the restatement used as checker at sizes without a fixture and as cpu_baseline) against
+    what robo.models.gaussian_process.GaussianProcess itself returned: train/predict/nll/grad_nll/incumbent"""
+    import make_golden_ref as G
+    for name in G.GP_CASES:
+        inp, gold = G.ref_inputs(name), _load(golden_dir, name)
+        gp = O.OracleGP(inp["kind"], inp["theta"], normalize_output=inp["nout"], lower=inp["lower"],
+                        upper=inp["upper"])
+        gp.train(inp["X"], inp["y"])
+        mu, var = gp.predict(inp["Xc"], diag_only=True)
+        np.testing.assert_allclose(mu, gold["mu"], rtol=1e-10, atol=1e-11)
+        np.testing.assert_allclose(var, gold["var"], rtol=0, atol=1e-10)
+        inc, val = gp.get_incumbent()
+        np.testing.assert_array_equal(inc, gold["inc"])
+        assert val == gold["inc_val"]
+        _, cov = gp.predict(inp["Xc"][:33], full_cov=True)
+        np.testing.assert_allclose(cov, gold["cov33"], rtol=0, atol=1e-10)
+        if "nll" in gold.files:
+            np.testing.assert_allclose([gp.nll(t) for t in gold["nll_thetas"]], gold["nll"], rtol=1e-12)
+            for t, ref in zip(gold["nll_thetas"][:3], gold["grad_nll"]):
+                g = -O.gp_grad_log_likelihood(inp["kind"], t, gp.X, gp.y, gp.mean)
+                np.testing.assert_allclose(g, ref, rtol=1e-9, atol=1e-10 * np.abs(ref).max())
+
+
+def test_refstub_kernels_equal_oracle_kernels():
+    """two independently written evaluations of the kernel contract: generic composition in
+    oracle/refstub/george/kernels.py vs the (kind, theta) form in oracle/gp_oracle.py, values and gradients"""
+    import sys
+    stub = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle", "refstub")
+    sys.path.insert(0, stub)
+    try:
+        import george
+    finally:
+        sys.path.remove(stub)
+    rs = np.random.RandomState(0)
+    D = 4
+    X1, X2 = rs.rand(23, D), rs.rand(17, D)
+    th = np.concatenate([[0.4], 0.5 * rs.randn(D)])
+    for kind, cls in (("matern52", george.kernels.Matern52Kernel), ("rbf", george.kernels.ExpSquaredKernel)):
+        k = 2.0 * cls(np.ones(D), ndim=D)
+        assert len(k) == D + 1 and np.isclose(k.get_parameter_vector()[0], np.log(2.0 / D))
+        k.set_parameter_vector(th)
+        np.testing.assert_allclose(k.get_value(X1, X2), O.kernel_matrix(kind, th, X1, X2), rtol=1e-13)
+        np.testing.assert_allclose(k.gradient(X1), O.kernel_gradient(kind, th, X1), rtol=1e-11, atol=1e-14)
+    # Fabolas product, built the way robo/fmin/fabolas.py:103-117 builds it
+    kern = 1
+    for d in range(D - 1):
+        kern *= george.kernels.Matern52Kernel(np.ones([1]) * 0.01, ndim=D, axes=d)
+    kern *= george.kernels.BayesianLinearRegressionKernel(log_a=0.1, log_b=0.1, ndim=D, axes=D - 1)
+    assert len(kern) == 1 + (D - 1) + 2
+    thf = np.concatenate([[-0.3], 0.5 * rs.randn(D - 1), [0.2, -0.4]])
+    kern.set_parameter_vector(thf)
+    np.testing.assert_allclose(kern.get_value(X1, X2), O.kernel_matrix("fabolas", thf, X1, X2), rtol=1e-13)
+    np.testing.assert_allclose(kern.gradient(X1), O.kernel_gradient("fabolas", thf, X1), rtol=1e-11, atol=1e-14)
+
+
+def test_ig_oracle_matches_reference_class_fixture(golden_dir):
+    """oracle/ig_oracle.py (restatement of _dh_fun / innovations) against InformationGain.compute itself"""
+    import make_golden_ref as G
+    from oracle import ig_oracle as IG
+    inp, gold = G.infogain_inputs(), _load(golden_dir, "ref_infogain")
+    gp = O.OracleGP("matern52", inp["theta"], lower=inp["lower"], upper=inp["upper"])
+    gp.train(inp["X"], inp["y"])
+    W = IG.outcome_quantiles(400)
+    zb = gold["zb"]
+    out = np.empty(60)
+    for c in range(60):
+        x = inp["Xc"][c:c + 1]
+        _, v = gp.predict(x)
+        _, cov = gp.predict(np.concatenate((zb, x)), full_cov=True)
+        out[c] = IG.dh_fun(v[0], cov[-1, :-1, None], float(gold["sn2"]), gold["logP"], gold["lmb"], gold["dlogPdMu"],
+                           gold["dlogPdSigma"], gold["dlogPdMudMu"], W)
+    np.testing.assert_allclose(out, gold["ig"][:60], rtol=1e-9, atol=1e-12)

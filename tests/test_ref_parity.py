@@ -1,0 +1,115 @@
+"""robo_amd's classes against fixtures made by the REFERENCE'S OWN GP-side classes (tests/ref_checks.py).
+
+-m gpu: through librobo_hip.so on the MI355X (the parity claim).  The `emulated` variants push the small
+cases through tests/hipemu on the CPU: they check host logic (normalisation, sampler draw order, quirks),
+nothing about the hardware.
+"""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+import ref_checks as R
+from robo_amd import _lib
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+@pytest.fixture(scope="module")
+def emu():
+    sys.path.insert(0, os.path.join(HERE, "hipemu"))
+    import build_emu
+    _lib.use_library(build_emu.build())
+    yield
+    _lib.use_library(None)
+
+
+@pytest.fixture(scope="module")
+def gpu():
+    _lib.use_library(None)
+    if _lib.device_count() < 1:
+        pytest.skip("no HIP device")
+    yield
+
+
+# ---- CPU (interpreter): host logic -----------------------------------------------------------------
+@pytest.mark.parametrize("name", ["ref_gp_matern", "ref_gp_rbf_nout"])
+def test_gp_class_emulated(emu, name):
+    R.check_ref_gp(name)
+
+
+def test_gp_retry_emulated(emu):
+    R.check_ref_gp_retry()
+
+
+def test_mcmc_chain_and_marginal_emulated(emu):
+    R.check_ref_mcmc()
+
+
+def test_fabolas_emulated(emu):
+    R.check_ref_fabolas()
+
+
+def test_infogain_emulated(emu):
+    R.check_ref_infogain()
+
+
+def test_infogain_per_unit_cost_emulated(emu):
+    R.check_ref_infogain_cost()
+
+
+def test_branin_replay_emulated(emu):
+    R.check_ref_branin_replay()
+
+
+# ---- MI355X ---------------------------------------------------------------------------------------------
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["ref_gp_matern", "ref_gp_rbf_nout", "ref_gp_headline_shape"])
+def test_gp_class(gpu, name):
+    R.check_ref_gp(name)
+
+
+@pytest.mark.gpu
+def test_gp_retry_and_optimize(gpu):
+    R.check_ref_gp_retry()
+    mine, ref = R.check_ref_gp_optimize()
+    print("optimised hypers", mine, "reference", ref)
+
+
+@pytest.mark.gpu
+def test_mcmc_chain_and_marginal(gpu):
+    R.check_ref_mcmc()
+
+
+@pytest.mark.gpu
+def test_fabolas(gpu):
+    R.check_ref_fabolas()
+
+
+@pytest.mark.gpu
+def test_infogain_every_candidate(gpu):
+    R.check_ref_infogain()
+
+
+@pytest.mark.gpu
+def test_infogain_per_unit_cost(gpu):
+    R.check_ref_infogain_cost()
+
+
+@pytest.mark.gpu
+def test_infogain_config4_shape(gpu):
+    R.check_ref_infogain_config4()
+
+
+@pytest.mark.gpu
+def test_branin_trajectory_replay(gpu):
+    assert R.check_ref_branin_replay() == 27
+
+
+@pytest.mark.gpu
+def test_branin_free_run(gpu):
+    same, f_mine, f_ref = R.check_ref_branin_free_run()
+    print("free run: identical choices for the first %d iterations; f_opt %.6f (reference %.6f)" % (same, f_mine, f_ref))
+    assert same >= 4
+    assert f_mine - 0.397887 <= max(2.0 * (f_ref - 0.397887), 0.5)
