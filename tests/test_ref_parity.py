@@ -111,5 +111,7 @@ def test_branin_trajectory_replay(gpu):
 def test_branin_free_run(gpu):
     same, f_mine, f_ref = R.check_ref_branin_free_run()
     print("free run: identical choices for the first %d iterations; f_opt %.6f (reference %.6f)" % (same, f_mine, f_ref))
-    assert same >= 4
-    assert f_mine - 0.397887 <= max(2.0 * (f_ref - 0.397887), 0.5)
+    # measured on the MI355X (r02a): the first 15 choices are identical although every iteration runs its own
+    # finite-difference L-BFGS-B; after the first diverging optimiser run the two are different random searches
+    assert same >= 8
+    assert f_mine - 0.397887 <= 1.0
