@@ -118,6 +118,17 @@ int32_t robo_gp_grad_loglik(robo_gp* gp, const double* theta, double mean_c, dou
  * batch workspace; the GP itself is left UNFITTED (call robo_gp_fit for the theta to keep).    */
 int32_t robo_gp_loglik_batch(robo_gp* gp, const double* thetas, int32_t S, double mean_c, double* out_loglik,
                              int32_t* out_status);
+
+/* The per-sample model fits of GaussianProcessMCMC.train (gaussian_process_mcmc.py:149-164: one
+ * GaussianProcess per hyper-parameter sample, each a gp.compute on the SAME X, y) as one batched pass
+ * that KEEPS the factors: gps[0] holds the training data (robo_gp_set_data); afterwards every gps[s]
+ * with out_status[s] == ROBO_OK is a fitted handle at thetas[s] (own copy of the data, factor, diagonal
+ * block inverses, scaled inputs), bit-identical to robo_gp_fit(gps[s], thetas[s]).  Samples whose K is not
+ * positive definite are left unfitted with out_status[s] = ROBO_NOT_POSITIVE_DEFINITE (the caller applies
+ * the reference's noise x 10 retry, gaussian_process.py:120-122, to those).  All handles: same context,
+ * kernel kind, dim, n_max >= n, pairwise distinct.                                                   */
+int32_t robo_gp_fit_batch(robo_gp* const* gps, int32_t S, const double* thetas, double mean_c, double* out_loglik,
+                          int32_t* out_status);
 /* copy the lower Cholesky factor (n x n, row-major, upper zeroed) back -- diagnostics/tests */
 int32_t robo_gp_get_factor(robo_gp* gp, double* out_L);
 int32_t robo_gp_get_gram(robo_gp* gp, const double* theta, double* out_K); /* K incl. noise, n x n  */

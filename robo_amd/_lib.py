@@ -28,7 +28,7 @@ SYMBOLS = [
     "robo_last_error_string", "robo_version_string",
     "robo_gp_create", "robo_gp_destroy", "robo_gp_set_data", "robo_gp_set_output_transform",
     "robo_gp_set_precision", "robo_theta_size",
-    "robo_gp_fit", "robo_gp_loglik_batch", "robo_gp_grad_loglik", "robo_gp_get_factor", "robo_gp_get_gram",
+    "robo_gp_fit", "robo_gp_loglik_batch", "robo_gp_fit_batch", "robo_gp_grad_loglik", "robo_gp_get_factor", "robo_gp_get_gram",
     "robo_cand_create", "robo_cand_destroy", "robo_cand_create_uniform", "robo_cand_get_points",
     "robo_cand_create_random", "robo_cand_get_point",
     "robo_gp_predict_cand", "robo_gp_predict", "robo_gp_predict_cov", "robo_gp_predict_mixture_cand",
@@ -106,6 +106,7 @@ def lib():
         "robo_theta_size": [i32, i32],
         "robo_gp_fit": [vp, _dp, dbl, _dp, C.POINTER(i32)],
         "robo_gp_loglik_batch": [vp, _dp, i32, dbl, _dp, C.POINTER(i32)],
+        "robo_gp_fit_batch": [pp, i32, _dp, dbl, _dp, C.POINTER(i32)],
         "robo_gp_grad_loglik": [vp, _dp, dbl, _dp, _dp, C.POINTER(i32)],
         "robo_gp_get_factor": [vp, _dp],
         "robo_gp_get_gram": [vp, _dp, _dp],
@@ -405,6 +406,22 @@ class DeviceGP(object):
             check(lib().robo_acq_eval(self._h, ACQ_KINDS[kind], float(par), float(eta), _arr(Xc), m,
                                       _arr(out) if want_values else None, C.byref(mx), C.byref(am), C.byref(fl)))
         return out, mx.value, am.value, fl.value
+
+
+def fit_batch(gps, thetas, mean_c):
+    """GaussianProcessMCMC.train's per-sample fits in one batched pass that keeps the factors:
+    gps[0] holds the data; afterwards gps[s] is fitted at thetas[s] wherever status[s] == OK.
+    -> (loglik (S,), status (S,))"""
+    S = len(gps)
+    thetas = _f64(thetas)
+    assert thetas.shape == (S, gps[0].n_theta)
+    arr = (C.c_void_p * S)(*[g._h for g in gps])
+    ll = np.empty(S)
+    st = np.empty(S, dtype=np.int32)
+    check(lib().robo_gp_fit_batch(arr, S, _arr(thetas), float(mean_c), _arr(ll), st.ctypes.data_as(C.POINTER(C.c_int32))))
+    for g in gps:
+        g.n = gps[0].n
+    return ll, st
 
 
 def predict_mixture(gps, cand):

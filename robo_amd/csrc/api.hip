@@ -365,14 +365,11 @@ static int batch_ensure(robo_gp* g, int S) {
     return ROBO_OK;
 }
 
-int32_t robo_gp_loglik_batch(robo_gp* g, const double* thetas, int32_t S, double mean_c, double* out_loglik,
-                             int32_t* out_status) {
-    if (!g || !thetas || S < 0 || !out_loglik) return ROBO_BAD_ARGUMENT;
-    if (!g->has_data) {
-        set_error("robo_gp_loglik_batch before robo_gp_set_data");
-        return ROBO_NOT_FITTED;
-    }
-    if (S == 0) return ROBO_OK;
+// S thetas on the training data of g, factorised by ONE sequence of launches per workspace chunk.  After each
+// chunk `keep(s0, ns, status)` may copy the chunk's factors out of the strided batch workspace (it runs before
+// the next chunk overwrites them).
+static int fit_batch_core(robo_gp* g, const double* thetas, int32_t S, double mean_c, double* out_loglik,
+                          int32_t* out_status, const std::function<int(int, int, const int*)>& keep) {
     robo_ctx* c = g->ctx;
     const int P = robo_theta_size(g->kind, g->dim), D = g->dim;
     const size_t np = (size_t)g->n_pad;
@@ -383,16 +380,15 @@ int32_t robo_gp_loglik_batch(robo_gp* g, const double* thetas, int32_t S, double
     if (chunk < 1) chunk = 1;
     if (chunk > S) chunk = S;
     ROBO_TRY(batch_ensure(g, chunk));
-    g->fitted = false;   // the GP's own factor is not touched, but the call documents "unfitted after"
     for (int s0 = 0; s0 < S; s0 += chunk) {
         const int ns = S - s0 < chunk ? S - s0 : chunk;
         ROBO_HIP_CHECK(hipStreamSynchronize(c->stream));   // staging buffer reuse
         FitSample* hsp = reinterpret_cast<FitSample*>(g->h_bstage);
         double* hism = reinterpret_cast<double*>(hsp + chunk);
-        std::vector<int> bad(ns, ROBO_OK);
+        std::vector<int> status(ns, ROBO_OK);
         for (int s = 0; s < ns; ++s) {
             const int st = theta_to_sample(g, thetas + (size_t)(s0 + s) * P, mean_c, hsp + s, hism + (size_t)s * D);
-            bad[s] = st;
+            status[s] = st;
             if (st != ROBO_OK) {   // keep the slot numerically harmless: unit kernel
                 static const double zeros[MAX_DIM + 8] = {0};
                 theta_to_sample(g, zeros, mean_c, hsp + s, hism + (size_t)s * D);
@@ -418,17 +414,94 @@ int32_t robo_gp_loglik_batch(robo_gp* g, const double* thetas, int32_t S, double
         ROBO_HIP_CHECK(hipMemcpyAsync(hfail, g->d_bfail, (size_t)ns * sizeof(int), hipMemcpyDeviceToHost, c->stream));
         ROBO_HIP_CHECK(hipStreamSynchronize(c->stream));
         for (int s = 0; s < ns; ++s) {
-            int st = bad[s];
             double ll = -HUGE_VAL;
-            if (st == ROBO_OK) {
-                if (hfail[s] != 0) st = ROBO_NOT_POSITIVE_DEFINITE;
+            if (status[s] == ROBO_OK) {
+                if (hfail[s] != 0) status[s] = ROBO_NOT_POSITIVE_DEFINITE;
                 else ll = -0.5 * (hout[2 * s] + hout[2 * s + 1] + (double)g->n * std::log(2.0 * M_PI));
             }
             out_loglik[s0 + s] = ll;
-            if (out_status) out_status[s0 + s] = st;
+            if (out_status) out_status[s0 + s] = status[s];
         }
+        if (keep) ROBO_TRY(keep(s0, ns, status.data()));
     }
     return ROBO_OK;
+}
+
+int32_t robo_gp_loglik_batch(robo_gp* g, const double* thetas, int32_t S, double mean_c, double* out_loglik,
+                             int32_t* out_status) {
+    if (!g || !thetas || S < 0 || !out_loglik) return ROBO_BAD_ARGUMENT;
+    if (!g->has_data) {
+        set_error("robo_gp_loglik_batch before robo_gp_set_data");
+        return ROBO_NOT_FITTED;
+    }
+    if (S == 0) return ROBO_OK;
+    g->fitted = false;   // the GP's own factor is not touched, but the call documents "unfitted after"
+    return fit_batch_core(g, thetas, S, mean_c, out_loglik, out_status, nullptr);
+}
+
+int32_t robo_gp_fit_batch(robo_gp* const* gps, int32_t S, const double* thetas, double mean_c, double* out_loglik,
+                          int32_t* out_status) {
+    if (!gps || !thetas || S < 0 || !out_loglik || !out_status) return ROBO_BAD_ARGUMENT;
+    if (S == 0) return ROBO_OK;
+    robo_gp* g0 = gps[0];
+    if (!g0) return ROBO_BAD_ARGUMENT;
+    if (!g0->has_data) {
+        set_error("robo_gp_fit_batch: gps[0] has no data (robo_gp_set_data)");
+        return ROBO_NOT_FITTED;
+    }
+    robo_ctx* c = g0->ctx;
+    const int D = g0->dim, n = g0->n;
+    for (int s = 0; s < S; ++s) {
+        robo_gp* g = gps[s];
+        if (!g || g->ctx != c || g->kind != g0->kind || g->dim != D || g->n_max < n) {
+            set_error("robo_gp_fit_batch: gps[%d] must share context, kernel kind and dim with gps[0] and hold n=%d rows",
+                      s, n);
+            return ROBO_BAD_SHAPE;
+        }
+        for (int t = 0; t < s; ++t)
+            if (gps[t] == g) {
+                set_error("robo_gp_fit_batch: gps[%d] and gps[%d] are the same handle", t, s);
+                return ROBO_BAD_ARGUMENT;
+            }
+        g->fitted = false;
+    }
+    const size_t np = (size_t)g0->n_pad;
+    const int P = robo_theta_size(g0->kind, D);
+    auto keep = [&](int s0, int ns, const int* status) -> int {
+        for (int s = 0; s < ns; ++s) {
+            if (status[s] != ROBO_OK) continue;
+            robo_gp* g = gps[s0 + s];
+            if (g != g0) {   // every handle ends up self-contained: same training data as gps[0]
+                ROBO_HIP_CHECK(hipMemcpyAsync(g->d_X, g0->d_X, (size_t)n * D * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+                ROBO_HIP_CHECK(hipMemcpyAsync(g->d_y, g0->d_y, (size_t)n * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+                g->n = n;
+                g->n_pad = g0->n_pad;
+                g->has_data = true;
+                g->fp32_gram = g0->fp32_gram;
+            }
+            ROBO_HIP_CHECK(hipMemcpyAsync(g->d_K, g0->d_bK + (size_t)s * np * np, np * np * sizeof(double),
+                                          hipMemcpyDeviceToDevice, c->stream));
+            ROBO_HIP_CHECK(hipMemcpyAsync(g->d_Linv, g0->d_bLinv + (size_t)s * np * NB, np * NB * sizeof(double),
+                                          hipMemcpyDeviceToDevice, c->stream));
+            ROBO_HIP_CHECK(hipMemcpyAsync(g->d_Xs, g0->d_bXs + (size_t)s * np * D, np * D * sizeof(double),
+                                          hipMemcpyDeviceToDevice, c->stream));
+            ROBO_HIP_CHECK(hipMemcpyAsync(g->d_theta, g0->d_bism + (size_t)s * D, (size_t)D * sizeof(double),
+                                          hipMemcpyDeviceToDevice, c->stream));
+            ROBO_HIP_CHECK(hipMemcpyAsync(g->d_sp, g0->d_bsp + s, sizeof(FitSample), hipMemcpyDeviceToDevice, c->stream));
+            FitSample sp;
+            double ism[MAX_DIM];
+            ROBO_TRY(theta_to_sample(g, thetas + (size_t)(s0 + s) * P, mean_c, &sp, ism));
+            g->cov = sp.cov;
+            g->amp = sp.cov.amp;
+            g->noise = sp.noise;
+            g->mean_c = mean_c;
+            g->loglik = out_loglik[s0 + s];
+            g->fitted = true;
+        }
+        ROBO_HIP_CHECK(hipStreamSynchronize(c->stream));
+        return ROBO_OK;
+    };
+    return fit_batch_core(g0, thetas, S, mean_c, out_loglik, out_status, keep);
 }
 
 int32_t robo_gp_get_factor(robo_gp* g, double* out_L) {

@@ -35,6 +35,10 @@ class FabolasGP(GaussianProcess):
         self.original_X = X
         return super(FabolasGP, self).train(self.normalize(X), y, do_optimize)
 
+    def _host_train_raw(self, X, y):
+        self.original_X = X
+        return self._host_train(self.normalize(X), y)
+
     def predict(self, X_test, full_cov=False, **kwargs):
         return super(FabolasGP, self).predict(self.normalize(X_test), full_cov)
 

@@ -105,8 +105,9 @@ class GaussianProcess(BaseModel):
             self.gp.set_output_transform(0.0, 1.0)
 
     # ---- BaseModel ----------------------------------------------------------------------------
-    @BaseModel._check_shapes_train
-    def train(self, X, y, do_optimize=True):
+    def _host_train(self, X, y):
+        """the host half of train() (gaussian_process.py:89-104): normalisation and the constant mean;
+        returns the device handle sized for the data, nothing uploaded yet"""
         if self.normalize_input:
             self.X, self.lower, self.upper = normalization.zero_one_normalization(X, self.lower, self.upper)
         else:
@@ -118,11 +119,25 @@ class GaussianProcess(BaseModel):
         else:
             self.y = y
         self.mean = np.mean(self.y, axis=0)
+        self.is_trained = False
+        return self._ensure_gp(self.X.shape[0], self.X.shape[1])
 
-        gp = self._ensure_gp(self.X.shape[0], self.X.shape[1])
+    def _host_train_raw(self, X, y):
+        """_host_train on the caller's raw inputs (FabolasGP maps them through normalize() first)"""
+        return self._host_train(X, y)
+
+    def _adopt_fit(self, theta):
+        """this model's device handle was fitted at theta by a batched pass (robo_gp_fit_batch)"""
+        self.hypers = np.append(self.kernel.get_parameter_vector(), np.log(self.noise))
+        self._set_transform()
+        self._fitted_theta = np.array(theta, dtype=np.float64)
+        self.is_trained = True
+
+    @BaseModel._check_shapes_train
+    def train(self, X, y, do_optimize=True):
+        gp = self._host_train(X, y)
         gp.set_data(self.X, self.y)
         self._set_transform()
-        self.is_trained = False
 
         if do_optimize:
             self.hypers = self.optimize()

@@ -8,6 +8,7 @@ then gets its own device-resident GaussianProcess (``self.models``), which is wh
 MarginalizationGPMCMC iterates over (marginalization.py:34-46,118).
 """
 import logging
+import os
 from copy import deepcopy
 
 import numpy as np
@@ -130,12 +131,38 @@ class GaussianProcessMCMC(BaseModel):
                 model.lower, model.upper = self.lower, self.upper
             else:
                 model = self._make_model(kernel, np.exp(sample[-1]))
-            model.train(X, y, do_optimize=False)
             self.models.append(model)
         for m in old[len(self.models):]:
             if getattr(m, "gp", None) is not None:
                 m.gp.close()
+        self._fit_models(X, y)
         self.is_trained = True
+
+    def _fit_models(self, X, y):
+        """``model.train(X, y, do_optimize=False)`` for every hyper-parameter sample
+        (gaussian_process_mcmc.py:149-164) -- S Cholesky factorisations of the same data.  With more than one
+        sample they run as ONE batched device pass that leaves S fitted handles (robo_gp_fit_batch,
+        bit-identical to S sequential fits); a sample whose K is not positive definite goes through the
+        model's own train(), i.e. the reference's noise x 10 retry (gaussian_process.py:120-122)."""
+        models = self.models
+        if len(models) < 2 or os.environ.get("ROBO_MCMC_SEQUENTIAL_FITS") == "1":
+            for model in models:
+                model.train(X, y, do_optimize=False)
+            return
+        gps = [model._host_train_raw(X, y) for model in models]
+        m0 = models[0]
+        if len({id(g) for g in gps}) != len(gps) or any(g.n_max < m0.X.shape[0] for g in gps):
+            for model in models:
+                model.train(X, y, do_optimize=False)
+            return
+        gps[0].set_data(m0.X, m0.y)
+        thetas = np.array([np.append(m.kernel.get_parameter_vector(), np.log(m.noise)) for m in models])
+        _, st = _lib.fit_batch(gps, thetas, m0.mean)
+        for model, theta, status in zip(models, thetas, st):
+            if status == _lib.OK:
+                model._adopt_fit(theta)
+            else:
+                model.train(X, y, do_optimize=False)
 
     def _keep_hypers_without_optimize(self):
         # FabolasGPMCMC keeps the previous samples when do_optimize=False (fabolas_gp.py:80-84);

@@ -371,6 +371,57 @@ def check_batched_likelihoods(ctx, sizes=((60, 3), (300, 4))):
         g.close()
 
 
+def check_fit_batch(ctx, sizes=((60, 3), (300, 4)), kind="matern52"):
+    """robo_gp_fit_batch (the per-sample model fits of GaussianProcessMCMC.train in one batched pass that keeps
+    the factors) == S sequential robo_gp_fit calls on S handles: log-likelihood, Cholesky factor and posterior bit
+    for bit; a sample with a non-PD K is reported and left unfitted without disturbing its neighbours."""
+    import pytest
+    rs = np.random.RandomState(29)
+    for N, D in sizes:
+        X = rs.rand(N, D)
+        y = np.sin(3 * X.sum(axis=1))
+        P = O.n_kernel_params(kind, D) + 1
+        base = np.zeros(P)
+        base[1:1 + D if kind != "fabolas" else D] = np.log(0.3 * D)
+        base[-1] = np.log(1e-2)
+        S = 6
+        thetas = base[None, :] + 0.4 * rs.randn(S, P)
+        thetas[2, 0] = 710.0                          # amplitude e^710 = inf: inf / inf = NaN pivots (deterministic)
+        mean_c = float(y.mean())
+        Xc = rs.rand(40, D)
+        seq = []
+        for s in range(S):
+            g = _lib.DeviceGP(ctx, kind, N, D)
+            g.set_data(X, y)
+            try:
+                ll = g.fit(thetas[s], mean_c)
+                seq.append((ll, g.factor(), g.predict(Xc)))
+            except np.linalg.LinAlgError:
+                seq.append(None)
+            g.close()
+        assert seq[2] is None, "the stress sample was meant to be not positive definite"
+        gps = [_lib.DeviceGP(ctx, kind, N + 7 * s, D) for s in range(S)]     # different capacities
+        gps[0].set_data(X, y)
+        ll, st = _lib.fit_batch(gps, thetas, mean_c)
+        for s in range(S):
+            if seq[s] is None:
+                assert st[s] == _lib.NOT_POSITIVE_DEFINITE and ll[s] == -np.inf
+                with pytest.raises(Exception, match="trained first"):
+                    gps[s].predict(Xc)
+                continue
+            assert st[s] == _lib.OK
+            assert ll[s] == seq[s][0]
+            np.testing.assert_array_equal(gps[s].factor(), seq[s][1])
+            mu, var = gps[s].predict(Xc)
+            np.testing.assert_array_equal(mu, seq[s][2][0])
+            np.testing.assert_array_equal(var, seq[s][2][1])
+        # a kept handle is a full handle: it can be refitted on its own copy of the data
+        ll1 = gps[1].fit(thetas[0], mean_c)
+        assert ll1 == seq[0][0]
+        for g in gps:
+            g.close()
+
+
 def check_grad_loglik(ctx, cases=(("matern52", 70, 3), ("rbf", 200, 5), ("fabolas", 150, 4), ("matern52", 300, 20),
                                   ("matern52", 650, 2))):
     """robo_gp_grad_loglik == the oracle's restatement of GaussianProcess.grad_nll

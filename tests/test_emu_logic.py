@@ -61,6 +61,11 @@ def test_uniform_generator(emu_ctx):
     P.check_uniform_generator(emu_ctx)
 
 
+def test_fit_batch_keeps_factors(emu_ctx):
+    P.check_fit_batch(emu_ctx)
+    P.check_fit_batch(emu_ctx, sizes=((90, 4),), kind="fabolas")
+
+
 def test_batched_likelihoods(emu_ctx):
     P.check_batched_likelihoods(emu_ctx)
 

@@ -64,6 +64,12 @@ def test_uniform_generator(ctx):
     P.check_uniform_generator(ctx)
 
 
+def test_fit_batch_keeps_factors(ctx):
+    P.check_fit_batch(ctx, sizes=((60, 3), (300, 4), (1500, 8)))
+    P.check_fit_batch(ctx, sizes=((200, 6),), kind="fabolas")
+    P.check_fit_batch(ctx, sizes=((130, 3),), kind="rbf")
+
+
 def test_batched_likelihoods(ctx):
     P.check_batched_likelihoods(ctx, sizes=((60, 3), (300, 4), (1500, 8)))
 
