@@ -83,6 +83,31 @@ __device__ __forceinline__ v4d blk_mma_nn(const double* A, const double* B, int 
     return acc;
 }
 
+// fragments of a 16x16 LDS block for four consecutive MFMAs (k = 0..15): "row" form = element
+// [lane & 15][4 kk + (lane >> 4)] (the A operand, and the B operand of an NT product), "col" form = element
+// [4 kk + (lane >> 4)][lane & 15] (the B operand of an NN product)
+struct Frag4 {
+    double v[4];
+};
+__device__ __forceinline__ Frag4 frag_row(const double* A, int lane) {
+    Frag4 f;
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) f.v[kk] = A[bidx(lane & 15, kk * 4 + (lane >> 4))];
+    return f;
+}
+__device__ __forceinline__ Frag4 frag_col(const double* B, int lane) {
+    Frag4 f;
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) f.v[kk] = B[bidx(kk * 4 + (lane >> 4), lane & 15)];
+    return f;
+}
+template <bool NEG>
+__device__ __forceinline__ v4d frag_mma(const Frag4& a, const Frag4& b, v4d acc) {
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) acc = mfma_f64(NEG ? -a.v[kk] : a.v[kk], b.v[kk], acc);
+    return acc;
+}
+
 // broadcast lane `src`'s double to the whole wave through SGPRs (v_readlane_b32 x2; `src` is a
 // compile-time constant after unrolling)
 __device__ __forceinline__ double bcast_lane(double x, int src) {
@@ -108,9 +133,18 @@ __device__ __forceinline__ double bcast_lane(double x, int src) {
 // the forward substitutions.  g0 = global index of the block's first row; rows >= n_real have their
 // pivot forced to 1 (augmented row and identity padding).  Returns the first failing global
 // column + 1, or 0.
+// 1 / sqrt(p) for a finite p > 0: v_rsq_f64 and one third-order correction r (1 + e/2 + 3 e^2/8), e = 1 - p r^2
+// -- the sequence the compiler's rsqrt() expands to, minus its special-case selects (p = 0 / inf / NaN cannot
+// reach this point: the pivot test above it replaces them, and an inf pivot only has to end in a flagged failure,
+// which inf * 0 = NaN at the next pivot guarantees).
+__device__ __forceinline__ double pivot_rsqrt(double p) {
+    double r = __builtin_amdgcn_rsq(p);
+    const double e = fma(-p * r, r, 1.0);
+    return fma(r * e, fma(e, 0.375, 0.5), r);
+}
+
 template <bool GUARD>
-__device__ __forceinline__ int potf2_16_impl(double* Ld, double* Wd, double* rd, double* colbuf, int lane, int g0,
-                                             int n_real) {
+__device__ __forceinline__ int potf2_16_impl(double* Ld, double* Wd, double* colbuf, int lane, int g0, int n_real) {
     const int row = lane & 15, grp = lane >> 4;
     // lanes 16..31 run the SAME instruction stream on different data: instead of row `row` of the block
     // they hold column `row` of W = L^-1, started as a unit vector -- the forward substitution
@@ -135,7 +169,7 @@ __device__ __forceinline__ int potf2_16_impl(double* Ld, double* Wd, double* rd,
             if (fail == 0) fail = g0 + k + 1;
             p = 1.0;
         }
-        const double ri = rsqrt(p);
+        const double ri = pivot_rsqrt(p);
         if (k > 0) {
             // deferred bulk update by column k-1 (independent of the rsqrt chain above)
             const double* cbp = colbuf + ((k - 1) & 1) * SB;
@@ -143,10 +177,11 @@ __device__ __forceinline__ int potf2_16_impl(double* Ld, double* Wd, double* rd,
             for (int j = k + 1; j < SB; ++j) a[j] = fma(-lprev, cbp[j], a[j]);
         }
         // rows < k (columns > k of W) hold garbage (zeros) here, never read
-        const double lik = (row == k && !isW) ? p * ri : a[k] * ri;
+        // lane k's a[k] IS the pivot unless the guard / failure path replaced p, so without the guard the
+        // scale needs no select (a failed factorisation is flagged; its numbers are garbage either way)
+        const double lik = (GUARD && row == k && !isW) ? p * ri : a[k] * ri;
         a[k] = lik;
         cbw[(k & 1) * SB + row] = lik;    // no exec masking or branches on the chain
-        rd[k] = ri;
         if (k + 1 < SB) {
             const double l1 = bcast_lane(lik, k + 1);        // L[k+1][k]
             a[k + 1] = fma(-lik, l1, a[k + 1]);              // fast path: column k+1 is complete
@@ -163,90 +198,161 @@ __device__ __forceinline__ int potf2_16_impl(double* Ld, double* Wd, double* rd,
 }
 
 // the pivot guard for rows >= n_real only exists in the block(s) that hold the augmented row / padding
-__device__ __forceinline__ int potf2_16(double* Ld, double* Wd, double* rd, double* colbuf, int lane, int g0,
-                                        int n_real) {
-    if (g0 + SB <= n_real) return potf2_16_impl<false>(Ld, Wd, rd, colbuf, lane, g0, n_real);
-    return potf2_16_impl<true>(Ld, Wd, rd, colbuf, lane, g0, n_real);
+__device__ __forceinline__ int potf2_16(double* Ld, double* Wd, double* colbuf, int lane, int g0, int n_real) {
+    if (g0 + SB <= n_real) return potf2_16_impl<false>(Ld, Wd, colbuf, lane, g0, n_real);
+    return potf2_16_impl<true>(Ld, Wd, colbuf, lane, g0, n_real);
 }
 
 constexpr int TLD = SB + 2;   // padded leading dimension of the per-wave transposition scratch
 
 // ---- the 128x128 diagonal block, block-packed in LDS -------------------------------------
 // sL: 36 lower 16x16 blocks of A -> L in place; sW: 36 blocks of W = L^-1; sT: per-wave 16 x TLD
-// scratch; sRd: 128 reciprocal pivots; sCol: 4 x 2 x 16 column exchange buffers (wave 0).
-// Schedule per 16-column step s (two barriers):
-//   A  all waves : sub-panel  L_is = A_is W_ss^T  (one 16x16x16 MFMA product per block, W_ss = L_ss^-1)
-//   B  wave 0    : trailing tile (s+1,s+1), potf2(s+1) -- which also yields W_s+1,s+1 on lanes
-//                  16..31 of the same instruction stream --             <- the critical path
-//      waves 1-3 : block row s of W = L^-1 (s tiles) and the other trailing tiles
-// so the inverse and the MFMA updates ride in the shadow of the pivot chain.
+// scratch; sRd: task counters of the helper waves (8 ints); sCol: 4 x 2 x 16 column exchange buffers (wave 0).
+//
+// LEFT-LOOKING schedule (r02): wave 0 is the pivot wave and does nothing but the chain
+//      potf2(s) -> L_{s+1,s} = A~_{s+1,s} W_ss^T -> A~_{s+1,s+1} -= L_{s+1,s} L_{s+1,s}^T -> potf2(s+1)
+// i.e. two 16x16x16 MFMA products between consecutive 16-pivot chains.  Every other product runs on
+// waves 1-3 in the shadow of a potf2:  a block A_ij is touched exactly twice -- once to receive ALL its
+// updates  A~_ij = A_ij - sum_{c<j} L_ic L_jc^T  (accumulated in registers, one LDS round trip), once for
+// its solve with W_jj.  The right-looking form of r01 re-read and re-wrote every trailing 16x16 block at
+// every step (27, 20, 14 ... blocks on three waves: the early steps took 11-13k cycles against the pivot
+// wave's 6.4k) and put a four-wave sub-panel phase plus a barrier on the chain.
+// Interval s (two barriers, Ba at its start right after potf2(s), Bb in the middle):
+//   wave 0     : C1  L_{s+1,s};  C2  pivot block (s+1,s+1) finished;  [Bb]  potf2(s+1)
+//   waves 1-3  : solves L_{i,s}, i >= s+2   [Bb]   block column s+1 and pivot block (s+2,s+2) receive all
+//                their updates (columns 0..s); the inverse advances by block row s, column by column (see the
+//                task list in the loop).  One product per block of row 7 of W is left after the last pivot.
 __device__ __forceinline__ void diag128_factor_invert(double* sL, double* sW, double* sT, double* sRd, double* sCol,
                                                       int kbase, int n_real, int* fail, long long* dbg) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    int* ctr = reinterpret_cast<int*>(sRd);     // one task counter per interval
+    if (tid >= 64 && tid < 64 + NSB) ctr[tid - 64] = 0;
     if (wave == 0) {
-        const int f = potf2_16(sL + blk_off(0, 0), sW + blk_off(0, 0), sRd, sCol, lane, kbase, n_real);
+        const int f = potf2_16(sL + blk_off(0, 0), sW + blk_off(0, 0), sCol, lane, kbase, n_real);
         if (f != 0 && lane == 0 && *fail == 0) *fail = f;
     }
-    __syncthreads();
+    __syncthreads();                                              // Ba(0)
     if (dbg && tid == 0) dbg[2] = clock64();
-    for (int s = 0; s < NSB; ++s) {
-        // ---- phase A: sub-panel blocks L_is = A_is W_ss^T, wave w takes blocks s+1+w, s+5+w
-        for (int bi = s + 1 + wave; bi < NSB; bi += 4) {
-            double* A = sL + blk_off(bi, s);
-            v4d acc = {0.0, 0.0, 0.0, 0.0};
-            acc = blk_mma_nt<false>(A, sW + blk_off(s, s), lane, acc);
-            wave_lds_fence();   // all fragment reads of A before it is overwritten
-            blk_store_c(A, lane, acc);
-        }
-        __syncthreads();
-        if (dbg && tid == 0 && s == 0) dbg[3] = clock64();
-        // ---- phase B
-        const int rem = NSB - 1 - s;
-        const int cnt = rem * (rem + 1) / 2;          // trailing tiles; tile 0 is (s+1, s+1)
-        if (wave == 0 && s + 1 < NSB) {
+    for (int s = 0; s + 1 < NSB; ++s) {
+        if (wave == 0) {
+            // C1: the TRANSPOSE Q = L_{s+1,s}^T = W_ss A~_{s+1,s}^T.  In the MFMA accumulator layout register r
+            // of lane l holds Q[(l >> 4) + 4 r][l & 15], which is at once the A fragment of columns 4r..4r+3 of Q^T
+            // and the B fragment of rows 4r..4r+3 of Q:
+            // C2: the pivot block's last update  T -= L L^T = Q^T Q  is four MFMAs straight from those registers,
+            // with no trip through LDS between the two products of the chain.
+            double* P = sL + blk_off(s + 1, s);
             double* C = sL + blk_off(s + 1, s + 1);
-            v4d acc = blk_load_c(C, lane);
-            acc = blk_mma_nt<true>(sL + blk_off(s + 1, s), sL + blk_off(s + 1, s), lane, acc);
-            blk_store_c(C, lane, acc);
+            v4d t = blk_load_c(C, lane);
+            v4d q = {0.0, 0.0, 0.0, 0.0};
+            q = blk_mma_nt<false>(sW + blk_off(s, s), P, lane, q);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) t = mfma_f64(-q[r], q[r], t);
+            blk_store_c(C, lane, t);
+            wave_lds_fence();   // (also orders the fragment reads of P before its overwrite)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) P[bidx(lane & 15, (lane >> 4) + 4 * r)] = q[r];   // L = Q^T for the helpers
             wave_lds_fence();
-            const int f = potf2_16(C, sW + blk_off(s + 1, s + 1), sRd + (s + 1) * SB, sCol, lane,
+        } else {
+            // solves of block column s below the pivot wave's own block
+            for (int bi = s + 2 + (wave - 1); bi < NSB; bi += 3) {
+                double* A = sL + blk_off(bi, s);
+                v4d acc = {0.0, 0.0, 0.0, 0.0};
+                acc = blk_mma_nt<false>(A, sW + blk_off(s, s), lane, acc);
+                wave_lds_fence();
+                blk_store_c(A, lane, acc);
+            }
+        }
+        __syncthreads();                                          // Bb(s): block column s of L is final
+        if (dbg && tid == 0 && s == 0) dbg[3] = clock64();
+        if (wave == 0) {
+            const int f = potf2_16(sL + blk_off(s + 1, s + 1), sW + blk_off(s + 1, s + 1), sCol, lane,
                                    kbase + (s + 1) * SB, n_real);
             if (f != 0 && lane == 0 && *fail == 0) *fail = f;
         } else {
-            // tasks: W tiles (s, j), j = 0..s-1  first (longer), then trailing tiles 1..cnt-1
-            const int nw = s + 1 < NSB ? 3 : 4;       // last step: wave 0 has no pivot work left
-            const int me = s + 1 < NSB ? wave - 1 : wave;
-            const int ntask = s + (cnt > 0 ? cnt - 1 : 0);
-            double* T = sT + wave * SB * TLD;
-            for (int t = me; t < ntask; t += nw) {
-                if (t < s) {
-                    // W_sj = -W_ss (sum_{j <= kb < s} L_s,kb W_kb,j)
-                    const int j = t;
-                    v4d acc = {0.0, 0.0, 0.0, 0.0};
-                    for (int kb = j; kb < s; ++kb)
-                        acc = blk_mma_nn<true>(sL + blk_off(s, kb), sW + blk_off(kb, j), lane, acc);
-                    blk_store_c(T, lane, acc);
-                    wave_lds_fence();
-                    v4d w = {0.0, 0.0, 0.0, 0.0};
-                    w = blk_mma_nn<false>(sW + blk_off(s, s), T, lane, w);
-                    wave_lds_fence();   // T is rewritten by this wave's next task
-                    blk_store_c(sW + blk_off(s, j), lane, w);
-                } else {
-                    const int tt = t - s + 1;          // 1 .. cnt-1
-                    int ii = 0;
-                    while ((ii + 1) * (ii + 2) / 2 <= tt) ++ii;
-                    const int jj = tt - ii * (ii + 1) / 2;
-                    const int bi = s + 1 + ii, bj = s + 1 + jj;
+            // Work of the interval, handed out dynamically (an LDS counter per interval; a task is wave-sized):
+            //   L task t < nL : one block of column s+1 (or the next pivot block) receives columns 0..s in one
+            //                   pass.  t = 0: (s+2, s+1) and t = 1: (s+2, s+2) are what the pivot wave needs
+            //                   first at the next interval; t >= 2: (s+1+t, s+1).
+            //   W task j <= s : block column j of the inverse advances by block row s.  With
+            //                   S_ij = sum_{j<=c<i} L_ic W_cj  kept in the W_ij slot until row i is final:
+            //                   W_sj = -W_ss S_sj  (j < s; W_ss itself came out of potf2(s)), then
+            //                   S_ij += L_is W_sj  for every block row i > s.
+            // Row-wise the inverse costs 0, 2, 5, 9, 14, 20, 27+35 products in intervals 0..6 -- the last ones
+            // made the pivot wave wait (r02b: 11.5k and 13.7k cycles against 6.1k of its own work); advanced
+            // column by column it is 7, 13, 17, 19, 19, 17, 13 and only the 7 final products of row 7 are left
+            // after the last pivot.
+            const int nL = s + 2 < NSB ? NSB - 1 - s : 0;
+#ifdef ROBO_EXP_SKIP_W
+            const int ntask = nL;
+#else
+            const int ntask = nL + s + 1;
+#endif
+            for (;;) {
+                int t = 0;
+                if (lane == 0) t = atomicAdd(ctr + s, 1);
+                t = __builtin_amdgcn_readlane(t, 0);
+                if (t >= ntask) break;
+                if (t < nL) {
+                    const int bi = t <= 1 ? s + 2 : s + 1 + t;
+                    const int bj = t == 1 ? s + 2 : s + 1;
                     double* C = sL + blk_off(bi, bj);
+                    // fragments of product c+1 are in flight while the MFMAs of product c issue
+                    Frag4 a = frag_row(sL + blk_off(bi, 0), lane), b = frag_row(sL + blk_off(bj, 0), lane);
                     v4d acc = blk_load_c(C, lane);
-                    acc = blk_mma_nt<true>(sL + blk_off(bi, s), sL + blk_off(bj, s), lane, acc);
+                    for (int c = 0; c <= s; ++c) {
+                        Frag4 an = a, bn = b;
+                        if (c < s) {
+                            an = frag_row(sL + blk_off(bi, c + 1), lane);
+                            bn = frag_row(sL + blk_off(bj, c + 1), lane);
+                        }
+                        acc = frag_mma<true>(a, b, acc);
+                        a = an;
+                        b = bn;
+                    }
                     blk_store_c(C, lane, acc);
+                } else {
+                    const int j = t - nL;
+                    double* Wsj = sW + blk_off(s, j);
+                    if (j < s) {
+                        v4d w = {0.0, 0.0, 0.0, 0.0};
+                        w = blk_mma_nn<true>(sW + blk_off(s, s), Wsj, lane, w);
+                        wave_lds_fence();   // S_sj fully read before W_sj replaces it
+                        blk_store_c(Wsj, lane, w);
+                        wave_lds_fence();
+                    }
+                    // B fragments of W_sj are the same for every block row below; operands of block row i+1 are in
+                    // flight while the MFMAs of block row i issue
+                    const Frag4 b = frag_col(Wsj, lane);
+                    const v4d zero = {0.0, 0.0, 0.0, 0.0};
+                    Frag4 a = frag_row(sL + blk_off(s + 1, s), lane);
+                    v4d acc = j < s ? blk_load_c(sW + blk_off(s + 1, j), lane) : zero;
+                    for (int i = s + 1; i < NSB; ++i) {
+                        Frag4 an = a;
+                        v4d accn = zero;
+                        if (i + 1 < NSB) {
+                            an = frag_row(sL + blk_off(i + 1, s), lane);
+                            if (j < s) accn = blk_load_c(sW + blk_off(i + 1, j), lane);
+                        }
+                        acc = frag_mma<false>(a, b, acc);
+                        blk_store_c(sW + blk_off(i, j), lane, acc);
+                        a = an;
+                        acc = accn;
+                    }
                 }
             }
         }
-        __syncthreads();
-        if (dbg && tid == 0 && s < NSB - 1) dbg[4 + s] = clock64();
+        __syncthreads();                                          // Ba(s+1)
+        if (dbg && tid == 0) dbg[4 + s] = clock64();
     }
+    // block row 7 of W: W_7j = -W_77 S_7j
+    for (int j = wave; j < NSB - 1; j += 4) {
+        double* S = sW + blk_off(NSB - 1, j);
+        v4d w = {0.0, 0.0, 0.0, 0.0};
+        w = blk_mma_nn<true>(sW + blk_off(NSB - 1, NSB - 1), S, lane, w);
+        wave_lds_fence();
+        blk_store_c(S, lane, w);
+    }
+    __syncthreads();
     if (dbg && tid == 0) dbg[11] = clock64();
 }
 
