@@ -6,7 +6,7 @@
 //
 // Per panel k (block column k of the n_pad x n_pad lower matrix, in place):
 //   potrf_diag_kernel   1 workgroup : L_kk = chol(A_kk), W_k = L_kk^-1            (LDS resident)
-//   potrf_panel_kernel  nb-k-1 WGs  : A_ik <- A_ik * W_k^T          (fp64 MFMA, gemm_f64.h)
+//   potrf_panel_kernel  2(nb-k-1) WGs: A_ik <- A_ik * L_kk^-T by 16-column block substitution (fp64 MFMA, registers)
 //   potrf_step_kernel   tri tiles   : A_ij <- A_ij - A_ik * A_jk^T  (fp64 MFMA, gemm_f64.h); the
 //                                     workgroup of tile (k+1, k+1) then factors it (next diagonal block)
 // Because row n of the matrix is the augmented right-hand side (gram.hip), the finished
@@ -270,89 +270,43 @@ __device__ __forceinline__ void diag128_factor_invert(double* sL, double* sW, do
             if (f != 0 && lane == 0 && *fail == 0) *fail = f;
         } else {
             // Work of the interval, handed out dynamically (an LDS counter per interval; a task is wave-sized):
-            //   L task t < nL : one block of column s+1 (or the next pivot block) receives columns 0..s in one
-            //                   pass.  t = 0: (s+2, s+1) and t = 1: (s+2, s+2) are what the pivot wave needs
-            //                   first at the next interval; t >= 2: (s+1+t, s+1).
-            //   W task j <= s : block column j of the inverse advances by block row s.  With
-            //                   S_ij = sum_{j<=c<i} L_ic W_cj  kept in the W_ij slot until row i is final:
-            //                   W_sj = -W_ss S_sj  (j < s; W_ss itself came out of potf2(s)), then
-            //                   S_ij += L_is W_sj  for every block row i > s.
-            // Row-wise the inverse costs 0, 2, 5, 9, 14, 20, 27+35 products in intervals 0..6 -- the last ones
-            // made the pivot wave wait (r02b: 11.5k and 13.7k cycles against 6.1k of its own work); advanced
-            // column by column it is 7, 13, 17, 19, 19, 17, 13 and only the 7 final products of row 7 are left
-            // after the last pivot.
-            const int nL = s + 2 < NSB ? NSB - 1 - s : 0;
-#ifdef ROBO_EXP_SKIP_W
-            const int ntask = nL;
-#else
-            const int ntask = nL + s + 1;
-#endif
+            // one block of column s+1 (or the next pivot block) receives columns 0..s in one pass.
+            // t = 0: (s+2, s+1) and t = 1: (s+2, s+2) are what the pivot wave needs first at the next
+            // interval; t >= 2: (s+1+t, s+1).
+            // The off-diagonal blocks of the inverse W = L^-1 are NOT formed here (r02f): advanced alongside the
+            // factorisation they cost 112 more 16x16x16 products on these three waves and made the pivot wave
+            // wait (84.7k cycles per diagonal block against 68.2k without them).  The panel solve needs only the
+            // eight W_ss that fall out of potf2 (potrf_panel_kernel substitutes block column by block column);
+            // the full inverses, which the posterior's TRSM and the likelihood gradient use, are produced for
+            // all diagonal blocks at once by potrf_inverse_kernel after the factorisation.
+            const int ntask = s + 2 < NSB ? NSB - 1 - s : 0;
             for (;;) {
                 int t = 0;
                 if (lane == 0) t = atomicAdd(ctr + s, 1);
                 t = __builtin_amdgcn_readlane(t, 0);
                 if (t >= ntask) break;
-                if (t < nL) {
-                    const int bi = t <= 1 ? s + 2 : s + 1 + t;
-                    const int bj = t == 1 ? s + 2 : s + 1;
-                    double* C = sL + blk_off(bi, bj);
-                    // fragments of product c+1 are in flight while the MFMAs of product c issue
-                    Frag4 a = frag_row(sL + blk_off(bi, 0), lane), b = frag_row(sL + blk_off(bj, 0), lane);
-                    v4d acc = blk_load_c(C, lane);
-                    for (int c = 0; c <= s; ++c) {
-                        Frag4 an = a, bn = b;
-                        if (c < s) {
-                            an = frag_row(sL + blk_off(bi, c + 1), lane);
-                            bn = frag_row(sL + blk_off(bj, c + 1), lane);
-                        }
-                        acc = frag_mma<true>(a, b, acc);
-                        a = an;
-                        b = bn;
+                const int bi = t <= 1 ? s + 2 : s + 1 + t;
+                const int bj = t == 1 ? s + 2 : s + 1;
+                double* C = sL + blk_off(bi, bj);
+                // fragments of product c+1 are in flight while the MFMAs of product c issue
+                Frag4 a = frag_row(sL + blk_off(bi, 0), lane), b = frag_row(sL + blk_off(bj, 0), lane);
+                v4d acc = blk_load_c(C, lane);
+                for (int c = 0; c <= s; ++c) {
+                    Frag4 an = a, bn = b;
+                    if (c < s) {
+                        an = frag_row(sL + blk_off(bi, c + 1), lane);
+                        bn = frag_row(sL + blk_off(bj, c + 1), lane);
                     }
-                    blk_store_c(C, lane, acc);
-                } else {
-                    const int j = t - nL;
-                    double* Wsj = sW + blk_off(s, j);
-                    if (j < s) {
-                        v4d w = {0.0, 0.0, 0.0, 0.0};
-                        w = blk_mma_nn<true>(sW + blk_off(s, s), Wsj, lane, w);
-                        wave_lds_fence();   // S_sj fully read before W_sj replaces it
-                        blk_store_c(Wsj, lane, w);
-                        wave_lds_fence();
-                    }
-                    // B fragments of W_sj are the same for every block row below; operands of block row i+1 are in
-                    // flight while the MFMAs of block row i issue
-                    const Frag4 b = frag_col(Wsj, lane);
-                    const v4d zero = {0.0, 0.0, 0.0, 0.0};
-                    Frag4 a = frag_row(sL + blk_off(s + 1, s), lane);
-                    v4d acc = j < s ? blk_load_c(sW + blk_off(s + 1, j), lane) : zero;
-                    for (int i = s + 1; i < NSB; ++i) {
-                        Frag4 an = a;
-                        v4d accn = zero;
-                        if (i + 1 < NSB) {
-                            an = frag_row(sL + blk_off(i + 1, s), lane);
-                            if (j < s) accn = blk_load_c(sW + blk_off(i + 1, j), lane);
-                        }
-                        acc = frag_mma<false>(a, b, acc);
-                        blk_store_c(sW + blk_off(i, j), lane, acc);
-                        a = an;
-                        acc = accn;
-                    }
+                    acc = frag_mma<true>(a, b, acc);
+                    a = an;
+                    b = bn;
                 }
+                blk_store_c(C, lane, acc);
             }
         }
         __syncthreads();                                          // Ba(s+1)
         if (dbg && tid == 0) dbg[4 + s] = clock64();
     }
-    // block row 7 of W: W_7j = -W_77 S_7j
-    for (int j = wave; j < NSB - 1; j += 4) {
-        double* S = sW + blk_off(NSB - 1, j);
-        v4d w = {0.0, 0.0, 0.0, 0.0};
-        w = blk_mma_nn<true>(sW + blk_off(NSB - 1, NSB - 1), S, lane, w);
-        wave_lds_fence();
-        blk_store_c(S, lane, w);
-    }
-    __syncthreads();
     if (dbg && tid == 0) dbg[11] = clock64();
 }
 
@@ -371,17 +325,20 @@ __device__ __forceinline__ DiagSmem diag_carve(double* base) {
     return m;
 }
 
-// L into K (lower sub-blocks), W into its 128x128 row-major block (lower sub-blocks; the strictly upper
-// ones were zeroed when the buffer was allocated and are never written)
+// L into K (lower sub-blocks); the eight W_ss = L_ss^-1 into the diagonal sub-blocks of the 128x128 row-major
+// inverse block (its off-diagonal sub-blocks are filled in by potrf_inverse_kernel; the strictly upper ones were
+// zeroed when the buffer was allocated and are never written)
 __device__ __forceinline__ void diag_writeback(const DiagSmem& m, double* __restrict__ Kd, int ld,
                                                double* __restrict__ Wg) {
     const int tid = threadIdx.x;
-    for (int bi = 0; bi < NSB; ++bi)
+    for (int bi = 0; bi < NSB; ++bi) {
         for (int bj = 0; bj <= bi; ++bj) {
             const int r = bi * SB + (tid >> 4), c = bj * SB + (tid & 15);
             Kd[(size_t)r * ld + c] = m.sL[blk_off(bi, bj) + bidx(tid >> 4, tid & 15)];
-            Wg[r * NB + c] = m.sW[blk_off(bi, bj) + bidx(tid >> 4, tid & 15)];
         }
+        const int r = bi * SB + (tid >> 4), c = bi * SB + (tid & 15);
+        Wg[r * NB + c] = m.sW[blk_off(bi, bi) + bidx(tid >> 4, tid & 15)];
+    }
 }
 
 __global__ __launch_bounds__(256) void potrf_diag_kernel(double* __restrict__ K, size_t k_stride, int ld, int k,
@@ -410,24 +367,128 @@ __global__ __launch_bounds__(256) void potrf_diag_kernel(double* __restrict__ K,
     if (dbg && tid == 0) dbg[12] = clock64();
 }
 
-// A_ik <- A_ik * W_k^T for the rows below the diagonal block of panel k, 32 rows per workgroup
-// (4x more workgroups than 128-row tiles: with <= 32 block rows the panel would otherwise
-// occupy an eighth of the chip for a full 512-MFMA-deep tile)
+// Panel solve  X L_kk^T = A_ik  for the rows below the diagonal block of panel k, by block forward substitution
+// over the eight 16-column blocks with only the diagonal inverses W_ss (no 128x128 inverse is needed, so the
+// diagonal-block kernel does not have to form one on the fit's critical path).  64 rows per workgroup, one
+// 16-row strip per wave, entirely in registers:  with Y_s = X_s^T (16 x 16: panel column within block s by strip
+// row) held in the MFMA accumulator layout,
+//      Y_s = W_ss (A_s^T - sum_{c<s} L_sc Y_c)
+// and register r of an accumulator-layout Y_c IS the B fragment of its rows 4r..4r+3, so every product takes its
+// B operand straight from the previous results and its A operand (L_sc or W_ss, shared by the whole workgroup)
+// from the LDS image of the diagonal block: 36 products = 144 MFMAs per strip, no LDS round trip on the chain.
+constexpr int PANEL_SMEM_DOUBLES = (NBLK + NSB) * BLK;   // 36 blocks of L_kk + 8 W_ss: 88 KB
+
 __global__ __launch_bounds__(256) void potrf_panel_kernel(double* __restrict__ K, size_t k_stride, int ld, int k,
                                                           const double* __restrict__ Linv, size_t linv_stride) {
-    __shared__ double smem[gemm_smem_doubles<1>()];
+    __shared__ double smem[PANEL_SMEM_DOUBLES];
+    double* sL = smem;
+    double* sWd = smem + NBLK * BLK;      // W_ss, s = 0..7
     K += (size_t)blockIdx.y * k_stride;
     Linv += (size_t)blockIdx.y * linv_stride;
-    const size_t row0 = (size_t)(k + 1) * NB + (size_t)blockIdx.x * 32;
-    double* A = K + row0 * ld + (size_t)k * NB;
-    const double* W = Linv + (size_t)k * NB * NB;
-    AccT<1> acc;
-    acc_zero(acc);
-    gemm_nt<1, false>(A, ld, W, NB, 0, NB, acc, smem);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const double* Kd = K + ((size_t)k * NB) * ld + (size_t)k * NB;
+    const double* Wg = Linv + (size_t)k * NB * NB;
+    // this strip's rows, transposed into the accumulator layout: register r of lane l <- A[row l & 15][16 s + (l >> 4) + 4 r]
+    const size_t row = (size_t)(k + 1) * NB + (size_t)blockIdx.x * 64 + wave * 16 + (lane & 15);
+    double* Arow = K + row * ld + (size_t)k * NB + (lane >> 4);
+    v4d y[NSB];
 #pragma unroll
-    for (int tn = 0; tn < 4; ++tn)
+    for (int s = 0; s < NSB; ++s)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) A[(size_t)acc_row<1>(0, r) * ld + acc_col(tn)] = acc.t[0][tn][r];
+        for (int r = 0; r < 4; ++r) y[s][r] = Arow[s * SB + 4 * r];
+    for (int bi = 0; bi < NSB; ++bi) {
+        for (int bj = 0; bj <= bi; ++bj)
+            sL[blk_off(bi, bj) + bidx(tid >> 4, tid & 15)] = Kd[(size_t)(bi * SB + (tid >> 4)) * ld + bj * SB + (tid & 15)];
+        sWd[bi * BLK + bidx(tid >> 4, tid & 15)] = Wg[(bi * SB + (tid >> 4)) * NB + bi * SB + (tid & 15)];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int s = 0; s < NSB; ++s) {
+        v4d t = y[s];
+#pragma unroll
+        for (int c = 0; c < s; ++c) {
+            const Frag4 a = frag_row(sL + blk_off(s, c), lane);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) t = mfma_f64(-a.v[r], y[c][r], t);
+        }
+        const Frag4 w = frag_row(sWd + s * BLK, lane);
+        v4d o = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int r = 0; r < 4; ++r) o = mfma_f64(w.v[r], t[r], o);
+        y[s] = o;
+    }
+#pragma unroll
+    for (int s = 0; s < NSB; ++s)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) Arow[s * SB + 4 * r] = y[s][r];
+}
+
+// Off-diagonal 16x16 blocks of the inverses W = L_kk^-1 of ALL diagonal blocks at once (one workgroup per block,
+// after the factorisation): the posterior's TRSM (predict.hip) and the likelihood gradient (gradient.hip) multiply
+// with explicit 128 x 128 inverses.  Column by column: with S_ij = sum_{j<=c<i} L_ic W_cj kept in the W_ij slot
+// until block row i is final, stage s does  W_sj = -W_ss S_sj  (j < s)  and then  S_ij += L_is W_sj  for every
+// block row i > s -- 7, 13, 17, 19, 19, 17, 13 independent products in stages 0..6, handed out dynamically to the
+// four waves, one barrier per half-stage.
+__global__ __launch_bounds__(256) void potrf_inverse_kernel(const double* __restrict__ K, size_t k_stride, int ld,
+                                                            double* __restrict__ Linv, size_t linv_stride) {
+    __shared__ double smem[2 * NBLK * BLK + 32];
+    double* sL = smem;
+    double* sW = smem + NBLK * BLK;
+    int* ctr = reinterpret_cast<int*>(smem + 2 * NBLK * BLK);
+    K += (size_t)blockIdx.y * k_stride;
+    const int k = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const double* Kd = K + ((size_t)k * NB) * ld + (size_t)k * NB;
+    double* Wg = Linv + (size_t)blockIdx.y * linv_stride + (size_t)k * NB * NB;
+    for (int bi = 0; bi < NSB; ++bi) {
+        for (int bj = 0; bj <= bi; ++bj)
+            sL[blk_off(bi, bj) + bidx(tid >> 4, tid & 15)] = Kd[(size_t)(bi * SB + (tid >> 4)) * ld + bj * SB + (tid & 15)];
+        sW[blk_off(bi, bi) + bidx(tid >> 4, tid & 15)] = Wg[(bi * SB + (tid >> 4)) * NB + bi * SB + (tid & 15)];
+    }
+    if (tid < 2 * NSB) ctr[tid] = 0;
+    __syncthreads();
+    const v4d zero = {0.0, 0.0, 0.0, 0.0};
+    for (int s = 0; s + 1 < NSB; ++s) {
+        // finalise block row s: W_sj = -W_ss S_sj, j < s
+        for (;;) {
+            int j = 0;
+            if (lane == 0) j = atomicAdd(ctr + 2 * s, 1);
+            j = __builtin_amdgcn_readlane(j, 0);
+            if (j >= s) break;
+            double* Wsj = sW + blk_off(s, j);
+            v4d w = zero;
+            w = blk_mma_nn<true>(sW + blk_off(s, s), Wsj, lane, w);
+            wave_lds_fence();   // S_sj fully read before W_sj replaces it
+            blk_store_c(Wsj, lane, w);
+        }
+        __syncthreads();
+        // S_ij += L_is W_sj for i > s, j <= s: (7 - s)(s + 1) independent products
+        const int rows = NSB - 1 - s, ntask = rows * (s + 1);
+        for (;;) {
+            int t = 0;
+            if (lane == 0) t = atomicAdd(ctr + 2 * s + 1, 1);
+            t = __builtin_amdgcn_readlane(t, 0);
+            if (t >= ntask) break;
+            const int j = t / rows, i = s + 1 + t % rows;
+            double* Sij = sW + blk_off(i, j);
+            const Frag4 a = frag_row(sL + blk_off(i, s), lane), b = frag_col(sW + blk_off(s, j), lane);
+            v4d acc = j < s ? blk_load_c(Sij, lane) : zero;
+            acc = frag_mma<false>(a, b, acc);
+            blk_store_c(Sij, lane, acc);
+        }
+        __syncthreads();
+    }
+    // block row 7: W_7j = -W_77 S_7j
+    for (int j = wave; j < NSB - 1; j += 4) {
+        double* S = sW + blk_off(NSB - 1, j);
+        v4d w = zero;
+        w = blk_mma_nn<true>(sW + blk_off(NSB - 1, NSB - 1), S, lane, w);
+        wave_lds_fence();
+        blk_store_c(S, lane, w);
+    }
+    __syncthreads();
+    for (int bi = 1; bi < NSB; ++bi)
+        for (int bj = 0; bj < bi; ++bj)
+            Wg[(bi * SB + (tid >> 4)) * NB + bj * SB + (tid & 15)] = sW[blk_off(bi, bj) + bidx(tid >> 4, tid & 15)];
 }
 
 // Tile (k+1, k+1) of the trailing update for the fused diagonal workgroup:  C_lower - P P^T  straight
@@ -585,7 +646,7 @@ int launch_potrf(robo_gp* gp, const FitBuffers& fb) {
     hipLaunchKernelGGL(potrf_diag_kernel, dim3(S), dim3(256), 0, ctx->stream, fb.K, fb.k_stride, ld, (KK), gp->n, \
                        fb.Linv, fb.linv_stride, fb.fail, (long long*)nullptr)
 #define ROBO_PANEL(KK)                                                                                         \
-    hipLaunchKernelGGL(potrf_panel_kernel, dim3((nb - (KK)-1) * 4, S), dim3(256), 0, ctx->stream, fb.K,        \
+    hipLaunchKernelGGL(potrf_panel_kernel, dim3((nb - (KK)-1) * 2, S), dim3(256), 0, ctx->stream, fb.K,        \
                        fb.k_stride, ld, (KK), (const double*)fb.Linv, fb.linv_stride)
 #define ROBO_STEP(TM, F, GRID, BASE, KOP, DEPTH, FIRST)                                                        \
     hipLaunchKernelGGL((potrf_step_kernel<TM, F>), dim3((GRID), S), dim3(256), 0, ctx->stream, fb.K, fb.k_stride, \
@@ -634,6 +695,9 @@ int launch_potrf(robo_gp* gp, const FitBuffers& fb) {
 #undef ROBO_STEP
 #undef ROBO_PANEL
 #undef ROBO_DIAG
+    // the explicit 128 x 128 inverses of all diagonal blocks, off the factorisation's critical path
+    hipLaunchKernelGGL(potrf_inverse_kernel, dim3(nb, S), dim3(256), 0, ctx->stream, (const double*)fb.K, fb.k_stride, ld,
+                       fb.Linv, fb.linv_stride);
     ROBO_LAUNCH_CHECK();
     return ROBO_OK;
 }
