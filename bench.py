@@ -12,6 +12,13 @@ candidate axis is sharded (weak scaling: every rank evaluates its own --m candid
 against its own replica of the fitted GP); the only exchange is the all-gather of one
 (max, index) pair per rank over RCCL.  GP-fit ms (gram + Cholesky + log-likelihood) is
 reported next to it.  Prints ONE JSON line on rank 0.
+
+``--config`` selects one of BASELINE.json's other configurations (same JSON shape, their own workload and
+roofline; the default, and what the driver runs, is the headline):
+    c2   GP Matern-5/2 N=1024 D=8, 65 536 candidates, EI                          (candidate shard)
+    c3   50 hyper-parameter samples, N=2048 D=16, marginal LogEI over 65 536      (SAMPLE shard, 13/13/12/12 at 4)
+    c4   Fabolas kernel N=4096 D=10+1, information gain per unit cost, 8192/GPU   (candidate shard)
+    c5   N=8192 D=64, LCB, 2^17 Sobol candidates per GPU, fp32 K-build            (candidate shard)
 """
 import argparse
 import json
@@ -26,6 +33,12 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 FP64_MFMA_PEAK_TFLOPS = 78.6   # MI355X datasheet, dense fp64 matrix (= 32 FLOP/clk/SIMD * 1024 SIMD * 2.4 GHz)
+METRIC = "EI evals/sec + GP-fit ms at N=4096,D=16; 1/2/4/8 MI355X vs host CPU"
+
+
+def default_theta(D, extra=0):
+    """log amp 0, log l^2 = log(0.25 D), log sigma^2 = log 1e-3"""
+    return np.concatenate([[0.0], np.full(D, np.log(0.25 * D)), np.zeros(extra), [np.log(1e-3)]])
 
 
 def synthetic(N, D, M, rank):
@@ -33,29 +46,35 @@ def synthetic(N, D, M, rank):
     X = np.random.RandomState(0).rand(N, D)
     y = np.sinc(X * 10 - 5).sum(axis=1)
     y = (y - y.mean()) / y.std()
-    theta = np.concatenate([[0.0], np.full(D, np.log(0.25 * D)), [np.log(1e-3)]])
     Xc = np.random.RandomState(1 + rank).rand(M, D)
-    return X, y, theta, Xc
+    return X, y, default_theta(D), Xc
 
 
-def cpu_baseline(N, D, theta, X, y, budget_s=20.0):
-    """The reference CPU path restated by the oracle: gp.predict with the FULL covariance in
-    batches of the reference's own 500 candidates (robo/maximizers/random_sampling.py:9,
-    robo/models/gaussian_process.py:280-286) + EI, timed on a bounded sample."""
+def flops_ei(N, D):
+    """algorithmic flops of one acquisition evaluation"""
+    return float(N) * N + N * (3.0 * D + 20.0)
+
+
+def cpu_baseline(N, D, theta, X, y, budget_s=12.0):
+    """The reference CPU path as a RESTATEMENT (george is not installable here): the oracle makes
+    the reference's call sequence -- gp.predict with the FULL covariance in batches of the reference's own 500
+    candidates (robo/maximizers/random_sampling.py:9, robo/models/gaussian_process.py:280-286) + EI -- timed on a
+    bounded sample; next to it the "fair" diag-only variant (no M x M covariance), so that the GPU/CPU ratio is
+    not inflated by the reference's wasted O(M^2) work."""
     from oracle import gp_oracle as O
     try:
         from threadpoolctl import threadpool_info
-        cores = max([p.get("num_threads", 1) for p in threadpool_info()] + [1])
+        blas_threads = max([p.get("num_threads", 1) for p in threadpool_info()] + [1])
     except Exception:
-        cores = os.cpu_count() or 1
+        blas_threads = os.cpu_count() or 1
     t0 = time.perf_counter()
     gp = O.OracleGP("matern52", theta, lower=np.zeros(D), upper=np.ones(D))
     gp.train(X, y)
     fit_s = time.perf_counter() - t0
     eta = y.min()
     rs = np.random.RandomState(99)
-    done, t_pred = 0, 0.0
     gp.predict(rs.rand(500, D))   # warm-up
+    done, t_pred = 0, 0.0
     while t_pred < budget_s and done < 20000:
         Xb = rs.rand(500, D)
         t0 = time.perf_counter()
@@ -63,68 +82,127 @@ def cpu_baseline(N, D, theta, X, y, budget_s=20.0):
         O.ei(mu, var, eta)
         t_pred += time.perf_counter() - t0
         done += 500
-    return {"value": done / t_pred, "unit": "EI evals/s", "cores": int(cores), "kind": "port",
+    fair_done, t_fair = 0, 0.0
+    while t_fair < budget_s / 2 and fair_done < 65536:
+        Xb = rs.rand(4096, D)
+        t0 = time.perf_counter()
+        mu, var = gp.predict(Xb, diag_only=True)
+        O.ei(mu, var, eta)
+        t_fair += time.perf_counter() - t0
+        fair_done += 4096
+    return {"value": done / t_pred, "unit": "EI evals/s", "cores": int(blas_threads), "kind": "port",
+            "os_cpu_count": os.cpu_count(),
+            "note": "restatement of the george call sequence on NumPy/SciPy (george itself is not installable: "
+                    "BASELINE.md 3.5); cores = BLAS threads in use",
             "sample": "%d candidates in batches of 500 (reference call sequence: full MxM covariance, np.diag), "
                       "N=%d D=%d; oracle fit %.0f ms" % (done, N, D, fit_s * 1e3),
+            "fair_diag_only": {"value": fair_done / t_fair, "unit": "EI evals/s",
+                               "sample": "%d candidates in batches of 4096, diagonal variance only" % fair_done},
             "gp_fit_ms": fit_s * 1e3}
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--n", type=int, default=4096)
-    ap.add_argument("--d", type=int, default=16)
-    ap.add_argument("--m", type=int, default=65536, help="candidates per GPU")
-    ap.add_argument("--acq", default="ei")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--lib", default=None, help="alternative build of librobo_hip.so (A/B runs of kernel variants)")
-    args = ap.parse_args()
+class Dist(object):
+    """process group plumbing (one process per GPU; backend nccl = RCCL over xGMI)"""
 
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    dist = None
-    if world > 1 or os.environ.get("ROBO_BENCH_FORCE_DIST") == "1":   # the latter: exercise the RCCL path on one rank
+    def __init__(self):
+        self.rank = int(os.environ.get("RANK", "0"))
+        self.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+        self.world = int(os.environ.get("WORLD_SIZE", "1"))
+        self.dist = None
+        if self.world > 1 or os.environ.get("ROBO_BENCH_FORCE_DIST") == "1":   # the latter: the RCCL path on one rank
+            import torch
+            import torch.distributed as dist
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29533")
+            torch.cuda.set_device(self.local_rank)
+            dist.init_process_group(backend="nccl", rank=self.rank, world_size=self.world)
+            self.dist = dist
+
+    def barrier(self, ctx):
+        ctx.synchronize()
+        if self.dist is not None:
+            import torch
+            self.dist.barrier()
+            torch.cuda.synchronize()
+
+    def max_over_ranks(self, seconds):
+        if self.dist is None:
+            return seconds
         import torch
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend="nccl", rank=rank, world_size=world)
+        t = torch.tensor([seconds], dtype=torch.float64, device="cuda")
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+        return float(t.item())
 
-    from robo_amd import _lib, sharding
-    if args.lib:
-        _lib.use_library(os.path.abspath(args.lib))
+    def close(self):
+        if self.dist is not None:
+            self.dist.barrier()
+            self.dist.destroy_process_group()
 
-    ctx = _lib.Context(local_rank if world > 1 else int(os.environ.get("ROBO_DEVICE", "0")))
+
+def timed_steps(D_, ctx, step, steps, warmup):
+    for _ in range(warmup):
+        step()
+    D_.barrier(ctx)
+    t0 = time.perf_counter()
+    last = None
+    trsm_ms = 0.0
+    for _ in range(steps):
+        last = step()
+        trsm_ms += ctx.elapsed_ms(25, 26)
+    D_.barrier(ctx)
+    return D_.max_over_ranks(time.perf_counter() - t0), last, trsm_ms / steps
+
+
+def roofline_trsm(ctx, N, M_rows, trsm_ms_per_step, passes=1, kernel="trsm_step_gen_kernel", traffic=None):
+    """the dominant kernel of every configuration is the block-row solve: algorithmic flops per launch =
+    rows N^2 / nb (SURVEY.md 8d's triangular-solve term), duration from HIP events on the library's stream
+    (slots 25 -> 26) averaged over the nb launches of a pass"""
+    nb = (N + 127) // 128
+    avg_launch_ms = trsm_ms_per_step / (nb * passes)
+    achieved = (float(M_rows) * N * N / nb) / (avg_launch_ms * 1e-3) / 1e12
+    return {"bound": "mfma", "kernel": kernel, "achieved": achieved, "peak": FP64_MFMA_PEAK_TFLOPS,
+            "unit": "TFLOP/s", "frac": achieved / FP64_MFMA_PEAK_TFLOPS, "traffic": traffic,
+            "traffic_unit": "bytes per launch (PMC, profiles/trsm_traffic.json)",
+            "algorithmic_flops_per_launch": float(M_rows) * N * N / nb, "launches_per_step": nb * passes,
+            "avg_launch_ms": avg_launch_ms}
+
+
+# ----------------------------------------------------------------------------------------------------
+# headline and config 2: one fitted GP, candidate shard
+# ----------------------------------------------------------------------------------------------------
+def run_headline(args, D_, _lib, sharding):
+    rank, world = D_.rank, D_.world
+    ctx = _lib.Context(D_.local_rank if world > 1 else int(os.environ.get("ROBO_DEVICE", "0")))
     N, D, M = args.n, args.d, args.m
     X, y, theta, Xc = synthetic(N, D, M, rank)
-    mean_c = float(np.mean(y))
-    eta = float(y.min())
-
+    mean_c, eta = float(np.mean(y)), float(y.min())
     gp = _lib.DeviceGP(ctx, "matern52", N, D)
     gp.set_data(X, y)
     cand = _lib.Candidates(ctx, Xc)          # candidates resident in HBM before the timed region
 
     # ---- GP fit (replicated on every rank) ------------------------------------------------
-    fit_ms, fit_chol_ms = [], []
-    for i in range(3):
+    fit_ms, fit_phase = [], []
+    for _ in range(3):
         t0 = time.perf_counter()
         gp.fit(theta, mean_c)
         fit_ms.append((time.perf_counter() - t0) * 1e3)
-        fit_chol_ms.append((ctx.elapsed_ms(20, 21), ctx.elapsed_ms(21, 22), ctx.elapsed_ms(22, 23)))
-    gram_ms, chol_ms, ll_ms = fit_chol_ms[int(np.argmin(fit_ms))]
-    # the MCMC inner loop evaluates half an ensemble of thetas at once (n_hypers = 3 (D + 2) made
-    # even = 54 at D = 16 -> 27 per half-step; robo/fmin/bayesian_optimization.py:85-87):
-    # robo_gp_loglik_batch runs them through ONE sequence of launches
+        fit_phase.append((ctx.elapsed_ms(20, 21), ctx.elapsed_ms(21, 22), ctx.elapsed_ms(22, 23)))
+    gram_ms, chol_ms, ll_ms = fit_phase[int(np.argmin(fit_ms))]
+    # SURVEY 8(d)'s definition of GP-fit: incl. H2D of X, y, theta and D2H of the log-likelihood
+    fit_h2d = []
+    for _ in range(3):
+        t0 = time.perf_counter()
+        gp.set_data(X, y)
+        gp.fit(theta, mean_c)
+        fit_h2d.append((time.perf_counter() - t0) * 1e3)
+    # the MCMC inner loop evaluates half an ensemble of thetas at once (n_hypers = 3 (D + 2) made even = 54 at
+    # D = 16 -> 27 per half-step; robo/fmin/bayesian_optimization.py:85-87): one batched pass
     S_half = max(1, (3 * (D + 2) + (3 * (D + 2)) % 2) // 2)
     thetas = theta[None, :] + 0.1 * np.random.RandomState(7).randn(S_half, theta.size)
     gp.loglik_batch(thetas, mean_c)
     t0 = time.perf_counter()
     gp.loglik_batch(thetas, mean_c)
     batch_ms = (time.perf_counter() - t0) * 1e3
-    # analytic likelihood gradient (fit + W^T + A + reductions)
     gp.grad_loglik(theta, mean_c)
     t0 = time.perf_counter()
     gp.grad_loglik(theta, mean_c)
@@ -132,103 +210,263 @@ def main():
     grad_dev_ms = ctx.elapsed_ms(28, 29)
     gp.fit(theta, mean_c)          # the batch call leaves the GP unfitted
 
-    def barrier():
-        ctx.synchronize()
-        if dist is not None:
-            dist.barrier()
-            import torch
-            torch.cuda.synchronize()
-
     def step():
         _, mx, am, _ = gp.acq(args.acq, 0.0, eta, cand, want_values=False)
         return sharding.allgather_argmax(mx, am + rank * M)
 
-    for _ in range(args.warmup):
-        step()
-    barrier()
-    t0 = time.perf_counter()
-    trsm_ms = cross_ms = 0.0
-    for _ in range(args.steps):
-        best = step()
-        cross_ms += ctx.elapsed_ms(24, 25)
-        trsm_ms += ctx.elapsed_ms(25, 26)
-    barrier()
-    elapsed = time.perf_counter() - t0
-    if dist is not None:
-        import torch
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    elapsed, best, trsm_ms = timed_steps(D_, ctx, step, args.steps, args.warmup)
 
+    # SURVEY 8(d)'s full definition of an "EI eval" (PCIe-inclusive: H2D of the candidate batch into an existing
+    # handle, D2H of the result) -- reported next to `value`, which is the resident-input rate
+    def step_pcie():
+        cand.set_points(Xc)
+        _, mx, am, _ = gp.acq(args.acq, 0.0, eta, cand, want_values=False)
+        return sharding.allgather_argmax(mx, am + rank * M)
+
+    elapsed_pcie, _, _ = timed_steps(D_, ctx, step_pcie, max(2, args.steps // 2), 1)
+    pcie_steps = max(2, args.steps // 2)
+
+    out = None
     if rank == 0:
-        nb = (N + 127) // 128     # trsm_step_kernel launches per step (block rows holding training points)
         ms_per_step = elapsed / args.steps * 1e3
         value = world * M * args.steps / elapsed
-        # dominant kernel: trsm_step_gen_kernel (nb launches per step; cross-gram tile generated in registers).  Algorithmic flops of one
-        # step's launches: M * N^2 (the lower-triangular solve term of flops_ei);
-        # per launch = M N^2 / nb; avg launch duration = trsm time / nb (HIP events on the
-        # library's stream, slots 25->26).
-        trsm_avg_launch_ms = trsm_ms / args.steps / nb
-        achieved = (float(M) * N * N / nb) / (trsm_avg_launch_ms * 1e-3) / 1e12
         try:
             mb = ctx.microbench_mfma_f64_detail(4000)
-            mfma_ceiling = mb["tflops"]
         except Exception:
-            mb, mfma_ceiling = None, None
-        # shader clock under an operand-streaming fp64 MFMA load (GEMM in the step kernel's shape): the
-        # datasheet peak assumes 2.4 GHz, the chip holds 2.0-2.2 GHz on this kind of kernel
+            mb = None
         try:
             g_tf, g_mhz = ctx.microbench_gemm_f64(0, 512, 2048, 3)
             clock_peak = FP64_MFMA_PEAK_TFLOPS * g_mhz / 2400.0
-            gemm_mb = {"lds_core_tflops": g_tf, "shader_mhz_under_load": g_mhz,
-                       "peak_at_that_clock_tflops": clock_peak, "frac_of_peak_at_that_clock": achieved / clock_peak}
         except Exception:
-            gemm_mb = None
-        traffic = None
-        try:   # PMC-measured HBM bytes per launch for this exact workload (collected by tools/gpu_pmc.sh)
+            g_tf = g_mhz = clock_peak = None
+        traffic = traffic_src = None
+        try:   # PMC-measured HBM bytes per launch for this exact workload (tools/gpu_pmc.sh writes it, with the commit)
             tj = json.load(open(os.path.join(ROOT, "profiles", "trsm_traffic.json")))
             if tj["workload"] == {"n_train": N, "dim": D, "candidates_per_gpu": M}:
-                traffic = tj["bytes_per_launch"]
+                traffic, traffic_src = tj["bytes_per_launch"], tj.get("commit")
         except Exception:
             pass
+        roof = roofline_trsm(ctx, N, M, trsm_ms, traffic=traffic)
+        roof["traffic_measured_at_commit"] = traffic_src
+        roof["mfma_f64_microbench"] = mb
+        if clock_peak:
+            roof["gemm_f64_microbench"] = {"lds_core_tflops": g_tf, "shader_mhz_under_load": g_mhz,
+                                           "peak_at_that_clock_tflops": clock_peak,
+                                           "frac_of_peak_at_that_clock": roof["achieved"] / clock_peak}
+        k1_bytes = 8.0 * N * (N + 1) / 2 + 8.0 * N * D
+        name = "BASELINE headline" if (N, D) == (4096, 16) else "BASELINE config 2" if (N, D) == (1024, 8) else "custom"
         out = {
-            "metric": "EI evals/sec + GP-fit ms at N=4096,D=16; 1/2/4/8 MI355X vs host CPU",
-            "value": value, "unit": "EI evals/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f64", "data": "synthetic",
+            "metric": METRIC, "value": value, "unit": "EI evals/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": "GP Matern-5/2 ARD N=%d D=%d, %d uniform candidates per GPU, %s xi=0, fp64, "
-                                   "candidate shard per GPU (BASELINE headline)" % (N, D, M, args.acq.upper()),
+                                   "candidate shard per GPU (%s)" % (N, D, M, args.acq.upper(), name),
                        "n_train": N, "dim": D, "candidates_per_gpu": M, "acquisition": args.acq,
                        "parallelism": "candidate-shard x%d, replicated fit" % world},
+            "algorithmic_tflops_whole_step": value * flops_ei(N, D) / 1e12,
+            "pcie_inclusive": {"value": world * M * pcie_steps / elapsed_pcie, "unit": "EI evals/s",
+                               "ms_per_step": elapsed_pcie / pcie_steps * 1e3,
+                               "what": "SURVEY 8(d) definition: H2D of the %d x %d candidate batch (pageable host memory, "
+                                       "into an existing handle) + evaluation + D2H of (max, argmax)" % (M, D)},
             "gp_fit_ms": float(np.min(fit_ms)),
+            "gp_fit_incl_h2d_ms": float(np.min(fit_h2d)),
             "gp_fit_phases_ms": {"gram": gram_ms, "cholesky": chol_ms, "loglik": ll_ms},
-            # north_star's two side figures: K-assembly against the HBM roofline (lower
-            # triangle written once + X read once) and the factorisation against the fp64 MFMA peak
-            "k_assembly": {"bytes": 8.0 * N * (N + 1) / 2 + 8.0 * N * D, "ms": gram_ms,
-                           "GB_per_s": (8.0 * N * (N + 1) / 2 + 8.0 * N * D) / (gram_ms * 1e-3) / 1e9,
-                           "frac_of_8TBps": (8.0 * N * (N + 1) / 2 + 8.0 * N * D) / (gram_ms * 1e-3) / 8.0e12},
+            "gp_fit_frac_of_mfma_peak": (N ** 3 / 3.0 + N * (N + 1) / 2.0 * (3 * D + 16) + 2.0 * N * N)
+            / (float(np.min(fit_ms)) * 1e-3) / 1e12 / FP64_MFMA_PEAK_TFLOPS,
+            "k_assembly": {"bytes": k1_bytes, "ms": gram_ms, "GB_per_s": k1_bytes / (gram_ms * 1e-3) / 1e9,
+                           "frac_of_8TBps": k1_bytes / (gram_ms * 1e-3) / 8.0e12},
             "cholesky": {"flops": N ** 3 / 3.0, "ms": chol_ms, "TFLOP_per_s": N ** 3 / 3.0 / (chol_ms * 1e-3) / 1e12,
-                         "frac_of_mfma_peak": N ** 3 / 3.0 / (chol_ms * 1e-3) / 1e12 / FP64_MFMA_PEAK_TFLOPS,
-                         "note": "latency-bound by the 128 sequential pivots of each diagonal block; the trailing "
-                                 "MFMA updates alone run at ~27 TFLOP/s (profiles/*_kernel_stats.csv)"},
+                         "frac_of_mfma_peak": N ** 3 / 3.0 / (chol_ms * 1e-3) / 1e12 / FP64_MFMA_PEAK_TFLOPS},
             "gp_fit_batched": {"thetas": S_half, "ms_total": batch_ms, "ms_per_theta": batch_ms / S_half},
             "gp_grad_loglik_ms": {"total_incl_fit": grad_ms, "after_factorisation": grad_dev_ms},
-            "ei_eval_phases_ms_per_step": {"cross_gram": cross_ms / args.steps, "trsm": trsm_ms / args.steps},
-            "argmax": list(best),
-            "roofline": {"bound": "mfma", "kernel": "trsm_step_gen_kernel", "achieved": achieved,
-                         "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / FP64_MFMA_PEAK_TFLOPS,
-                         "traffic": traffic, "traffic_unit": "bytes per launch (PMC, profiles/trsm_traffic.json)",
-                         "algorithmic_flops_per_launch": float(M) * N * N / nb, "launches_per_step": nb, "avg_launch_ms": trsm_avg_launch_ms,
-                         "mfma_f64_microbench_tflops": mfma_ceiling, "mfma_f64_microbench": mb,
-                         "gemm_f64_microbench": gemm_mb},
-            "device": ctx.name,
+            "argmax": list(best), "roofline": roof, "device": ctx.name,
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(N, D, theta, X, y)
+    return out
+
+
+# ----------------------------------------------------------------------------------------------------
+# config 3: GP-MCMC marginalisation, hyper-parameter samples sharded over the ranks
+# ----------------------------------------------------------------------------------------------------
+def run_c3(args, D_, _lib, sharding):
+    rank, world = D_.rank, D_.world
+    ctx = _lib.Context(D_.local_rank if world > 1 else int(os.environ.get("ROBO_DEVICE", "0")))
+    N, D, M, S = args.n, args.d, args.m, 50
+    X, y, theta, Xc = synthetic(N, D, M, 0)       # every rank sees ALL candidates; the samples are sharded
+    thetas = theta[None, :] + 0.3 * np.random.RandomState(2).randn(S, theta.size)
+    mean_c, eta = float(np.mean(y)), float(y.min())
+    b, e = sharding.shard_range(S, rank, world)
+    gps = [_lib.DeviceGP(ctx, "matern52", N, D) for _ in range(e - b)]
+    gps[0].set_data(X, y)
+    cand = _lib.Candidates(ctx, Xc)
+    etas = np.full(e - b, eta)
+    fit_s = []
+
+    def step():
+        t0 = time.perf_counter()
+        _, st = _lib.fit_batch(gps, thetas[b:e], mean_c)          # S_r factorisations in one batched pass
+        assert np.all(st == _lib.OK)
+        fit_s.append(time.perf_counter() - t0)
+        part, _, _, _ = _lib.acq_marginal(gps, "log_ei", 0.0, etas, cand, reduce="sum")
+        total = sharding.allgather_ordered_sum(part) / S          # 512 KB per rank
+        return float(total.max()), int(np.argmax(total))
+
+    elapsed, best, trsm_ms = timed_steps(D_, ctx, step, args.steps, args.warmup)
+    if rank != 0:
+        return None
+    ms = elapsed / args.steps * 1e3
+    # elapsed_ms(25, 26) brackets the LAST sample's solve of a step
+    roof = roofline_trsm(ctx, N, M, trsm_ms)
+    return {"metric": METRIC, "value": S * M * args.steps / elapsed, "unit": "LogEI sample-evals/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": True,
+            "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": "BASELINE config 3: 50 hyper-parameter samples (theta + 0.3 randn), N=2048 D=16, "
+                                   "marginal LogEI over %d candidates; a step = batched fit of the rank's samples + their "
+                                   "posteriors + ordered all-gather sum + argmax" % M,
+                       "n_train": N, "dim": D, "candidates": M, "samples": S, "acquisition": "log_ei",
+                       "parallelism": "sample-shard x%d (%s)" % (world, "/".join(
+                           str(sharding.shard_range(S, r, world)[1] - sharding.shard_range(S, r, world)[0])
+                           for r in range(world)))},
+            "end_to_end_ms": ms, "fit_batch_ms_rank0": float(np.median(fit_s)) * 1e3,
+            "fit_ms_per_sample": float(np.median(fit_s)) * 1e3 / (e - b),
+            "algorithmic_tflops_whole_step": S * M * flops_ei(N, D) / (ms * 1e-3) / 1e12,
+            "argmax": list(best), "roofline": roof, "device": ctx.name}
+
+
+# ----------------------------------------------------------------------------------------------------
+# config 4: Fabolas kernel, information gain per unit cost, candidate shard
+# ----------------------------------------------------------------------------------------------------
+def run_c4(args, D_, _lib, sharding):
+    from robo_amd.util import epmgp
+    from scipy.stats import norm
+    rank, world = D_.rank, D_.world
+    ctx = _lib.Context(D_.local_rank if world > 1 else int(os.environ.get("ROBO_DEVICE", "0")))
+    N, D, M, Nb, Np = args.n, args.d, args.m, 50, 400
+    rs = np.random.RandomState(3)
+    X = np.random.RandomState(0).rand(N, D)
+    s = rs.rand(N)
+    X[:, -1] = (1.0 - s) ** 2                                     # basis (1 - s)^2 on the fidelity column
+    y = np.sinc(X[:, :-1] * 10 - 5).sum(axis=1)
+    y = (y - y.mean()) / y.std() + 0.5 * X[:, -1]
+    cost = np.log(0.2 + 3.0 * s)
+    theta = default_theta(D - 1, extra=2)                          # [amp, D-1 metrics, log_a, log_b, noise]
+    mean_c = float(np.mean(y))
+    gp, gc = _lib.DeviceGP(ctx, "fabolas", N, D), _lib.DeviceGP(ctx, "fabolas", N, D)
+    gp.set_data(X, y)
+    gp.fit(theta, mean_c)
+    Xcost = X.copy()
+    Xcost[:, -1] = s                                               # linear basis for the cost model
+    gc.set_data(Xcost, cost)
+    gc.fit(theta, float(np.mean(cost)))
+    Xc = np.random.RandomState(1 + rank).rand(M, D)
+    Xc_cost = Xc.copy()
+    Xc[:, -1] = (1.0 - Xc[:, -1]) ** 2
+    zb = np.random.RandomState(4).rand(Nb, D)
+    zb[:, -1] = 0.0                                                # representers on the s = 1 subspace
+    lmb = np.random.RandomState(5).randn(Nb)
+    mu_b, cov_b = gp.predict_cov(zb)
+    logP, dMu, dSig, dMM = epmgp.joint_min(mu_b, np.clip(cov_b, np.finfo(float).eps, np.inf), with_derivatives=True)
+    W = norm.ppf(np.linspace(1. / (Np + 1), 1 - 1. / (Np + 1), Np))[np.newaxis, :]
+    ep = _lib.EPState(logP, lmb, W, dMu, dSig, dMM)
+    cand, cand_cost, rep = _lib.Candidates(ctx, Xc), _lib.Candidates(ctx, Xc_cost), _lib.Candidates(ctx, zb)
+    sn2 = float(np.exp(theta[-1]))
+
+    def step():
+        ig, _, _ = _lib.ig_eval(gp, cand, rep, ep, sn2)            # posterior + cross-covariances + entropy change
+        log_cost, _ = gc.predict(cand_cost)
+        val = ig / np.exp(log_cost)                                # information gain per unit cost
+        j = int(np.argmax(val))
+        return sharding.allgather_argmax(float(val[j]), j + rank * M)
+
+    elapsed, best, trsm_ms = timed_steps(D_, ctx, step, args.steps, args.warmup)
+    if rank != 0:
+        return None
+    ms = elapsed / args.steps * 1e3
+    return {"metric": METRIC, "value": world * M * args.steps / elapsed, "unit": "information gains/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": "BASELINE config 4: Fabolas product kernel N=4096 D=10+1, information gain per unit "
+                                   "cost (Nb=50, Np=400, objective + cost GP), %d candidates per GPU" % M,
+                       "n_train": N, "dim": D, "candidates_per_gpu": M, "acquisition": "information_gain_per_unit_cost",
+                       "parallelism": "candidate-shard x%d, replicated fits" % world},
+            "argmax": list(best), "roofline": roofline_trsm(ctx, N, M, trsm_ms), "device": ctx.name,
+            "note": "roofline: the block-row solve of the LAST posterior of a step (the cost model's)"}
+
+
+# ----------------------------------------------------------------------------------------------------
+# config 5: D = 64, N = 8192, LCB, Sobol candidates, fp32 K-build
+# ----------------------------------------------------------------------------------------------------
+def run_c5(args, D_, _lib, sharding):
+    from scipy.stats import qmc
+    rank, world = D_.rank, D_.world
+    ctx = _lib.Context(D_.local_rank if world > 1 else int(os.environ.get("ROBO_DEVICE", "0")))
+    N, D, M = args.n, args.d, args.m
+    X, y, theta, _ = synthetic(N, D, 1, 0)
+    gp = _lib.DeviceGP(ctx, "matern52", N, D)
+    gp.set_precision(True)
+    gp.set_data(X, y)
+    t0 = time.perf_counter()
+    gp.fit(theta, float(np.mean(y)))
+    fit_ms = (time.perf_counter() - t0) * 1e3
+    t0 = time.perf_counter()
+    gp.fit(theta, float(np.mean(y)))
+    fit_ms = min(fit_ms, (time.perf_counter() - t0) * 1e3)
+    # this rank's slice of the 2^20-point scrambled Sobol sequence
+    sob = qmc.Sobol(d=D, scramble=True, seed=0)
+    if rank > 0:
+        sob.fast_forward(rank * M)
+    Xc = sob.random(M)
+    cand = _lib.Candidates(ctx, Xc)
+
+    def step():
+        _, mx, am, _ = gp.acq("lcb", 1.0, 0.0, cand, want_values=False)
+        return sharding.allgather_argmax(mx, am + rank * M)
+
+    elapsed, best, trsm_ms = timed_steps(D_, ctx, step, args.steps, args.warmup)
+    if rank != 0:
+        return None
+    ms = elapsed / args.steps * 1e3
+    return {"metric": METRIC, "value": world * M * args.steps / elapsed, "unit": "LCB evals/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f64 (covariance entries f32)", "data": "synthetic",
+            "config": {"workload": "BASELINE config 5: N=8192 D=64, LCB kappa=1, %d scrambled-Sobol candidates per GPU "
+                                   "(slice of 2^20), fp32 K-build + fp64 Cholesky/solve" % M,
+                       "n_train": N, "dim": D, "candidates_per_gpu": M, "acquisition": "lcb",
+                       "parallelism": "candidate-shard x%d, replicated fit" % world},
+            "gp_fit_ms": fit_ms, "algorithmic_tflops_whole_step": world * M * flops_ei(N, D) / (ms * 1e-3) / 1e12,
+            "argmax": list(best), "roofline": roofline_trsm(ctx, N, M, trsm_ms, kernel="trsm_step_kernel"),
+            "device": ctx.name}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--config", default="headline", choices=["headline", "c2", "c3", "c4", "c5"])
+    ap.add_argument("--n", type=int, default=None)
+    ap.add_argument("--d", type=int, default=None)
+    ap.add_argument("--m", type=int, default=None, help="candidates per GPU (config 3: candidates in total)")
+    ap.add_argument("--acq", default="ei")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--lib", default=None, help="alternative build of librobo_hip.so (A/B runs of kernel variants)")
+    args = ap.parse_args()
+    defaults = {"headline": (4096, 16, 65536), "c2": (1024, 8, 65536), "c3": (2048, 16, 65536),
+                "c4": (4096, 11, 8192), "c5": (8192, 64, 131072)}[args.config]
+    args.n = args.n or defaults[0]
+    args.d = args.d or defaults[1]
+    args.m = args.m or defaults[2]
+
+    D_ = Dist()
+    from robo_amd import _lib, sharding
+    if args.lib:
+        _lib.use_library(os.path.abspath(args.lib))
+    runner = {"headline": run_headline, "c2": run_headline, "c3": run_c3, "c4": run_c4, "c5": run_c5}[args.config]
+    out = runner(args, D_, _lib, sharding)
+    if D_.rank == 0:
         print(json.dumps(out), flush=True)
-    if dist is not None:
-        dist.barrier()
-        dist.destroy_process_group()
+    D_.close()
 
 
 if __name__ == "__main__":

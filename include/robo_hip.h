@@ -137,6 +137,9 @@ int32_t robo_gp_get_gram(robo_gp* gp, const double* theta, double* out_K); /* K 
 /* Xc: (m, dim) candidates in the GP's (normalised) input space; copied H2D here, once.    */
 int32_t robo_cand_create(robo_ctx* ctx, const double* Xc, int64_t m, int32_t dim, robo_cand** out);
 int32_t robo_cand_destroy(robo_cand* cand);
+/* a new batch of the SAME size into an existing handle (H2D only; buffers and solve workspace are kept): what a BO
+ * loop does once per iteration with robo/maximizers/random_sampling.py:38-47's fresh candidate matrix            */
+int32_t robo_cand_set_points(robo_cand* cand, const double* Xc, int64_t m);
 /* device-side generation, no H2D: uniform [0,1)^dim, counter-based (Philox-4x32-10)         */
 int32_t robo_cand_create_uniform(robo_ctx* ctx, int64_t m, int32_t dim, uint64_t seed, robo_cand** out);
 /* RandomSampling.maximize's candidate recipe on the device (random_sampling.py:38-47), in the
@@ -159,6 +162,14 @@ int32_t robo_gp_predict_mixture_cand(robo_gp* const* gps, int32_t S, robo_cand* 
                                      double* out_var);
 /* full covariance (m x m), small m only (predict(full_cov=True), predict_variance,
  * sample_functions: gaussian_process.py:221-248,298-332)                                    */
+/* Gradients of the posterior w.r.t. the test inputs: what model.predictive_gradients(X) supplies to the
+ * reference's acquisition derivatives (robo/acquisition_functions/ei.py:80-85, pi.py:65-71, lcb.py:66-68) and to
+ * robo/util/posterior_optimization.py:38-40,96-104 (no model in the reference tree implements it).
+ * Xc (m x D) in the GP's normalised input space; out_dmean / out_dvar (m x D, row-major): derivatives of the
+ * values out_mean / out_var w.r.t. those coordinates (output transform applied; the variance floor is not
+ * differentiated).  Cost: D + 1 right-hand sides of the blocked forward substitution per point.            */
+int32_t robo_gp_predict_grad(robo_gp* gp, const double* Xc, int64_t m, double* out_mean, double* out_var,
+                             double* out_dmean, double* out_dvar);
 int32_t robo_gp_predict_cov(robo_gp* gp, const double* Xc, int64_t m, double* out_mean, double* out_cov);
 
 /* ---- acquisition: replaces EI/LogEI/PI/LCB.compute + the argmax of

@@ -42,7 +42,8 @@ from scipy.special import erfc, erfcx
 
 __all__ = [
     "JITTER", "EPS", "kernel_matrix", "kernel_diag", "n_kernel_params", "gp_compute",
-    "gp_log_likelihood", "gp_grad_log_likelihood", "kernel_gradient", "gp_predict", "gp_predict_diag", "OracleGP", "mcmc_mixture",
+    "gp_log_likelihood", "gp_grad_log_likelihood", "kernel_gradient", "kernel_input_gradient",
+    "gp_predictive_gradients", "gp_predict", "gp_predict_diag", "OracleGP", "mcmc_mixture",
     "norm_cdf", "norm_pdf", "norm_logpdf", "norm_logcdf",
     "ei", "log_ei", "pi", "lcb", "marginalize", "np_argmax",
     "zero_one_normalization", "zero_one_unnormalization",
@@ -369,6 +370,18 @@ class OracleGP(object):
         var = np.clip(var, EPS, np.inf)   # :290-294 (the ':294' line is a no-op after the clip)
         return mu, var
 
+    def predictive_gradients(self, X_test):
+        """(dmdx (M, D, 1), dvdx (M, D)) in the caller's input space, GPy convention (see gp_predictive_gradients)"""
+        if self.normalize_input:
+            Xt, _, _ = zero_one_normalization(X_test, self.lower, self.upper)
+            scale = 1.0 / (np.asarray(self.upper, dtype=np.float64) - np.asarray(self.lower, dtype=np.float64))
+        else:
+            Xt, scale = X_test, 1.0
+        dm, dv = gp_predictive_gradients(self.kind, self.theta, self.L, self.X, self.y, self.mean, Xt)
+        if self.normalize_output:
+            dm, dv = dm * self.y_std, dv * self.y_std ** 2
+        return (dm * scale)[:, :, None], dv * scale
+
     # gaussian_process.py:334-352 / base_model.py:94-106
     def get_incumbent(self):
         best = np.argmin(self.y)
@@ -378,6 +391,63 @@ class OracleGP(object):
         if self.normalize_output:
             inc_value = zero_mean_unit_var_unnormalization(inc_value, self.y_mean, self.y_std)
         return inc, inc_value
+
+
+def kernel_input_gradient(kind, theta_k, x, X):
+    """d k(x, X_n) / d x_d for one test point x (D,) against the rows of X -> (N, D), plus d k(x, x) / d x (D,).
+    Exact derivatives of :func:`kernel_matrix` (PARITY UNPINNED like the kernel values); pinned against central
+    differences of kernel_matrix in tests/test_oracle.py."""
+    x = np.asarray(x, dtype=np.float64)
+    X = np.asarray(X, dtype=np.float64)
+    amp = np.exp(theta_k[0])
+    if kind == "fabolas":
+        D = X.shape[1] - 1
+        m = np.exp(np.asarray(theta_k[1:1 + D], dtype=np.float64))
+        a, b = np.exp(theta_k[1 + D]), np.exp(theta_k[2 + D])
+        diff = (x[None, :D] - X[:, :D]) / np.sqrt(m)
+        s2 = diff * diff
+        t = np.sqrt(5.0 * s2)
+        f = (1.0 + t + 5.0 * s2 / 3.0) * np.exp(-t)
+        prod = np.prod(f, axis=1)
+        lin = a + b * x[D] * X[:, D]
+        k = amp * prod * lin
+        G = np.empty((X.shape[0], D + 1))
+        # f'(s2)/f(s2) = -(5/6)(1 + t)/(1 + t + 5 s2/3); d s2 / d x_d = 2 diff / sqrt(m_d)
+        G[:, :D] = k[:, None] * (-(5.0 / 6.0) * (1.0 + t) / (1.0 + t + 5.0 * s2 / 3.0)) * 2.0 * diff / np.sqrt(m)
+        G[:, D] = amp * prod * b * X[:, D]
+        dself = np.zeros(D + 1)
+        dself[D] = 2.0 * amp * b * x[D]
+        return G, dself
+    m = np.exp(np.asarray(theta_k[1:], dtype=np.float64))
+    diff = (x[None, :] - X) / np.sqrt(m)
+    r2 = np.sum(diff * diff, axis=1)
+    if kind == "matern52":
+        t = np.sqrt(5.0 * r2)
+        dk = -amp * (5.0 / 6.0) * (1.0 + t) * np.exp(-t)
+    elif kind == "rbf":
+        dk = -0.5 * amp * np.exp(-0.5 * r2)
+    else:
+        raise ValueError(kind)
+    return dk[:, None] * 2.0 * diff / np.sqrt(m), np.zeros(X.shape[1])
+
+
+def gp_predictive_gradients(kind, theta, L, X, y, mean, Xs):
+    """d mean / d x and d var / d x of the (un-normalised-output) posterior at the rows of Xs -> (M, D), (M, D):
+    d mu = (d k_*)^T alpha,  d var = d k(x,x) - 2 (d k_*)^T K^-1 k_*   -- what ``model.predictive_gradients`` has
+    to supply to robo/acquisition_functions/ei.py:80-85 (no reference model implements it; the pin is central
+    differences of :func:`gp_predict_diag`, tests/test_oracle.py)."""
+    theta = np.asarray(theta, dtype=np.float64)
+    r = y - mean
+    alpha = sla.cho_solve((L, True), r, check_finite=False)
+    dm = np.empty(Xs.shape)
+    dv = np.empty(Xs.shape)
+    for i, x in enumerate(Xs):
+        G, dself = kernel_input_gradient(kind, theta[:-1], x, X)
+        ks = kernel_matrix(kind, theta[:-1], x[None, :], X)[0]
+        beta = sla.cho_solve((L, True), ks, check_finite=False)
+        dm[i] = G.T @ alpha
+        dv[i] = dself - 2.0 * (G.T @ beta)
+    return dm, dv
 
 
 def mcmc_mixture(mu, var):

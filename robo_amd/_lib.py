@@ -29,9 +29,9 @@ SYMBOLS = [
     "robo_gp_create", "robo_gp_destroy", "robo_gp_set_data", "robo_gp_set_output_transform",
     "robo_gp_set_precision", "robo_theta_size",
     "robo_gp_fit", "robo_gp_loglik_batch", "robo_gp_fit_batch", "robo_gp_grad_loglik", "robo_gp_get_factor", "robo_gp_get_gram",
-    "robo_cand_create", "robo_cand_destroy", "robo_cand_create_uniform", "robo_cand_get_points",
+    "robo_cand_create", "robo_cand_destroy", "robo_cand_set_points", "robo_cand_create_uniform", "robo_cand_get_points",
     "robo_cand_create_random", "robo_cand_get_point",
-    "robo_gp_predict_cand", "robo_gp_predict", "robo_gp_predict_cov", "robo_gp_predict_mixture_cand",
+    "robo_gp_predict_cand", "robo_gp_predict", "robo_gp_predict_cov", "robo_gp_predict_grad", "robo_gp_predict_mixture_cand",
     "robo_acq_eval_cand", "robo_acq_eval", "robo_acq_eval_moments", "robo_acq_eval_marginal_cand", "robo_acq_eval_sum_cand",
     "robo_ig_eval_cand", "robo_ig_eval_moments", "robo_gp_cross_cov",
     "robo_selftest_mfma_layout", "robo_microbench_mfma_f64", "robo_microbench_mfma_f64_detail", "robo_microbench_gemm_f64",
@@ -112,6 +112,7 @@ def lib():
         "robo_gp_get_gram": [vp, _dp, _dp],
         "robo_cand_create": [vp, _dp, i64, i32, pp],
         "robo_cand_destroy": [vp],
+        "robo_cand_set_points": [vp, _dp, i64],
         "robo_cand_create_uniform": [vp, i64, i32, C.c_uint64, pp],
         "robo_cand_get_points": [vp, _dp],
         "robo_cand_create_random": [vp, i64, i32, C.c_uint64, i64, _dp, _dp, pp],
@@ -119,6 +120,7 @@ def lib():
         "robo_gp_predict_cand": [vp, vp, _dp, _dp],
         "robo_gp_predict": [vp, _dp, i64, _dp, _dp],
         "robo_gp_predict_cov": [vp, _dp, i64, _dp, _dp],
+        "robo_gp_predict_grad": [vp, _dp, i64, _dp, _dp, _dp, _dp],
         "robo_gp_predict_mixture_cand": [pp, i32, vp, _dp, _dp],
         "robo_acq_eval_cand": [vp, i32, dbl, dbl, vp, _dp, _dp, C.POINTER(i64), C.POINTER(C.c_uint32)],
         "robo_acq_eval": [vp, i32, dbl, dbl, _dp, i64, _dp, _dp, C.POINTER(i64), C.POINTER(C.c_uint32)],
@@ -271,6 +273,11 @@ class Candidates(object):
             self.m, self.dim = int(m), int(dim)
             check(lib().robo_cand_create_uniform(ctx._h, self.m, self.dim, int(seed or 0), C.byref(self._h)))
 
+    def set_points(self, Xc):
+        """upload a new batch of the same shape into this handle (H2D only)"""
+        Xc = _f64(Xc, (self.m, self.dim))
+        check(lib().robo_cand_set_points(self._h, _arr(Xc), self.m))
+
     def point(self, index):
         out = np.empty(self.dim)
         check(lib().robo_cand_get_point(self._h, int(index), _arr(out)))
@@ -388,6 +395,15 @@ class DeviceGP(object):
         mean, cov = np.empty(m), np.empty((m, m))
         check(lib().robo_gp_predict_cov(self._h, _arr(Xc), m, _arr(mean), _arr(cov)))
         return mean, cov
+
+    def predict_grad(self, Xc):
+        """-> (mean (M,), var (M,), d mean / d x (M, D), d var / d x (M, D)) in the GP's input space"""
+        Xc = _f64(Xc)
+        assert Xc.ndim == 2 and Xc.shape[1] == self.dim
+        m = Xc.shape[0]
+        mean, var, dm, dv = np.empty(m), np.empty(m), np.empty((m, self.dim)), np.empty((m, self.dim))
+        check(lib().robo_gp_predict_grad(self._h, _arr(Xc), m, _arr(mean), _arr(var), _arr(dm), _arr(dv)))
+        return mean, var, dm, dv
 
     def acq(self, kind, par, eta, Xc, want_values=True):
         """-> (values or None, max, argmax, flags)"""

@@ -92,9 +92,16 @@ class ClosedFormAcquisition(BaseAcquisitionFunction):
             return int(am)
         return int(np.argmax(self.compute(X, eta=eta)))
 
-    def _no_derivative(self, derivative):
-        if derivative:
-            # the reference needs model.predictive_gradients, which no GP model in the tree
-            # implements
-            raise NotImplementedError("%s: derivative=True needs predictive_gradients, which no "
-                                      "reference GP model provides" % self.__class__.__name__)
+    def _moment_gradients(self, X):
+        """(mean, var, d mean / d x (M, D), d var / d x (M, D)) from ``model.predictive_gradients`` -- the
+        protocol of ei.py:80-85 / pi.py:65-71 / lcb.py:66-68 (GPy shapes: dmdx (M, D, 1), dvdx (M, D))."""
+        if not hasattr(self.model, "predictive_gradients"):
+            raise NotImplementedError("%s: derivative=True needs model.predictive_gradients"
+                                      % self.__class__.__name__)
+        m, v = self.model.predict(X)
+        dmdx, dvdx = self.model.predictive_gradients(X)
+        dmdx = np.asarray(dmdx, dtype=np.float64)
+        if dmdx.ndim == 3:
+            dmdx = dmdx[:, :, 0]
+        return np.asarray(m, dtype=np.float64), np.asarray(v, dtype=np.float64), dmdx, \
+            np.asarray(dvdx, dtype=np.float64)

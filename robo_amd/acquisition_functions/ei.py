@@ -22,11 +22,21 @@ class EI(ClosedFormAcquisition):
         super(EI, self).__init__(model, par)
 
     def compute(self, X, derivative=False, eta=None, **kwargs):
-        self._no_derivative(derivative)
         f, flags = self._evaluate(X, eta)
         if flags & _lib.FLAG_ZERO_SIGMA:
-            return np.array([[0]])
+            f = np.array([[0]])
+            return (f, np.zeros((1, X.shape[1]))) if derivative else f      # ei.py:72-74
         if flags & _lib.FLAG_NEGATIVE_EI:
             logger.error("Expected Improvement is smaller than 0!")
             raise ValueError
-        return f
+        if not derivative:
+            return f
+        # ei.py:80-85:  dEI/dx = -dm/dx Phi(z) + ds/dx phi(z),  ds/dx = dv/dx / (2 s).  The reference takes
+        # ``dmdx[0]`` -- it is written for one point (1, D); here every row gets its own gradient, which is the
+        # same thing for the (1, D) calls of robo/maximizers/scipy_optimizer.py.
+        from scipy.stats import norm
+        m, v, dmdx, dvdx = self._moment_gradients(X)
+        s = np.sqrt(v)
+        z = (self._eta(eta) - m - self.par) / s
+        df = -dmdx * norm.cdf(z)[:, None] + (dvdx / (2 * s)[:, None]) * norm.pdf(z)[:, None]
+        return f, df

@@ -32,6 +32,10 @@ class MarginalizationGPMCMC(BaseAcquisitionFunction):
         self._build_estimators()
         self.last_max = None
         self.last_argmax = None
+        # sample shard (SURVEY.md 8e axis 2): with one process per GPU and ``sample_shard = True`` every rank
+        # evaluates only ITS hyper-parameter samples on all candidates; the per-rank partial sums are exchanged
+        # and added in rank order (robo_amd.sharding.allgather_ordered_sum)
+        self.sample_shard = False
 
     def _build_estimators(self):
         for i in range(len(self.model.models)):
@@ -61,11 +65,45 @@ class MarginalizationGPMCMC(BaseAcquisitionFunction):
                 self.estimators[i].update(self.model.models[i], **kwargs)
 
     def _native(self):
+        if self._shard() is not None:
+            return False
         if not isinstance(self.acquisition_func, ClosedFormAcquisition) or not self.estimators:
             return False
         gps = [getattr(e.model, "gp", None) for e in self.estimators]
         return all(isinstance(g, _lib.DeviceGP) for g in gps) and len({id(g.ctx) for g in gps}) == 1 \
             and all(getattr(e.model, "is_trained", False) for e in self.estimators)
+
+    def _shard(self):
+        from robo_amd import sharding
+        _, rank, world = sharding.dist_info()
+        if not self.sample_shard or world == 1:
+            return None
+        return sharding.shard_range(len(self.estimators), rank, world)
+
+    def _sharded_eval(self, X_test):
+        """mean over ALL samples from per-rank partial sums; -> values (M,), identical on every rank"""
+        from robo_amd import sharding
+        b, e = self._shard()
+        est = self.estimators[b:e]
+        S = len(self.estimators)
+        if est and isinstance(self.acquisition_func, ClosedFormAcquisition) and \
+                all(isinstance(getattr(x.model, "gp", None), _lib.DeviceGP) and x.model.is_trained for x in est):
+            models = [x.model for x in est]
+            norm = models[0].normalize if hasattr(models[0], "normalize") else models[0]._normalised
+            cand = _lib.Candidates(models[0].gp.ctx, norm(X_test))
+            try:
+                part, _, _, flags = _lib.acq_marginal([m.gp for m in models], est[0].kind, est[0].par,
+                                                      np.array([x._eta(None) for x in est]), cand, reduce="sum")
+            finally:
+                cand.close()
+            if est[0].kind == "ei" and flags & _lib.FLAG_NEGATIVE_EI:
+                raise ValueError
+        else:
+            part = np.zeros(X_test.shape[0])
+            for x in est:
+                part = part + np.asarray(x.compute(X_test), dtype=np.float64).reshape(-1)
+        total = sharding.allgather_ordered_sum(part)
+        return total / S
 
     def _native_eval(self, X_test, want_values):
         est = self.estimators
@@ -87,6 +125,8 @@ class MarginalizationGPMCMC(BaseAcquisitionFunction):
         return vals, flags
 
     def compute(self, X_test, derivative=False):
+        if not derivative and self._shard() is not None:
+            return self._sharded_eval(X_test)
         if not derivative and self._native():
             vals, flags = self._native_eval(X_test, True)
             if self.estimators[0].kind == "ei":
@@ -106,6 +146,8 @@ class MarginalizationGPMCMC(BaseAcquisitionFunction):
         return acquisition_values.mean(axis=0)
 
     def argmax(self, X_test):
+        if self._shard() is not None:
+            return int(np.argmax(self._sharded_eval(X_test)))
         if self._native():
             _, flags = self._native_eval(X_test, False)
             if self.estimators[0].kind != "ei" or not flags & (_lib.FLAG_ZERO_SIGMA | _lib.FLAG_NEGATIVE_EI):

@@ -574,6 +574,18 @@ int32_t robo_cand_create(robo_ctx* ctx, const double* Xc, int64_t m, int32_t dim
     return ROBO_OK;
 }
 
+int32_t robo_cand_set_points(robo_cand* k, const double* Xc, int64_t m) {
+    if (!k || !Xc) return ROBO_BAD_ARGUMENT;
+    if (m != k->m) {
+        set_error("robo_cand_set_points: batch holds %lld points, got %lld", (long long)k->m, (long long)m);
+        return ROBO_BAD_SHAPE;
+    }
+    ROBO_HIP_CHECK(hipSetDevice(k->ctx->device));
+    ROBO_HIP_CHECK(hipMemcpyAsync(k->d_Xc, Xc, (size_t)m * k->dim * sizeof(double), hipMemcpyHostToDevice, k->ctx->stream));
+    ROBO_HIP_CHECK(hipStreamSynchronize(k->ctx->stream));   // the caller's buffer is only borrowed for the call
+    return ROBO_OK;
+}
+
 int32_t robo_cand_create_uniform(robo_ctx* ctx, int64_t m, int32_t dim, uint64_t seed, robo_cand** out) {
     robo_cand* k = nullptr;
     ROBO_TRY(cand_alloc(ctx, m, dim, &k));
@@ -756,6 +768,61 @@ int32_t robo_gp_predict(robo_gp* g, const double* Xc, int64_t m, double* out_mea
     const int st = robo_gp_predict_cand(g, k, out_mean, out_var);
     robo_cand_destroy(k);
     return st;
+}
+
+int32_t robo_gp_predict_grad(robo_gp* g, const double* Xc, int64_t m, double* out_mean, double* out_var,
+                             double* out_dmean, double* out_dvar) {
+    if (!g || !Xc || !out_dmean || !out_dvar) return ROBO_BAD_ARGUMENT;
+    if (!g->fitted) {
+        set_error("Model has to be trained first!");
+        return ROBO_NOT_FITTED;
+    }
+    const int D = g->dim, E = D + 1;
+    robo_ctx* c = g->ctx;
+    hipStream_t st = c->stream;
+    robo_cand* kc = nullptr;   // the real candidates (upload + scaling + output buffers)
+    ROBO_TRY(robo_cand_create(c, Xc, m, D, &kc));
+    // candidates per pass: D + 1 workspace rows each, rows padded to the 128-row solve tile
+    const size_t row_bytes = (size_t)g->n_pad * sizeof(double);
+    int64_t per = (int64_t)(workspace_bytes() / row_bytes / NB * NB) / E;
+    if (per < 1) per = 1;
+    if (per > m) per = m;
+    const int64_t rows_pad = round_up64(per * E, NB);
+    robo_cand* ws = nullptr;   // the pseudo-row solve workspace
+    double *d_dm = nullptr, *d_dv = nullptr;
+    int status = cand_alloc(c, rows_pad, 1, &ws);
+    if (status == ROBO_OK) status = cand_ensure_workspace(ws, g->n_pad, true);
+    if (status == ROBO_OK) status = dev_alloc(&d_dm, (size_t)m * D);
+    if (status == ROBO_OK) status = dev_alloc(&d_dv, (size_t)m * D);
+    if (status == ROBO_OK) status = launch_scale_inputs(c, kc->d_Xc, kc->d_Xcs, g->d_theta, kc->m, kc->m_pad, D);
+    for (int64_t c0 = 0; status == ROBO_OK && c0 < m; c0 += per) {
+        const int64_t cn = m - c0 < per ? m - c0 : per;
+        const int64_t rp = round_up64(cn * E, NB);
+        status = launch_cross_grad(g, kc->d_Xcs, ws->d_V, c0, cn, rp);
+        if (status == ROBO_OK) status = launch_trsm(g, ws, 0, rp);
+        if (status == ROBO_OK)
+            status = launch_predgrad_post(g, ws->d_V, ws->d_q, ws->d_mu, kc->d_Xcs, c0, cn, kc->d_mean, kc->d_var, d_dm, d_dv);
+    }
+    if (status == ROBO_OK) {
+        hipError_t e = hipSuccess;
+        if (out_mean) e = hipMemcpyAsync(out_mean, kc->d_mean, (size_t)m * sizeof(double), hipMemcpyDeviceToHost, st);
+        if (e == hipSuccess && out_var)
+            e = hipMemcpyAsync(out_var, kc->d_var, (size_t)m * sizeof(double), hipMemcpyDeviceToHost, st);
+        if (e == hipSuccess) e = hipMemcpyAsync(out_dmean, d_dm, (size_t)m * D * sizeof(double), hipMemcpyDeviceToHost, st);
+        if (e == hipSuccess) e = hipMemcpyAsync(out_dvar, d_dv, (size_t)m * D * sizeof(double), hipMemcpyDeviceToHost, st);
+        if (e == hipSuccess) e = hipStreamSynchronize(st);
+        if (e != hipSuccess) {
+            set_error("robo_gp_predict_grad copy-out failed: %s", hipGetErrorString(e));
+            status = ROBO_RUNTIME_ERROR;
+        }
+    } else {
+        hipStreamSynchronize(st);
+    }
+    hipFree(d_dm);
+    hipFree(d_dv);
+    robo_cand_destroy(ws);
+    robo_cand_destroy(kc);
+    return status;
 }
 
 int32_t robo_gp_predict_cov(robo_gp* g, const double* Xc, int64_t m, double* out_mean, double* out_cov) {

@@ -184,28 +184,35 @@ template <int KIND>
 __global__ __launch_bounds__(256, 2) void trsm_step_gen_kernel(const double* __restrict__ Xcs,
                                                                const double* __restrict__ Xs, double* __restrict__ V,
                                                                int ldv, const double* __restrict__ L, int ld,
-                                                               const double* __restrict__ Linv, int i, int n,
+                                                               const double* __restrict__ Linv, int i0, int i1, int n,
                                                                double* __restrict__ q, double* __restrict__ mu,
                                                                long long c0, CovParams cp) {
     __shared__ double smem[GEMM_SMEM_DOUBLES];
     double* Vrow = V + (size_t)blockIdx.x * NB * ldv;
-    double* Vt = Vrow + (size_t)i * NB;
-    Acc acc;
-    gen_cross_tile<KIND>(cp, Xcs + (size_t)(c0 + (long long)blockIdx.x * NB) * cp.dim, Xs + (size_t)i * NB * cp.dim,
-                         n - i * NB, smem, acc);
-    if (i > 0) {
-        gemm_nt<4, true>(Vrow, ldv, L + (size_t)i * NB * ld, ld, 0, i * NB, acc, smem);
+    // block rows i0 .. i1-1 in one launch (ROBO_TRSM_ROWS, default 1): a block row only reads columns this same
+    // workgroup wrote, so the launch boundary is not needed for correctness -- it is what keeps the workgroups in
+    // step on the same rows of L (see above); a few rows per launch trade a little of that for fewer launch
+    // ramps/tails
+    for (int i = i0; i < i1; ++i) {
+        double* Vt = Vrow + (size_t)i * NB;
+        Acc acc;
+        gen_cross_tile<KIND>(cp, Xcs + (size_t)(c0 + (long long)blockIdx.x * NB) * cp.dim,
+                             Xs + (size_t)i * NB * cp.dim, n - i * NB, smem, acc);
+        if (i > 0) {
+            gemm_nt<4, true>(Vrow, ldv, L + (size_t)i * NB * ld, ld, 0, i * NB, acc, smem);
+        }
+#pragma unroll
+        for (int tm = 0; tm < 4; ++tm)
+#pragma unroll
+            for (int tn = 0; tn < 4; ++tn)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) Vt[(size_t)acc_row(tm, r) * ldv + acc_col(tn)] = acc.t[tm][tn][r];
+        __syncthreads();   // T visible to the whole workgroup (global memory, workgroup scope)
+        acc_zero(acc);
+        gemm_nt<4, false>(Vt, ldv, Linv + (size_t)i * NB * NB, NB, 0, NB, acc, smem);
+        trsm_epilogue(acc, Vt, ldv, L + (size_t)n * ld, i, n, smem, q, mu, c0);
+        __syncthreads();   // V_i (global) and the reduction scratch before the next block row
     }
-#pragma unroll
-    for (int tm = 0; tm < 4; ++tm)
-#pragma unroll
-        for (int tn = 0; tn < 4; ++tn)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) Vt[(size_t)acc_row(tm, r) * ldv + acc_col(tn)] = acc.t[tm][tn][r];
-    __syncthreads();   // T visible to the whole workgroup (global memory, workgroup scope)
-    acc_zero(acc);
-    gemm_nt<4, false>(Vt, ldv, Linv + (size_t)i * NB * NB, NB, 0, NB, acc, smem);
-    trsm_epilogue(acc, Vt, ldv, L + (size_t)n * ld, i, n, smem, q, mu, c0);
 }
 
 // mean/var from the reductions, with the reference's output transform and variance floor
@@ -269,9 +276,14 @@ int launch_predict_fused(robo_gp* gp, robo_cand* cand, int64_t c0, int64_t cn) {
 #define ROBO_STEP_CALL(KIND)                                                                                   \
     hipLaunchKernelGGL(trsm_step_gen_kernel<KIND>, grid, dim3(256), 0, gp->ctx->stream,                        \
                        (const double*)cand->d_Xcs, (const double*)gp->d_Xs, cand->d_V, gp->n_pad,             \
-                       (const double*)gp->d_K, gp->n_pad, (const double*)gp->d_Linv, i, gp->n, cand->d_q,      \
-                       cand->d_mu, (long long)c0, gp->cov)
-    for (int i = 0; i < nbk; ++i) {
+                       (const double*)gp->d_K, gp->n_pad, (const double*)gp->d_Linv, i,                       \
+                       (i + rows < nbk ? i + rows : nbk), gp->n, cand->d_q, cand->d_mu, (long long)c0, gp->cov)
+    static const int rows = [] {
+        const char* e = getenv("ROBO_TRSM_ROWS");
+        const int r = e ? atoi(e) : 1;
+        return r < 1 ? 1 : r;
+    }();
+    for (int i = 0; i < nbk; i += rows) {
         if (gp->kind == ROBO_KERNEL_MATERN52_ARD) ROBO_STEP_CALL(ROBO_KERNEL_MATERN52_ARD);
         else if (gp->kind == ROBO_KERNEL_RBF_ARD) ROBO_STEP_CALL(ROBO_KERNEL_RBF_ARD);
         else ROBO_STEP_CALL(ROBO_KERNEL_FABOLAS);

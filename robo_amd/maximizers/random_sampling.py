@@ -46,6 +46,10 @@ class RandomSampling(BaseMaximizer):
 
     def maximize(self):
         X = self.candidates()
+        from robo_amd import sharding
+        if sharding.dist_info()[2] > 1:
+            # one process per GPU: same seeds, hence the same X, on every rank; each evaluates its slice
+            return X[sharding.sharded_argmax(self.objective_func, X)]
         if self.device_argmax and hasattr(self.objective_func, "argmax"):
             return X[self.objective_func.argmax(X)]
         y = self.objective_func(X)
@@ -79,10 +83,24 @@ class DeviceRandomSampling(BaseMaximizer):
         loc = (inc - lower) / (upper - lower)
         scale = 0.1 / (upper - lower)
         seed = int(self.rng.randint(0, 2 ** 31 - 1))
-        cand = _lib.Candidates(sub.gp.ctx, m=self.n_samples, seed=seed, n_uniform=int(self.n_samples * .7), loc=loc,
-                               scale=scale)
+        from robo_amd import sharding
+        _, rank, world = sharding.dist_info()
+        # candidate shard (one process per GPU, same rng seed everywhere): rank r generates and evaluates rows
+        # [b, e) of the recipe -- its own Philox stream, the 70 % / 30 % split kept globally -- and only the
+        # per-shard incumbent (16 B) and the winning point (D doubles) are exchanged
+        b, e = sharding.shard_range(self.n_samples, rank, world)
+        n_uniform = int(self.n_samples * .7)
+        cand = _lib.Candidates(sub.gp.ctx, m=max(e - b, 1), seed=seed + 7919 * rank,
+                               n_uniform=min(max(n_uniform - b, 0), max(e - b, 1)), loc=loc, scale=scale)
         try:
             best = acq.argmax(cand)
-            return lower + (upper - lower) * cand.point(best)
+            point = cand.point(best)
+            if world > 1:
+                _, win = sharding.allgather_argmax(acq.last_max, b + best)
+                points = sharding.allgather_rows(point)
+                owner = [r for r in range(world) if sharding.shard_range(self.n_samples, r, world)[0] <= win
+                         < sharding.shard_range(self.n_samples, r, world)[1]][0]
+                point = points[owner]
+            return lower + (upper - lower) * point
         finally:
             cand.close()

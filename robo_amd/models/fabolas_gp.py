@@ -35,15 +35,28 @@ class FabolasGP(GaussianProcess):
         self.original_X = X
         return super(FabolasGP, self).train(self.normalize(X), y, do_optimize)
 
-    def _host_train_raw(self, X, y):
+    def _host_train_raw(self, X, y, alloc=True):
         self.original_X = X
-        return self._host_train(self.normalize(X), y)
+        return self._host_train(self.normalize(X), y, alloc)
 
     def predict(self, X_test, full_cov=False, **kwargs):
         return super(FabolasGP, self).predict(self.normalize(X_test), full_cov)
 
     def sample_functions(self, X_test, n_funcs=1):
         return super(FabolasGP, self).sample_functions(self.normalize(X_test), n_funcs)
+
+    def predictive_gradients(self, X_test):
+        """as GaussianProcess.predictive_gradients, through normalize(): configuration columns scaled by the
+        bounds, the fidelity column by the derivative of the basis function (central difference of the user's
+        callable, h = 1e-6)"""
+        X_test = np.asarray(X_test, dtype=np.float64)
+        dm, dv = super(FabolasGP, self).predictive_gradients(self.normalize(X_test))
+        s = X_test[:, -1]
+        h = 1e-6
+        scale = np.ones_like(X_test)
+        scale[:, :-1] = 1.0 / (np.asarray(self.upper, dtype=np.float64) - np.asarray(self.lower, dtype=np.float64))
+        scale[:, -1] = (self.basis_function(s + h) - self.basis_function(s - h)) / (2 * h)
+        return dm * scale[:, :, np.newaxis], dv * scale
 
     def acquisition(self, kind, par, eta, X_test, want_values=True):
         return super(FabolasGP, self).acquisition(kind, par, eta, self.normalize(X_test), want_values)

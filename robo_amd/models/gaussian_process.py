@@ -105,9 +105,9 @@ class GaussianProcess(BaseModel):
             self.gp.set_output_transform(0.0, 1.0)
 
     # ---- BaseModel ----------------------------------------------------------------------------
-    def _host_train(self, X, y):
+    def _host_train(self, X, y, alloc=True):
         """the host half of train() (gaussian_process.py:89-104): normalisation and the constant mean;
-        returns the device handle sized for the data, nothing uploaded yet"""
+        returns the device handle sized for the data (``alloc``), nothing uploaded yet"""
         if self.normalize_input:
             self.X, self.lower, self.upper = normalization.zero_one_normalization(X, self.lower, self.upper)
         else:
@@ -120,11 +120,11 @@ class GaussianProcess(BaseModel):
             self.y = y
         self.mean = np.mean(self.y, axis=0)
         self.is_trained = False
-        return self._ensure_gp(self.X.shape[0], self.X.shape[1])
+        return self._ensure_gp(self.X.shape[0], self.X.shape[1]) if alloc else None
 
-    def _host_train_raw(self, X, y):
+    def _host_train_raw(self, X, y, alloc=True):
         """_host_train on the caller's raw inputs (FabolasGP maps them through normalize() first)"""
-        return self._host_train(X, y)
+        return self._host_train(X, y, alloc)
 
     def _adopt_fit(self, theta):
         """this model's device handle was fitted at theta by a batched pass (robo_gp_fit_batch)"""
@@ -256,6 +256,22 @@ class GaussianProcess(BaseModel):
         eps = np.finfo(cov.dtype).eps
         cov = np.clip(cov, eps, np.inf)
         return mu, cov
+
+    def predictive_gradients(self, X_test):
+        """Gradients of the predictive mean and variance w.r.t. the inputs, in the convention the reference's
+        callers index (GPy's): ``dmdx`` (M, D, 1), ``dvdx`` (M, D)  (robo/acquisition_functions/ei.py:80-85,
+        lcb.py:66-68, robo/util/posterior_optimization.py:38-40,96-104).  No model of the reference implements
+        this; here every point costs D + 1 right-hand sides of the device's blocked forward substitution
+        (robo_gp_predict_grad)."""
+        if not self.is_trained:
+            raise Exception('Model has to be trained first!')
+        self._materialise()
+        X_test = np.asarray(X_test, dtype=np.float64)
+        _, _, dm, dv = self.gp.predict_grad(self._normalised(X_test))
+        if self.normalize_input:
+            scale = 1.0 / (np.asarray(self.upper, dtype=np.float64) - np.asarray(self.lower, dtype=np.float64))
+            dm, dv = dm * scale, dv * scale         # d x_normalised / d x
+        return dm[:, :, np.newaxis], dv
 
     def sample_functions(self, X_test, n_funcs=1):
         """Draw n_funcs functions from the posterior at X_test -> (F, N)."""

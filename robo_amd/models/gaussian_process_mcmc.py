@@ -48,6 +48,9 @@ class GaussianProcessMCMC(BaseModel):
         self.upper = upper
         self.device = device
         self.gp = None                  # scratch device GP for the likelihood evaluations
+        # one process per GPU: fit only this rank's shard of the hyper-parameter samples (the MCMC itself is
+        # replicated -- same seeds, same chain on every rank); used with MarginalizationGPMCMC.sample_shard
+        self.sample_shard = False
 
     def _ensure_gp(self, n, dim):
         if self.gp is None or self.gp.dim != dim or self.gp.n_max < n or self.gp.kind != self.kernel.kind:
@@ -145,6 +148,15 @@ class GaussianProcessMCMC(BaseModel):
         bit-identical to S sequential fits); a sample whose K is not positive definite goes through the
         model's own train(), i.e. the reference's noise x 10 retry (gaussian_process.py:120-122)."""
         models = self.models
+        if self.sample_shard:
+            from robo_amd import sharding
+            _, rank, world = sharding.dist_info()
+            if world > 1:
+                b, e = sharding.shard_range(len(models), rank, world)
+                for i, model in enumerate(models):
+                    if not b <= i < e:
+                        model._host_train_raw(X, y, alloc=False)   # host state only; never evaluated on this rank
+                models = models[b:e]
         if len(models) < 2 or os.environ.get("ROBO_MCMC_SEQUENTIAL_FITS") == "1":
             for model in models:
                 model.train(X, y, do_optimize=False)
@@ -195,6 +207,20 @@ class GaussianProcessMCMC(BaseModel):
     def predict(self, X_test, **kwargs):
         if not self.is_trained:
             raise Exception('Model has to be trained first!')
+        if self.sample_shard:
+            from robo_amd import sharding
+            _, rank, world = sharding.dist_info()
+            if world > 1:
+                # mixture from per-rank partial sums (3 M doubles per rank): mean_s mu_s and
+                # var_s(mu_s) + mean_s var_s with var_s(mu) = mean(mu^2) - mean(mu)^2
+                b, e = sharding.shard_range(len(self.models), rank, world)
+                part = np.zeros((3, X_test.shape[0]))
+                for model in self.models[b:e]:
+                    mu_s, var_s = model.predict(X_test)
+                    part += np.stack((mu_s, mu_s * mu_s, var_s))
+                tot = sharding.allgather_ordered_sum(part) / len(self.models)
+                v = (tot[1] - tot[0] * tot[0]) + tot[2]
+                return tot[0], np.clip(v, np.finfo(v.dtype).eps, np.inf)
         gps = [getattr(m, "gp", None) for m in self.models]
         if all(isinstance(g, _lib.DeviceGP) for g in gps) and all(m.is_trained for m in self.models):
             # all samples live on the device: S posteriors on one candidate upload + mixture kernel

@@ -15,6 +15,17 @@ and evaluates its own contiguous shard.  The only exchanges are
 import numpy as np
 
 
+def dist_info():
+    """(torch.distributed module or None, rank, world_size) of the initialised default process group"""
+    try:
+        import torch.distributed as dist
+    except Exception:       # torch is plumbing for multi-GPU runs only; single-GPU use never needs it
+        return None, 0, 1
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        return dist, dist.get_rank(), dist.get_world_size()
+    return None, 0, 1
+
+
 def shard_range(n_items, rank, world):
     """Contiguous [begin, end) of rank's shard; the first n_items % world ranks get one more
     (config 3 of BASELINE.json: 50 samples over 4 GPUs -> 13/13/12/12)."""
@@ -75,3 +86,37 @@ def allgather_ordered_sum(partial_sum, device=None):
     for t in out[1:]:
         total += t
     return total.cpu().numpy()
+
+
+def allgather_rows(row, device=None):
+    """every rank contributes one fp64 row (D,) -> (world, D), identical on every rank"""
+    import torch
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return np.asarray(row, dtype=np.float64)[None, :]
+    world = dist.get_world_size()
+    dev = device if device is not None else ("cuda" if dist.get_backend() == "nccl" else "cpu")
+    mine = torch.as_tensor(np.ascontiguousarray(row, dtype=np.float64)).to(dev)
+    out = [torch.empty_like(mine) for _ in range(world)]
+    dist.all_gather(out, mine)
+    return np.stack([t.cpu().numpy() for t in out])
+
+
+def sharded_argmax(acq, X):
+    """Candidate shard of one acquisition maximisation (SURVEY.md 8e axis 1): every rank evaluates its contiguous
+    slice of the SAME candidate matrix X against its own replica of the model and the per-shard incumbents are
+    exchanged (16 B per rank).  Returns the global np.argmax index, identical on every rank and identical to the
+    single-process result (values are computed per candidate, so sharding does not change them)."""
+    _, rank, world = dist_info()
+    if world == 1:
+        return int(acq.argmax(X)) if hasattr(acq, "argmax") else int(np.argmax(acq(X)))
+    b, e = shard_range(X.shape[0], rank, world)
+    if e > b:
+        vals = np.asarray(acq(X[b:e]), dtype=np.float64).reshape(-1)
+        if vals.shape[0] != e - b:          # EI's whole-batch collapse to [[0]] (ei.py:72-74): every value is 0
+            vals = np.zeros(e - b)
+        j = int(np.argmax(vals))
+        local = (float(vals[j]), b + j)
+    else:
+        local = (-np.inf, -1)
+    return allgather_argmax(local[0], local[1])[1]

@@ -573,3 +573,104 @@ def check_shape_sweep(ctx, n_cases=40, seed=123, max_n=700):
         gap = srt[-1] - srt[-2] if M > 1 else 1.0
         assert am == want or gap <= 1e-7 * max(abs(eo[want]), 1e-300), tag
         g.close()
+
+
+def check_predictive_gradients(ctx, cases=(("matern52", 70, 3, 9), ("rbf", 150, 5, 40), ("fabolas", 140, 4, 33)),
+                               device=None):
+    """robo_gp_predict_grad (D + 1 right-hand sides of the blocked forward substitution per point) and the
+    host classes' predictive_gradients / derivative=True against the oracle's analytic gradients (themselves pinned
+    to central differences in tests/test_oracle.py) and against central differences of the DEVICE's own predict."""
+    from robo_amd import acquisition_functions as A
+    from robo_amd.kernels import ExpSquaredKernel, FabolasKernel, Matern52Kernel
+    from robo_amd.models import FabolasGP, GaussianProcess
+    rs = np.random.RandomState(41)
+    for kind, N, D, M in cases:
+        lower, upper = np.full(D, -1.0), np.full(D, 2.0)
+        X01 = rs.rand(N, D)
+        X = lower + (upper - lower) * X01
+        y = np.sin(3 * X01.sum(axis=1)) * 1.5 + 0.2
+        P = O.n_kernel_params(kind, D) + 1
+        theta = 0.3 * rs.randn(P)
+        theta[-1] = np.log(1e-2)
+        Xt01 = rs.rand(M, D)
+        # ---- C ABI on the GP's own input space
+        ogp = O.OracleGP(kind, theta, normalize_input=False)
+        ogp.train(X01, y)
+        g = _lib.DeviceGP(ctx, kind, N, D)
+        g.set_data(X01, y)
+        g.fit(theta, ogp.mean)
+        mean, var, dm, dv = g.predict_grad(Xt01)
+        mo, vo = ogp.predict(Xt01, diag_only=True)
+        dmo, dvo = ogp.predictive_gradients(Xt01)
+        amp = float(np.max(O.kernel_diag(kind, theta[:-1], Xt01)))
+        np.testing.assert_allclose(mean, mo, rtol=MU_RTOL, atol=MU_ATOL)
+        np.testing.assert_allclose(var, vo, rtol=0, atol=VAR_ATOL_REL_AMP * amp)
+        np.testing.assert_allclose(dm, dmo[:, :, 0], rtol=1e-8, atol=1e-9 * np.abs(dmo).max())
+        np.testing.assert_allclose(dv, dvo, rtol=1e-7, atol=1e-8 * max(np.abs(dvo).max(), amp))
+        # the same values as the plain posterior path (fused kernel)
+        m2, v2 = g.predict(Xt01)
+        np.testing.assert_allclose(mean, m2, rtol=1e-11, atol=1e-12)
+        np.testing.assert_allclose(var, v2, rtol=0, atol=1e-11 * amp)
+        # central differences of the device's own posterior
+        h = 1e-5
+        for d in (0, D - 1):
+            e = np.zeros(D)
+            e[d] = h
+            mp, vp = g.predict(Xt01 + e)
+            mm, vm = g.predict(Xt01 - e)
+            np.testing.assert_allclose(dm[:, d], (mp - mm) / (2 * h), rtol=1e-5, atol=1e-6)
+            np.testing.assert_allclose(dv[:, d], (vp - vm) / (2 * h), rtol=1e-4, atol=1e-6 * amp)
+        g.close()
+        # ---- host classes: input / output normalisation chain rule, GPy shapes, acquisition derivatives
+        if kind == "fabolas":
+            kern = FabolasKernel(D)
+            kern.set_parameter_vector(theta[:-1])
+            model = FabolasGP(kern, basis_function=lambda s: (1 - s) ** 2, noise=np.exp(theta[-1]), lower=lower[:-1],
+                              upper=upper[:-1], rng=np.random.RandomState(1), device=device)
+            Xr = np.concatenate((X[:, :-1], X01[:, -1:]), axis=1)
+            Xq = np.concatenate((lower[:-1] + (upper[:-1] - lower[:-1]) * Xt01[:, :-1], Xt01[:, -1:]), axis=1)
+        else:
+            kern = (Matern52Kernel if kind == "matern52" else ExpSquaredKernel)(np.ones(D), ndim=D)
+            kern.set_parameter_vector(theta[:-1])
+            model = GaussianProcess(kern, noise=np.exp(theta[-1]), normalize_output=(kind == "rbf"), lower=lower,
+                                    upper=upper, rng=np.random.RandomState(1), device=device)
+            Xr, Xq = X, lower + (upper - lower) * Xt01
+        model.train(Xr, y, do_optimize=False)
+        dmdx, dvdx = model.predictive_gradients(Xq)
+        assert dmdx.shape == (M, D, 1) and dvdx.shape == (M, D)
+        h = 1e-5
+        for d in range(D):
+            e = np.zeros(D)
+            e[d] = h
+            mp, vp = model.predict(Xq + e)
+            mm, vm = model.predict(Xq - e)
+            np.testing.assert_allclose(dmdx[:, d, 0], (mp - mm) / (2 * h), rtol=1e-5, atol=1e-6)
+            np.testing.assert_allclose(dvdx[:, d], (vp - vm) / (2 * h), rtol=1e-4, atol=1e-6)
+        for cls in (A.EI, A.PI, A.LCB):
+            acq = cls(model)
+            f, df = acq.compute(Xq, derivative=True)
+            assert df.shape == (M, D)
+            np.testing.assert_allclose(f, acq.compute(Xq), rtol=1e-12)
+            for d in (0, D - 1):
+                e = np.zeros(D)
+                e[d] = h
+                fd = (acq.compute(Xq + e) - acq.compute(Xq - e)) / (2 * h)
+                np.testing.assert_allclose(df[:, d], fd, rtol=2e-4, atol=1e-6 * max(1.0, np.abs(fd).max()))
+        # the single-point form the reference's optimisers use (1, D) -> (1, D)
+        f1, df1 = A.EI(model).compute(Xq[:1], derivative=True)
+        assert df1.shape == (1, D)
+        if kind == "matern52" and N <= 200:
+            # robo/util/posterior_optimization.py with_gradients=True: the consumer of predictive_gradients
+            from robo_amd.util.posterior_optimization import posterior_mean_optimization, \
+                posterior_mean_plus_std_optimization
+            np.random.seed(3)
+            xa = posterior_mean_optimization(model, lower, upper, n_restarts=3, with_gradients=True)
+            np.random.seed(3)
+            xb = posterior_mean_optimization(model, lower, upper, n_restarts=3, with_gradients=False)
+            fa, fb = model.predict(xa[None, :])[0][0], model.predict(xb[None, :])[0][0]
+            assert fa <= fb + 1e-6 * max(1.0, abs(fb))          # analytic gradients do at least as well
+            np.random.seed(3)
+            xc = posterior_mean_plus_std_optimization(model, lower, upper, n_restarts=2, with_gradients=True)
+            assert np.all(xc >= lower) and np.all(xc <= upper)
+        if getattr(model, "gp", None) is not None:
+            model.gp.close()

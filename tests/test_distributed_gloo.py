@@ -52,3 +52,93 @@ def test_sharded_exchange_world2(tmp_path):
     a = np.load(tmp_path / "total_0.npy")
     b = np.load(tmp_path / "total_1.npy")
     np.testing.assert_array_equal(a, b)        # bit-identical on both ranks
+
+
+def _class_worker(rank, world, port, out_dir):
+    """the product classes under torch.distributed (gloo), device code through the interpreter build"""
+    import sys
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    here = os.path.dirname(os.path.abspath(__file__))
+    sys.path.insert(0, os.path.join(here, "hipemu"))
+    import build_emu
+    from robo_amd import _lib, sharding
+    _lib.use_library(build_emu.build())
+    from robo_amd import acquisition_functions as A
+    from robo_amd.kernels import Matern52Kernel
+    from robo_amd.maximizers import DeviceRandomSampling, RandomSampling
+    from robo_amd.models import GaussianProcess, GaussianProcessMCMC
+    from robo_amd.priors import DefaultPrior
+
+    D = 3
+    lo, hi = np.array([-1.0, 0.0, 2.0]), np.array([1.0, 5.0, 3.0])
+    rs = np.random.RandomState(11)
+    X = lo + (hi - lo) * rs.rand(30, D)
+    y = np.sinc((X - lo) / (hi - lo) * 10 - 5).sum(axis=1)
+    Xc = lo + (hi - lo) * np.random.RandomState(12).rand(301, D)      # 301: ragged shards (151 / 150)
+
+    def mcmc(shard):
+        kernel = 2 * Matern52Kernel(np.ones(D), ndim=D)
+        m = GaussianProcessMCMC(kernel, prior=DefaultPrior(len(kernel) + 1, rng=np.random.RandomState(5)), n_hypers=10,
+                                chain_length=3, burnin_steps=3, lower=lo, upper=hi, rng=np.random.RandomState(6))
+        m.sample_shard = shard
+        m.train(X, y, do_optimize=True)
+        return m
+
+    full, part = mcmc(False), mcmc(True)
+    np.testing.assert_array_equal(np.array(full.hypers), np.array(part.hypers))     # replicated chain
+    b, e = sharding.shard_range(10, rank, world)
+    assert [m.is_trained for m in part.models] == [b <= i < e for i in range(10)]
+    assert all(m.gp is None for i, m in enumerate(part.models) if not b <= i < e)   # no device memory off-shard
+    # sample shard: marginal acquisition and mixture posterior == the single-rank result
+    for cls in (A.LogEI, A.EI, A.LCB):
+        ref = A.MarginalizationGPMCMC(cls(full))
+        sh = A.MarginalizationGPMCMC(cls(part))
+        sh.sample_shard = True
+        want, got = ref.compute(Xc), sh.compute(Xc)
+        np.testing.assert_allclose(got, want, rtol=1e-12, atol=1e-14)
+        assert sh.argmax(Xc) == ref.argmax(Xc) == int(np.argmax(want))
+    m_ref, v_ref = full.predict(Xc)
+    m_sh, v_sh = part.predict(Xc)
+    np.testing.assert_allclose(m_sh, m_ref, rtol=1e-12, atol=1e-13)
+    np.testing.assert_allclose(v_sh, v_ref, rtol=1e-9, atol=1e-12)
+    # candidate shard: RandomSampling under a process group == plain np.argmax over the same candidates
+    gp = GaussianProcess(2 * Matern52Kernel(np.ones(D), ndim=D), noise=1e-3, lower=lo, upper=hi,
+                         rng=np.random.RandomState(7))
+    gp.train(X, y, do_optimize=False)
+    acq = A.EI(gp)
+    np.random.seed(21)
+    x_sharded = RandomSampling(acq, lo, hi, n_samples=203, rng=np.random.RandomState(8)).maximize()
+    np.random.seed(21)
+    cands = RandomSampling(acq, lo, hi, n_samples=203, rng=np.random.RandomState(8)).candidates()
+    np.testing.assert_array_equal(x_sharded, cands[int(np.argmax(acq.compute(cands)))])
+    assert sharding.sharded_argmax(acq, Xc) == int(np.argmax(acq.compute(Xc)))
+    # device-generated candidates: per-rank Philox shards, the winner's point travels to every rank
+    x_dev = DeviceRandomSampling(acq, lo, hi, n_samples=1001, rng=np.random.RandomState(9)).maximize()
+    assert np.all(x_dev >= lo) and np.all(x_dev <= hi)
+    np.save(os.path.join(out_dir, "xdev_%d.npy" % rank), x_dev)
+    # ... and it is the best point of the union of the shards, re-evaluated here on one rank
+    best = (-np.inf, None)
+    seed = int(np.random.RandomState(9).randint(0, 2 ** 31 - 1))
+    for r in range(world):
+        rb, re = sharding.shard_range(1001, r, world)
+        c = _lib.Candidates(gp.gp.ctx, m=re - rb, seed=seed + 7919 * r, n_uniform=min(max(700 - rb, 0), re - rb),
+                            loc=(gp.get_incumbent()[0] - lo) / (hi - lo), scale=0.1 / (hi - lo))
+        pts = lo + (hi - lo) * c.points()
+        vals = acq.compute(pts)
+        j = int(np.argmax(vals))
+        if vals[j] > best[0]:
+            best = (vals[j], pts[j])
+        c.close()
+    np.testing.assert_allclose(x_dev, best[1], rtol=1e-13)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_product_classes_sharded_world2(tmp_path):
+    """GaussianProcessMCMC / MarginalizationGPMCMC sample shard and RandomSampling / DeviceRandomSampling candidate
+    shard under torch.distributed (world_size 2, gloo): equal to the single-rank results"""
+    port = _free_port()
+    mp.spawn(_class_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    np.testing.assert_array_equal(np.load(tmp_path / "xdev_0.npy"), np.load(tmp_path / "xdev_1.npy"))

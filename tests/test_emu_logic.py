@@ -135,3 +135,7 @@ def test_multi_panel_factorisation(emu_ctx):
     np.testing.assert_allclose(ll, ogp.loglikelihood(theta), rtol=1e-10)
     np.testing.assert_allclose(g.factor(), ogp.L, rtol=0, atol=1e-11)
     g.close()
+
+
+def test_predictive_gradients(emu_ctx):
+    P.check_predictive_gradients(emu_ctx, cases=(("matern52", 70, 3, 9), ("fabolas", 60, 3, 7)))

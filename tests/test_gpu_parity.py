@@ -335,3 +335,9 @@ def test_host_classes_on_gpu(ctx):
                               model_type="gp_mcmc", acquisition_func="log_ei", rng=np.random.RandomState(1),
                               chain_length=20, burnin_steps=20)
     assert np.all(np.array(r["x_opt"]) >= [-5, 0]) and np.all(np.array(r["x_opt"]) <= [10, 15])
+
+
+def test_predictive_gradients(ctx):
+    """f4: d mean / d x, d var / d x on the device and derivative=True of EI / PI / LCB"""
+    P.check_predictive_gradients(ctx)
+    P.check_predictive_gradients(ctx, cases=(("matern52", 1500, 16, 300),))

@@ -278,3 +278,31 @@ def test_ig_oracle_matches_reference_class_fixture(golden_dir):
         out[c] = IG.dh_fun(v[0], cov[-1, :-1, None], float(gold["sn2"]), gold["logP"], gold["lmb"], gold["dlogPdMu"],
                            gold["dlogPdSigma"], gold["dlogPdMudMu"], W)
     np.testing.assert_allclose(out, gold["ig"][:60], rtol=1e-9, atol=1e-12)
+
+
+def test_oracle_predictive_gradients_match_central_differences():
+    """the checker of robo_gp_predict_grad: analytic input gradients of the oracle posterior == central
+    differences of the oracle's own predict, every kernel kind, input + output normalisation"""
+    rs = np.random.RandomState(3)
+    for kind, D, nout in (("matern52", 3, False), ("rbf", 4, True), ("fabolas", 4, False)):
+        N = 40
+        lower, upper = np.full(D, -1.0), np.full(D, 2.0)
+        X = lower + (upper - lower) * rs.rand(N, D)
+        y = np.sin(X.sum(axis=1)) * 2 + 0.3
+        P = O.n_kernel_params(kind, D) + 1
+        theta = 0.3 * rs.randn(P)
+        theta[-1] = np.log(1e-2)
+        norm_in = kind != "fabolas"
+        gp = O.OracleGP(kind, theta, normalize_output=nout, normalize_input=norm_in, lower=lower, upper=upper)
+        gp.train(X if norm_in else (X - lower) / (upper - lower), y)
+        Xt = (lower + (upper - lower) * rs.rand(6, D)) if norm_in else rs.rand(6, D)
+        dm, dv = gp.predictive_gradients(Xt)
+        assert dm.shape == (6, D, 1) and dv.shape == (6, D)
+        h = 1e-6
+        for d in range(D):
+            e = np.zeros(D)
+            e[d] = h
+            mp, vp = gp.predict(Xt + e, diag_only=True)
+            mm, vm = gp.predict(Xt - e, diag_only=True)
+            np.testing.assert_allclose(dm[:, d, 0], (mp - mm) / (2 * h), rtol=1e-6, atol=1e-7)
+            np.testing.assert_allclose(dv[:, d], (vp - vm) / (2 * h), rtol=1e-5, atol=1e-7)
