@@ -147,6 +147,14 @@ int32_t robo_cand_create_uniform(robo_ctx* ctx, int64_t m, int32_t dim, uint64_t
  * (loc = normalised incumbent, scale_d = 0.1 / (upper_d - lower_d)).                           */
 int32_t robo_cand_create_random(robo_ctx* ctx, int64_t m, int32_t dim, uint64_t seed, int64_t n_uniform,
                                 const double* loc, const double* scale, robo_cand** out);
+/* points first_index .. first_index + m - 1 of a (scrambled) Sobol' sequence in [0,1)^dim, generated on the device
+ * from the direction numbers sv (dim x bits, row-major) and the digital shift (dim):
+ *   x_k[d] = (shift[d] ^ XOR_{b in gray(k)} sv[d][b]) / 2^bits.   BASELINE config 5 names 2^20 Sobol candidates
+ * (scipy.stats.qmc.Sobol(d=64, scramble=True, seed=0).random_base2(20); the reference itself has no
+ * Sobol sampler); with sv / shift of a SciPy engine the sequence equals engine.random() bit for bit, and a rank of a
+ * candidate shard generates its own slice through first_index.                                            */
+int32_t robo_cand_create_sobol(robo_ctx* ctx, int64_t m, int32_t dim, const uint64_t* sv, const uint64_t* shift,
+                               int32_t bits, uint64_t first_index, robo_cand** out);
 int32_t robo_cand_get_points(robo_cand* cand, double* out_Xc);
 int32_t robo_cand_get_point(robo_cand* cand, int64_t index, double* out_x); /* one row: the winner */
 

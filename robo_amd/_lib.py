@@ -30,7 +30,7 @@ SYMBOLS = [
     "robo_gp_set_precision", "robo_theta_size",
     "robo_gp_fit", "robo_gp_loglik_batch", "robo_gp_fit_batch", "robo_gp_grad_loglik", "robo_gp_get_factor", "robo_gp_get_gram",
     "robo_cand_create", "robo_cand_destroy", "robo_cand_set_points", "robo_cand_create_uniform", "robo_cand_get_points",
-    "robo_cand_create_random", "robo_cand_get_point",
+    "robo_cand_create_random", "robo_cand_create_sobol", "robo_cand_get_point",
     "robo_gp_predict_cand", "robo_gp_predict", "robo_gp_predict_cov", "robo_gp_predict_grad", "robo_gp_predict_mixture_cand",
     "robo_acq_eval_cand", "robo_acq_eval", "robo_acq_eval_moments", "robo_acq_eval_marginal_cand", "robo_acq_eval_sum_cand",
     "robo_ig_eval_cand", "robo_ig_eval_moments", "robo_gp_cross_cov",
@@ -116,6 +116,7 @@ def lib():
         "robo_cand_create_uniform": [vp, i64, i32, C.c_uint64, pp],
         "robo_cand_get_points": [vp, _dp],
         "robo_cand_create_random": [vp, i64, i32, C.c_uint64, i64, _dp, _dp, pp],
+        "robo_cand_create_sobol": [vp, i64, i32, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), i32, C.c_uint64, pp],
         "robo_cand_get_point": [vp, i64, _dp],
         "robo_gp_predict_cand": [vp, vp, _dp, _dp],
         "robo_gp_predict": [vp, _dp, i64, _dp, _dp],
@@ -254,10 +255,25 @@ def default_context(device=None):
 class Candidates(object):
     """robo_cand: a device-resident candidate batch (normalised input space) + workspace."""
 
-    def __init__(self, ctx, Xc=None, m=None, dim=None, seed=None, n_uniform=None, loc=None, scale=None):
+    def __init__(self, ctx, Xc=None, m=None, dim=None, seed=None, n_uniform=None, loc=None, scale=None, sobol=None,
+                 first=0):
         self.ctx = ctx
         self._h = C.c_void_p()
-        if loc is not None:
+        if sobol is not None:
+            # sobol: a scipy.stats.qmc.Sobol engine (its direction numbers and digital shift are read, the engine is
+            # not advanced) or a (sv (dim, bits), shift (dim,), bits) triple; points first .. first + m - 1
+            if hasattr(sobol, "_sv"):
+                sv, shift, bits = sobol._sv, sobol._shift, int(sobol.bits)
+            else:
+                sv, shift, bits = sobol
+            sv = np.ascontiguousarray(sv, dtype=np.uint64)
+            shift = np.ascontiguousarray(shift, dtype=np.uint64)
+            assert sv.ndim == 2 and sv.shape[1] == bits and shift.shape == (sv.shape[0],)
+            self.m, self.dim = int(m), int(sv.shape[0])
+            u64p = C.POINTER(C.c_uint64)
+            check(lib().robo_cand_create_sobol(ctx._h, self.m, self.dim, sv.ctypes.data_as(u64p),
+                                               shift.ctypes.data_as(u64p), bits, int(first), C.byref(self._h)))
+        elif loc is not None:
             loc, scale = _f64(loc), _f64(scale)
             self.m, self.dim = int(m), int(loc.shape[0])
             assert scale.shape == loc.shape

@@ -280,6 +280,46 @@ int launch_argmax(robo_cand* cand, const double* d_vals, double div) {
     return ROBO_OK;
 }
 
+// Points first .. first + m - 1 of a (scrambled) Sobol' sequence, straight from the direction numbers:
+//     x_k[d] = (shift[d] ^ XOR_{b : bit b of gray(k) is set} sv[d][b]) * 2^-bits,     gray(k) = k ^ (k >> 1)
+// which is what SciPy's qmc.Sobol produces point after point (its _draw walks the Gray code incrementally); with
+// sv / shift taken from a scipy engine the device sequence is bit-identical to engine.random(), any slice of it
+// (fast_forward) included -- BASELINE config 5's 2^20 x 64 candidates never exist on the host and the 8 ranks of a
+// candidate shard generate their own slices.  Pad rows replicate point `first`.
+__global__ __launch_bounds__(256) void sobol_kernel(double* __restrict__ out, long long m, long long m_pad, int dim,
+                                                    const unsigned long long* __restrict__ sv,
+                                                    const unsigned long long* __restrict__ shift, int bits,
+                                                    unsigned long long first, double scale) {
+    const long long total = m_pad * dim;
+    for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long long)gridDim.x * 256) {
+        const long long row = e / dim;
+        const int d = (int)(e - row * dim);
+        const unsigned long long k = first + (unsigned long long)(row < m ? row : 0);
+        unsigned long long g = k ^ (k >> 1), x = shift[d];
+        const unsigned long long* v = sv + (size_t)d * bits;
+        while (g) {
+            const int b = __ffsll((long long)g) - 1;
+            x ^= v[b];
+            g &= g - 1;
+        }
+        out[e] = (double)x * scale;
+    }
+}
+
+int launch_sobol(robo_ctx* ctx, double* d_out, int64_t m, int64_t m_pad, int dim, const unsigned long long* d_sv,
+                 const unsigned long long* d_shift, int bits, uint64_t first) {
+    const long long total = (long long)m_pad * dim;
+    int blocks = (int)((total + 255) / 256);
+    if (blocks > 8192) blocks = 8192;
+    if (blocks < 1) blocks = 1;
+    double scale = 1.0;
+    for (int b = 0; b < bits; ++b) scale *= 0.5;
+    hipLaunchKernelGGL(sobol_kernel, dim3(blocks), dim3(256), 0, ctx->stream, d_out, (long long)m, (long long)m_pad, dim,
+                       d_sv, d_shift, bits, (unsigned long long)first, scale);
+    ROBO_LAUNCH_CHECK();
+    return ROBO_OK;
+}
+
 int launch_uniform(robo_ctx* ctx, double* d_out, int64_t m, int64_t m_pad, int dim, uint64_t seed) {
     const long long pairs = ((long long)m_pad * dim + 1) / 2;
     int blocks = (int)((pairs + 255) / 256);

@@ -595,6 +595,41 @@ int32_t robo_cand_create_uniform(robo_ctx* ctx, int64_t m, int32_t dim, uint64_t
     return ROBO_OK;
 }
 
+int32_t robo_cand_create_sobol(robo_ctx* ctx, int64_t m, int32_t dim, const uint64_t* sv, const uint64_t* shift,
+                               int32_t bits, uint64_t first_index, robo_cand** out) {
+    if (!sv || !shift || bits < 1 || bits > 64) return ROBO_BAD_ARGUMENT;
+    if (bits < 64 && (first_index + (uint64_t)m) > (1ull << bits)) {
+        set_error("Sobol: points %llu .. %llu exceed 2^%d", (unsigned long long)first_index,
+                  (unsigned long long)(first_index + (uint64_t)m), bits);
+        return ROBO_BAD_SHAPE;
+    }
+    robo_cand* k = nullptr;
+    ROBO_TRY(cand_alloc(ctx, m, dim, &k));
+    // the direction numbers (dim x bits) and the digital shift (dim) ride in the still unused scaled-candidate buffer
+    if ((size_t)dim * bits + dim > (size_t)k->m_pad * dim) {
+        robo_cand_destroy(k);
+        set_error("Sobol: batch too small to stage the direction numbers (m_pad %lld < bits + 1)", (long long)k->m_pad);
+        return ROBO_BAD_SHAPE;
+    }
+    unsigned long long* d_sv = reinterpret_cast<unsigned long long*>(k->d_Xcs);
+    unsigned long long* d_shift = d_sv + (size_t)dim * bits;
+    int st = ROBO_OK;
+    hipError_t e = hipMemcpyAsync(d_sv, sv, (size_t)dim * bits * sizeof(uint64_t), hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(d_shift, shift, (size_t)dim * sizeof(uint64_t), hipMemcpyHostToDevice, ctx->stream);
+    if (e != hipSuccess) {
+        set_error("Sobol: upload of the direction numbers failed: %s", hipGetErrorString(e));
+        st = ROBO_RUNTIME_ERROR;
+    }
+    if (st == ROBO_OK) st = launch_sobol(ctx, k->d_Xc, m, k->m_pad, dim, d_sv, d_shift, bits, first_index);
+    if (st == ROBO_OK && hipStreamSynchronize(ctx->stream) != hipSuccess) st = ROBO_RUNTIME_ERROR;
+    if (st != ROBO_OK) {
+        robo_cand_destroy(k);
+        return st;
+    }
+    *out = k;
+    return ROBO_OK;
+}
+
 int32_t robo_cand_create_random(robo_ctx* ctx, int64_t m, int32_t dim, uint64_t seed, int64_t n_uniform,
                                 const double* loc, const double* scale, robo_cand** out) {
     if (!loc || !scale || n_uniform < 0 || n_uniform > m) return ROBO_BAD_ARGUMENT;

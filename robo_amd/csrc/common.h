@@ -179,6 +179,8 @@ int launch_ig_dh(robo_ctx* ctx, const double* d_S, const double* d_var, double* 
 int launch_random_candidates(robo_ctx* ctx, double* d_out, int64_t m_pad, int dim, uint64_t seed, int64_t n_uniform,
                              const double* d_loc, const double* d_scale);
 int launch_uniform(robo_ctx* ctx, double* d_out, int64_t m, int64_t m_pad, int dim, uint64_t seed);
+int launch_sobol(robo_ctx* ctx, double* d_out, int64_t m, int64_t m_pad, int dim, const unsigned long long* d_sv,
+                 const unsigned long long* d_shift, int bits, uint64_t first);
 int launch_mfma_selftest(robo_ctx* ctx, double* out_err);
 int launch_gemm_microbench(robo_ctx* ctx, int variant, int wgs, int K, int reps, double* out_tflops);
 int launch_mfma_microbench(robo_ctx* ctx, int iters, double* out_tflops, double* out_cycles_per_mfma,

@@ -1,1 +1,2 @@
-from robo_amd.maximizers.random_sampling import BaseMaximizer, DeviceRandomSampling, RandomSampling  # noqa: F401
+from robo_amd.maximizers.random_sampling import (BaseMaximizer, DeviceRandomSampling, DeviceSobolSampling,  # noqa: F401
+                                                    RandomSampling)

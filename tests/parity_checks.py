@@ -674,3 +674,31 @@ def check_predictive_gradients(ctx, cases=(("matern52", 70, 3, 9), ("rbf", 150, 
             assert np.all(xc >= lower) and np.all(xc <= upper)
         if getattr(model, "gp", None) is not None:
             model.gp.close()
+
+
+def check_sobol_candidates(ctx, dims=(3, 64), m=1000):
+    """robo_cand_create_sobol == scipy.stats.qmc.Sobol(scramble=True) bit for bit, any slice of the sequence
+    (the per-rank slices of BASELINE config 5's candidate shard), and the unscrambled sequence too"""
+    from scipy.stats import qmc
+    for d in dims:
+        for scramble in (True, False):
+            eng = qmc.Sobol(d=d, scramble=scramble, seed=0)
+            c = _lib.Candidates(ctx, m=m, sobol=eng, first=0)
+            got = c.points()
+            c.close()
+            ref = qmc.Sobol(d=d, scramble=scramble, seed=0)
+            import warnings
+            with warnings.catch_warnings():
+                warnings.simplefilter("ignore")
+                want = ref.random(m)
+            np.testing.assert_array_equal(got, want)
+            assert got.min() >= 0.0 and got.max() < 1.0
+            # a later slice (rank 3 of 8 with 300 points per rank)
+            c = _lib.Candidates(ctx, m=300, sobol=eng, first=900)
+            ref = qmc.Sobol(d=d, scramble=scramble, seed=0)
+            ref.fast_forward(900)
+            with warnings.catch_warnings():
+                warnings.simplefilter("ignore")
+                want = ref.random(300)
+            np.testing.assert_array_equal(c.points(), want)
+            c.close()

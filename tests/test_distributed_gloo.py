@@ -132,6 +132,15 @@ def _class_worker(rank, world, port, out_dir):
             best = (vals[j], pts[j])
         c.close()
     np.testing.assert_allclose(x_dev, best[1], rtol=1e-13)
+    # Sobol candidates: per-rank slices of ONE sequence -> exactly the single-process winner
+    from robo_amd.maximizers import DeviceSobolSampling
+    from scipy.stats import qmc
+    x_sob = DeviceSobolSampling(acq, lo, hi, n_samples=513, seed=4).maximize()
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        pts = lo + (hi - lo) * qmc.Sobol(d=D, scramble=True, seed=4).random(513)
+    np.testing.assert_array_equal(x_sob, pts[int(np.argmax(acq.compute(pts)))])
     dist.barrier()
     dist.destroy_process_group()
 

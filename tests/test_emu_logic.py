@@ -139,3 +139,7 @@ def test_multi_panel_factorisation(emu_ctx):
 
 def test_predictive_gradients(emu_ctx):
     P.check_predictive_gradients(emu_ctx, cases=(("matern52", 70, 3, 9), ("fabolas", 60, 3, 7)))
+
+
+def test_sobol_candidates(emu_ctx):
+    P.check_sobol_candidates(emu_ctx, dims=(3, 17), m=300 + 900)

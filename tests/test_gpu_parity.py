@@ -341,3 +341,16 @@ def test_predictive_gradients(ctx):
     """f4: d mean / d x, d var / d x on the device and derivative=True of EI / PI / LCB"""
     P.check_predictive_gradients(ctx)
     P.check_predictive_gradients(ctx, cases=(("matern52", 1500, 16, 300),))
+
+
+def test_sobol_candidates(ctx):
+    """f2: scrambled-Sobol candidates generated on the device == SciPy's sequence; 2^20 x 64 stays on the device"""
+    P.check_sobol_candidates(ctx, dims=(3, 64), m=4096)
+    from scipy.stats import qmc
+    eng = qmc.Sobol(d=64, scramble=True, seed=0)
+    c = _lib.Candidates(ctx, m=2 ** 20, sobol=eng)             # config 5's full candidate set: 537 MB, generated in HBM
+    p = c.point(2 ** 20 - 1)
+    ref = qmc.Sobol(d=64, scramble=True, seed=0)
+    ref.fast_forward(2 ** 20 - 1)
+    np.testing.assert_array_equal(p, ref.random(1)[0])
+    c.close()
