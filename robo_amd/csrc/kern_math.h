@@ -20,6 +20,66 @@ __device__ __forceinline__ T matern52_unit(T r2) {
     return (T(1) + s + T(5) * r2 / T(3)) * exp(-s);
 }
 
+// fp64 specialisation.  K1 (gram_kernel) is bound by fp64 VALU issue, not by HBM (r02i PMC: 111 VALU instructions per
+// pair, >= 61 % of the kernel's cycles with every one at full rate), and about half of those instructions were
+// the library expansions of sqrt() and exp() with their denormal / overflow / special-value handling.  Here the
+// argument ranges are known: t = 5 r2 >= 0 finite, and exp only ever sees -s in (-inf, 0].
+//   sqrt:  y = v_rsq_f64(t) with one third-order correction, s0 = t y, s = s0 + (t - s0^2) y / 2   (<= 1 ulp; t = 0 -> 0)
+//   exp:   n = rint(-s log2 e), r = -s - n ln2 (two-constant Cody-Waite), |r| <= 0.347, degree-12 Taylor
+//          polynomial by Horner (remainder 0.347^13 / 13! = 1.7e-16), scaled by 2^n with v_ldexp_f64;
+//          below -745 the result underflows to 0 like the library's.
+// Same formula as before, so values agree with the oracle to a few ulp (tests: rtol 1e-13 on K).
+__device__ __forceinline__ double pos_sqrt(double t) {
+    double y = __builtin_amdgcn_rsq(t);                   // ~2^-23 relative
+    const double e = fma(-t * y, y, 1.0);
+    y = fma(y * e, fma(e, 0.375, 0.5), y);                // third-order correction: ~e^3
+    const double s0 = t * y;
+    const double s = fma(fma(-s0, s0, t), 0.5 * y, s0);   // final rounding step
+    return t > 0.0 ? s : 0.0;                             // rsq(0) = inf: 0 * inf
+}
+
+__device__ __forceinline__ double exp_nonpos(double x) {   // x <= 0
+    const double n = rint(x * 1.4426950408889634074);
+    double r = fma(n, -6.93147180369123816490e-01, x);     // ln2 hi (low bits zero: n * hi is exact)
+    r = fma(n, -1.90821492927058770002e-10, r);            // ln2 lo
+    double p = 2.08767569878680989792e-09;                  // 1/12!
+    p = fma(p, r, 2.50521083854417187751e-08);              // 1/11!
+    p = fma(p, r, 2.75573192239858906526e-07);              // 1/10!
+    p = fma(p, r, 2.75573192239858906526e-06);              // 1/9!
+    p = fma(p, r, 2.48015873015873015873e-05);              // 1/8!
+    p = fma(p, r, 1.98412698412698412698e-04);              // 1/7!
+    p = fma(p, r, 1.38888888888888888889e-03);              // 1/6!
+    p = fma(p, r, 8.33333333333333333333e-03);              // 1/5!
+    p = fma(p, r, 4.16666666666666666667e-02);              // 1/4!
+    p = fma(p, r, 1.66666666666666666667e-01);              // 1/3!
+    p = fma(p, r, 0.5);
+    p = fma(p, r, 1.0);
+    p = fma(p, r, 1.0);
+    return x < -745.2 ? 0.0 : ldexp(p, (int)n);
+}
+
+// exp of a non-positive argument: the trimmed fp64 form above, the library's for fp32
+template <class T>
+__device__ __forceinline__ T exp_np(T x) {
+    return exp(x);
+}
+#ifndef ROBO_TRIMMED_MATH
+#define ROBO_TRIMMED_MATH 1     // 0: the library's sqrt()/exp() everywhere (A/B builds)
+#endif
+#if ROBO_TRIMMED_MATH
+template <>
+__device__ __forceinline__ double exp_np<double>(double x) {
+    return exp_nonpos(x);
+}
+
+template <>
+__device__ __forceinline__ double matern52_unit<double>(double r2) {
+    const double t = 5.0 * r2;
+    const double s = pos_sqrt(t);
+    return (1.0 + s + t * (1.0 / 3.0)) * exp_nonpos(-s);
+}
+#endif
+
 // KIND < 0: decided at run time from p.kind (cold paths); otherwise compiled in (the tiled
 // gram kernels are instantiated per kind: a run-time branch in their inner loop cost 2x)
 template <class T, int KIND = -1>
@@ -49,7 +109,7 @@ template <class T, int KIND = -1>
 __device__ __forceinline__ double cov_finish(const CovParams& p, T acc, T uu) {
     const int kind = KIND < 0 ? p.kind : KIND;
     if (kind == ROBO_KERNEL_MATERN52_ARD) return (double)(T(p.amp) * matern52_unit(acc));
-    if (kind == ROBO_KERNEL_RBF_ARD) return (double)(T(p.amp) * exp(T(-0.5) * acc));
+    if (kind == ROBO_KERNEL_RBF_ARD) return (double)(T(p.amp) * exp_np(T(-0.5) * acc));
     return (double)(T(p.amp) * acc * (T(p.blr_a) + T(p.blr_b) * uu));
 }
 

@@ -40,6 +40,34 @@ def test_config2_subset(ctx):
     P.check_case(ctx, "config2_sub", full=True)
 
 
+def test_config2_full_size(ctx):
+    """BASELINE config 2 at its stated size: N=1024, D=8, ALL 65 536 candidates -- posterior, EI values and the
+    argmax index against the oracle (which evaluates every candidate on the box's host cores, ~70 GFLOP)"""
+    N, D, M = 1024, 8, 65536
+    X, y, theta, Xc = _headline_inputs(N, D, M)
+    g = _lib.DeviceGP(ctx, "matern52", N, D)
+    g.set_data(X, y)
+    ogp = O.OracleGP("matern52", theta, lower=np.zeros(D), upper=np.ones(D))
+    ogp.train(X, y)
+    np.testing.assert_allclose(g.fit(theta, float(y.mean())), ogp.loglikelihood(theta), rtol=LOGLIK_RTOL)
+    eta = float(y.min())
+    cand = _lib.Candidates(ctx, Xc)
+    vals, mx, am, _ = g.acq("ei", 0.0, eta, cand)
+    mu, var = g.predict(cand)
+    mo, vo = ogp.predict(Xc, diag_only=True)
+    np.testing.assert_allclose(mu, mo, rtol=MU_RTOL, atol=MU_ATOL)
+    np.testing.assert_allclose(var, vo, rtol=0, atol=VAR_ATOL_REL_AMP)
+    eo = O.ei(mo, vo, eta)
+    well = np.abs((eta - mo) / np.sqrt(vo)) < 8
+    np.testing.assert_allclose(vals[well], eo[well], rtol=1e-6, atol=1e-12)
+    want = int(np.argmax(eo))
+    srt = np.sort(eo)
+    assert am == want or srt[-1] - srt[-2] <= 1e-7 * srt[-1]
+    assert am == int(np.argmax(vals)) and mx == vals[am]
+    cand.close()
+    g.close()
+
+
 def test_mcmc_marginal(ctx):
     P.check_mcmc_marginal(ctx)
 
