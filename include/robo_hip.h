@@ -234,7 +234,7 @@ int32_t robo_selftest_mfma_layout(robo_ctx* ctx, double* out_max_err);
 int32_t robo_microbench_mfma_f64(robo_ctx* ctx, int32_t iters, double* out_tflops);
 /* shader-clock offsets of the phase boundaries of one potrf_diag_kernel (panel 0 of the gram
  * matrix at theta): load, potf2(0), sub-panel(0), steps 0..6, inverse, write-back              */
-int32_t robo_selftest_diag_timeline(robo_gp* gp, const double* theta, double* out13);
+int32_t robo_selftest_diag_timeline(robo_gp* gp, const double* theta, double* out17);
 /* out3[4] = {full-chip TFLOP/s, shader cycles per MFMA of one wave alone (8 independent
  * accumulators), shader MHz under load, cycles per MFMA in a fully dependent chain}            */
 int32_t robo_microbench_mfma_f64_detail(robo_ctx* ctx, int32_t iters, double* out3);

@@ -389,7 +389,7 @@ class DeviceGP(object):
 
     def diag_timeline(self, theta):
         theta = _f64(theta, (self.n_theta,))
-        out = np.zeros(13)
+        out = np.zeros(17)
         check(lib().robo_selftest_diag_timeline(self._h, _arr(theta), _arr(out)))
         return out
 

@@ -1170,14 +1170,15 @@ int32_t robo_selftest_diag_timeline(robo_gp* g, const double* theta, double* out
     g->fitted = false;
     ROBO_TRY(gp_build_gram(g, theta, 0.0));
     long long* d = nullptr;
-    ROBO_HIP_CHECK(hipMalloc((void**)&d, 16 * sizeof(long long)));
-    ROBO_HIP_CHECK(hipMemsetAsync(d, 0, 16 * sizeof(long long), g->ctx->stream));
+    ROBO_HIP_CHECK(hipMalloc((void**)&d, 24 * sizeof(long long)));
+    ROBO_HIP_CHECK(hipMemsetAsync(d, 0, 24 * sizeof(long long), g->ctx->stream));
     ROBO_TRY(launch_diag_timeline(g, d));
-    long long h[16];
+    long long h[24];
     ROBO_HIP_CHECK(hipMemcpyAsync(h, d, sizeof(h), hipMemcpyDeviceToHost, g->ctx->stream));
     ROBO_HIP_CHECK(hipStreamSynchronize(g->ctx->stream));
     ROBO_HIP_CHECK(hipFree(d));
     for (int i = 0; i < 13; ++i) out13[i] = (double)(h[i] - h[0]);
+    for (int i = 0; i < 4; ++i) out13[13 + i] = (double)(h[16 + i] - h[16]);   // panel kernel (out has 17 entries)
     return ROBO_OK;
 }
 

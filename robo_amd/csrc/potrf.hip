@@ -378,8 +378,21 @@ __global__ __launch_bounds__(256) void potrf_diag_kernel(double* __restrict__ K,
 // from the LDS image of the diagonal block: 36 products = 144 MFMAs per strip, no LDS round trip on the chain.
 constexpr int PANEL_SMEM_DOUBLES = (NBLK + NSB) * BLK;   // 36 blocks of L_kk + 8 W_ss: 88 KB
 
+// Within every 16-block the panel kernel indexes panel columns through the 4x4 index transpose pi(a) = (a >> 2) | ((a & 3) << 2)
+// (an involution): register r of lane (i = l & 15, g = l >> 4) of an accumulator-layout Y_s is then X[strip row i][16 s + 4 g + r],
+// i.e. FOUR CONSECUTIVE doubles of the strip's row -- the strip is loaded and stored with 16-byte accesses (r02o: the
+// 8-byte column-strided form cost 11.2k cycles of loads and 7k of stores around a 11.8k-cycle chain).  The LDS images of
+// L_sc and W_ss are permuted the same way in rows and columns when they are staged, which costs nothing.
+__device__ __forceinline__ constexpr int pi16(int a) { return (a >> 2) | ((a & 3) << 2); }
+__device__ __forceinline__ constexpr int tri_row(int b) {      // block index -> (bi, bj) of blk_off, compile time
+    int i = 0;
+    while ((i + 1) * (i + 2) / 2 <= b) ++i;
+    return i;
+}
+
 __global__ __launch_bounds__(256) void potrf_panel_kernel(double* __restrict__ K, size_t k_stride, int ld, int k,
-                                                          const double* __restrict__ Linv, size_t linv_stride) {
+                                                          const double* __restrict__ Linv, size_t linv_stride,
+                                                          long long* __restrict__ dbg) {
     __shared__ double smem[PANEL_SMEM_DOUBLES];
     double* sL = smem;
     double* sWd = smem + NBLK * BLK;      // W_ss, s = 0..7
@@ -388,20 +401,45 @@ __global__ __launch_bounds__(256) void potrf_panel_kernel(double* __restrict__ K
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const double* Kd = K + ((size_t)k * NB) * ld + (size_t)k * NB;
     const double* Wg = Linv + (size_t)k * NB * NB;
-    // this strip's rows, transposed into the accumulator layout: register r of lane l <- A[row l & 15][16 s + (l >> 4) + 4 r]
+    if (dbg && tid == 0 && blockIdx.x == 0) dbg[0] = clock64();
+    // this strip's rows in the (column-permuted) accumulator layout: registers 0..3 of lane l <- A[row l & 15][16 s + 4 (l >> 4) + 0..3]
     const size_t row = (size_t)(k + 1) * NB + (size_t)blockIdx.x * 64 + wave * 16 + (lane & 15);
-    double* Arow = K + row * ld + (size_t)k * NB + (lane >> 4);
+    double* Arow = K + row * ld + (size_t)k * NB + 4 * (lane >> 4);
     v4d y[NSB];
 #pragma unroll
-    for (int s = 0; s < NSB; ++s)
+    for (int s = 0; s < NSB; ++s) {
+        const double2* p = reinterpret_cast<const double2*>(Arow + s * SB);
+        const double2 lo = p[0], hi = p[1];
+        y[s] = v4d{lo.x, lo.y, hi.x, hi.y};
+    }
+    // stage L_kk (36 blocks) and the eight W_ss, two adjacent columns per thread and step, rows and columns permuted
+    {
+        const int half = tid >> 7, pr = tid & 127, r = pr >> 3, c = (pr & 7) * 2;
+        const int pos0 = bidx(pi16(r), pi16(c)), pos1 = bidx(pi16(r), pi16(c + 1));
+        double2 v[(NBLK + NSB) / 2];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) y[s][r] = Arow[s * SB + 4 * r];
-    for (int bi = 0; bi < NSB; ++bi) {
-        for (int bj = 0; bj <= bi; ++bj)
-            sL[blk_off(bi, bj) + bidx(tid >> 4, tid & 15)] = Kd[(size_t)(bi * SB + (tid >> 4)) * ld + bj * SB + (tid & 15)];
-        sWd[bi * BLK + bidx(tid >> 4, tid & 15)] = Wg[(bi * SB + (tid >> 4)) * NB + bi * SB + (tid & 15)];
+        for (int e = 0; e < (NBLK + NSB) / 2; ++e) {
+            const int b0 = 2 * e, b1 = 2 * e + 1;        // this step's two blocks (threads 0..127 / 128..255)
+            const double* src;
+            if (b0 < NBLK) {
+                const int bi0 = tri_row(b0), bj0 = b0 - bi0 * (bi0 + 1) / 2, bi1 = tri_row(b1), bj1 = b1 - bi1 * (bi1 + 1) / 2;
+                const int bi = half ? bi1 : bi0, bj = half ? bj1 : bj0;
+                src = Kd + (size_t)(bi * SB + r) * ld + bj * SB + c;
+            } else {
+                const int sblk = (half ? b1 : b0) - NBLK;
+                src = Wg + (sblk * SB + r) * NB + sblk * SB + c;
+            }
+            v[e] = *reinterpret_cast<const double2*>(src);
+        }
+#pragma unroll
+        for (int e = 0; e < (NBLK + NSB) / 2; ++e) {
+            double* dst = smem + (2 * e + half) * BLK;     // blocks 36..43 are the W_ss: sWd = smem + 36 BLK
+            dst[pos0] = v[e].x;
+            dst[pos1] = v[e].y;
+        }
     }
     __syncthreads();
+    if (dbg && tid == 0 && blockIdx.x == 0) dbg[1] = clock64();
 #pragma unroll
     for (int s = 0; s < NSB; ++s) {
         v4d t = y[s];
@@ -417,10 +455,14 @@ __global__ __launch_bounds__(256) void potrf_panel_kernel(double* __restrict__ K
         for (int r = 0; r < 4; ++r) o = mfma_f64(w.v[r], t[r], o);
         y[s] = o;
     }
+    if (dbg && tid == 0 && blockIdx.x == 0) dbg[2] = clock64() + (long long)(y[NSB - 1][0] == 12345.678);
 #pragma unroll
-    for (int s = 0; s < NSB; ++s)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) Arow[s * SB + 4 * r] = y[s][r];
+    for (int s = 0; s < NSB; ++s) {
+        double2* p = reinterpret_cast<double2*>(Arow + s * SB);
+        p[0] = make_double2(y[s][0], y[s][1]);
+        p[1] = make_double2(y[s][2], y[s][3]);
+    }
+    if (dbg && tid == 0 && blockIdx.x == 0) dbg[3] = clock64();
 }
 
 // Off-diagonal 16x16 blocks of the inverses W = L_kk^-1 of ALL diagonal blocks at once (one workgroup per block,
@@ -647,7 +689,7 @@ int launch_potrf(robo_gp* gp, const FitBuffers& fb) {
                        fb.Linv, fb.linv_stride, fb.fail, (long long*)nullptr)
 #define ROBO_PANEL(KK)                                                                                         \
     hipLaunchKernelGGL(potrf_panel_kernel, dim3((nb - (KK)-1) * 2, S), dim3(256), 0, ctx->stream, fb.K,        \
-                       fb.k_stride, ld, (KK), (const double*)fb.Linv, fb.linv_stride)
+                       fb.k_stride, ld, (KK), (const double*)fb.Linv, fb.linv_stride, (long long*)nullptr)
 #define ROBO_STEP(TM, F, GRID, BASE, KOP, DEPTH, FIRST)                                                        \
     hipLaunchKernelGGL((potrf_step_kernel<TM, F>), dim3((GRID), S), dim3(256), 0, ctx->stream, fb.K, fb.k_stride, \
                        ld, (BASE), gp->n, fb.Linv, fb.linv_stride, fb.fail, (KOP), (DEPTH), (FIRST))
@@ -706,6 +748,11 @@ int launch_potrf(robo_gp* gp, const FitBuffers& fb) {
 int launch_diag_timeline(robo_gp* gp, long long* d_stamps) {
     hipLaunchKernelGGL(potrf_diag_kernel, dim3(1), dim3(256), 0, gp->ctx->stream, gp->d_K, (size_t)0, gp->n_pad, 0,
                        gp->n, gp->d_Linv, (size_t)0, gp->ctx->d_fail, d_stamps);
+    // ... and the panel solve below it (stamps 16..19: start, operands in LDS, chain done, stored)
+    const int nb = gp->n_pad / NB;
+    if (nb > 1)
+        hipLaunchKernelGGL(potrf_panel_kernel, dim3((nb - 1) * 2, 1), dim3(256), 0, gp->ctx->stream, gp->d_K, (size_t)0,
+                           gp->n_pad, 0, (const double*)gp->d_Linv, (size_t)0, d_stamps + 16);
     ROBO_LAUNCH_CHECK();
     return ROBO_OK;
 }

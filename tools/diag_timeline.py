@@ -13,5 +13,8 @@ for _ in range(3):
     t = g.diag_timeline(theta)
 names = ["start", "load", "potf2(0)", "subpanel(0)"] + ["step%d" % i for i in range(7)] + ["inverse", "writeback"]
 prev = 0
-for n, v in zip(names, t):
+for n, v in zip(names, t[:13]):
     print("%-12s %8.0f cycles  (+%6.0f)" % (n, v, v - prev)); prev = v
+prev = 0
+for n, v in zip(["panel start", "operands in LDS", "144-MFMA chain", "stored"], t[13:17]):
+    print("%-16s %8.0f cycles  (+%6.0f)" % (n, v, v - prev)); prev = v
