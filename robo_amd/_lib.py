@@ -15,6 +15,7 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 DEFAULT_LIBRARY = os.path.join(_HERE, "librobo_hip.so")
+DEFAULT_DIAG_LIBRARY = os.path.join(_HERE, "librobo_hip_diag.so")   # self-checks / micro-benchmarks (not product)
 
 OK, NOT_POSITIVE_DEFINITE, NOT_FITTED, BAD_SHAPE, RUNTIME_ERROR, BAD_ARGUMENT = range(6)
 KERNEL_KINDS = {"matern52": 0, "rbf": 1, "fabolas": 2}
@@ -34,6 +35,9 @@ SYMBOLS = [
     "robo_gp_predict_cand", "robo_gp_predict", "robo_gp_predict_cov", "robo_gp_predict_grad", "robo_gp_predict_mixture_cand",
     "robo_acq_eval_cand", "robo_acq_eval", "robo_acq_eval_moments", "robo_acq_eval_marginal_cand", "robo_acq_eval_sum_cand",
     "robo_ig_eval_cand", "robo_ig_eval_moments", "robo_gp_cross_cov",
+]
+# include/robo_hip_diag.h (librobo_hip_diag.so: tests, bench.py's roofline block, tools/)
+DIAG_SYMBOLS = [
     "robo_selftest_mfma_layout", "robo_microbench_mfma_f64", "robo_microbench_mfma_f64_detail", "robo_microbench_gemm_f64",
     "robo_selftest_diag_timeline",
 ]
@@ -49,6 +53,7 @@ class RoboHipError(RuntimeError):
 
 _lib = None
 _lib_path = None
+_diag = None
 _dp = C.POINTER(C.c_double)
 
 
@@ -65,8 +70,9 @@ def _f64(a, shape=None):
 
 def use_library(path):
     """Point the binding at another build of the same C ABI (test hook)."""
-    global _lib, _lib_path, _default_ctx
+    global _lib, _lib_path, _default_ctx, _diag
     _lib = None
+    _diag = None
     _lib_path = path
     _default_ctx = {}
 
@@ -132,11 +138,6 @@ def lib():
         "robo_ig_eval_cand": [vp, vp, vp, i32, dbl, _dp, _dp, _dp, _dp, _dp, _dp, _dp, _dp, C.POINTER(i64)],
         "robo_ig_eval_moments": [vp, i64, i32, i32, dbl, _dp, _dp, _dp, _dp, _dp, _dp, _dp, _dp, _dp],
         "robo_gp_cross_cov": [vp, vp, vp, _dp],
-        "robo_selftest_mfma_layout": [vp, _dp],
-        "robo_microbench_mfma_f64": [vp, i32, _dp],
-        "robo_microbench_mfma_f64_detail": [vp, i32, _dp],
-        "robo_microbench_gemm_f64": [vp, i32, i32, i32, i32, _dp],
-        "robo_selftest_diag_timeline": [vp, _dp, _dp],
     }
     for name, args in sig.items():
         fn = getattr(L, name)
@@ -152,6 +153,28 @@ def lib():
         raise RoboHipUnavailable("librobo_hip loaded but no HIP device is visible (robo_amd has no CPU fallback)")
     _lib = L
     return L
+
+
+def diag():
+    """the diagnostics library (self-checks, micro-benchmarks); the interpreter build of the tests is monolithic"""
+    global _diag
+    if _diag is not None:
+        return _diag
+    lib()                                            # the product library first (the diagnostics link against it)
+    path = _lib_path or DEFAULT_DIAG_LIBRARY
+    if not os.path.exists(path):
+        raise RoboHipUnavailable("%s not found: build it with `python -m robo_amd.build`" % path)
+    D = C.CDLL(path)
+    vp, i32 = C.c_void_p, C.c_int32
+    for name, args in {"robo_selftest_mfma_layout": [vp, _dp], "robo_microbench_mfma_f64": [vp, i32, _dp],
+                       "robo_microbench_mfma_f64_detail": [vp, i32, _dp],
+                       "robo_microbench_gemm_f64": [vp, i32, i32, i32, i32, _dp],
+                       "robo_selftest_diag_timeline": [vp, _dp, _dp]}.items():
+        fn = getattr(D, name)
+        fn.argtypes = args
+        fn.restype = i32
+    _diag = D
+    return D
 
 
 def last_error():
@@ -218,24 +241,24 @@ class Context(object):
 
     def selftest_mfma_layout(self):
         e = C.c_double(0)
-        check(lib().robo_selftest_mfma_layout(self._h, C.byref(e)))
+        check(diag().robo_selftest_mfma_layout(self._h, C.byref(e)))
         return e.value
 
     def microbench_mfma_f64_detail(self, iters=2000):
         """-> dict(full-chip tflops, issue interval of one lone wave in shader cycles, MHz under load)"""
         out = np.zeros(4)
-        check(lib().robo_microbench_mfma_f64_detail(self._h, int(iters), _arr(out)))
+        check(diag().robo_microbench_mfma_f64_detail(self._h, int(iters), _arr(out)))
         return {"tflops": out[0], "cycles_per_mfma_single_wave": out[1], "shader_mhz": out[2],
                 "cycles_per_mfma_dependent_chain": out[3]}
 
     def microbench_gemm_f64(self, variant, wgs=512, k=4096, reps=5):
         out = np.zeros(2)
-        check(lib().robo_microbench_gemm_f64(self._h, int(variant), int(wgs), int(k), int(reps), _arr(out)))
+        check(diag().robo_microbench_gemm_f64(self._h, int(variant), int(wgs), int(k), int(reps), _arr(out)))
         return float(out[0]), float(out[1])    # TFLOP/s, shader MHz
 
     def microbench_mfma_f64(self, iters=2000):
         t = C.c_double(0)
-        check(lib().robo_microbench_mfma_f64(self._h, int(iters), C.byref(t)))
+        check(diag().robo_microbench_mfma_f64(self._h, int(iters), C.byref(t)))
         return t.value
 
 
@@ -390,7 +413,7 @@ class DeviceGP(object):
     def diag_timeline(self, theta):
         theta = _f64(theta, (self.n_theta,))
         out = np.zeros(17)
-        check(lib().robo_selftest_diag_timeline(self._h, _arr(theta), _arr(out)))
+        check(diag().robo_selftest_diag_timeline(self._h, _arr(theta), _arr(out)))
         return out
 
     def predict(self, Xc):

@@ -1152,47 +1152,4 @@ int32_t robo_ig_eval_moments(robo_ctx* ctx, int64_t m, int32_t nb, int32_t npts,
 }
 
 // ---------------------------------------------------------------------------------------
-int32_t robo_selftest_mfma_layout(robo_ctx* ctx, double* out_max_err) {
-    if (!ctx || !out_max_err) return ROBO_BAD_ARGUMENT;
-    ROBO_HIP_CHECK(hipSetDevice(ctx->device));
-    return launch_mfma_selftest(ctx, out_max_err);
-}
-
-int32_t robo_microbench_mfma_f64(robo_ctx* ctx, int32_t iters, double* out_tflops) {
-    if (!ctx || !out_tflops || iters < 1) return ROBO_BAD_ARGUMENT;
-    ROBO_HIP_CHECK(hipSetDevice(ctx->device));
-    return launch_mfma_microbench(ctx, iters, out_tflops, nullptr, nullptr, nullptr);
-}
-
-int32_t robo_selftest_diag_timeline(robo_gp* g, const double* theta, double* out13) {
-    if (!g || !theta || !out13) return ROBO_BAD_ARGUMENT;
-    if (!g->has_data) return ROBO_NOT_FITTED;
-    g->fitted = false;
-    ROBO_TRY(gp_build_gram(g, theta, 0.0));
-    long long* d = nullptr;
-    ROBO_HIP_CHECK(hipMalloc((void**)&d, 24 * sizeof(long long)));
-    ROBO_HIP_CHECK(hipMemsetAsync(d, 0, 24 * sizeof(long long), g->ctx->stream));
-    ROBO_TRY(launch_diag_timeline(g, d));
-    long long h[24];
-    ROBO_HIP_CHECK(hipMemcpyAsync(h, d, sizeof(h), hipMemcpyDeviceToHost, g->ctx->stream));
-    ROBO_HIP_CHECK(hipStreamSynchronize(g->ctx->stream));
-    ROBO_HIP_CHECK(hipFree(d));
-    for (int i = 0; i < 13; ++i) out13[i] = (double)(h[i] - h[0]);
-    for (int i = 0; i < 4; ++i) out13[13 + i] = (double)(h[16 + i] - h[16]);   // panel kernel (out has 17 entries)
-    return ROBO_OK;
-}
-
-int32_t robo_microbench_gemm_f64(robo_ctx* ctx, int32_t variant, int32_t wgs, int32_t k, int32_t reps,
-                                 double* out_tflops) {
-    if (!ctx || !out_tflops) return ROBO_BAD_ARGUMENT;
-    ROBO_HIP_CHECK(hipSetDevice(ctx->device));
-    return launch_gemm_microbench(ctx, variant, wgs, k, reps, out_tflops);
-}
-
-int32_t robo_microbench_mfma_f64_detail(robo_ctx* ctx, int32_t iters, double* out3) {
-    if (!ctx || !out3 || iters < 1) return ROBO_BAD_ARGUMENT;
-    ROBO_HIP_CHECK(hipSetDevice(ctx->device));
-    return launch_mfma_microbench(ctx, iters, out3, out3 + 1, out3 + 2, out3 + 3);
-}
-
 }  // extern "C"

@@ -12,8 +12,8 @@
 //    2 % SLOWER than the LDS core in a same-box A/B (17.65 vs 18.0 ms per 65 536 candidates): the
 //    scattered 8-byte stores of the packed tile and a less favourable slope at large K ate the
 //    gain.  The product path keeps the LDS core; the packed core lives on here only.
-#include "common.h"
-#include "gemm_f64.h"
+#include "../common.h"
+#include "../gemm_f64.h"
 
 namespace robo {
 // ---- fragment-packed operands: barrier-free streaming straight into MFMA fragments --------------

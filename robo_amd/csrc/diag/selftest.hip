@@ -4,7 +4,7 @@
 //   * an MFMA-only loop to measure the fp64 matrix-pipe ceiling of the board the bench runs
 //     on (the local microarchitecture guide lists no fp64 MFMA peak; the datasheet figure is
 //     78.6 TFLOP/s).
-#include "common.h"
+#include "../common.h"
 
 namespace robo {
 

@@ -14,10 +14,11 @@ OUT = os.path.join(HERE, "_build", "librobo_emu.so")
 
 
 def build(force=False):
-    srcs = sorted(glob.glob(os.path.join(ROOT, "robo_amd", "csrc", "*.hip")))
+    srcs = sorted(glob.glob(os.path.join(ROOT, "robo_amd", "csrc", "*.hip")) +
+                  glob.glob(os.path.join(ROOT, "robo_amd", "csrc", "diag", "*.hip")))   # one interpreter library
     deps = srcs + glob.glob(os.path.join(ROOT, "robo_amd", "csrc", "*.h")) + \
         [os.path.join(HERE, "hipemu.cpp"), os.path.join(HERE, "hip", "hip_runtime.h"),
-         os.path.join(ROOT, "include", "robo_hip.h")]
+         os.path.join(ROOT, "include", "robo_hip.h"), os.path.join(ROOT, "include", "robo_hip_diag.h")]
     if not force and os.path.exists(OUT) and all(os.path.getmtime(d) <= os.path.getmtime(OUT) for d in deps):
         return OUT
     os.makedirs(os.path.dirname(OUT), exist_ok=True)

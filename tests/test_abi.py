@@ -11,23 +11,28 @@ from robo_amd import _lib
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _declared():
-    text = open(os.path.join(ROOT, "include", "robo_hip.h")).read()
+def _declared(header="robo_hip.h"):
+    text = open(os.path.join(ROOT, "include", header)).read()
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
     return sorted(set(re.findall(r"\b(robo_[a-z0-9_]+)\s*\(", text)))
 
 
 def test_binding_lists_every_declared_symbol():
     assert _declared() == sorted(_lib.SYMBOLS)
+    assert _declared("robo_hip_diag.h") == sorted(_lib.DIAG_SYMBOLS)
 
 
 def test_library_exports_every_declared_symbol():
-    if not os.path.exists(_lib.DEFAULT_LIBRARY):
+    if not os.path.exists(_lib.DEFAULT_LIBRARY) or not os.path.exists(_lib.DEFAULT_DIAG_LIBRARY):
         from robo_amd import build
         build.build(verbose=False)
     handle = ctypes.CDLL(_lib.DEFAULT_LIBRARY)
     missing = [s for s in _declared() if not hasattr(handle, s)]
     assert not missing, missing
+    # measurement code is not in the product library
+    assert not [s for s in _lib.DIAG_SYMBOLS if hasattr(handle, s)]
+    diag = ctypes.CDLL(_lib.DEFAULT_DIAG_LIBRARY)
+    assert not [s for s in _declared("robo_hip_diag.h") if not hasattr(diag, s)]
 
 
 def test_no_torch_types_in_the_abi():
