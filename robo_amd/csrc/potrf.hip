@@ -227,13 +227,19 @@ __device__ __forceinline__ void diag128_factor_invert(double* sL, double* sW, do
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     int* ctr = reinterpret_cast<int*>(sRd);     // one task counter per interval
     if (tid >= 64 && tid < 64 + NSB) ctr[tid - 64] = 0;
+    // 16-row blocks that hold training rows or the augmented row; the ones behind them are identity padding (their
+    // factor and inverse are the identity and nothing couples them to the rest), so the chain stops there: at the
+    // N < 128 of a Bayesian-optimisation run the single diagonal block is mostly padding (N = 30: 2 of 8 blocks).
+    int nsb = (n_real + 1 - kbase + SB - 1) / SB;
+    nsb = nsb < 1 ? 1 : (nsb > NSB ? NSB : nsb);
+    for (int bi = nsb; bi < NSB; ++bi) sW[blk_off(bi, bi) + bidx(tid >> 4, tid & 15)] = (tid >> 4) == (tid & 15) ? 1.0 : 0.0;
     if (wave == 0) {
         const int f = potf2_16(sL + blk_off(0, 0), sW + blk_off(0, 0), sCol, lane, kbase, n_real);
         if (f != 0 && lane == 0 && *fail == 0) *fail = f;
     }
     __syncthreads();                                              // Ba(0)
     if (dbg && tid == 0) dbg[2] = clock64();
-    for (int s = 0; s + 1 < NSB; ++s) {
+    for (int s = 0; s + 1 < nsb; ++s) {
         if (wave == 0) {
             // C1: the TRANSPOSE Q = L_{s+1,s}^T = W_ss A~_{s+1,s}^T.  In the MFMA accumulator layout register r
             // of lane l holds Q[(l >> 4) + 4 r][l & 15], which is at once the A fragment of columns 4r..4r+3 of Q^T
@@ -254,7 +260,7 @@ __device__ __forceinline__ void diag128_factor_invert(double* sL, double* sW, do
             wave_lds_fence();
         } else {
             // solves of block column s below the pivot wave's own block
-            for (int bi = s + 2 + (wave - 1); bi < NSB; bi += 3) {
+            for (int bi = s + 2 + (wave - 1); bi < nsb; bi += 3) {
                 double* A = sL + blk_off(bi, s);
                 v4d acc = {0.0, 0.0, 0.0, 0.0};
                 acc = blk_mma_nt<false>(A, sW + blk_off(s, s), lane, acc);
@@ -279,7 +285,7 @@ __device__ __forceinline__ void diag128_factor_invert(double* sL, double* sW, do
             // eight W_ss that fall out of potf2 (potrf_panel_kernel substitutes block column by block column);
             // the full inverses, which the posterior's TRSM and the likelihood gradient use, are produced for
             // all diagonal blocks at once by potrf_inverse_kernel after the factorisation.
-            const int ntask = s + 2 < NSB ? NSB - 1 - s : 0;
+            const int ntask = s + 2 < nsb ? nsb - 1 - s : 0;
             for (;;) {
                 int t = 0;
                 if (lane == 0) t = atomicAdd(ctr + s, 1);
@@ -472,7 +478,7 @@ __global__ __launch_bounds__(256) void potrf_panel_kernel(double* __restrict__ K
 // block row i > s -- 7, 13, 17, 19, 19, 17, 13 independent products in stages 0..6, handed out dynamically to the
 // four waves, one barrier per half-stage.
 __global__ __launch_bounds__(256) void potrf_inverse_kernel(const double* __restrict__ K, size_t k_stride, int ld,
-                                                            double* __restrict__ Linv, size_t linv_stride) {
+                                                            double* __restrict__ Linv, size_t linv_stride, int n_real) {
     __shared__ double smem[2 * NBLK * BLK + 32];
     double* sL = smem;
     double* sW = smem + NBLK * BLK;
@@ -489,7 +495,10 @@ __global__ __launch_bounds__(256) void potrf_inverse_kernel(const double* __rest
     if (tid < 2 * NSB) ctr[tid] = 0;
     __syncthreads();
     const v4d zero = {0.0, 0.0, 0.0, 0.0};
-    for (int s = 0; s + 1 < NSB; ++s) {
+    // block rows behind the augmented row are identity padding: their off-diagonal inverse blocks are zero
+    int nsb = (n_real + 1 - k * NB + SB - 1) / SB;
+    nsb = nsb < 1 ? 1 : (nsb > NSB ? NSB : nsb);
+    for (int s = 0; s + 1 < nsb; ++s) {
         // finalise block row s: W_sj = -W_ss S_sj, j < s
         for (;;) {
             int j = 0;
@@ -504,7 +513,7 @@ __global__ __launch_bounds__(256) void potrf_inverse_kernel(const double* __rest
         }
         __syncthreads();
         // S_ij += L_is W_sj for i > s, j <= s: (7 - s)(s + 1) independent products
-        const int rows = NSB - 1 - s, ntask = rows * (s + 1);
+        const int rows = nsb - 1 - s, ntask = rows * (s + 1);
         for (;;) {
             int t = 0;
             if (lane == 0) t = atomicAdd(ctr + 2 * s + 1, 1);
@@ -519,18 +528,19 @@ __global__ __launch_bounds__(256) void potrf_inverse_kernel(const double* __rest
         }
         __syncthreads();
     }
-    // block row 7: W_7j = -W_77 S_7j
-    for (int j = wave; j < NSB - 1; j += 4) {
-        double* S = sW + blk_off(NSB - 1, j);
+    // last block row: W_lj = -W_ll S_lj
+    for (int j = wave; j < nsb - 1; j += 4) {
+        double* S = sW + blk_off(nsb - 1, j);
         v4d w = zero;
-        w = blk_mma_nn<true>(sW + blk_off(NSB - 1, NSB - 1), S, lane, w);
+        w = blk_mma_nn<true>(sW + blk_off(nsb - 1, nsb - 1), S, lane, w);
         wave_lds_fence();
         blk_store_c(S, lane, w);
     }
     __syncthreads();
     for (int bi = 1; bi < NSB; ++bi)
         for (int bj = 0; bj < bi; ++bj)
-            Wg[(bi * SB + (tid >> 4)) * NB + bj * SB + (tid & 15)] = sW[blk_off(bi, bj) + bidx(tid >> 4, tid & 15)];
+            Wg[(bi * SB + (tid >> 4)) * NB + bj * SB + (tid & 15)] =
+                bi < nsb ? sW[blk_off(bi, bj) + bidx(tid >> 4, tid & 15)] : 0.0;
 }
 
 // Tile (k+1, k+1) of the trailing update for the fused diagonal workgroup:  C_lower - P P^T  straight
@@ -739,7 +749,7 @@ int launch_potrf(robo_gp* gp, const FitBuffers& fb) {
 #undef ROBO_DIAG
     // the explicit 128 x 128 inverses of all diagonal blocks, off the factorisation's critical path
     hipLaunchKernelGGL(potrf_inverse_kernel, dim3(nb, S), dim3(256), 0, ctx->stream, (const double*)fb.K, fb.k_stride, ld,
-                       fb.Linv, fb.linv_stride);
+                       fb.Linv, fb.linv_stride, gp->n);
     ROBO_LAUNCH_CHECK();
     return ROBO_OK;
 }
