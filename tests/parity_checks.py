@@ -532,6 +532,34 @@ def check_device_random_candidates(ctx):
     np.testing.assert_array_equal(_lib.Candidates(ctx, m=m, seed=5, n_uniform=nu, loc=loc, scale=scale).points(), P_)
 
 
+def check_candidate_reupload(ctx):
+    """robo_cand_set_points: a new batch of the same shape into an existing handle (the per-iteration H2D of a BO
+    loop) == a fresh handle, bit for bit; wrong shapes are refused"""
+    import pytest
+    rs = np.random.RandomState(77)
+    N, D, M = 150, 4, 333
+    X = rs.rand(N, D)
+    y = np.sin(3 * X.sum(axis=1))
+    theta = np.concatenate([[0.1], np.log(0.3 * D) + 0.1 * rs.randn(D), [np.log(1e-3)]])
+    g = _lib.DeviceGP(ctx, "matern52", N, D)
+    g.set_data(X, y)
+    g.fit(theta, float(y.mean()))
+    A, B = rs.rand(M, D), rs.rand(M, D)
+    c = _lib.Candidates(ctx, A)
+    first = g.acq("ei", 0.0, float(y.min()), c)
+    c.set_points(B)
+    again = g.acq("ei", 0.0, float(y.min()), c)
+    fresh = _lib.Candidates(ctx, B)
+    want = g.acq("ei", 0.0, float(y.min()), fresh)
+    np.testing.assert_array_equal(again[0], want[0])
+    assert again[1:] == want[1:] and not np.array_equal(first[0], again[0])
+    np.testing.assert_array_equal(c.points(), B)
+    with pytest.raises(AssertionError):
+        c.set_points(rs.rand(M + 1, D))
+    for h in (c, fresh, g):
+        h.close()
+
+
 def check_shape_sweep(ctx, n_cases=40, seed=123, max_n=700):
     """randomised shapes: N, D (incl. D > 16: several LDS coordinate chunks), M, kernel kind, output
     normalisation; fit + posterior + EI argmax against the oracle."""

@@ -143,3 +143,7 @@ def test_predictive_gradients(emu_ctx):
 
 def test_sobol_candidates(emu_ctx):
     P.check_sobol_candidates(emu_ctx, dims=(3, 17), m=300 + 900)
+
+
+def test_candidate_reupload(emu_ctx):
+    P.check_candidate_reupload(emu_ctx)

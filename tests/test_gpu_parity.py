@@ -382,3 +382,7 @@ def test_sobol_candidates(ctx):
     ref.fast_forward(2 ** 20 - 1)
     np.testing.assert_array_equal(p, ref.random(1)[0])
     c.close()
+
+
+def test_candidate_reupload(ctx):
+    P.check_candidate_reupload(ctx)
