@@ -201,8 +201,8 @@ def run_headline(args, D_, _lib, sharding):
         t0 = time.perf_counter()
         gp.fit(theta, mean_c)
         fit_ms.append((time.perf_counter() - t0) * 1e3)
-        fit_phase.append((ctx.elapsed_ms(20, 21), ctx.elapsed_ms(21, 22), ctx.elapsed_ms(22, 23)))
-    gram_ms, chol_ms, ll_ms = fit_phase[int(np.argmin(fit_ms))]
+        fit_phase.append((ctx.elapsed_ms(20, 21), ctx.elapsed_ms(21, 22), ctx.elapsed_ms(22, 23), ctx.elapsed_ms(19, 21)))
+    gram_ms, chol_ms, ll_ms, k1_ms = fit_phase[int(np.argmin(fit_ms))]
     # SURVEY 8(d)'s definition of GP-fit: incl. H2D of X, y, theta and D2H of the log-likelihood
     fit_h2d = []
     for _ in range(3):
@@ -288,8 +288,10 @@ def run_headline(args, D_, _lib, sharding):
             "gp_fit_phases_ms": {"gram": gram_ms, "cholesky": chol_ms, "loglik": ll_ms},
             "gp_fit_frac_of_mfma_peak": (N ** 3 / 3.0 + N * (N + 1) / 2.0 * (3 * D + 16) + 2.0 * N * N)
             / (float(np.min(fit_ms)) * 1e-3) / 1e12 / FP64_MFMA_PEAK_TFLOPS,
-            "k_assembly": {"bytes": k1_bytes, "ms": gram_ms, "GB_per_s": k1_bytes / (gram_ms * 1e-3) / 1e9,
-                           "frac_of_8TBps": k1_bytes / (gram_ms * 1e-3) / 8.0e12},
+            # K1 against the HBM roofline: the gram kernel alone (event slots 19 -> 21); "gram" above also holds the
+            # staging of theta and the input scaling
+            "k_assembly": {"bytes": k1_bytes, "ms": k1_ms, "GB_per_s": k1_bytes / (k1_ms * 1e-3) / 1e9,
+                           "frac_of_8TBps": k1_bytes / (k1_ms * 1e-3) / 8.0e12},
             "cholesky": {"flops": N ** 3 / 3.0, "ms": chol_ms, "TFLOP_per_s": N ** 3 / 3.0 / (chol_ms * 1e-3) / 1e12,
                          "frac_of_mfma_peak": N ** 3 / 3.0 / (chol_ms * 1e-3) / 1e12 / FP64_MFMA_PEAK_TFLOPS},
             "gp_fit_batched": {"thetas": S_half, "ms_total": batch_ms, "ms_per_theta": batch_ms / S_half},
@@ -477,6 +479,13 @@ def main():
     from robo_amd import _lib, sharding
     if args.lib:
         _lib.use_library(os.path.abspath(args.lib))
+    try:
+        # the diagnostics library (micro-benchmarks of the roofline block) is loaded BEFORE the first kernel launch:
+        # under rocprofv3 a code object that appears after thousands of dispatches crashed the profiler's launch
+        # interception (r02v: SIGSEGV at the first mfma_bench_kernel launch)
+        _lib.diag()
+    except Exception:
+        pass
     runner = {"headline": run_headline, "c2": run_headline, "c3": run_c3, "c4": run_c4, "c5": run_c5}[args.config]
     out = runner(args, D_, _lib, sharding)
     if D_.rank == 0:

@@ -275,6 +275,7 @@ static int gp_build_gram(robo_gp* g, const double* theta, double mean_c) {
     ROBO_HIP_CHECK(hipMemcpyAsync(g->d_theta, g->h_theta, ((size_t)D + 8) * sizeof(double) + sizeof(FitSample),
                                   hipMemcpyHostToDevice, c->stream));
     ROBO_TRY(launch_scale_inputs(c, g->d_X, g->d_Xs, g->d_theta, g->n, g->n_pad, D));
+    ROBO_HIP_CHECK(hipEventRecord(c->events[19], c->stream));   // slot 19 -> 21: the gram kernel alone (K1)
     ROBO_TRY(launch_gram(g, own_buffers(g)));
     return ROBO_OK;
 }
