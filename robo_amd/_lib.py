@@ -285,7 +285,10 @@ class Candidates(object):
         if sobol is not None:
             # sobol: a scipy.stats.qmc.Sobol engine (its direction numbers and digital shift are read, the engine is
             # not advanced) or a (sv (dim, bits), shift (dim,), bits) triple; points first .. first + m - 1
-            if hasattr(sobol, "_sv"):
+            if hasattr(sobol, "random"):          # a scipy.stats.qmc.Sobol engine
+                if not all(hasattr(sobol, a) for a in ("_sv", "_shift", "bits")):
+                    raise RoboHipError("this SciPy's qmc.Sobol does not expose its direction numbers (_sv, _shift, "
+                                       "bits; SciPy 1.7-1.15 do): pass a (sv, shift, bits) triple instead")
                 sv, shift, bits = sobol._sv, sobol._shift, int(sobol.bits)
             else:
                 sv, shift, bits = sobol
