@@ -164,11 +164,17 @@ __device__ __forceinline__ int potf2_16_impl(double* Ld, double* Wd, double* col
 #pragma unroll
     for (int k = 0; k < SB; ++k) {
         double p = bcast_lane(a[k], k);   // pivot: complete (bulk updates <= k-2, fast path k-1)
-        if (GUARD && g0 + k >= n_real) p = 1.0;
-        if (!(p > 0.0)) {                 // also catches NaN
-            if (fail == 0) fail = g0 + k + 1;
-            p = 1.0;
+        if (GUARD) {
+            if (g0 + k >= n_real) p = 1.0;
+            if (!(p > 0.0)) {             // also catches NaN
+                if (fail == 0) fail = g0 + k + 1;
+                p = 1.0;
+            }
         }
+        // Without the guard (every block that holds only training rows) the pivot is NOT tested on the chain: a
+        // non-positive or NaN pivot makes v_rsq_f64 return NaN / inf, L_kk = p * rsqrt(p) comes out NaN, and so does
+        // everything after it -- the failing column is read off the diagonal once the block is done (below).  Four
+        // scalar/vector instructions and the select in front of the rsq less per pivot on an issue-bound wave.
         const double ri = pivot_rsqrt(p);
         if (k > 0) {
             // deferred bulk update by column k-1 (independent of the rsqrt chain above)
@@ -188,6 +194,15 @@ __device__ __forceinline__ int potf2_16_impl(double* Ld, double* Wd, double* col
         }
         lprev = lik;
         wave_lds_fence();
+    }
+    if (!GUARD) {
+        // first column whose diagonal entry is not a positive finite number (lanes 0..15 hold L_rr in a[row])
+        double diag = 0.0;
+#pragma unroll
+        for (int j = 0; j < SB; ++j) diag = row == j ? a[j] : diag;
+        const bool bad = grp == 0 && !(diag > 0.0 && diag < 1.0e300);
+        const unsigned long long m = __ballot(bad);
+        if (m != 0ull) fail = g0 + (__ffsll((long long)m) - 1) + 1;
     }
 #pragma unroll
     for (int j = 0; j < SB; ++j) {
