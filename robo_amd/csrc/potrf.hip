@@ -212,10 +212,106 @@ __device__ __forceinline__ int potf2_16_impl(double* Ld, double* Wd, double* col
     return fail;
 }
 
+// ---- all four 16-lane groups at work (r02w) -----------------------------------------------------------------
+// The version above keeps a whole row (16 entries) per lane and uses two of the four lane groups (rows of L,
+// columns of W); its lone wave is bound by instruction ISSUE (~34 instructions per pivot at ~10 cycles), and a third
+// of them are the rank-1 update of up to 15 entries per lane.  Here a lane holds the entries of ONE COLUMN PARITY:
+//     group 0: rows of L, even columns     group 2: rows of L, odd columns
+//     group 1: columns of W, even rows     group 3: columns of W, odd rows
+// i.e. 8 entries a[h] <-> second index j = 2 h + par, so the rank-1 update is at most 8 FMAs per pivot, and the
+// scaled column goes through LDS de-interleaved ([even rows | odd rows]) so that a lane's operands are contiguous.
+// The pivot chain does not pass through any lane's registers: the next diagonal entry with columns <= k-1 applied is
+// broadcast as a uniform value d1 and  p_{k+1} = d1 - l_{k+1,k}^2  is one FMA on the broadcast l_{k+1,k} -- every
+// entry of column k+1 (the diagonal one included) receives column k's contribution with the regular deferred update
+// one iteration later, whose multiplier l_{row,k} a lane of the other parity reads back from the exchange buffer.
+// colbuf: [4 groups][2 buffers][16], 1 KB.
+template <bool GUARD>
+__device__ __forceinline__ int potf2_16_split(double* Ld, double* Wd, double* colbuf, int lane, int g0, int n_real) {
+    const int row = lane & 15, grp = lane >> 4, par = grp >> 1;
+    const bool isW = (grp & 1) != 0;
+    constexpr int H = SB / 2;
+    double a[H];
+#pragma unroll
+    for (int h = 0; h < H; ++h) {
+        const int j = 2 * h + par;
+        const double l = j <= row ? Ld[bidx(row, j)] : 0.0;
+        a[h] = isW ? (j == row ? 1.0 : 0.0) : l;
+    }
+    const int pos = (row & 1) * H + (row >> 1);               // de-interleaved position of this lane's row
+    double* cb_own = colbuf + grp * 2 * SB + pos;             // where this lane publishes its scaled entry
+    const double* cb_mult = colbuf + (grp & 1) * 2 * SB + pos;   // + owner parity * 4 SB: this row's multiplier
+    const double* cb_col = colbuf + par * H;                  // + owner parity * 4 SB: column values for own j's
+    int fail = 0;
+    double p = bcast_lane(a[0], 0);                           // L_00's pivot: group 0, lane 0
+#pragma unroll
+    for (int k = 0; k < SB; ++k) {
+        constexpr int dummy = 0;
+        (void)dummy;
+        const int pk = k & 1, hk = k >> 1;
+        if (k > 0) {
+            // deferred update by column k-1 (owner parity pq, buffer (k-1) & 1) of every own column j >= k
+            const int pq = (k - 1) & 1, buf = (k - 1) & 1;
+            const double lprev = cb_mult[pq * 4 * SB + buf * SB];
+            const double* c = cb_col + pq * 4 * SB + buf * SB;
+#pragma unroll
+            for (int h = hk; h < H; ++h) {
+                // h = hk is column k for the lanes of parity pk; for the other parity it is column k+1 (k even) or the
+                // finished column k-1 (k odd), which must not be touched
+                const double m = (pk == 1 && h == hk) ? (par == 1 ? lprev : 0.0) : lprev;
+                a[h] = fma(-m, c[h], a[h]);
+            }
+        }
+        // the next diagonal entry (columns <= k-1 applied), uniform: lane (row k+1, L group of parity (k+1) & 1)
+        double d1 = 0.0;
+        if (k + 1 < SB) d1 = bcast_lane(a[(k + 1) >> 1], (k + 1) + 32 * ((k + 1) & 1));
+        if (GUARD) {
+            if (g0 + k >= n_real) p = 1.0;
+            if (!(p > 0.0)) {             // also catches NaN
+                if (fail == 0) fail = g0 + k + 1;
+                p = 1.0;
+            }
+        }
+        const double ri = pivot_rsqrt(p);
+        double lik = a[hk] * ri;                              // meaningful in the lanes of parity pk
+        if (GUARD && row == k && !isW) lik = p * ri;
+        a[hk] = par == pk ? lik : a[hk];
+        cb_own[(k & 1) * SB] = lik;                           // the other parity's copies are never read
+        if (k + 1 < SB) {
+            const double l1 = bcast_lane(lik, (k + 1) + 32 * pk);   // L[k+1][k]
+            p = fma(-l1, l1, d1);
+        }
+        wave_lds_fence();
+    }
+    if (!GUARD) {
+        // first column whose diagonal entry is not a positive finite number
+        double diag = 0.0;
+#pragma unroll
+        for (int h = 0; h < H; ++h) diag = (row >> 1) == h ? a[h] : diag;
+        const bool bad = !isW && par == (row & 1) && !(diag > 0.0 && diag < 1.0e300);
+        const unsigned long long m = __ballot(bad);
+        if (m != 0ull) fail = g0 + ((__ffsll((long long)m) - 1) & 15) + 1;
+    }
+#pragma unroll
+    for (int h = 0; h < H; ++h) {
+        const int j = 2 * h + par;
+        if (isW) Wd[bidx(j, row)] = a[h];                     // W[j][c], zero above the diagonal
+        else Ld[bidx(row, j)] = j <= row ? a[h] : 0.0;
+    }
+    return fail;
+}
+
+#ifndef ROBO_POTF2_SPLIT
+#define ROBO_POTF2_SPLIT 1      // 0: the two-group version above (A/B builds)
+#endif
 // the pivot guard for rows >= n_real only exists in the block(s) that hold the augmented row / padding
 __device__ __forceinline__ int potf2_16(double* Ld, double* Wd, double* colbuf, int lane, int g0, int n_real) {
+#if ROBO_POTF2_SPLIT
+    if (g0 + SB <= n_real) return potf2_16_split<false>(Ld, Wd, colbuf, lane, g0, n_real);
+    return potf2_16_split<true>(Ld, Wd, colbuf, lane, g0, n_real);
+#else
     if (g0 + SB <= n_real) return potf2_16_impl<false>(Ld, Wd, colbuf, lane, g0, n_real);
     return potf2_16_impl<true>(Ld, Wd, colbuf, lane, g0, n_real);
+#endif
 }
 
 constexpr int TLD = SB + 2;   // padded leading dimension of the per-wave transposition scratch
