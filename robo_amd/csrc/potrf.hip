@@ -344,6 +344,14 @@ __device__ __forceinline__ void diag128_factor_invert(double* sL, double* sW, do
     int nsb = (n_real + 1 - kbase + SB - 1) / SB;
     nsb = nsb < 1 ? 1 : (nsb > NSB ? NSB : nsb);
     for (int bi = nsb; bi < NSB; ++bi) sW[blk_off(bi, bi) + bidx(tid >> 4, tid & 15)] = (tid >> 4) == (tid & 15) ? 1.0 : 0.0;
+    // this lane's offsets inside a 16x16 block: fragment form [lane & 15][4 kk + (lane >> 4)], accumulator form
+    // [(lane >> 4) + 4 r][lane & 15]
+    int fo[4], co[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        fo[q] = bidx(lane & 15, q * 4 + (lane >> 4));
+        co[q] = bidx((lane >> 4) + 4 * q, lane & 15);
+    }
     if (wave == 0) {
         const int f = potf2_16(sL + blk_off(0, 0), sW + blk_off(0, 0), sCol, lane, kbase, n_real);
         if (f != 0 && lane == 0 && *fail == 0) *fail = f;
@@ -396,29 +404,27 @@ __device__ __forceinline__ void diag128_factor_invert(double* sL, double* sW, do
             // eight W_ss that fall out of potf2 (potrf_panel_kernel substitutes block column by block column);
             // the full inverses, which the posterior's TRSM and the likelihood gradient use, are produced for
             // all diagonal blocks at once by potrf_inverse_kernel after the factorisation.
+            // Static hand-out (task t to wave 1 + t % 3), lane offsets computed once per kernel.  (Dynamic hand-out
+            // through an LDS counter, pairing blocks that share an operand, and software-pipelined fragment loads
+            // were all measured within noise of this: intervals 1-3 take 6.0-7.2k cycles against 4.5k for the pivot
+            // wave alone, whatever the bookkeeping -- the pivot wave's own LDS exchange slows down while the helpers'
+            // fragment reads share the LDS pipe.)
             const int ntask = s + 2 < nsb ? nsb - 1 - s : 0;
-            for (;;) {
-                int t = 0;
-                if (lane == 0) t = atomicAdd(ctr + s, 1);
-                t = __builtin_amdgcn_readlane(t, 0);
-                if (t >= ntask) break;
+            for (int t = wave - 1; t < ntask; t += 3) {
                 const int bi = t <= 1 ? s + 2 : s + 1 + t;
                 const int bj = t == 1 ? s + 2 : s + 1;
                 double* C = sL + blk_off(bi, bj);
-                // fragments of product c+1 are in flight while the MFMAs of product c issue
-                Frag4 a = frag_row(sL + blk_off(bi, 0), lane), b = frag_row(sL + blk_off(bj, 0), lane);
-                v4d acc = blk_load_c(C, lane);
+                const double* Ai = sL + blk_off(bi, 0);
+                const double* Bj = sL + blk_off(bj, 0);
+                v4d acc;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) acc[r] = C[co[r]];
                 for (int c = 0; c <= s; ++c) {
-                    Frag4 an = a, bn = b;
-                    if (c < s) {
-                        an = frag_row(sL + blk_off(bi, c + 1), lane);
-                        bn = frag_row(sL + blk_off(bj, c + 1), lane);
-                    }
-                    acc = frag_mma<true>(a, b, acc);
-                    a = an;
-                    b = bn;
+#pragma unroll
+                    for (int kk = 0; kk < 4; ++kk) acc = mfma_f64(-Ai[c * BLK + fo[kk]], Bj[c * BLK + fo[kk]], acc);
                 }
-                blk_store_c(C, lane, acc);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) C[co[r]] = acc[r];
             }
         }
         __syncthreads();                                          // Ba(s+1)
