@@ -101,13 +101,48 @@ __device__ __forceinline__ void tile_store_lds(double* S, const Tile4 t) {
 #ifndef ROBO_SETPRIO
 #define ROBO_SETPRIO 1
 #endif
-template <int TM, bool NEG>
+// PIPE: the fragments of k-step kk+1 are requested before the MFMAs of k-step kk are issued.  A wave issues in
+// order, so without it every k-step ends in  ds_read x (TM+4) -> s_waitcnt -> 4 TM MFMAs  with the matrix pipe idle
+// for one LDS round trip; a second workgroup on the CU fills that bubble, a workgroup that is alone on its CU (the
+// fused Cholesky step: the diagonal block's LDS image sizes every workgroup) cannot.
+#ifndef ROBO_GEMM_PIPE
+#define ROBO_GEMM_PIPE 0
+#endif
+template <int TM, bool NEG, bool PIPE = false>
 __device__ __forceinline__ void tile_mfma(const double* sA, const double* sB, AccT<TM>& acc) {
     constexpr bool SETPRIO = ROBO_SETPRIO != 0;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int wy = wave >> 1, wx = wave & 1;
     const double* pa = sA + (wy * (16 * TM) + (lane & 15)) * LDS_LD + (lane >> 4);
     const double* pb = sB + (wx * 64 + (lane & 15)) * LDS_LD + (lane >> 4);
+    if (PIPE) {
+        double a[2][TM], b[2][4];
+#pragma unroll
+        for (int t = 0; t < TM; ++t) a[0][t] = pa[t * 16 * LDS_LD];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) b[0][t] = pb[t * 16 * LDS_LD];
+#pragma unroll
+        for (int kk = 0; kk < BK / 4; ++kk) {
+            const int c = kk & 1, n = c ^ 1;
+            if (kk + 1 < BK / 4) {
+#pragma unroll
+                for (int t = 0; t < TM; ++t) a[n][t] = pa[t * 16 * LDS_LD + (kk + 1) * 4];
+#pragma unroll
+                for (int t = 0; t < 4; ++t) b[n][t] = pb[t * 16 * LDS_LD + (kk + 1) * 4];
+            }
+            if (NEG) {
+#pragma unroll
+                for (int t = 0; t < TM; ++t) a[c][t] = -a[c][t];
+            }
+            if (SETPRIO) __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+            for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+                for (int tn = 0; tn < 4; ++tn) acc.t[tm][tn] = mfma_f64(a[c][tm], b[c][tn], acc.t[tm][tn]);
+            if (SETPRIO) __builtin_amdgcn_s_setprio(0);
+        }
+        return;
+    }
 #pragma unroll
     for (int kk = 0; kk < BK / 4; ++kk) {
         double a[TM], b[4];
@@ -149,7 +184,7 @@ __device__ __forceinline__ void gemm_nt(const double* __restrict__ A, int lda, c
             ra = tile_load_regs<32 * TM>(A, lda, kbeg + (kt + 1) * BK);
             rb = tile_load_regs<128>(B, ldb, kbeg + (kt + 1) * BK);
         }
-        tile_mfma<TM, NEG>(cur, cur + SA, acc);
+        tile_mfma<TM, NEG, ROBO_GEMM_PIPE != 0>(cur, cur + SA, acc);
         if (more) {
             tile_store_lds<32 * TM>(nxt, ra);
             tile_store_lds<128>(nxt + SA, rb);

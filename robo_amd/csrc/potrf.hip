@@ -705,6 +705,142 @@ __device__ __forceinline__ void diag_tile_update(const double* __restrict__ P, c
     }
 }
 
+// t-th tile of the lower triangle, row-major: t = ii (ii + 1) / 2 + jj
+__device__ __forceinline__ void tri_decode(int t, int& ii, int& jj) {
+    int q = (int)((sqrt(8.0 * (double)t + 1.0) - 1.0) * 0.5);
+    while ((q + 1) * (q + 2) / 2 <= t) ++q;
+    while (q * (q + 1) / 2 > t) --q;
+    ii = q;
+    jj = t - q * (q + 1) / 2;
+}
+
+// 128-deep updates of the 128 x 128 tiles t = t0, t0 + stride, ... < ntiles of the trailing matrix by ONE workgroup
+// (the fused step kernel runs one workgroup per CU: the diagonal block's LDS image sizes every workgroup).
+// Phase stamps of the one-tile-per-workgroup version (r02y): read C + first operands 10.9k cycles, k-loop 42.5k
+// (512 MFMAs per wave = 32.8k at 64 cycles; the chip holds ~2.0 GHz of its 2.4 under this load), store 4.4k; with every
+// workgroup launched at the same instant, rounds of tiles simply add up (kernel trace: 26-29 us per round, 52-59 us
+// for two, 81 us for three).  Here
+//   * the next tile's C arrives in a second accumulator set while the current tile is multiplied (two 16 x 16 blocks
+//     per k-tile, so an operand wait never waits for more than 1/8 of C), its first operand k-tile is requested before
+//     the current tile is stored, and the stores drain under the next tile's MFMAs;
+//   * the 32 k-steps of a tile are one software pipeline (a wave issues in order and is alone on its SIMD): fragments
+//     of step g+1 are read before the MFMAs of step g, the next k-tile goes to LDS before the last step of the
+//     current one, and the barrier + first fragment read of the next k-tile sit in the MIDDLE of that step's MFMAs.
+// Measured: k-loop 42.5k -> 40.1k cycles, two tiles 52-59 -> 50 us, three 81 -> 75 us, fit 1.87 -> 1.82 ms.
+// Same arithmetic as gemm_nt<4, true> on acc = C: products are accumulated on top of the stored value in ascending k.
+__device__ __forceinline__ void update_tiles_persistent(double* __restrict__ K, int ld, int k, int t0, int stride,
+                                                        int ntiles, double* smem) {
+    constexpr int SA = stage_a<4>(), ST = SA + STAGE_B, NK = NB / BK;
+    int ii, jj;
+    tri_decode(t0, ii, jj);
+    const double* A = K + ((size_t)(k + 1 + ii) * NB) * ld + (size_t)k * NB;
+    const double* B = K + ((size_t)(k + 1 + jj) * NB) * ld + (size_t)k * NB;
+    double* C = K + ((size_t)(k + 1 + ii) * NB) * ld + (size_t)(k + 1 + jj) * NB;
+    Acc acc, nxt;
+#pragma unroll
+    for (int tm = 0; tm < 4; ++tm)
+#pragma unroll
+        for (int tn = 0; tn < 4; ++tn)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc.t[tm][tn][r] = C[(size_t)acc_row<4>(tm, r) * ld + acc_col(tn)];
+    Tile4 ra = tile_load_regs<128>(A, ld, 0), rb = tile_load_regs<128>(B, ld, 0);
+    for (int t = t0;; t += stride) {
+        const int tn_ = t + stride;
+        const bool more = tn_ < ntiles;
+        const double *An = A, *Bn = B;
+        double* Cn = C;
+        if (more) {
+            tri_decode(tn_, ii, jj);
+            An = K + ((size_t)(k + 1 + ii) * NB) * ld + (size_t)k * NB;
+            Bn = K + ((size_t)(k + 1 + jj) * NB) * ld + (size_t)k * NB;
+            Cn = K + ((size_t)(k + 1 + ii) * NB) * ld + (size_t)(k + 1 + jj) * NB;
+        }
+        tile_store_lds<128>(smem, ra);
+        tile_store_lds<128>(smem + SA, rb);
+        __syncthreads();
+        // 32 k-steps (8 k-tiles x 4) as one software pipeline: fragments of step g+1 are read before the MFMAs of
+        // step g; the next k-tile goes to LDS before the last step of the current one, and the barrier + the first
+        // fragment read of the next k-tile sit in the MIDDLE of that step's 16 MFMAs
+        {
+            const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+            const int fa_off = ((wave >> 1) * 64 + (lane & 15)) * LDS_LD + (lane >> 4);
+            const int fb_off = SA + ((wave & 1) * 64 + (lane & 15)) * LDS_LD + (lane >> 4);
+            double fa[2][4], fb[2][4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                fa[0][q] = smem[fa_off + q * 16 * LDS_LD];
+                fb[0][q] = smem[fb_off + q * 16 * LDS_LD];
+            }
+#pragma unroll
+            for (int g = 0; g < 4 * NK; ++g) {
+                const int kt = g >> 2, kk = g & 3, c = g & 1, n = c ^ 1;
+                const double* cur = smem + (kt & 1) * ST;
+                double* oth = smem + ((kt + 1) & 1) * ST;
+                if (kk == 0) {
+                    if (kt + 1 < NK) {
+                        ra = tile_load_regs<128>(A, ld, (kt + 1) * BK);
+                        rb = tile_load_regs<128>(B, ld, (kt + 1) * BK);
+                    } else if (more) {
+                        ra = tile_load_regs<128>(An, ld, 0);
+                        rb = tile_load_regs<128>(Bn, ld, 0);
+                    }
+                    if (more) {
+#pragma unroll
+                        for (int h = 0; h < 2; ++h) {
+                            const int tm = (2 * kt + h) >> 2, tn = (2 * kt + h) & 3;
+#pragma unroll
+                            for (int r = 0; r < 4; ++r)
+                                nxt.t[tm][tn][r] = Cn[(size_t)acc_row<4>(tm, r) * ld + acc_col(tn)];
+                        }
+                    }
+                }
+                if (kk < 3) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        fa[n][q] = cur[fa_off + q * 16 * LDS_LD + (kk + 1) * 4];
+                        fb[n][q] = cur[fb_off + q * 16 * LDS_LD + (kk + 1) * 4];
+                    }
+                } else if (kt + 1 < NK) {
+                    tile_store_lds<128>(oth, ra);
+                    tile_store_lds<128>(oth + SA, rb);
+                }
+#pragma unroll
+                for (int q = 0; q < 4; ++q) fa[c][q] = -fa[c][q];
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+                    for (int tn = 0; tn < 4; ++tn) acc.t[tm][tn] = mfma_f64(fa[c][tm], fb[c][tn], acc.t[tm][tn]);
+                __builtin_amdgcn_sched_barrier(0);
+                if (kk == 3 && kt + 1 < NK) {
+                    __syncthreads();
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        fa[n][q] = oth[fa_off + q * 16 * LDS_LD];
+                        fb[n][q] = oth[fb_off + q * 16 * LDS_LD];
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+#pragma unroll
+                for (int tm = 2; tm < 4; ++tm)
+#pragma unroll
+                    for (int tn = 0; tn < 4; ++tn) acc.t[tm][tn] = mfma_f64(fa[c][tm], fb[c][tn], acc.t[tm][tn]);
+            }
+        }
+#pragma unroll
+        for (int tm = 0; tm < 4; ++tm)
+#pragma unroll
+            for (int tn = 0; tn < 4; ++tn)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) C[(size_t)acc_row<4>(tm, r) * ld + acc_col(tn)] = acc.t[tm][tn][r];
+        if (!more) break;
+        acc = nxt;
+        A = An;
+        B = Bn;
+        C = Cn;
+    }
+}
+
 // Trailing update of step k fused with the NEXT diagonal block:
 //   A_ij <- A_ij - A_ik * A_jk^T   for k < j <= i (right-looking, K = 128), and workgroup 0 -- which
 //   owns tile (k+1, k+1) -- goes on to factor and invert it (diag128_factor_invert) while the other
@@ -722,7 +858,8 @@ __device__ __forceinline__ void diag_tile_update(const double* __restrict__ P, c
 template <int TM, bool FUSED>
 __global__ __launch_bounds__(256) void potrf_step_kernel(double* __restrict__ K, size_t k_stride, int ld, int k,
                                                          int n_real, double* __restrict__ Linv, size_t linv_stride,
-                                                         int* __restrict__ fail, int kop, int depth, int first_col) {
+                                                         int* __restrict__ fail, int kop, int depth, int first_col,
+                                                         int ntiles) {
     // k: trailing base (tiles cover block rows/columns > k); kop: first block column of the panel
     // operand(s); depth: contraction length (128, or 256 = two panels at once, see launch_potrf);
     // first_col != 0: block column k+1 only
@@ -738,6 +875,11 @@ __global__ __launch_bounds__(256) void potrf_step_kernel(double* __restrict__ K,
         __syncthreads();
         diag128_factor_invert(m.sL, m.sW, m.sT, m.sRd, m.sCol, (k + 1) * NB, n_real, fail + blockIdx.y, nullptr);
         diag_writeback(m, C, ld, Linv + (size_t)blockIdx.y * linv_stride + (size_t)(k + 1) * NB * NB);
+        return;
+    }
+    if (FUSED && TM == 4) {
+        // workgroups 1 .. gridDim.x-1 share tiles 1 .. ntiles-1 (tile 0 is workgroup 0's)
+        update_tiles_persistent(K, ld, k, (int)blockIdx.x, (int)gridDim.x - 1, ntiles, smem);
         return;
     }
     constexpr int SPLIT = 4 / TM;                    // row sub-tiles per 128-row block
@@ -810,31 +952,39 @@ int launch_potrf(robo_gp* gp, const FitBuffers& fb) {
     robo_ctx* ctx = gp->ctx;
     const int ld = gp->n_pad, nb = gp->n_pad / NB, S = fb.S;
     ROBO_HIP_CHECK(hipMemsetAsync(fb.fail, 0, (size_t)S * sizeof(int), ctx->stream));
-    const bool fused = S <= 2;
+    static const bool allow_fused = [] { const char* e = getenv("ROBO_POTRF_FUSED"); return !e || atoi(e) != 0; }();
+    const bool fused = S <= 2 && allow_fused;
 #define ROBO_DIAG(KK)                                                                                          \
     hipLaunchKernelGGL(potrf_diag_kernel, dim3(S), dim3(256), 0, ctx->stream, fb.K, fb.k_stride, ld, (KK), gp->n, \
                        fb.Linv, fb.linv_stride, fb.fail, (long long*)nullptr)
 #define ROBO_PANEL(KK)                                                                                         \
     hipLaunchKernelGGL(potrf_panel_kernel, dim3((nb - (KK)-1) * 2, S), dim3(256), 0, ctx->stream, fb.K,        \
                        fb.k_stride, ld, (KK), (const double*)fb.Linv, fb.linv_stride, (long long*)nullptr)
-#define ROBO_STEP(TM, F, GRID, BASE, KOP, DEPTH, FIRST)                                                        \
+#define ROBO_STEP(TM, F, GRID, BASE, KOP, DEPTH, FIRST, NT)                                                       \
     hipLaunchKernelGGL((potrf_step_kernel<TM, F>), dim3((GRID), S), dim3(256), 0, ctx->stream, fb.K, fb.k_stride, \
-                       ld, (BASE), gp->n, fb.Linv, fb.linv_stride, fb.fail, (KOP), (DEPTH), (FIRST))
+                       ld, (BASE), gp->n, fb.Linv, fb.linv_stride, fb.fail, (KOP), (DEPTH), (FIRST), (NT))
     // tile height, measured (N = 4096, S = 1): 128-row tiles 43 us/step at 384..528 blocks, 64-row tiles
     // slower (55 us: B panel re-read twice), 32-row tiles 16 us vs 21 us once blocks < 96
 #define ROBO_UPDATE(TILES, BASE, KOP, DEPTH, FIRST)                                                            \
     do {                                                                                                       \
-        if ((TILES) * S >= 96) ROBO_STEP(4, false, (TILES), BASE, KOP, DEPTH, FIRST);                          \
-        else if ((TILES) > 0) ROBO_STEP(1, false, (TILES)*4, BASE, KOP, DEPTH, FIRST);                         \
+        if ((TILES) * S >= 96) ROBO_STEP(4, false, (TILES), BASE, KOP, DEPTH, FIRST, 0);                          \
+        else if ((TILES) > 0) ROBO_STEP(1, false, (TILES)*4, BASE, KOP, DEPTH, FIRST, 0);                         \
     } while (0)
+    // test knobs (tests/: the emulator reaches the persistent multi-tile path at small N through them)
+    const char* e_tm4 = getenv("ROBO_POTRF_TM4_MIN");
+    const char* e_wg = getenv("ROBO_POTRF_MAX_WG");
+    const int tm4_min = e_tm4 ? atoi(e_tm4) : 96, wg_cap = e_wg ? atoi(e_wg) : 0;
+    const int max_wg = wg_cap >= 2 ? wg_cap : ctx->num_cu;
     if (fused) {
         // single theta: trailing update of step k + diagonal block k+1 (workgroup 0) in one launch
         ROBO_DIAG(0);
         for (int k = 0; k + 1 < nb; ++k) {
             const int rem = nb - k - 1, tiles = rem * (rem + 1) / 2;
             ROBO_PANEL(k);
-            if (tiles * S >= 96) ROBO_STEP(4, true, tiles, k, k, NB, 0);
-            else ROBO_STEP(1, true, 1 + (tiles - 1) * 4, k, k, NB, 0);
+            // 128-row tiles: one diagonal workgroup + at most (CUs - 1) persistent tile workgroups (one per CU: the
+            // diagonal block's LDS image sizes every workgroup of the launch)
+            if (tiles * S >= tm4_min) ROBO_STEP(4, true, tiles < max_wg ? tiles : max_wg, k, k, NB, 0, tiles);
+            else ROBO_STEP(1, true, 1 + (tiles - 1) * 4, k, k, NB, 0, tiles);
         }
     } else {
         // batched thetas: the chip is full, and a 128-deep update is bound by reading and writing its C

@@ -137,6 +137,32 @@ def test_multi_panel_factorisation(emu_ctx):
     g.close()
 
 
+def test_persistent_tile_updates(emu_ctx, monkeypatch):
+    """the 128-row trailing update with several tiles per workgroup (next tile's C prefetched while
+    the current one is multiplied): forced at N = 520 through the launcher's test knobs; same bits
+    as the one-tile-per-workgroup schedule"""
+    from oracle import gp_oracle as O
+    rs = np.random.RandomState(13)
+    N, D = 520, 3
+    X = rs.rand(N, D)
+    y = np.cos(3 * X.sum(axis=1))
+    theta = np.array([0.1, np.log(0.5), np.log(0.7), np.log(0.9), np.log(1e-2)])
+    ogp = O.OracleGP("matern52", theta, normalize_input=False)
+    ogp.train(X, y)
+    g = _lib.DeviceGP(emu_ctx, "matern52", N, D)
+    g.set_data(X, y)
+    g.fit(theta, ogp.mean)
+    L_ref = g.factor().copy()
+    monkeypatch.setenv("ROBO_POTRF_TM4_MIN", "1")
+    for cap in ("4", "3", "64"):          # 3 / 2 tile workgroups sharing 9 tiles; one tile each
+        monkeypatch.setenv("ROBO_POTRF_MAX_WG", cap)
+        ll = g.fit(theta, ogp.mean)
+        np.testing.assert_allclose(ll, ogp.loglikelihood(theta), rtol=1e-10)
+        np.testing.assert_array_equal(g.factor(), L_ref)
+    np.testing.assert_allclose(L_ref, ogp.L, rtol=0, atol=1e-11)
+    g.close()
+
+
 def test_predictive_gradients(emu_ctx):
     P.check_predictive_gradients(emu_ctx, cases=(("matern52", 70, 3, 9), ("fabolas", 60, 3, 7)))
 
