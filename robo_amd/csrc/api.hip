@@ -156,6 +156,7 @@ int32_t robo_gp_create(robo_ctx* ctx, int32_t kind, int32_t n_max, int32_t dim, 
     ROBO_TRY(dev_alloc(&g->d_Linv, np * NB));
     // the strictly upper 16x16 sub-blocks of every inverted diagonal block are zero and never written
     ROBO_HIP_CHECK(hipMemset(g->d_Linv, 0, np * NB * sizeof(double)));
+    ROBO_TRY(dev_alloc(&g->d_LinvP, (np / NB) * WP_BLOCK));
     ROBO_TRY(dev_alloc(&g->d_theta, (size_t)dim + 8 + sizeof(FitSample) / sizeof(double)));
     g->d_sp = reinterpret_cast<FitSample*>(g->d_theta + dim + 8);
     ROBO_HIP_CHECK(hipHostMalloc((void**)&g->h_theta, ((size_t)dim + 8) * sizeof(double) + sizeof(FitSample), 0));
@@ -172,6 +173,7 @@ int32_t robo_gp_destroy(robo_gp* g) {
     hipFree(g->d_y);
     hipFree(g->d_K);
     hipFree(g->d_Linv);
+    hipFree(g->d_LinvP);
     hipFree(g->d_theta);
     hipHostFree(g->h_theta);
     hipFree(g->d_gV);
@@ -484,6 +486,7 @@ int32_t robo_gp_fit_batch(robo_gp* const* gps, int32_t S, const double* thetas, 
                                           hipMemcpyDeviceToDevice, c->stream));
             ROBO_HIP_CHECK(hipMemcpyAsync(g->d_Linv, g0->d_bLinv + (size_t)s * np * NB, np * NB * sizeof(double),
                                           hipMemcpyDeviceToDevice, c->stream));
+            ROBO_TRY(launch_pack_linv(g));
             ROBO_HIP_CHECK(hipMemcpyAsync(g->d_Xs, g0->d_bXs + (size_t)s * np * D, np * D * sizeof(double),
                                           hipMemcpyDeviceToDevice, c->stream));
             ROBO_HIP_CHECK(hipMemcpyAsync(g->d_theta, g0->d_bism + (size_t)s * D, (size_t)D * sizeof(double),

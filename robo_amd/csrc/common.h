@@ -81,6 +81,15 @@ struct robo_ctx {
     double* h_pinned;    // small pinned staging (64 doubles)
 };
 
+namespace robo {
+// Packed inverse diagonal blocks for the transposed block-row solve (predict.hip): the 36 lower 16x16 sub-blocks x 4
+// k-steps of a 128x128 inverse as 64-lane MFMA A-operand fragments, in the order the solve consumes them (row block
+// 7 first, column blocks ascending).
+constexpr int WP_FRAGS = 144;
+constexpr int WP_BLOCK = WP_FRAGS * 64;
+__host__ __device__ constexpr int wp_offset(int cb) { return 4 * (36 - (cb + 1) * (cb + 2) / 2); }
+}  // namespace robo
+
 struct robo_gp {
     robo_ctx* ctx;
     int kind, dim, n_max;
@@ -98,6 +107,7 @@ struct robo_gp {
     double* d_y;        // (n_max)
     double* d_K;        // (n_pad_max, n_pad_max) gram -> Cholesky factor in place (lower)
     double* d_Linv;     // (n_pad_max / NB) x NB x NB inverses of the diagonal blocks
+    double* d_LinvP;    // the same inverses as packed MFMA A-operand fragments (WP_BLOCK doubles per block, predict.hip)
     double* d_theta;    // inverse sqrt metric (dim) of the current theta
     double* h_theta;    // pinned staging: [FitSample | inverse sqrt metric (dim)]
     robo::FitSample* d_sp;   // device copy of the current FitSample
@@ -162,6 +172,7 @@ int launch_diag_timeline(robo_gp* gp, long long* d_stamps);
 int launch_cross_gram(robo_gp* gp, robo_cand* cand, int64_t c0, int64_t cn);
 int launch_trsm(robo_gp* gp, robo_cand* cand, int64_t c0, int64_t cn);
 int launch_predict_fused(robo_gp* gp, robo_cand* cand, int64_t c0, int64_t cn);
+int launch_pack_linv(robo_gp* gp);
 int launch_grad_loglik(robo_gp* gp, double* d_V, double* d_A, double* d_alpha, double* d_part, double* d_out);
 int launch_post(robo_gp* gp, robo_cand* cand, int64_t c0, int64_t cn);
 int launch_cross_grad(robo_gp* gp, const double* d_Xcs, double* d_V, int64_t c_first, int64_t c_count, int64_t rows_pad);

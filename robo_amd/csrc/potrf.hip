@@ -920,6 +920,30 @@ __global__ __launch_bounds__(256) void potrf_step_kernel(double* __restrict__ K,
             for (int r = 0; r < 4; ++r) C[(size_t)acc_row<TM>(tm, r) * ld + acc_col(tn)] = acc.t[tm][tn][r];
 }
 
+// Linv blocks -> packed A-operand fragments for the transposed block-row solve (predict.hip, trsm_step_t_kernel):
+// fragment s = wp_offset(cb) + 4 jb + kk of diagonal block b, lane l:
+//     Linv_b[16 cb + pi16(l & 15)][16 jb + 4 kk + (l >> 4)]
+// (pi16 on the row slot: register r of lane group g of the product is then row 16 cb + 4 g + r of the result --
+// four consecutive rows per lane, stored as two 16-byte pieces).
+__global__ __launch_bounds__(256) void linv_pack_kernel(const double* __restrict__ Linv, double* __restrict__ Wp) {
+    const double* W = Linv + (size_t)blockIdx.x * NB * NB;
+    double* out = Wp + (size_t)blockIdx.x * WP_BLOCK;
+    for (int idx = threadIdx.x; idx < WP_BLOCK; idx += 256) {
+        const int f = idx >> 6, l = idx & 63;
+        int cb = 7;
+        while (f >= wp_offset(cb) + 4 * (cb + 1)) --cb;
+        const int rel = f - wp_offset(cb), jb = rel >> 2, kk = rel & 3;
+        out[idx] = W[(size_t)(16 * cb + pi16(l & 15)) * NB + 16 * jb + 4 * kk + (l >> 4)];
+    }
+}
+
+int launch_pack_linv(robo_gp* gp) {
+    hipLaunchKernelGGL(linv_pack_kernel, dim3(gp->n_pad / NB), dim3(256), 0, gp->ctx->stream, (const double*)gp->d_Linv,
+                       gp->d_LinvP);
+    ROBO_LAUNCH_CHECK();
+    return ROBO_OK;
+}
+
 // out[0] = z.z, out[1] = 2 sum_{i<n} log L_ii   (z = row n of the factor); fixed summation order
 __global__ __launch_bounds__(256) void loglik_kernel(const double* __restrict__ K, size_t k_stride, int ld, int n,
                                                      double* __restrict__ out) {
@@ -1018,6 +1042,7 @@ int launch_potrf(robo_gp* gp, const FitBuffers& fb) {
     hipLaunchKernelGGL(potrf_inverse_kernel, dim3(nb, S), dim3(256), 0, ctx->stream, (const double*)fb.K, fb.k_stride, ld,
                        fb.Linv, fb.linv_stride, gp->n);
     ROBO_LAUNCH_CHECK();
+    if (fb.Linv == gp->d_Linv) return launch_pack_linv(gp);   // the GP's own factor: fragments for the posterior
     return ROBO_OK;
 }
 

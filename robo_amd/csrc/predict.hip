@@ -103,26 +103,48 @@ __global__ __launch_bounds__(256) void trsm_step_kernel(double* __restrict__ V, 
     trsm_epilogue(acc, Vt, ldv, L + (size_t)n * ld, i, n, smem, q, mu, c0);
 }
 
-// ---- cross-gram tile in registers ----------------------------------------------------------
-// The tile K*_i (128 candidates x 128 training points) is generated straight into the
-// accumulator registers (C-layout) from LDS-staged coordinates instead of being written to and
-// re-read from HBM by a separate pass (4.6 % of the step at N = 4096, 2.2 GB written + read); its
-// fp64 VALU work (sqrt/exp) overlaps the other resident workgroup's MFMAs.
+// ---- block-row step with the cross-gram tile generated in registers, TRANSPOSED tile ---------------------------
+// Per 128 candidates (one workgroup) and block row i the step is
+//     T   = K*_i - V[:, 0:128 i] L[blk i, 0:128 i]^T          (128 candidates x 128 training points)
+//     V_i = T Linv_ii^T
+// The workgroup holds T TRANSPOSED in its accumulators: rows = training points, columns = candidates, every wave
+// all 128 rows of its own 32 candidates (8 x 2 MFMA tiles).  In that orientation
+//   * T never goes back to memory between the two products: register r of an accumulator tile holds rows
+//     (lane >> 4) + 4 r, which is exactly the B operand of k-step r of  V_i^T = Linv_ii T^T  (fragment maps in
+//     gemm_f64.h) -- the first version stored T (128 KB per workgroup), waited for the store and staged it back
+//     through LDS (phase stamps r02z: 27k of 174k fixed cycles per block row, plus a 56k-cycle second GEMM);
+//   * only the 36 lower-triangular 16x16 blocks of Linv_ii are multiplied (288 MFMAs per wave instead of 512); its
+//     A-operand fragments come pre-packed from the fit (linv_pack_kernel: one coalesced 512-byte load per
+//     fragment, read straight from L2 -- no LDS, no barrier in the solve);
+//   * result row block cb (cb = 7 .. 0) is final as soon as its (cb + 1) column blocks are accumulated, so its
+//     store and its share of the |v|^2, v.z reductions overlap the MFMAs of the next row block; with the pi16 row
+//     permutation baked into the packed fragments a lane holds four consecutive entries of a candidate's row
+//     (two 16-byte stores), and the reductions are register sums + two cross-lane adds.
+// One launch per block row is kept on purpose: a fully fused (persistent, all block rows per workgroup) variant was
+// measured 2x SLOWER -- the launch boundary keeps the 512 workgroups in lock-step on the same L block row, which is
+// what makes L an L2 hit; free-running workgroups drift apart and stream L from the Infinity Cache instead (r01k:
+// 36 ms vs 18.4 ms per 65 536 candidates).
+
+struct AccTt {
+    v4d t[8][2];   // [training-row block][candidate block of this wave]
+};
+
+// K*_i^T into the accumulators: rows = 128 scaled training points (Xt), columns = 128 scaled candidates (Xc);
+// rows >= n_valid are written as 0.  smem: [GD][GXL] for each operand.
 template <int KIND>
-__device__ __forceinline__ void gen_cross_tile(const CovParams& cp, const double* __restrict__ Xc,
-                                               const double* __restrict__ Xt, int n_valid, double* smem, Acc& acc) {
-    // Xc: 128 scaled candidates (rows of the tile), Xt: 128 scaled training points (columns);
-    // columns >= n_valid are written as 0.  smem: [GD][GXL] for each operand.
+__device__ __forceinline__ void gen_cross_tile_t(const CovParams& cp, const double* __restrict__ Xc,
+                                                 const double* __restrict__ Xt, int n_valid, double* smem,
+                                                 AccTt& acc) {
     constexpr int GD = 16, GXL = NB + 2;
     double* sC = smem;
     double* sX = smem + GD * GXL;
-    const int t = threadIdx.x, lane = t & 63, wave = t >> 6, wy = wave >> 1, wx = wave & 1, dim = cp.dim;
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6, dim = cp.dim;
     const bool fab = KIND == ROBO_KERNEL_FABOLAS;
 #pragma unroll
-    for (int tm = 0; tm < 4; ++tm)
+    for (int rb = 0; rb < 8; ++rb)
 #pragma unroll
-        for (int tn = 0; tn < 4; ++tn) acc.t[tm][tn] = fab ? v4d{1.0, 1.0, 1.0, 1.0} : v4d{0.0, 0.0, 0.0, 0.0};
-    const int rbase = wy * 64 + (lane >> 4), cbase = wx * 64 + (lane & 15);
+        for (int mb = 0; mb < 2; ++mb) acc.t[rb][mb] = fab ? v4d{1.0, 1.0, 1.0, 1.0} : v4d{0.0, 0.0, 0.0, 0.0};
+    const int rbase = lane >> 4, cbase = wave * 32 + (lane & 15);
     for (int d0 = 0; d0 < dim; d0 += GD) {
         __syncthreads();   // previous chunk (or previous user of smem) fully consumed
 #pragma unroll
@@ -137,81 +159,181 @@ __device__ __forceinline__ void gen_cross_tile(const CovParams& cp, const double
         const int dn = dim - d0 < GD ? dim - d0 : GD;
         for (int d = 0; d < dn; ++d) {
             if (fab && d0 + d == dim - 1) break;   // fidelity column: handled in the finish
-            double xj[4];
+            double xi[2];
 #pragma unroll
-            for (int tn = 0; tn < 4; ++tn) xj[tn] = sX[d * GXL + cbase + tn * 16];
+            for (int mb = 0; mb < 2; ++mb) xi[mb] = sC[d * GXL + cbase + mb * 16];
 #pragma unroll
-            for (int tm = 0; tm < 4; ++tm)
+            for (int rb = 0; rb < 8; ++rb)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const double xi = sC[d * GXL + rbase + tm * 16 + 4 * r];
+                    const double xj = sX[d * GXL + rb * 16 + rbase + 4 * r];
 #pragma unroll
-                    for (int tn = 0; tn < 4; ++tn) {
-                        const double df = xi - xj[tn];
-                        if (fab) acc.t[tm][tn][r] *= matern52_unit(df * df);
-                        else acc.t[tm][tn][r] = fma(df, df, acc.t[tm][tn][r]);
+                    for (int mb = 0; mb < 2; ++mb) {
+                        const double df = xi[mb] - xj;
+                        if (fab) acc.t[rb][mb][r] *= matern52_unit(df * df);
+                        else acc.t[rb][mb][r] = fma(df, df, acc.t[rb][mb][r]);
                     }
                 }
         }
     }
-    // finish: covariance function of the accumulated distances; the last staged chunk still holds
-    // the fidelity column (dim - 1) for the Fabolas kernel
+    // finish: covariance function of the accumulated distances; the last staged chunk still holds the fidelity
+    // column (dim - 1) for the Fabolas kernel
     const int dl = (dim - 1) % GD;
 #pragma unroll
-    for (int tm = 0; tm < 4; ++tm)
+    for (int rb = 0; rb < 8; ++rb)
 #pragma unroll
-        for (int tn = 0; tn < 4; ++tn) {
-            const int col = cbase + tn * 16;
+        for (int r = 0; r < 4; ++r) {
+            const int row = rb * 16 + rbase + 4 * r;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
+            for (int mb = 0; mb < 2; ++mb) {
                 double uu = 0.0;
-                if (fab) uu = sC[dl * GXL + rbase + tm * 16 + 4 * r] * sX[dl * GXL + col];
-                const double v = cov_finish<double, KIND>(cp, acc.t[tm][tn][r], uu);
-                acc.t[tm][tn][r] = col < n_valid ? v : 0.0;
+                if (fab) uu = sC[dl * GXL + cbase + mb * 16] * sX[dl * GXL + row];
+                const double v = cov_finish<double, KIND>(cp, acc.t[rb][mb][r], uu);
+                acc.t[rb][mb][r] = row < n_valid ? v : 0.0;
             }
         }
     __syncthreads();   // smem free for the GEMM stages
 }
 
-// Step kernel with the cross-gram tile generated in registers: block row i of
-//     V = L^-1 K*^T   for 128 candidates per workgroup,
-// identical to trsm_step_kernel except that K*_i never exists in HBM.  One launch per block row
-// is kept on purpose: a fully fused (persistent, all block rows per workgroup) variant was
-// measured 2x SLOWER -- the launch boundary keeps the 512 workgroups in lock-step on the same
-// L block row, which is what makes L an L2 hit; free-running workgroups drift apart and stream L
-// from the Infinity Cache instead (r01k: 36 ms vs 18.4 ms per 65 536 candidates).
+// acc(8 x 2 tiles per wave) -= A[0:128, k-tile] * B[0:128, k-tile]^T restricted to the wave's 32 B rows
+__device__ __forceinline__ void tile_mfma_t(const double* sA, const double* sB, AccTt& acc) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const double* pa = sA + (lane & 15) * LDS_LD + (lane >> 4);
+    const double* pb = sB + (wave * 32 + (lane & 15)) * LDS_LD + (lane >> 4);
+#pragma unroll
+    for (int kk = 0; kk < BK / 4; ++kk) {
+        double a[8], b[2];
+#pragma unroll
+        for (int rb = 0; rb < 8; ++rb) a[rb] = pa[rb * 16 * LDS_LD + kk * 4];
+#pragma unroll
+        for (int mb = 0; mb < 2; ++mb) b[mb] = -pb[mb * 16 * LDS_LD + kk * 4];
+        if (ROBO_SETPRIO) __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int rb = 0; rb < 8; ++rb)
+#pragma unroll
+            for (int mb = 0; mb < 2; ++mb) acc.t[rb][mb] = mfma_f64(a[rb], b[mb], acc.t[rb][mb]);
+        if (ROBO_SETPRIO) __builtin_amdgcn_s_setprio(0);
+    }
+}
+
+// acc -= A[:, 0:kend] * B[:, 0:kend]^T  (A: 128 rows of L, B: the workgroup's 128 rows of V; both k-contiguous);
+// staging and pipeline of gemm_nt<4, .> (gemm_f64.h), wave tiling 1 x 4 instead of 2 x 2
+__device__ __forceinline__ void gemm_t(const double* __restrict__ A, int lda, const double* __restrict__ B, int ldb,
+                                       int kend, AccTt& acc, double* smem) {
+    constexpr int SA = stage_a<4>(), ST = SA + STAGE_B;
+    const int nk = kend / BK;
+    if (nk <= 0) return;
+    Tile4 ra = tile_load_regs<128>(A, lda, 0);
+    Tile4 rb = tile_load_regs<128>(B, ldb, 0);
+    tile_store_lds<128>(smem, ra);
+    tile_store_lds<128>(smem + SA, rb);
+    __syncthreads();
+    for (int kt = 0; kt < nk; ++kt) {
+        double* cur = smem + (kt & 1) * ST;
+        double* nxt = smem + ((kt + 1) & 1) * ST;
+        const bool more = kt + 1 < nk;
+        if (more) {
+            ra = tile_load_regs<128>(A, lda, (kt + 1) * BK);
+            rb = tile_load_regs<128>(B, ldb, (kt + 1) * BK);
+        }
+        tile_mfma_t(cur, cur + SA, acc);
+        if (more) {
+            tile_store_lds<128>(nxt, ra);
+            tile_store_lds<128>(nxt + SA, rb);
+        }
+        __syncthreads();
+    }
+}
+
+// V_i^T = Linv_ii T^T from the accumulators, stores and reductions (see the header of this section).
+// Wp: packed fragments of block i; z: row n of L at column 128 i; Vt: the workgroup's V rows at column 128 i.
+__device__ __forceinline__ void solve_store_reduce_t(const AccTt& T, const double* __restrict__ Wp,
+                                                     const double* __restrict__ z, int n_valid, double* __restrict__ Vt,
+                                                     int ldv, double* __restrict__ q, double* __restrict__ mu,
+                                                     bool first) {
+    constexpr int PF = 8;   // fragments in flight (L2 hits): 16 MFMAs = 1024 cycles of cover
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = lane >> 4, nn = lane & 15;
+    const double* wp = Wp + lane;
+    double wf[PF];
+#pragma unroll
+    for (int s = 0; s < PF; ++s) wf[s] = wp[s * 64];
+    double sq[2] = {0.0, 0.0}, sz[2] = {0.0, 0.0};
+    double* vrow[2];
+#pragma unroll
+    for (int mb = 0; mb < 2; ++mb) vrow[mb] = Vt + (size_t)(wave * 32 + mb * 16 + nn) * ldv + 4 * g;
+#pragma unroll
+    for (int cbi = 0; cbi < 8; ++cbi) {
+        const int cb = 7 - cbi;
+        v4d o[2] = {v4d{0.0, 0.0, 0.0, 0.0}, v4d{0.0, 0.0, 0.0, 0.0}};
+#pragma unroll
+        for (int jb = 0; jb <= cb; ++jb)
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) {
+                const int s = wp_offset(cb) + 4 * jb + kk;
+                const double a = wf[s % PF];
+                if (s + PF < WP_FRAGS) wf[s % PF] = wp[(s + PF) * 64];
+#pragma unroll
+                for (int mb = 0; mb < 2; ++mb) o[mb] = mfma_f64(a, T.t[jb][mb][kk], o[mb]);
+            }
+        // rows 16 cb + 4 g + r (r = 0..3) of the result for candidates nn (+16) of this wave
+        const int c0 = 16 * cb + 4 * g;
+        double zc[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) zc[r] = c0 + r < n_valid ? z[c0 + r] : 0.0;
+#pragma unroll
+        for (int mb = 0; mb < 2; ++mb) {
+            double v[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                v[r] = c0 + r < n_valid ? o[mb][r] : 0.0;
+                sq[mb] = fma(v[r], v[r], sq[mb]);
+                sz[mb] = fma(v[r], zc[r], sz[mb]);
+            }
+            double2* dst = reinterpret_cast<double2*>(vrow[mb] + 16 * cb);
+            dst[0] = make_double2(v[0], v[1]);
+            dst[1] = make_double2(v[2], v[3]);
+        }
+    }
+#pragma unroll
+    for (int mb = 0; mb < 2; ++mb) {
+        sq[mb] += __shfl_xor(sq[mb], 16);
+        sz[mb] += __shfl_xor(sz[mb], 16);
+        sq[mb] += __shfl_xor(sq[mb], 32);
+        sz[mb] += __shfl_xor(sz[mb], 32);
+        if (g == 0) {
+            const int c = wave * 32 + mb * 16 + nn;
+            if (first) {
+                q[c] = sq[mb];
+                mu[c] = sz[mb];
+            } else {
+                q[c] += sq[mb];
+                mu[c] += sz[mb];
+            }
+        }
+    }
+}
+
 template <int KIND>
 __global__ __launch_bounds__(256, 2) void trsm_step_gen_kernel(const double* __restrict__ Xcs,
                                                                const double* __restrict__ Xs, double* __restrict__ V,
                                                                int ldv, const double* __restrict__ L, int ld,
-                                                               const double* __restrict__ Linv, int i0, int i1, int n,
+                                                               const double* __restrict__ LinvP, int i0, int i1, int n,
                                                                double* __restrict__ q, double* __restrict__ mu,
                                                                long long c0, CovParams cp) {
     __shared__ double smem[GEMM_SMEM_DOUBLES];
     double* Vrow = V + (size_t)blockIdx.x * NB * ldv;
+    const long long cw = c0 + (long long)blockIdx.x * NB;   // first candidate of this workgroup
     // block rows i0 .. i1-1 in one launch (ROBO_TRSM_ROWS, default 1): a block row only reads columns this same
     // workgroup wrote, so the launch boundary is not needed for correctness -- it is what keeps the workgroups in
     // step on the same rows of L (see above); a few rows per launch trade a little of that for fewer launch
     // ramps/tails
     for (int i = i0; i < i1; ++i) {
-        double* Vt = Vrow + (size_t)i * NB;
-        Acc acc;
-        gen_cross_tile<KIND>(cp, Xcs + (size_t)(c0 + (long long)blockIdx.x * NB) * cp.dim,
-                             Xs + (size_t)i * NB * cp.dim, n - i * NB, smem, acc);
-        if (i > 0) {
-            gemm_nt<4, true>(Vrow, ldv, L + (size_t)i * NB * ld, ld, 0, i * NB, acc, smem);
-        }
-#pragma unroll
-        for (int tm = 0; tm < 4; ++tm)
-#pragma unroll
-            for (int tn = 0; tn < 4; ++tn)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) Vt[(size_t)acc_row(tm, r) * ldv + acc_col(tn)] = acc.t[tm][tn][r];
-        __syncthreads();   // T visible to the whole workgroup (global memory, workgroup scope)
-        acc_zero(acc);
-        gemm_nt<4, false>(Vt, ldv, Linv + (size_t)i * NB * NB, NB, 0, NB, acc, smem);
-        trsm_epilogue(acc, Vt, ldv, L + (size_t)n * ld, i, n, smem, q, mu, c0);
-        __syncthreads();   // V_i (global) and the reduction scratch before the next block row
+        AccTt acc;
+        gen_cross_tile_t<KIND>(cp, Xcs + (size_t)cw * cp.dim, Xs + (size_t)i * NB * cp.dim, n - i * NB, smem, acc);
+        if (i > 0) gemm_t(L + (size_t)i * NB * ld, ld, Vrow, ldv, i * NB, acc, smem);
+        solve_store_reduce_t(acc, LinvP + (size_t)i * WP_BLOCK, L + (size_t)n * ld + (size_t)i * NB, n - i * NB,
+                             Vrow + (size_t)i * NB, ldv, q + cw, mu + cw, i == 0);
+        __syncthreads();   // V_i (global, workgroup scope) before the next block row stages it
     }
 }
 
@@ -276,7 +398,7 @@ int launch_predict_fused(robo_gp* gp, robo_cand* cand, int64_t c0, int64_t cn) {
 #define ROBO_STEP_CALL(KIND)                                                                                   \
     hipLaunchKernelGGL(trsm_step_gen_kernel<KIND>, grid, dim3(256), 0, gp->ctx->stream,                        \
                        (const double*)cand->d_Xcs, (const double*)gp->d_Xs, cand->d_V, gp->n_pad,             \
-                       (const double*)gp->d_K, gp->n_pad, (const double*)gp->d_Linv, i,                       \
+                       (const double*)gp->d_K, gp->n_pad, (const double*)gp->d_LinvP, i,                      \
                        (i + rows < nbk ? i + rows : nbk), gp->n, cand->d_q, cand->d_mu, (long long)c0, gp->cov)
     static const int rows = [] {
         const char* e = getenv("ROBO_TRSM_ROWS");
