@@ -72,11 +72,15 @@ int32_t robo_ctx_destroy(robo_ctx* ctx);
 int32_t robo_ctx_synchronize(robo_ctx* ctx);
 int32_t robo_ctx_device_name(robo_ctx* ctx, char* buf, int32_t buf_len);
 /* HIP-event timing on the context's stream (what bench.py uses).  Slots 0..19 are the
- * caller's; the library itself records 20..23 around the phases of robo_gp_fit (gram,
- * Cholesky, log-likelihood) and 24..27 around the phases of the posterior evaluation
- * (cross-gram, triangular solve, post) of the last candidate chunk.                        */
+ * caller's; the library itself records 24..27 around the phases of the posterior evaluation
+ * (cross-gram, triangular solve, post) of the last candidate chunk and, when switched on with
+ * robo_ctx_set_phase_events (off by default: four event packets cost a 1.8 ms fit ~30 us; the
+ * environment variable ROBO_PHASE_EVENTS=1 switches them on at context creation), 19..23 around
+ * the phases of robo_gp_fit (19 -> 21 gram kernel, 20 -> 21 gram phase, 21 -> 22 Cholesky,
+ * 22 -> 23 log-likelihood).                                                                 */
 int32_t robo_ctx_event_record(robo_ctx* ctx, int32_t slot);
 int32_t robo_ctx_event_elapsed_ms(robo_ctx* ctx, int32_t slot_begin, int32_t slot_end, float* out_ms);
+int32_t robo_ctx_set_phase_events(robo_ctx* ctx, int32_t on);
 const char* robo_last_error_string(void);
 const char* robo_version_string(void);
 

@@ -77,6 +77,10 @@ int32_t robo_ctx_create(int32_t device, void* hip_stream, robo_ctx** out) {
         c->own_stream = true;
     }
     for (int i = 0; i < 32; ++i) ROBO_HIP_CHECK(hipEventCreate(&c->events[i]));
+    {   // internal phase events of robo_gp_fit (slots 19..23): off unless ROBO_PHASE_EVENTS=1 / set_phase_events
+        const char* e = getenv("ROBO_PHASE_EVENTS");
+        c->phase_events = e && atoi(e) != 0;
+    }
     hipDeviceProp_t prop;
     ROBO_HIP_CHECK(hipGetDeviceProperties(&prop, device));
     snprintf(c->name, sizeof(c->name), "%s (%s)", prop.name, prop.gcnArchName);
@@ -115,6 +119,12 @@ int32_t robo_ctx_device_name(robo_ctx* c, char* buf, int32_t len) {
 int32_t robo_ctx_event_record(robo_ctx* c, int32_t slot) {
     if (slot < 0 || slot >= 32) return ROBO_BAD_ARGUMENT;
     ROBO_HIP_CHECK(hipEventRecord(c->events[slot], c->stream));
+    return ROBO_OK;
+}
+
+int32_t robo_ctx_set_phase_events(robo_ctx* c, int32_t on) {
+    if (!c) return ROBO_BAD_ARGUMENT;
+    c->phase_events = on != 0;
     return ROBO_OK;
 }
 
@@ -277,7 +287,7 @@ static int gp_build_gram(robo_gp* g, const double* theta, double mean_c) {
     ROBO_HIP_CHECK(hipMemcpyAsync(g->d_theta, g->h_theta, ((size_t)D + 8) * sizeof(double) + sizeof(FitSample),
                                   hipMemcpyHostToDevice, c->stream));
     ROBO_TRY(launch_scale_inputs(c, g->d_X, g->d_Xs, g->d_theta, g->n, g->n_pad, D));
-    ROBO_HIP_CHECK(hipEventRecord(c->events[19], c->stream));   // slot 19 -> 21: the gram kernel alone (K1)
+    if (c->phase_events) ROBO_HIP_CHECK(hipEventRecord(c->events[19], c->stream));   // slot 19 -> 21: the gram kernel alone (K1)
     ROBO_TRY(launch_gram(g, own_buffers(g)));
     return ROBO_OK;
 }
@@ -292,13 +302,13 @@ int32_t robo_gp_fit(robo_gp* g, const double* theta, double mean_c, double* out_
     g->fitted = false;
     // event slots 20..23: 20 -> 21 gram build, 21 -> 22 Cholesky, 22 -> 23 log-likelihood reduce
     ROBO_HIP_CHECK(hipStreamSynchronize(c->stream));
-    ROBO_HIP_CHECK(hipEventRecord(c->events[20], c->stream));
+    if (c->phase_events) ROBO_HIP_CHECK(hipEventRecord(c->events[20], c->stream));
     ROBO_TRY(gp_build_gram(g, theta, mean_c));
-    ROBO_HIP_CHECK(hipEventRecord(c->events[21], c->stream));
+    if (c->phase_events) ROBO_HIP_CHECK(hipEventRecord(c->events[21], c->stream));
     ROBO_TRY(launch_potrf(g, own_buffers(g)));
-    ROBO_HIP_CHECK(hipEventRecord(c->events[22], c->stream));
+    if (c->phase_events) ROBO_HIP_CHECK(hipEventRecord(c->events[22], c->stream));
     ROBO_TRY(launch_loglik(g, own_buffers(g)));
-    ROBO_HIP_CHECK(hipEventRecord(c->events[23], c->stream));
+    if (c->phase_events) ROBO_HIP_CHECK(hipEventRecord(c->events[23], c->stream));
     double* hp = c->h_pinned;
     ROBO_HIP_CHECK(hipMemcpyAsync(hp, c->d_scalars, 2 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
     ROBO_HIP_CHECK(hipMemcpyAsync(hp + 4, c->d_fail, sizeof(int), hipMemcpyDeviceToHost, c->stream));

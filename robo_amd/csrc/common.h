@@ -73,6 +73,7 @@ struct robo_ctx {
     hipStream_t stream;
     bool own_stream;
     hipEvent_t events[32];
+    bool phase_events;   // record the internal phase events of robo_gp_fit (robo_ctx_set_phase_events, default off)
     char name[256];
     int num_cu;
     // scratch shared by every call on this context

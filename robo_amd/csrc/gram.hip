@@ -154,7 +154,9 @@ template <class T, int KIND>
 __global__ __launch_bounds__(256, 6) void gram_kernel(const double* __restrict__ Xs, size_t xs_stride,
                                                    const double* __restrict__ y, double* __restrict__ K,
                                                    size_t k_stride, int n, int n_pad,
-                                                   const FitSample* __restrict__ sp) {
+                                                   const FitSample* __restrict__ sp, int* __restrict__ fail) {
+    // the factorisation's failure flag of this sample starts at 0 (one memset launch less in front of the Cholesky)
+    if (blockIdx.x == 0 && threadIdx.x == 0) fail[blockIdx.y] = 0;
     __shared__ double sI[GD * GLD];
     __shared__ double sJ[GD * GLD];
     __shared__ double sN[2 * GT];
@@ -266,7 +268,7 @@ int launch_gram(robo_gp* gp, const FitBuffers& fb) {
     const int tiles = T * (T + 1) / 2;
 #define ROBO_GRAM_CALL(TYPE, KIND)                                                                              \
     hipLaunchKernelGGL((gram_kernel<TYPE, KIND>), dim3(tiles, fb.S), dim3(256), 0, gp->ctx->stream, fb.Xs,      \
-                       fb.xs_stride, (const double*)gp->d_y, fb.K, fb.k_stride, gp->n, gp->n_pad, fb.sp)
+                       fb.xs_stride, (const double*)gp->d_y, fb.K, fb.k_stride, gp->n, gp->n_pad, fb.sp, fb.fail)
     ROBO_DISPATCH_COV(gp->fp32_gram, gp->kind, ROBO_GRAM_CALL);
 #undef ROBO_GRAM_CALL
     ROBO_LAUNCH_CHECK();

@@ -975,7 +975,7 @@ __global__ __launch_bounds__(256) void loglik_kernel(const double* __restrict__ 
 int launch_potrf(robo_gp* gp, const FitBuffers& fb) {
     robo_ctx* ctx = gp->ctx;
     const int ld = gp->n_pad, nb = gp->n_pad / NB, S = fb.S;
-    ROBO_HIP_CHECK(hipMemsetAsync(fb.fail, 0, (size_t)S * sizeof(int), ctx->stream));
+    // fb.fail[0 .. S) was zeroed by the gram kernel (launch_gram always precedes this)
     static const bool allow_fused = [] { const char* e = getenv("ROBO_POTRF_FUSED"); return !e || atoi(e) != 0; }();
     const bool fused = S <= 2 && allow_fused;
 #define ROBO_DIAG(KK)                                                                                          \
