@@ -167,6 +167,9 @@ int32_t robo_gp_create(robo_ctx* ctx, int32_t kind, int32_t n_max, int32_t dim, 
     // the strictly upper 16x16 sub-blocks of every inverted diagonal block are zero and never written
     ROBO_HIP_CHECK(hipMemset(g->d_Linv, 0, np * NB * sizeof(double)));
     ROBO_TRY(dev_alloc(&g->d_LinvP, (np / NB) * WP_BLOCK));
+    ROBO_TRY(dev_alloc(&g->d_llpart, (np / NB) * 2));
+    ROBO_TRY(dev_alloc(&g->d_llctr, (size_t)1));
+    ROBO_HIP_CHECK(hipMemset(g->d_llctr, 0, sizeof(int)));
     ROBO_TRY(dev_alloc(&g->d_theta, (size_t)dim + 8 + sizeof(FitSample) / sizeof(double)));
     g->d_sp = reinterpret_cast<FitSample*>(g->d_theta + dim + 8);
     ROBO_HIP_CHECK(hipHostMalloc((void**)&g->h_theta, ((size_t)dim + 8) * sizeof(double) + sizeof(FitSample), 0));
@@ -184,6 +187,10 @@ int32_t robo_gp_destroy(robo_gp* g) {
     hipFree(g->d_K);
     hipFree(g->d_Linv);
     hipFree(g->d_LinvP);
+    hipFree(g->d_llpart);
+    hipFree(g->d_llctr);
+    hipFree(g->d_bllpart);
+    hipFree(g->d_bllctr);
     hipFree(g->d_theta);
     hipHostFree(g->h_theta);
     hipFree(g->d_gV);
@@ -267,6 +274,10 @@ static FitBuffers own_buffers(robo_gp* g) {
     fb.sp = g->d_sp;
     fb.fail = g->ctx->d_fail;
     fb.out = g->ctx->d_scalars;
+    fb.ll_part = g->d_llpart;
+    fb.ll_ctr = g->d_llctr;
+    fb.LinvP = g->d_LinvP;
+    fb.host_out = g->ctx->h_pinned;
     fb.S = 1;
     return fb;
 }
@@ -307,14 +318,11 @@ int32_t robo_gp_fit(robo_gp* g, const double* theta, double mean_c, double* out_
     if (c->phase_events) ROBO_HIP_CHECK(hipEventRecord(c->events[21], c->stream));
     ROBO_TRY(launch_potrf(g, own_buffers(g)));
     if (c->phase_events) ROBO_HIP_CHECK(hipEventRecord(c->events[22], c->stream));
-    ROBO_TRY(launch_loglik(g, own_buffers(g)));
     if (c->phase_events) ROBO_HIP_CHECK(hipEventRecord(c->events[23], c->stream));
+    // the tail kernel of the factorisation wrote (z.z, log det, failure flag) straight into the pinned buffer
     double* hp = c->h_pinned;
-    ROBO_HIP_CHECK(hipMemcpyAsync(hp, c->d_scalars, 2 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
-    ROBO_HIP_CHECK(hipMemcpyAsync(hp + 4, c->d_fail, sizeof(int), hipMemcpyDeviceToHost, c->stream));
     ROBO_HIP_CHECK(hipStreamSynchronize(c->stream));
-    int fail = 0;
-    memcpy(&fail, hp + 4, sizeof(int));
+    const int fail = (int)hp[2];
     if (fail != 0) {
         if (out_fail_col) *out_fail_col = fail - 1;
         if (out_loglik) *out_loglik = -HUGE_VAL;
@@ -356,10 +364,10 @@ int32_t robo_gp_grad_loglik(robo_gp* g, const double* theta, double mean_c, doub
 static int batch_ensure(robo_gp* g, int S) {
     if (g->b_cap >= S && g->b_npad == g->n_pad) return ROBO_OK;
     hipFree(g->d_bK); hipFree(g->d_bLinv); hipFree(g->d_bXs); hipFree(g->d_bism); hipFree(g->d_bout);
-    hipFree(g->d_bsp); hipFree(g->d_bfail);
+    hipFree(g->d_bsp); hipFree(g->d_bfail); hipFree(g->d_bllpart); hipFree(g->d_bllctr);
     if (g->h_bstage) hipHostFree(g->h_bstage);
     g->d_bK = g->d_bLinv = g->d_bXs = g->d_bism = g->d_bout = g->h_bstage = nullptr;
-    g->d_bsp = nullptr; g->d_bfail = nullptr;
+    g->d_bsp = nullptr; g->d_bfail = nullptr; g->d_bllpart = nullptr; g->d_bllctr = nullptr;
     g->b_cap = 0;
     const size_t np = (size_t)g->n_pad, D = (size_t)g->dim;
     ROBO_TRY(dev_alloc(&g->d_bK, (size_t)S * np * np));
@@ -370,6 +378,9 @@ static int batch_ensure(robo_gp* g, int S) {
     ROBO_TRY(dev_alloc(&g->d_bout, (size_t)S * 2));
     ROBO_TRY(dev_alloc(&g->d_bsp, (size_t)S));
     ROBO_TRY(dev_alloc(&g->d_bfail, (size_t)S));
+    ROBO_TRY(dev_alloc(&g->d_bllpart, (size_t)S * (np / NB) * 2));
+    ROBO_TRY(dev_alloc(&g->d_bllctr, (size_t)S));
+    ROBO_HIP_CHECK(hipMemset(g->d_bllctr, 0, (size_t)S * sizeof(int)));
     // pinned staging: [S x FitSample | S x D ism] up, [S x 2 doubles | S ints] down
     const size_t bytes = (size_t)S * (sizeof(FitSample) + D * sizeof(double) + 2 * sizeof(double) + sizeof(int)) + 64;
     ROBO_HIP_CHECK(hipHostMalloc((void**)&g->h_bstage, bytes, 0));
@@ -416,11 +427,14 @@ static int fit_batch_core(robo_gp* g, const double* thetas, int32_t S, double me
         fb.sp = g->d_bsp;
         fb.fail = g->d_bfail;
         fb.out = g->d_bout;
+        fb.ll_part = g->d_bllpart;
+        fb.ll_ctr = g->d_bllctr;
+        fb.LinvP = nullptr;
+        fb.host_out = nullptr;
         fb.S = ns;
         ROBO_TRY(launch_scale_inputs(c, g->d_X, g->d_bXs, g->d_bism, g->n, g->n_pad, D, ns, np * D, (size_t)D));
         ROBO_TRY(launch_gram(g, fb));
-        ROBO_TRY(launch_potrf(g, fb));
-        ROBO_TRY(launch_loglik(g, fb));
+        ROBO_TRY(launch_potrf(g, fb));   // its tail kernel also reduces the log-likelihood terms into fb.out
         double* hout = hism + (size_t)chunk * D;
         int* hfail = reinterpret_cast<int*>(hout + 2 * (size_t)chunk);
         ROBO_HIP_CHECK(hipMemcpyAsync(hout, g->d_bout, (size_t)ns * 2 * sizeof(double), hipMemcpyDeviceToHost, c->stream));

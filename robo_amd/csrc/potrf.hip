@@ -594,8 +594,19 @@ __global__ __launch_bounds__(256) void potrf_panel_kernel(double* __restrict__ K
 // until block row i is final, stage s does  W_sj = -W_ss S_sj  (j < s)  and then  S_ij += L_is W_sj  for every
 // block row i > s -- 7, 13, 17, 19, 19, 17, 13 independent products in stages 0..6, handed out dynamically to the
 // four waves, one barrier per half-stage.
+//
+// Tail of the factorisation, in the same launch (r02z: the separate pack and log-likelihood launches and the two
+// device-to-host copies behind them cost a 1.8 ms fit ~25 us):
+//   * Wp != nullptr: the inverse is also written as packed MFMA A-operand fragments (see linv_pack_kernel);
+//   * every workgroup reduces its 128 rows' share of  sum log L_ii  and  z.z  (z = row n of the factor) into
+//     ll_part; the LAST workgroup of a sample to arrive (agent-scope counter) adds the partials in block order --
+//     a fixed summation order -- into out[2 s .. 2 s + 1] and, when host_out is given (pinned, device-visible),
+//     writes (z.z, 2 sum log L_ii, failure flag) straight to the host.
 __global__ __launch_bounds__(256) void potrf_inverse_kernel(const double* __restrict__ K, size_t k_stride, int ld,
-                                                            double* __restrict__ Linv, size_t linv_stride, int n_real) {
+                                                            double* __restrict__ Linv, size_t linv_stride, int n_real,
+                                                            double* __restrict__ Wp, double* __restrict__ ll_part,
+                                                            int* __restrict__ ll_ctr, double* __restrict__ out,
+                                                            const int* __restrict__ fail, double* __restrict__ host_out) {
     __shared__ double smem[2 * NBLK * BLK + 32];
     double* sL = smem;
     double* sW = smem + NBLK * BLK;
@@ -658,6 +669,64 @@ __global__ __launch_bounds__(256) void potrf_inverse_kernel(const double* __rest
         for (int bj = 0; bj < bi; ++bj)
             Wg[(bi * SB + (tid >> 4)) * NB + bj * SB + (tid & 15)] =
                 bi < nsb ? sW[blk_off(bi, bj) + bidx(tid >> 4, tid & 15)] : 0.0;
+    if (Wp) {
+        double* wp = Wp + (size_t)k * WP_BLOCK;
+        for (int idx = tid; idx < WP_BLOCK; idx += 256) {
+            const int f = idx >> 6, l = idx & 63;
+            int cb = 7;
+            while (f >= wp_offset(cb) + 4 * (cb + 1)) --cb;
+            const int rel = f - wp_offset(cb), jb = rel >> 2, kk = rel & 3;
+            wp[idx] = (cb == jb || cb < nsb) ? sW[blk_off(cb, jb) + bidx(pi16(l & 15), 4 * kk + (l >> 4))] : 0.0;
+        }
+    }
+    // ---- log-likelihood terms of rows 128 k .. 128 k + 127 (rows >= n_real: augmented row / padding, no share)
+    {
+        double q = 0.0, lg = 0.0;
+        const int r = k * NB + tid;
+        if (tid < NB && r < n_real) {
+            const double zi = K[(size_t)n_real * ld + r];
+            q = zi * zi;
+            lg = log(sL[blk_off(tid >> 4, tid >> 4) + bidx(tid & 15, tid & 15)]);
+        }
+        for (int o = 32; o > 0; o >>= 1) {
+            q += __shfl_xor(q, o);
+            lg += __shfl_xor(lg, o);
+        }
+        __syncthreads();            // sW / the counters are dead: reuse the scratch
+        double* red = smem + 2 * NBLK * BLK;
+        if (lane == 0 && wave < 2) {
+            red[wave] = q;
+            red[2 + wave] = lg;
+        }
+        __syncthreads();
+        const int nbk = gridDim.x, smp = blockIdx.y;
+        double* part = ll_part + (size_t)smp * nbk * 2;
+        __shared__ int last;
+        if (tid == 0) {
+            part[2 * k] = red[0] + red[1];
+            part[2 * k + 1] = red[2] + red[3];
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            const int arrived = __hip_atomic_fetch_add(ll_ctr + smp, 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+            last = arrived == nbk - 1;
+        }
+        __syncthreads();
+        if (last && tid == 0) {
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            double sq = 0.0, sl = 0.0;
+            for (int b = 0; b < nbk; ++b) {
+                sq += __hip_atomic_load(part + 2 * b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                sl += __hip_atomic_load(part + 2 * b + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            out[2 * smp] = sq;
+            out[2 * smp + 1] = 2.0 * sl;
+            ll_ctr[smp] = 0;        // ready for the next factorisation
+            if (host_out) {
+                host_out[0] = sq;
+                host_out[1] = 2.0 * sl;
+                host_out[2] = (double)fail[smp];
+            }
+        }
+    }
 }
 
 // Tile (k+1, k+1) of the trailing update for the fused diagonal workgroup:  C_lower - P P^T  straight
@@ -944,34 +1013,6 @@ int launch_pack_linv(robo_gp* gp) {
     return ROBO_OK;
 }
 
-// out[0] = z.z, out[1] = 2 sum_{i<n} log L_ii   (z = row n of the factor); fixed summation order
-__global__ __launch_bounds__(256) void loglik_kernel(const double* __restrict__ K, size_t k_stride, int ld, int n,
-                                                     double* __restrict__ out) {
-    __shared__ double sq[4], sl[4];
-    K += (size_t)blockIdx.x * k_stride;
-    out += 2 * blockIdx.x;
-    double q = 0.0, l = 0.0;
-    const double* z = K + (size_t)n * ld;
-    for (int i = threadIdx.x; i < n; i += 256) {
-        const double zi = z[i];
-        q = fma(zi, zi, q);
-        l += log(K[(size_t)i * ld + i]);
-    }
-    for (int o = 32; o > 0; o >>= 1) {
-        q += __shfl_xor(q, o);
-        l += __shfl_xor(l, o);
-    }
-    if ((threadIdx.x & 63) == 0) {
-        sq[threadIdx.x >> 6] = q;
-        sl[threadIdx.x >> 6] = l;
-    }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        out[0] = (sq[0] + sq[1]) + (sq[2] + sq[3]);
-        out[1] = 2.0 * ((sl[0] + sl[1]) + (sl[2] + sl[3]));
-    }
-}
-
 int launch_potrf(robo_gp* gp, const FitBuffers& fb) {
     robo_ctx* ctx = gp->ctx;
     const int ld = gp->n_pad, nb = gp->n_pad / NB, S = fb.S;
@@ -1040,9 +1081,9 @@ int launch_potrf(robo_gp* gp, const FitBuffers& fb) {
 #undef ROBO_DIAG
     // the explicit 128 x 128 inverses of all diagonal blocks, off the factorisation's critical path
     hipLaunchKernelGGL(potrf_inverse_kernel, dim3(nb, S), dim3(256), 0, ctx->stream, (const double*)fb.K, fb.k_stride, ld,
-                       fb.Linv, fb.linv_stride, gp->n);
+                       fb.Linv, fb.linv_stride, gp->n, fb.LinvP, fb.ll_part, fb.ll_ctr, fb.out, (const int*)fb.fail,
+                       fb.host_out);
     ROBO_LAUNCH_CHECK();
-    if (fb.Linv == gp->d_Linv) return launch_pack_linv(gp);   // the GP's own factor: fragments for the posterior
     return ROBO_OK;
 }
 
@@ -1055,13 +1096,6 @@ int launch_diag_timeline(robo_gp* gp, long long* d_stamps) {
     if (nb > 1)
         hipLaunchKernelGGL(potrf_panel_kernel, dim3((nb - 1) * 2, 1), dim3(256), 0, gp->ctx->stream, gp->d_K, (size_t)0,
                            gp->n_pad, 0, (const double*)gp->d_Linv, (size_t)0, d_stamps + 16);
-    ROBO_LAUNCH_CHECK();
-    return ROBO_OK;
-}
-
-int launch_loglik(robo_gp* gp, const FitBuffers& fb) {
-    hipLaunchKernelGGL(loglik_kernel, dim3(fb.S), dim3(256), 0, gp->ctx->stream, (const double*)fb.K, fb.k_stride,
-                       gp->n_pad, gp->n, fb.out);
     ROBO_LAUNCH_CHECK();
     return ROBO_OK;
 }

@@ -207,3 +207,10 @@ template <class T> static inline T atomicMax(T* p, T v) { T o = *p; if (v > o) *
 template <class T> static inline T atomicOr(T* p, T v) { T o = *p; *p = o | v; return o; }
 template <class T> static inline T atomicExch(T* p, T v) { T o = *p; *p = v; return o; }
 template <class T> static inline T atomicCAS(T* p, T cmp, T v) { T o = *p; if (o == cmp) *p = v; return o; }
+// scoped atomics (clang builtins on the device): workgroups run one at a time here
+#ifndef __HIP_MEMORY_SCOPE_AGENT
+#define __HIP_MEMORY_SCOPE_AGENT 4
+#endif
+template <class T> static inline T __hip_atomic_fetch_add(T* p, T v, int, int) { T o = *p; *p = o + v; return o; }
+template <class T> static inline T __hip_atomic_load(const T* p, int, int) { return *p; }
+template <class T> static inline void __hip_atomic_store(T* p, T v, int, int) { *p = v; }
