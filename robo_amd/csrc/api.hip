@@ -168,8 +168,6 @@ int32_t robo_gp_create(robo_ctx* ctx, int32_t kind, int32_t n_max, int32_t dim, 
     ROBO_HIP_CHECK(hipMemset(g->d_Linv, 0, np * NB * sizeof(double)));
     ROBO_TRY(dev_alloc(&g->d_LinvP, (np / NB) * WP_BLOCK));
     ROBO_TRY(dev_alloc(&g->d_llpart, (np / NB) * 2));
-    ROBO_TRY(dev_alloc(&g->d_llctr, (size_t)1));
-    ROBO_HIP_CHECK(hipMemset(g->d_llctr, 0, sizeof(int)));
     ROBO_TRY(dev_alloc(&g->d_theta, (size_t)dim + 8 + sizeof(FitSample) / sizeof(double)));
     g->d_sp = reinterpret_cast<FitSample*>(g->d_theta + dim + 8);
     ROBO_HIP_CHECK(hipHostMalloc((void**)&g->h_theta, ((size_t)dim + 8) * sizeof(double) + sizeof(FitSample), 0));
@@ -188,9 +186,7 @@ int32_t robo_gp_destroy(robo_gp* g) {
     hipFree(g->d_Linv);
     hipFree(g->d_LinvP);
     hipFree(g->d_llpart);
-    hipFree(g->d_llctr);
     hipFree(g->d_bllpart);
-    hipFree(g->d_bllctr);
     hipFree(g->d_theta);
     hipHostFree(g->h_theta);
     hipFree(g->d_gV);
@@ -275,7 +271,6 @@ static FitBuffers own_buffers(robo_gp* g) {
     fb.fail = g->ctx->d_fail;
     fb.out = g->ctx->d_scalars;
     fb.ll_part = g->d_llpart;
-    fb.ll_ctr = g->d_llctr;
     fb.LinvP = g->d_LinvP;
     fb.host_out = g->ctx->h_pinned;
     fb.S = 1;
@@ -364,10 +359,10 @@ int32_t robo_gp_grad_loglik(robo_gp* g, const double* theta, double mean_c, doub
 static int batch_ensure(robo_gp* g, int S) {
     if (g->b_cap >= S && g->b_npad == g->n_pad) return ROBO_OK;
     hipFree(g->d_bK); hipFree(g->d_bLinv); hipFree(g->d_bXs); hipFree(g->d_bism); hipFree(g->d_bout);
-    hipFree(g->d_bsp); hipFree(g->d_bfail); hipFree(g->d_bllpart); hipFree(g->d_bllctr);
+    hipFree(g->d_bsp); hipFree(g->d_bfail); hipFree(g->d_bllpart);
     if (g->h_bstage) hipHostFree(g->h_bstage);
     g->d_bK = g->d_bLinv = g->d_bXs = g->d_bism = g->d_bout = g->h_bstage = nullptr;
-    g->d_bsp = nullptr; g->d_bfail = nullptr; g->d_bllpart = nullptr; g->d_bllctr = nullptr;
+    g->d_bsp = nullptr; g->d_bfail = nullptr; g->d_bllpart = nullptr;
     g->b_cap = 0;
     const size_t np = (size_t)g->n_pad, D = (size_t)g->dim;
     ROBO_TRY(dev_alloc(&g->d_bK, (size_t)S * np * np));
@@ -379,8 +374,6 @@ static int batch_ensure(robo_gp* g, int S) {
     ROBO_TRY(dev_alloc(&g->d_bsp, (size_t)S));
     ROBO_TRY(dev_alloc(&g->d_bfail, (size_t)S));
     ROBO_TRY(dev_alloc(&g->d_bllpart, (size_t)S * (np / NB) * 2));
-    ROBO_TRY(dev_alloc(&g->d_bllctr, (size_t)S));
-    ROBO_HIP_CHECK(hipMemset(g->d_bllctr, 0, (size_t)S * sizeof(int)));
     // pinned staging: [S x FitSample | S x D ism] up, [S x 2 doubles | S ints] down
     const size_t bytes = (size_t)S * (sizeof(FitSample) + D * sizeof(double) + 2 * sizeof(double) + sizeof(int)) + 64;
     ROBO_HIP_CHECK(hipHostMalloc((void**)&g->h_bstage, bytes, 0));
@@ -428,7 +421,6 @@ static int fit_batch_core(robo_gp* g, const double* thetas, int32_t S, double me
         fb.fail = g->d_bfail;
         fb.out = g->d_bout;
         fb.ll_part = g->d_bllpart;
-        fb.ll_ctr = g->d_bllctr;
         fb.LinvP = nullptr;
         fb.host_out = nullptr;
         fb.S = ns;

@@ -118,7 +118,6 @@ struct robo_gp {
     robo::FitSample* d_bsp;
     int* d_bfail;
     double *d_llpart, *d_bllpart;   // log-likelihood partials of the tail kernel (own factor / batch workspace)
-    int *d_llctr, *d_bllctr;
     // workspace of robo_gp_grad_loglik (lazy, sized for n_pad_max): W^T, A = alpha alpha^T - K^-1, ...
     double *d_gV, *d_gA, *d_galpha, *d_gpart, *d_gout;
 };
@@ -167,7 +166,6 @@ struct FitBuffers {
     int* fail;                           // [S]
     double* out;                         // [S][2]: z.z, 2 sum log diag
     double* ll_part;                     // [S][n_pad/128][2] per-block partial sums of the log-likelihood terms
-    int* ll_ctr;                         // [S] arrival counters of the tail kernel (zero between launches)
     double* LinvP;                       // packed inverse fragments of the GP's own factor, or nullptr (batch workspace)
     double* host_out;                    // pinned host [3]: z.z, 2 sum log diag, failure flag -- or nullptr
     int S;

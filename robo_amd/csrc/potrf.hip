@@ -596,17 +596,13 @@ __global__ __launch_bounds__(256) void potrf_panel_kernel(double* __restrict__ K
 // four waves, one barrier per half-stage.
 //
 // Tail of the factorisation, in the same launch (r02z: the separate pack and log-likelihood launches and the two
-// device-to-host copies behind them cost a 1.8 ms fit ~25 us):
+// device-to-host copies behind them cost a 1.8 ms fit ~25 us; one tiny finishing launch remains):
 //   * Wp != nullptr: the inverse is also written as packed MFMA A-operand fragments (see linv_pack_kernel);
 //   * every workgroup reduces its 128 rows' share of  sum log L_ii  and  z.z  (z = row n of the factor) into
-//     ll_part; the LAST workgroup of a sample to arrive (agent-scope counter) adds the partials in block order --
-//     a fixed summation order -- into out[2 s .. 2 s + 1] and, when host_out is given (pinned, device-visible),
-//     writes (z.z, 2 sum log L_ii, failure flag) straight to the host.
+//     ll_part (added up by loglik_finish_kernel).
 __global__ __launch_bounds__(256) void potrf_inverse_kernel(const double* __restrict__ K, size_t k_stride, int ld,
                                                             double* __restrict__ Linv, size_t linv_stride, int n_real,
-                                                            double* __restrict__ Wp, double* __restrict__ ll_part,
-                                                            int* __restrict__ ll_ctr, double* __restrict__ out,
-                                                            const int* __restrict__ fail, double* __restrict__ host_out) {
+                                                            double* __restrict__ Wp, double* __restrict__ ll_part) {
     __shared__ double smem[2 * NBLK * BLK + 32];
     double* sL = smem;
     double* sW = smem + NBLK * BLK;
@@ -670,14 +666,14 @@ __global__ __launch_bounds__(256) void potrf_inverse_kernel(const double* __rest
             Wg[(bi * SB + (tid >> 4)) * NB + bj * SB + (tid & 15)] =
                 bi < nsb ? sW[blk_off(bi, bj) + bidx(tid >> 4, tid & 15)] : 0.0;
     if (Wp) {
-        double* wp = Wp + (size_t)k * WP_BLOCK;
-        for (int idx = tid; idx < WP_BLOCK; idx += 256) {
-            const int f = idx >> 6, l = idx & 63;
-            int cb = 7;
-            while (f >= wp_offset(cb) + 4 * (cb + 1)) --cb;
-            const int rel = f - wp_offset(cb), jb = rel >> 2, kk = rel & 3;
-            wp[idx] = (cb == jb || cb < nsb) ? sW[blk_off(cb, jb) + bidx(pi16(l & 15), 4 * kk + (l >> 4))] : 0.0;
-        }
+        // one 16x16 block = 4 k-steps x 64 lanes = the 256 threads; nothing to decode
+        double* wp = Wp + (size_t)k * WP_BLOCK + tid;                 // tid = 64 kk + lane
+        const int src = bidx(pi16(lane & 15), 4 * wave + (lane >> 4));
+#pragma unroll
+        for (int cb = 0; cb < NSB; ++cb)
+#pragma unroll
+            for (int jb = 0; jb <= cb; ++jb)
+                wp[(wp_offset(cb) + 4 * jb) * 64] = (cb == jb || cb < nsb) ? sW[blk_off(cb, jb) + src] : 0.0;
     }
     // ---- log-likelihood terms of rows 128 k .. 128 k + 127 (rows >= n_real: augmented row / padding, no share)
     {
@@ -699,33 +695,35 @@ __global__ __launch_bounds__(256) void potrf_inverse_kernel(const double* __rest
             red[2 + wave] = lg;
         }
         __syncthreads();
-        const int nbk = gridDim.x, smp = blockIdx.y;
-        double* part = ll_part + (size_t)smp * nbk * 2;
-        __shared__ int last;
         if (tid == 0) {
-            part[2 * k] = red[0] + red[1];
-            part[2 * k + 1] = red[2] + red[3];
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-            const int arrived = __hip_atomic_fetch_add(ll_ctr + smp, 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
-            last = arrived == nbk - 1;
+            double* part = ll_part + ((size_t)blockIdx.y * gridDim.x + k) * 2;
+            part[0] = red[0] + red[1];
+            part[1] = red[2] + red[3];
         }
-        __syncthreads();
-        if (last && tid == 0) {
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-            double sq = 0.0, sl = 0.0;
-            for (int b = 0; b < nbk; ++b) {
-                sq += __hip_atomic_load(part + 2 * b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                sl += __hip_atomic_load(part + 2 * b + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
-            out[2 * smp] = sq;
-            out[2 * smp + 1] = 2.0 * sl;
-            ll_ctr[smp] = 0;        // ready for the next factorisation
-            if (host_out) {
-                host_out[0] = sq;
-                host_out[1] = 2.0 * sl;
-                host_out[2] = (double)fail[smp];
-            }
-        }
+    }
+}
+
+// (z.z, 2 sum log L_ii) of every sample from the per-block partials, added in block order (a fixed summation order);
+// with host_out (pinned, device-visible; single-sample fits) the result and the failure flag go straight to the host.
+// A launch of its own: handing the partials over INSIDE the tail kernel (agent-scope release + arrival counter) was
+// measured at +16 us -- the release writes back an L2 full of the factorisation's dirty lines (r02z).
+__global__ __launch_bounds__(64) void loglik_finish_kernel(const double* __restrict__ ll_part, int nbk,
+                                                           double* __restrict__ out, const int* __restrict__ fail,
+                                                           double* __restrict__ host_out) {
+    const int smp = blockIdx.x;
+    if (threadIdx.x != 0) return;
+    const double* part = ll_part + (size_t)smp * nbk * 2;
+    double sq = 0.0, sl = 0.0;
+    for (int b = 0; b < nbk; ++b) {
+        sq += part[2 * b];
+        sl += part[2 * b + 1];
+    }
+    out[2 * smp] = sq;
+    out[2 * smp + 1] = 2.0 * sl;
+    if (host_out) {
+        host_out[0] = sq;
+        host_out[1] = 2.0 * sl;
+        host_out[2] = (double)fail[smp];
     }
 }
 
@@ -1081,8 +1079,9 @@ int launch_potrf(robo_gp* gp, const FitBuffers& fb) {
 #undef ROBO_DIAG
     // the explicit 128 x 128 inverses of all diagonal blocks, off the factorisation's critical path
     hipLaunchKernelGGL(potrf_inverse_kernel, dim3(nb, S), dim3(256), 0, ctx->stream, (const double*)fb.K, fb.k_stride, ld,
-                       fb.Linv, fb.linv_stride, gp->n, fb.LinvP, fb.ll_part, fb.ll_ctr, fb.out, (const int*)fb.fail,
-                       fb.host_out);
+                       fb.Linv, fb.linv_stride, gp->n, fb.LinvP, fb.ll_part);
+    hipLaunchKernelGGL(loglik_finish_kernel, dim3(S), dim3(64), 0, ctx->stream, (const double*)fb.ll_part, nb, fb.out,
+                       (const int*)fb.fail, fb.host_out);
     ROBO_LAUNCH_CHECK();
     return ROBO_OK;
 }
