@@ -171,6 +171,12 @@ static inline v4d_emu __builtin_amdgcn_mfma_f64_16x16x4f64(double a, double b, v
 
 static inline void __builtin_amdgcn_s_setprio(int) {}
 static inline void __builtin_amdgcn_fence(int, const char*) {}
+static inline void __builtin_amdgcn_s_waitcnt(int) {}
+static inline int __builtin_amdgcn_readfirstlane(int v) { return v; }   // only used on wave-uniform values
+// LDS-direct load: lane l of the wave deposits `size` bytes at dst + l * size
+static inline void __builtin_amdgcn_global_load_lds(const void* src, void* dst, unsigned size, int offset, unsigned) {
+    std::memcpy(static_cast<char*>(dst) + offset + (size_t)(threadIdx.x & 63) * size, src, size);
+}
 // lanes are independent fibers here: the lock-step guarantee a real wave gives to
 // "store; wave_barrier; load another lane's element" has to be an explicit rendezvous
 static inline void __builtin_amdgcn_wave_barrier() {

@@ -730,3 +730,29 @@ def check_sobol_candidates(ctx, dims=(3, 64), m=1000):
                 want = ref.random(300)
             np.testing.assert_array_equal(c.points(), want)
             c.close()
+
+
+def check_phase_events(ctx):
+    """robo_ctx_set_phase_events: the library brackets the phases of robo_gp_fit with event slots 19..23 only when
+    asked to (off by default: the event packets cost a 1.8 ms fit ~30 us); caller slots work either way."""
+    rs = np.random.RandomState(3)
+    N, D = 200, 3
+    X = rs.rand(N, D)
+    y = np.sin(3 * X.sum(axis=1))
+    theta = np.concatenate([[0.0], np.full(D, np.log(0.5)), [np.log(1e-2)]])
+    g = _lib.DeviceGP(ctx, "matern52", N, D)
+    g.set_data(X, y)
+    ll0 = g.fit(theta, 0.0)
+    ctx.set_phase_events(True)
+    ll1 = g.fit(theta, 0.0)
+    gram, chol, llk, k1 = ctx.elapsed_ms(20, 21), ctx.elapsed_ms(21, 22), ctx.elapsed_ms(22, 23), ctx.elapsed_ms(19, 21)
+    ctx.set_phase_events(False)
+    assert ll1 == ll0
+    for v in (gram, chol, llk, k1):
+        assert np.isfinite(v) and v >= 0.0
+    assert chol > 0.0 and k1 <= gram + 1e-3
+    ctx.record(0)
+    ctx.record(1)
+    assert ctx.elapsed_ms(0, 1) >= 0.0
+    g.close()
+

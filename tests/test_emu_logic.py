@@ -173,3 +173,8 @@ def test_sobol_candidates(emu_ctx):
 
 def test_candidate_reupload(emu_ctx):
     P.check_candidate_reupload(emu_ctx)
+
+
+def test_phase_events(emu_ctx):
+    P.check_phase_events(emu_ctx)
+

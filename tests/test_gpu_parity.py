@@ -386,3 +386,8 @@ def test_sobol_candidates(ctx):
 
 def test_candidate_reupload(ctx):
     P.check_candidate_reupload(ctx)
+
+
+
+def test_phase_events(ctx):
+    P.check_phase_events(ctx)
