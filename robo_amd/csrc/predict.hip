@@ -8,100 +8,18 @@
 // (the reference builds the full M x M covariance and takes np.diag; the values are the
 // same, the O(M^2) work is not done.)
 //
-// Layout: V is (chunk, n_pad) row-major, candidate-major ("Vt"), so every product is the
-// NT form of gemm_f64.h with the candidates as the 128 output rows:
+// Layout: V is (chunk, n_pad) row-major, candidate-major ("Vt"): both operands of every product have the
+// contraction index contiguous (the NT form of gemm_f64.h).
 //   step i:  T   = V[:, blk i] - V[:, 0:i*128] * L[blk i, 0:i*128]^T      (K = i*128)
-//            V_i = T * Linv_i^T                                           (K = 128)
+//            V_i = T * Linv_i^T                                           (the 36 lower 16x16 blocks of Linv_i)
 // One launch per block row i (a launch boundary is the only inter-workgroup ordering the
 // algorithm needs: step i reads columns < i*128 written by the SAME workgroup earlier).
-// Flops per candidate: n_pad^2 + n_pad*128 MFMA flops.
+// MFMA flops per candidate: n_pad^2 - n_pad*128 + 72 n_pad.
 #include "common.h"
 #include "gemm_f64.h"
 #include "kern_math.h"
 
 namespace robo {
-
-// epilogue of a block-row step: store V_i (columns >= n zeroed: augmented row + padding), reduce
-// |v|^2 and v.z per candidate with wavefront shuffles in a fixed order, accumulate into q / mu
-__device__ __forceinline__ void trsm_epilogue(Acc& acc, double* __restrict__ Vt, int ldv,
-                                              const double* __restrict__ z, int i, int n, double* smem,
-                                              double* __restrict__ q, double* __restrict__ mu, long long c0) {
-    const int lane = threadIdx.x & 63, wx = (threadIdx.x >> 6) & 1;
-    double zc[4];
-    bool live[4];
-#pragma unroll
-    for (int tn = 0; tn < 4; ++tn) {
-        const int gn = i * NB + acc_col(tn);
-        live[tn] = gn < n;
-        zc[tn] = live[tn] ? z[gn] : 0.0;
-    }
-    double* red = smem;   // [2][2][128]
-#pragma unroll
-    for (int tm = 0; tm < 4; ++tm)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            double sq = 0.0, sz = 0.0;
-#pragma unroll
-            for (int tn = 0; tn < 4; ++tn) {
-                const double v = live[tn] ? acc.t[tm][tn][r] : 0.0;
-                Vt[(size_t)acc_row(tm, r) * ldv + acc_col(tn)] = v;
-                sq = fma(v, v, sq);
-                sz = fma(v, zc[tn], sz);
-            }
-#pragma unroll
-            for (int o = 1; o < 16; o <<= 1) {
-                sq += __shfl_xor(sq, o);
-                sz += __shfl_xor(sz, o);
-            }
-            if ((lane & 15) == 0) {
-                red[(0 * 2 + wx) * NB + acc_row(tm, r)] = sq;
-                red[(1 * 2 + wx) * NB + acc_row(tm, r)] = sz;
-            }
-        }
-    __syncthreads();
-    if (threadIdx.x < NB) {
-        const long long c = c0 + (long long)blockIdx.x * NB + threadIdx.x;
-        const double sq = red[0 * NB + threadIdx.x] + red[1 * NB + threadIdx.x];
-        const double sz = red[2 * NB + threadIdx.x] + red[3 * NB + threadIdx.x];
-        if (i == 0) {
-            q[c] = sq;
-            mu[c] = sz;
-        } else {
-            q[c] += sq;
-            mu[c] += sz;
-        }
-    }
-}
-
-__global__ __launch_bounds__(256) void trsm_step_kernel(double* __restrict__ V, int ldv, const double* __restrict__ L,
-                                                        int ld, const double* __restrict__ Linv, int i, int n,
-                                                        double* __restrict__ q, double* __restrict__ mu,
-                                                        long long c0) {
-    __shared__ double smem[GEMM_SMEM_DOUBLES];
-    double* Vrow = V + (size_t)blockIdx.x * NB * ldv;
-    double* Vt = Vrow + (size_t)i * NB;   // the tile being solved
-    Acc acc;
-    if (i > 0) {
-#pragma unroll
-        for (int tm = 0; tm < 4; ++tm)
-#pragma unroll
-            for (int tn = 0; tn < 4; ++tn)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) acc.t[tm][tn][r] = Vt[(size_t)acc_row(tm, r) * ldv + acc_col(tn)];
-        gemm_nt_128<true>(Vrow, ldv, L + (size_t)i * NB * ld, ld, 0, i * NB, acc, smem);
-#pragma unroll
-        for (int tm = 0; tm < 4; ++tm)
-#pragma unroll
-            for (int tn = 0; tn < 4; ++tn)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) Vt[(size_t)acc_row(tm, r) * ldv + acc_col(tn)] = acc.t[tm][tn][r];
-        __syncthreads();   // T visible to the whole workgroup (global memory, workgroup scope)
-    }
-    acc_zero(acc);
-    gemm_nt_128<false>(Vt, ldv, Linv + (size_t)i * NB * NB, NB, 0, NB, acc, smem);
-
-    trsm_epilogue(acc, Vt, ldv, L + (size_t)n * ld, i, n, smem, q, mu, c0);
-}
 
 // ---- block-row step with the cross-gram tile generated in registers, TRANSPOSED tile ---------------------------
 // Per 128 candidates (one workgroup) and block row i the step is
@@ -337,6 +255,31 @@ __global__ __launch_bounds__(256, 2) void trsm_step_gen_kernel(const double* __r
     }
 }
 
+// The same block-row step on a cross-gram that already lies in V (cross_gram_kernel: fp32 covariance entries of
+// BASELINE config 5, representer points, gradient right-hand sides): the tile is read from V into the transposed
+// accumulator layout instead of being generated.
+__global__ __launch_bounds__(256, 2) void trsm_step_kernel(double* __restrict__ V, int ldv, const double* __restrict__ L,
+                                                           int ld, const double* __restrict__ LinvP, int i, int n,
+                                                           double* __restrict__ q, double* __restrict__ mu,
+                                                           long long c0) {
+    __shared__ double smem[GEMM_SMEM_DOUBLES];
+    double* Vrow = V + (size_t)blockIdx.x * NB * ldv;
+    const long long cw = c0 + (long long)blockIdx.x * NB;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    AccTt acc;
+#pragma unroll
+    for (int mb = 0; mb < 2; ++mb) {
+        const double* src = Vrow + (size_t)(wave * 32 + mb * 16 + (lane & 15)) * ldv + (size_t)i * NB + (lane >> 4);
+#pragma unroll
+        for (int rb = 0; rb < 8; ++rb)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc.t[rb][mb][r] = src[rb * 16 + 4 * r];
+    }
+    if (i > 0) gemm_t(L + (size_t)i * NB * ld, ld, Vrow, ldv, i * NB, acc, smem);
+    solve_store_reduce_t(acc, LinvP + (size_t)i * WP_BLOCK, L + (size_t)n * ld + (size_t)i * NB, n - i * NB,
+                         Vrow + (size_t)i * NB, ldv, q + cw, mu + cw, i == 0);
+}
+
 // mean/var from the reductions, with the reference's output transform and variance floor
 // (robo/models/gaussian_process.py:282-294)
 __global__ __launch_bounds__(256) void post_kernel(const double* __restrict__ q, const double* __restrict__ mu,
@@ -384,7 +327,7 @@ int launch_trsm(robo_gp* gp, robo_cand* cand, int64_t c0, int64_t cn) {
     const int nbk = (gp->n + NB - 1) / NB;
     for (int i = 0; i < nbk; ++i) {
         hipLaunchKernelGGL(trsm_step_kernel, dim3((unsigned)(cn / NB)), dim3(256), 0, gp->ctx->stream, cand->d_V,
-                           gp->n_pad, (const double*)gp->d_K, gp->n_pad, (const double*)gp->d_Linv, i, gp->n,
+                           gp->n_pad, (const double*)gp->d_K, gp->n_pad, (const double*)gp->d_LinvP, i, gp->n,
                            cand->d_q, cand->d_mu, (long long)c0);
     }
     ROBO_LAUNCH_CHECK();
