@@ -255,6 +255,218 @@ __global__ __launch_bounds__(256, 2) void trsm_step_gen_kernel(const double* __r
     }
 }
 
+// ---- small candidate batches: 32 candidates per workgroup ---------------------------------------------------------
+// With fewer than ~2 workgroups of 128 candidates per CU the step above is bound by ONE wave's chain of 512 i + 288
+// MFMAs per block row (the reference's default 500 random candidates, the 50 representer points of entropy search,
+// a Fabolas incumbent projection or an 8192-candidate shard of config 4 occupy 4, 1, 32 and 64 of 256 CUs and all
+// take the same 11 ms at N = 4096).  Here a workgroup owns 32 candidates and its four waves split the 128 training
+// rows of the tile (2 x 2 MFMA tiles each): 128 i MFMAs per wave and block row in the update; for the solve the tile
+// goes through LDS once ([candidate block][row][16]: a fragment read is 16 consecutive doubles per lane group, two
+// groups 128 bytes apart in bank space) and wave w forms result row blocks w and 7 - w (9 of the 36 sub-blocks each).
+// Same arithmetic per element as the 128-candidate step -- products accumulate in the same order, and the |v|^2 /
+// v.z reductions are redone from an LDS copy of the result in exactly its order -- so both give the same bits.
+constexpr int SC = 32;                                    // candidates per workgroup
+constexpr int SMALL_STAGE = (NB + SC) * LDS_LD;           // doubles per staging stage: L tile | V tile
+constexpr int SMALL_SMEM_DOUBLES = 2 * 2 * NB * 16;       // T image + result image (64 KB) >= 2 stages (46 KB)
+
+struct AccS {
+    v4d t[2][2];   // [row block 2 wave + rbl][candidate block]
+};
+
+template <int KIND>
+__device__ __forceinline__ void gen_cross_tile_s(const CovParams& cp, const double* __restrict__ Xc,
+                                                 const double* __restrict__ Xt, int n_valid, double* smem, AccS& acc) {
+    constexpr int GD = 16, GXL = NB + 2, GCL = SC + 2;
+    double* sX = smem;                 // [GD][GXL] training points
+    double* sC = smem + GD * GXL;      // [GD][GCL] candidates
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6, dim = cp.dim;
+    const bool fab = KIND == ROBO_KERNEL_FABOLAS;
+#pragma unroll
+    for (int rbl = 0; rbl < 2; ++rbl)
+#pragma unroll
+        for (int mb = 0; mb < 2; ++mb) acc.t[rbl][mb] = fab ? v4d{1.0, 1.0, 1.0, 1.0} : v4d{0.0, 0.0, 0.0, 0.0};
+    const int rbase = wave * 32 + (lane >> 4), cbase = lane & 15;
+    for (int d0 = 0; d0 < dim; d0 += GD) {
+        __syncthreads();
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int idx = t + e * 256, row = idx >> 4, d = idx & 15;
+            sX[d * GXL + row] = d0 + d < dim ? Xt[(size_t)row * dim + d0 + d] : 0.0;
+        }
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            const int idx = t + e * 256, row = idx >> 4, d = idx & 15;
+            sC[d * GCL + row] = d0 + d < dim ? Xc[(size_t)row * dim + d0 + d] : 0.0;
+        }
+        __syncthreads();
+        const int dn = dim - d0 < GD ? dim - d0 : GD;
+        for (int d = 0; d < dn; ++d) {
+            if (fab && d0 + d == dim - 1) break;
+            double xi[2];
+#pragma unroll
+            for (int mb = 0; mb < 2; ++mb) xi[mb] = sC[d * GCL + cbase + mb * 16];
+#pragma unroll
+            for (int rbl = 0; rbl < 2; ++rbl)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const double xj = sX[d * GXL + rbl * 16 + rbase + 4 * r];
+#pragma unroll
+                    for (int mb = 0; mb < 2; ++mb) {
+                        const double df = xi[mb] - xj;
+                        if (fab) acc.t[rbl][mb][r] *= matern52_unit(df * df);
+                        else acc.t[rbl][mb][r] = fma(df, df, acc.t[rbl][mb][r]);
+                    }
+                }
+        }
+    }
+    const int dl = (dim - 1) % GD;
+#pragma unroll
+    for (int rbl = 0; rbl < 2; ++rbl)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int row = rbl * 16 + rbase + 4 * r;
+#pragma unroll
+            for (int mb = 0; mb < 2; ++mb) {
+                double uu = 0.0;
+                if (fab) uu = sC[dl * GCL + cbase + mb * 16] * sX[dl * GXL + row];
+                const double v = cov_finish<double, KIND>(cp, acc.t[rbl][mb][r], uu);
+                acc.t[rbl][mb][r] = row < n_valid ? v : 0.0;
+            }
+        }
+    __syncthreads();
+}
+
+// acc -= A[128 rows, 0:kend] * B[32 rows, 0:kend]^T, wave w on rows 32 w .. 32 w + 31
+__device__ __forceinline__ void gemm_s(const double* __restrict__ A, int lda, const double* __restrict__ B, int ldb,
+                                       int kend, AccS& acc, double* smem) {
+    constexpr int SA = NB * LDS_LD;
+    const int nk = kend / BK, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (nk <= 0) return;
+    Tile4 ra = tile_load_regs<128>(A, lda, 0);
+    Tile4 rb = tile_load_regs<SC>(B, ldb, 0);
+    tile_store_lds<128>(smem, ra);
+    tile_store_lds<SC>(smem + SA, rb);
+    __syncthreads();
+    for (int kt = 0; kt < nk; ++kt) {
+        const double* cur = smem + (kt & 1) * SMALL_STAGE;
+        double* nxt = smem + ((kt + 1) & 1) * SMALL_STAGE;
+        const bool more = kt + 1 < nk;
+        if (more) {
+            ra = tile_load_regs<128>(A, lda, (kt + 1) * BK);
+            rb = tile_load_regs<SC>(B, ldb, (kt + 1) * BK);
+        }
+        const double* pa = cur + (wave * 32 + (lane & 15)) * LDS_LD + (lane >> 4);
+        const double* pb = cur + SA + (lane & 15) * LDS_LD + (lane >> 4);
+#pragma unroll
+        for (int kk = 0; kk < BK / 4; ++kk) {
+            double a[2], b[2];
+#pragma unroll
+            for (int rbl = 0; rbl < 2; ++rbl) a[rbl] = pa[rbl * 16 * LDS_LD + kk * 4];
+#pragma unroll
+            for (int mb = 0; mb < 2; ++mb) b[mb] = -pb[mb * 16 * LDS_LD + kk * 4];
+#pragma unroll
+            for (int rbl = 0; rbl < 2; ++rbl)
+#pragma unroll
+                for (int mb = 0; mb < 2; ++mb) acc.t[rbl][mb] = mfma_f64(a[rbl], b[mb], acc.t[rbl][mb]);
+        }
+        if (more) {
+            tile_store_lds<128>(nxt, ra);
+            tile_store_lds<SC>(nxt + SA, rb);
+        }
+        __syncthreads();
+    }
+}
+
+template <int KIND>
+__global__ __launch_bounds__(256) void trsm_step_small_kernel(const double* __restrict__ Xcs,
+                                                              const double* __restrict__ Xs, double* __restrict__ V,
+                                                              int ldv, const double* __restrict__ L, int ld,
+                                                              const double* __restrict__ LinvP, int i, int n,
+                                                              double* __restrict__ q, double* __restrict__ mu,
+                                                              long long c0, CovParams cp) {
+    __shared__ double smem[SMALL_SMEM_DOUBLES];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = lane >> 4, nn = lane & 15;
+    double* Vrow = V + (size_t)blockIdx.x * SC * ldv;
+    const long long cw = c0 + (long long)blockIdx.x * SC;
+    const int n_valid = n - i * NB;
+    AccS acc;
+    gen_cross_tile_s<KIND>(cp, Xcs + (size_t)cw * cp.dim, Xs + (size_t)i * NB * cp.dim, n_valid, smem, acc);
+    if (i > 0) gemm_s(L + (size_t)i * NB * ld, ld, Vrow, ldv, i * NB, acc, smem);
+    // ---- T^T -> LDS: sT[mb][row][16]
+    double* sT = smem;
+    double* sO = smem + 2 * NB * 16;
+#pragma unroll
+    for (int rbl = 0; rbl < 2; ++rbl)
+#pragma unroll
+        for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                sT[(mb * NB + wave * 32 + rbl * 16 + g + 4 * r) * 16 + nn] = acc.t[rbl][mb][r];
+    __syncthreads();
+    // ---- result row blocks w and 7 - w:  out[cb] = sum_{jb <= cb} Linv[cb][jb] T[jb]
+    const double* wp = LinvP + (size_t)i * WP_BLOCK + lane;
+    const double* z = L + (size_t)n * ld + (size_t)i * NB;
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+        const int cb = half == 0 ? wave : 7 - wave;
+        v4d o[2] = {v4d{0.0, 0.0, 0.0, 0.0}, v4d{0.0, 0.0, 0.0, 0.0}};
+        const double* wf = wp + (size_t)wp_offset(cb) * 64;
+        for (int jb = 0; jb <= cb; ++jb) {
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) {
+                const double a = wf[(4 * jb + kk) * 64];
+#pragma unroll
+                for (int mb = 0; mb < 2; ++mb)
+                    o[mb] = mfma_f64(a, sT[(mb * NB + 16 * jb + 4 * kk + g) * 16 + nn], o[mb]);
+            }
+        }
+        const int r0 = 16 * cb + 4 * g;
+#pragma unroll
+        for (int mb = 0; mb < 2; ++mb) {
+            double v[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                v[r] = r0 + r < n_valid ? o[mb][r] : 0.0;
+                sO[(mb * NB + r0 + r) * 16 + nn] = v[r];
+            }
+            double2* dst = reinterpret_cast<double2*>(Vrow + (size_t)(mb * 16 + nn) * ldv + (size_t)i * NB + r0);
+            dst[0] = make_double2(v[0], v[1]);
+            dst[1] = make_double2(v[2], v[3]);
+        }
+    }
+    __syncthreads();
+    // ---- |v|^2 and v.z per candidate in the summation order of the 128-candidate step: wave mb, lane (g, nn)
+    if (wave < 2) {
+        const int mb = wave;
+        double sq = 0.0, sz = 0.0;
+#pragma unroll
+        for (int cbi = 0; cbi < 8; ++cbi) {
+            const int r0 = 16 * (7 - cbi) + 4 * g;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const double v = sO[(mb * NB + r0 + r) * 16 + nn];
+                const double zc = r0 + r < n_valid ? z[r0 + r] : 0.0;
+                sq = fma(v, v, sq);
+                sz = fma(v, zc, sz);
+            }
+        }
+        sq += __shfl_xor(sq, 16);
+        sz += __shfl_xor(sz, 16);
+        sq += __shfl_xor(sq, 32);
+        sz += __shfl_xor(sz, 32);
+        if (g == 0) {
+            const long long c = cw + mb * 16 + nn;
+            if (i == 0) {
+                q[c] = sq;
+                mu[c] = sz;
+            } else {
+                q[c] += sq;
+                mu[c] += sz;
+            }
+        }
+    }
+}
+
 // The same block-row step on a cross-gram that already lies in V (cross_gram_kernel: fp32 covariance entries of
 // BASELINE config 5, representer points, gradient right-hand sides): the tile is read from V into the transposed
 // accumulator layout instead of being generated.
@@ -338,6 +550,26 @@ int launch_trsm(robo_gp* gp, robo_cand* cand, int64_t c0, int64_t cn) {
 int launch_predict_fused(robo_gp* gp, robo_cand* cand, int64_t c0, int64_t cn) {
     const int nbk = (gp->n + NB - 1) / NB;
     const dim3 grid((unsigned)(cn / NB));
+    {   // batches that leave most CUs without a 128-candidate workgroup: 32 candidates per workgroup
+        const char* e = getenv("ROBO_TRSM_SMALL_MAX");
+        const int64_t small_max = e ? atoll(e) : 16384;
+        if (cn <= small_max) {
+            const dim3 sgrid((unsigned)(cn / SC));
+#define ROBO_SMALL_CALL(KIND)                                                                                  \
+    hipLaunchKernelGGL(trsm_step_small_kernel<KIND>, sgrid, dim3(256), 0, gp->ctx->stream,                     \
+                       (const double*)cand->d_Xcs, (const double*)gp->d_Xs, cand->d_V, gp->n_pad,             \
+                       (const double*)gp->d_K, gp->n_pad, (const double*)gp->d_LinvP, i, gp->n, cand->d_q,     \
+                       cand->d_mu, (long long)c0, gp->cov)
+            for (int i = 0; i < nbk; ++i) {
+                if (gp->kind == ROBO_KERNEL_MATERN52_ARD) ROBO_SMALL_CALL(ROBO_KERNEL_MATERN52_ARD);
+                else if (gp->kind == ROBO_KERNEL_RBF_ARD) ROBO_SMALL_CALL(ROBO_KERNEL_RBF_ARD);
+                else ROBO_SMALL_CALL(ROBO_KERNEL_FABOLAS);
+            }
+#undef ROBO_SMALL_CALL
+            ROBO_LAUNCH_CHECK();
+            return ROBO_OK;
+        }
+    }
 #define ROBO_STEP_CALL(KIND)                                                                                   \
     hipLaunchKernelGGL(trsm_step_gen_kernel<KIND>, grid, dim3(256), 0, gp->ctx->stream,                        \
                        (const double*)cand->d_Xcs, (const double*)gp->d_Xs, cand->d_V, gp->n_pad,             \

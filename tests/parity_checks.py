@@ -756,3 +756,30 @@ def check_phase_events(ctx):
     assert ctx.elapsed_ms(0, 1) >= 0.0
     g.close()
 
+
+def check_small_and_large_tiles_agree(ctx, monkeypatch, cases=(("matern52", 300, 5, 700), ("fabolas", 200, 4, 130))):
+    """the 32-candidate block-row step (small batches) and the 128-candidate one give the same bits"""
+    rs = np.random.RandomState(41)
+    for kind, N, D, M in cases:
+        X = rs.rand(N, D)
+        y = np.sin(3 * X.sum(axis=1))
+        P = O.n_kernel_params(kind, D) + 1
+        theta = np.zeros(P)
+        theta[1:1 + D if kind != "fabolas" else D] = np.log(0.4 * D)
+        theta[-1] = np.log(1e-2)
+        g = _lib.DeviceGP(ctx, kind, N, D)
+        g.set_data(X, y)
+        g.fit(theta, float(y.mean()))
+        Xc = rs.rand(M, D)
+        monkeypatch.setenv("ROBO_TRSM_SMALL_MAX", "0")
+        mu_l, var_l = g.predict(Xc)
+        _, mx_l, am_l, _ = g.acq("ei", 0.0, float(y.min()), Xc)
+        monkeypatch.setenv("ROBO_TRSM_SMALL_MAX", "1000000")
+        mu_s, var_s = g.predict(Xc)
+        _, mx_s, am_s, _ = g.acq("ei", 0.0, float(y.min()), Xc)
+        monkeypatch.delenv("ROBO_TRSM_SMALL_MAX")
+        np.testing.assert_array_equal(mu_s, mu_l)
+        np.testing.assert_array_equal(var_s, var_l)
+        assert (mx_s, am_s) == (mx_l, am_l)
+        g.close()
+

@@ -178,3 +178,7 @@ def test_candidate_reupload(emu_ctx):
 def test_phase_events(emu_ctx):
     P.check_phase_events(emu_ctx)
 
+
+def test_small_and_large_candidate_tiles_agree(emu_ctx, monkeypatch):
+    P.check_small_and_large_tiles_agree(emu_ctx, monkeypatch)
+

@@ -391,3 +391,8 @@ def test_candidate_reupload(ctx):
 
 def test_phase_events(ctx):
     P.check_phase_events(ctx)
+
+
+def test_small_and_large_candidate_tiles_agree(ctx, monkeypatch):
+    P.check_small_and_large_tiles_agree(ctx, monkeypatch)
+
