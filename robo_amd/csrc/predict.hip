@@ -265,18 +265,23 @@ __global__ __launch_bounds__(256, 2) void trsm_step_gen_kernel(const double* __r
 // groups 128 bytes apart in bank space) and wave w forms result row blocks w and 7 - w (9 of the 36 sub-blocks each).
 // Same arithmetic per element as the 128-candidate step -- products accumulate in the same order, and the |v|^2 /
 // v.z reductions are redone from an LDS copy of the result in exactly its order -- so both give the same bits.
-constexpr int SC = 32;                                    // candidates per workgroup
-constexpr int SMALL_STAGE = (NB + SC) * LDS_LD;           // doubles per staging stage: L tile | V tile
-constexpr int SMALL_SMEM_DOUBLES = 2 * 2 * NB * 16;       // T image + result image (64 KB) >= 2 stages (46 KB)
+// MB = candidate blocks of 16 per workgroup: 2 (32 candidates), or 1 (16 candidates: twice the workgroups, used while
+// that still means at most two per CU -- two short chains per CU overlap where one leaves the matrix pipe idle)
+template <int MB> constexpr int small_stage() { return (NB + 16 * MB) * LDS_LD; }   // staging stage: L tile | V tile
+template <int MB> constexpr int small_smem_doubles() {   // T image + result image, or the two staging stages
+    return 2 * MB * NB * 16 > 2 * small_stage<MB>() ? 2 * MB * NB * 16 : 2 * small_stage<MB>();
+}
 
+template <int MB>
 struct AccS {
-    v4d t[2][2];   // [row block 2 wave + rbl][candidate block]
+    v4d t[2][MB];   // [row block 2 wave + rbl][candidate block]
 };
 
-template <int KIND>
+template <int KIND, int MB>
 __device__ __forceinline__ void gen_cross_tile_s(const CovParams& cp, const double* __restrict__ Xc,
-                                                 const double* __restrict__ Xt, int n_valid, double* smem, AccS& acc) {
-    constexpr int GD = 16, GXL = NB + 2, GCL = SC + 2;
+                                                 const double* __restrict__ Xt, int n_valid, double* smem,
+                                                 AccS<MB>& acc) {
+    constexpr int SC = 16 * MB, GD = 16, GXL = NB + 2, GCL = SC + 2;
     double* sX = smem;                 // [GD][GXL] training points
     double* sC = smem + GD * GXL;      // [GD][GCL] candidates
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6, dim = cp.dim;
@@ -284,7 +289,7 @@ __device__ __forceinline__ void gen_cross_tile_s(const CovParams& cp, const doub
 #pragma unroll
     for (int rbl = 0; rbl < 2; ++rbl)
 #pragma unroll
-        for (int mb = 0; mb < 2; ++mb) acc.t[rbl][mb] = fab ? v4d{1.0, 1.0, 1.0, 1.0} : v4d{0.0, 0.0, 0.0, 0.0};
+        for (int mb = 0; mb < MB; ++mb) acc.t[rbl][mb] = fab ? v4d{1.0, 1.0, 1.0, 1.0} : v4d{0.0, 0.0, 0.0, 0.0};
     const int rbase = wave * 32 + (lane >> 4), cbase = lane & 15;
     for (int d0 = 0; d0 < dim; d0 += GD) {
         __syncthreads();
@@ -294,7 +299,7 @@ __device__ __forceinline__ void gen_cross_tile_s(const CovParams& cp, const doub
             sX[d * GXL + row] = d0 + d < dim ? Xt[(size_t)row * dim + d0 + d] : 0.0;
         }
 #pragma unroll
-        for (int e = 0; e < 2; ++e) {
+        for (int e = 0; e < MB; ++e) {
             const int idx = t + e * 256, row = idx >> 4, d = idx & 15;
             sC[d * GCL + row] = d0 + d < dim ? Xc[(size_t)row * dim + d0 + d] : 0.0;
         }
@@ -302,16 +307,16 @@ __device__ __forceinline__ void gen_cross_tile_s(const CovParams& cp, const doub
         const int dn = dim - d0 < GD ? dim - d0 : GD;
         for (int d = 0; d < dn; ++d) {
             if (fab && d0 + d == dim - 1) break;
-            double xi[2];
+            double xi[MB];
 #pragma unroll
-            for (int mb = 0; mb < 2; ++mb) xi[mb] = sC[d * GCL + cbase + mb * 16];
+            for (int mb = 0; mb < MB; ++mb) xi[mb] = sC[d * GCL + cbase + mb * 16];
 #pragma unroll
             for (int rbl = 0; rbl < 2; ++rbl)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const double xj = sX[d * GXL + rbl * 16 + rbase + 4 * r];
 #pragma unroll
-                    for (int mb = 0; mb < 2; ++mb) {
+                    for (int mb = 0; mb < MB; ++mb) {
                         const double df = xi[mb] - xj;
                         if (fab) acc.t[rbl][mb][r] *= matern52_unit(df * df);
                         else acc.t[rbl][mb][r] = fma(df, df, acc.t[rbl][mb][r]);
@@ -326,7 +331,7 @@ __device__ __forceinline__ void gen_cross_tile_s(const CovParams& cp, const doub
         for (int r = 0; r < 4; ++r) {
             const int row = rbl * 16 + rbase + 4 * r;
 #pragma unroll
-            for (int mb = 0; mb < 2; ++mb) {
+            for (int mb = 0; mb < MB; ++mb) {
                 double uu = 0.0;
                 if (fab) uu = sC[dl * GCL + cbase + mb * 16] * sX[dl * GXL + row];
                 const double v = cov_finish<double, KIND>(cp, acc.t[rbl][mb][r], uu);
@@ -336,10 +341,11 @@ __device__ __forceinline__ void gen_cross_tile_s(const CovParams& cp, const doub
     __syncthreads();
 }
 
-// acc -= A[128 rows, 0:kend] * B[32 rows, 0:kend]^T, wave w on rows 32 w .. 32 w + 31
+// acc -= A[128 rows, 0:kend] * B[16 MB rows, 0:kend]^T, wave w on rows 32 w .. 32 w + 31
+template <int MB>
 __device__ __forceinline__ void gemm_s(const double* __restrict__ A, int lda, const double* __restrict__ B, int ldb,
-                                       int kend, AccS& acc, double* smem) {
-    constexpr int SA = NB * LDS_LD;
+                                       int kend, AccS<MB>& acc, double* smem) {
+    constexpr int SA = NB * LDS_LD, SC = 16 * MB, SMALL_STAGE = small_stage<MB>();
     const int nk = kend / BK, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     if (nk <= 0) return;
     Tile4 ra = tile_load_regs<128>(A, lda, 0);
@@ -359,15 +365,15 @@ __device__ __forceinline__ void gemm_s(const double* __restrict__ A, int lda, co
         const double* pb = cur + SA + (lane & 15) * LDS_LD + (lane >> 4);
 #pragma unroll
         for (int kk = 0; kk < BK / 4; ++kk) {
-            double a[2], b[2];
+            double a[2], b[MB];
 #pragma unroll
             for (int rbl = 0; rbl < 2; ++rbl) a[rbl] = pa[rbl * 16 * LDS_LD + kk * 4];
 #pragma unroll
-            for (int mb = 0; mb < 2; ++mb) b[mb] = -pb[mb * 16 * LDS_LD + kk * 4];
+            for (int mb = 0; mb < MB; ++mb) b[mb] = -pb[mb * 16 * LDS_LD + kk * 4];
 #pragma unroll
             for (int rbl = 0; rbl < 2; ++rbl)
 #pragma unroll
-                for (int mb = 0; mb < 2; ++mb) acc.t[rbl][mb] = mfma_f64(a[rbl], b[mb], acc.t[rbl][mb]);
+                for (int mb = 0; mb < MB; ++mb) acc.t[rbl][mb] = mfma_f64(a[rbl], b[mb], acc.t[rbl][mb]);
         }
         if (more) {
             tile_store_lds<128>(nxt, ra);
@@ -377,28 +383,29 @@ __device__ __forceinline__ void gemm_s(const double* __restrict__ A, int lda, co
     }
 }
 
-template <int KIND>
+template <int KIND, int MB>
 __global__ __launch_bounds__(256) void trsm_step_small_kernel(const double* __restrict__ Xcs,
                                                               const double* __restrict__ Xs, double* __restrict__ V,
                                                               int ldv, const double* __restrict__ L, int ld,
                                                               const double* __restrict__ LinvP, int i, int n,
                                                               double* __restrict__ q, double* __restrict__ mu,
                                                               long long c0, CovParams cp) {
-    __shared__ double smem[SMALL_SMEM_DOUBLES];
+    constexpr int SC = 16 * MB;
+    __shared__ double smem[small_smem_doubles<MB>()];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = lane >> 4, nn = lane & 15;
     double* Vrow = V + (size_t)blockIdx.x * SC * ldv;
     const long long cw = c0 + (long long)blockIdx.x * SC;
     const int n_valid = n - i * NB;
-    AccS acc;
-    gen_cross_tile_s<KIND>(cp, Xcs + (size_t)cw * cp.dim, Xs + (size_t)i * NB * cp.dim, n_valid, smem, acc);
+    AccS<MB> acc;
+    gen_cross_tile_s<KIND, MB>(cp, Xcs + (size_t)cw * cp.dim, Xs + (size_t)i * NB * cp.dim, n_valid, smem, acc);
     if (i > 0) gemm_s(L + (size_t)i * NB * ld, ld, Vrow, ldv, i * NB, acc, smem);
     // ---- T^T -> LDS: sT[mb][row][16]
     double* sT = smem;
-    double* sO = smem + 2 * NB * 16;
+    double* sO = smem + MB * NB * 16;
 #pragma unroll
     for (int rbl = 0; rbl < 2; ++rbl)
 #pragma unroll
-        for (int mb = 0; mb < 2; ++mb)
+        for (int mb = 0; mb < MB; ++mb)
 #pragma unroll
             for (int r = 0; r < 4; ++r)
                 sT[(mb * NB + wave * 32 + rbl * 16 + g + 4 * r) * 16 + nn] = acc.t[rbl][mb][r];
@@ -409,20 +416,22 @@ __global__ __launch_bounds__(256) void trsm_step_small_kernel(const double* __re
 #pragma unroll
     for (int half = 0; half < 2; ++half) {
         const int cb = half == 0 ? wave : 7 - wave;
-        v4d o[2] = {v4d{0.0, 0.0, 0.0, 0.0}, v4d{0.0, 0.0, 0.0, 0.0}};
+        v4d o[MB];
+#pragma unroll
+        for (int mb = 0; mb < MB; ++mb) o[mb] = v4d{0.0, 0.0, 0.0, 0.0};
         const double* wf = wp + (size_t)wp_offset(cb) * 64;
         for (int jb = 0; jb <= cb; ++jb) {
 #pragma unroll
             for (int kk = 0; kk < 4; ++kk) {
                 const double a = wf[(4 * jb + kk) * 64];
 #pragma unroll
-                for (int mb = 0; mb < 2; ++mb)
+                for (int mb = 0; mb < MB; ++mb)
                     o[mb] = mfma_f64(a, sT[(mb * NB + 16 * jb + 4 * kk + g) * 16 + nn], o[mb]);
             }
         }
         const int r0 = 16 * cb + 4 * g;
 #pragma unroll
-        for (int mb = 0; mb < 2; ++mb) {
+        for (int mb = 0; mb < MB; ++mb) {
             double v[4];
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
@@ -436,7 +445,7 @@ __global__ __launch_bounds__(256) void trsm_step_small_kernel(const double* __re
     }
     __syncthreads();
     // ---- |v|^2 and v.z per candidate in the summation order of the 128-candidate step: wave mb, lane (g, nn)
-    if (wave < 2) {
+    if (wave < MB) {
         const int mb = wave;
         double sq = 0.0, sz = 0.0;
 #pragma unroll
@@ -554,12 +563,23 @@ int launch_predict_fused(robo_gp* gp, robo_cand* cand, int64_t c0, int64_t cn) {
         const char* e = getenv("ROBO_TRSM_SMALL_MAX");
         const int64_t small_max = e ? atoll(e) : 16384;
         if (cn <= small_max) {
-            const dim3 sgrid((unsigned)(cn / SC));
+            // 16 candidates per workgroup while that is at most two workgroups per CU, 32 beyond
+            const char* e_narrow = getenv("ROBO_TRSM_SMALL_NARROW");   // test knob: force either width
+            const bool narrow = e_narrow ? atoi(e_narrow) != 0 : cn / 16 <= 2 * (int64_t)gp->ctx->num_cu;
+            const dim3 sgrid((unsigned)(cn / (narrow ? 16 : 32)));
 #define ROBO_SMALL_CALL(KIND)                                                                                  \
-    hipLaunchKernelGGL(trsm_step_small_kernel<KIND>, sgrid, dim3(256), 0, gp->ctx->stream,                     \
-                       (const double*)cand->d_Xcs, (const double*)gp->d_Xs, cand->d_V, gp->n_pad,             \
-                       (const double*)gp->d_K, gp->n_pad, (const double*)gp->d_LinvP, i, gp->n, cand->d_q,     \
-                       cand->d_mu, (long long)c0, gp->cov)
+    do {                                                                                                       \
+        if (narrow)                                                                                            \
+            hipLaunchKernelGGL((trsm_step_small_kernel<KIND, 1>), sgrid, dim3(256), 0, gp->ctx->stream,        \
+                               (const double*)cand->d_Xcs, (const double*)gp->d_Xs, cand->d_V, gp->n_pad,     \
+                               (const double*)gp->d_K, gp->n_pad, (const double*)gp->d_LinvP, i, gp->n,        \
+                               cand->d_q, cand->d_mu, (long long)c0, gp->cov);                                 \
+        else                                                                                                   \
+            hipLaunchKernelGGL((trsm_step_small_kernel<KIND, 2>), sgrid, dim3(256), 0, gp->ctx->stream,        \
+                               (const double*)cand->d_Xcs, (const double*)gp->d_Xs, cand->d_V, gp->n_pad,     \
+                               (const double*)gp->d_K, gp->n_pad, (const double*)gp->d_LinvP, i, gp->n,        \
+                               cand->d_q, cand->d_mu, (long long)c0, gp->cov);                                 \
+    } while (0)
             for (int i = 0; i < nbk; ++i) {
                 if (gp->kind == ROBO_KERNEL_MATERN52_ARD) ROBO_SMALL_CALL(ROBO_KERNEL_MATERN52_ARD);
                 else if (gp->kind == ROBO_KERNEL_RBF_ARD) ROBO_SMALL_CALL(ROBO_KERNEL_RBF_ARD);
