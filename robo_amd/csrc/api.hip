@@ -170,7 +170,6 @@ int32_t robo_gp_create(robo_ctx* ctx, int32_t kind, int32_t n_max, int32_t dim, 
     ROBO_TRY(dev_alloc(&g->d_llpart, (np / NB) * 2));
     ROBO_TRY(dev_alloc(&g->d_theta, (size_t)dim + 8 + sizeof(FitSample) / sizeof(double)));
     g->d_sp = reinterpret_cast<FitSample*>(g->d_theta + dim + 8);
-    ROBO_HIP_CHECK(hipHostMalloc((void**)&g->h_theta, ((size_t)dim + 8) * sizeof(double) + sizeof(FitSample), 0));
     *out = g;
     return ROBO_OK;
 }
@@ -188,7 +187,6 @@ int32_t robo_gp_destroy(robo_gp* g) {
     hipFree(g->d_llpart);
     hipFree(g->d_bllpart);
     hipFree(g->d_theta);
-    hipHostFree(g->h_theta);
     hipFree(g->d_gV);
     hipFree(g->d_gA);
     hipFree(g->d_galpha);
@@ -197,7 +195,6 @@ int32_t robo_gp_destroy(robo_gp* g) {
     hipFree(g->d_bK);
     hipFree(g->d_bLinv);
     hipFree(g->d_bXs);
-    hipFree(g->d_bism);
     hipFree(g->d_bout);
     hipFree(g->d_bsp);
     hipFree(g->d_bfail);
@@ -282,17 +279,14 @@ static int gp_build_gram(robo_gp* g, const double* theta, double mean_c) {
     robo_ctx* c = g->ctx;
     const int D = g->dim;
     ROBO_HIP_CHECK(hipSetDevice(c->device));
-    // the pinned staging buffer is reused by every fit: the previous upload must have landed
-    ROBO_HIP_CHECK(hipStreamSynchronize(c->stream));
-    FitSample* hsp = reinterpret_cast<FitSample*>(g->h_theta + D + 8);
-    ROBO_TRY(theta_to_sample(g, theta, mean_c, hsp, g->h_theta));
-    g->cov = hsp->cov;
-    g->amp = hsp->cov.amp;
-    g->noise = hsp->noise;
+    ThetaArgs ta = {};
+    ROBO_TRY(theta_to_sample(g, theta, mean_c, &ta.sp, ta.ism));
+    g->cov = ta.sp.cov;
+    g->amp = ta.sp.cov.amp;
+    g->noise = ta.sp.noise;
     g->mean_c = mean_c;
-    ROBO_HIP_CHECK(hipMemcpyAsync(g->d_theta, g->h_theta, ((size_t)D + 8) * sizeof(double) + sizeof(FitSample),
-                                  hipMemcpyHostToDevice, c->stream));
-    ROBO_TRY(launch_scale_inputs(c, g->d_X, g->d_Xs, g->d_theta, g->n, g->n_pad, D));
+    // theta travels as kernel arguments; block 0 of the scaling kernel leaves d_theta (metrics) and d_sp behind
+    ROBO_TRY(launch_scale_inputs_theta(c, g->d_X, g->d_Xs, ta, g->n, g->n_pad, D, g->d_theta, g->d_sp));
     if (c->phase_events) ROBO_HIP_CHECK(hipEventRecord(c->events[19], c->stream));   // slot 19 -> 21: the gram kernel alone (K1)
     ROBO_TRY(launch_gram(g, own_buffers(g)));
     return ROBO_OK;
@@ -307,7 +301,6 @@ int32_t robo_gp_fit(robo_gp* g, const double* theta, double mean_c, double* out_
     robo_ctx* c = g->ctx;
     g->fitted = false;
     // event slots 20..23: 20 -> 21 gram build, 21 -> 22 Cholesky, 22 -> 23 log-likelihood reduce
-    ROBO_HIP_CHECK(hipStreamSynchronize(c->stream));
     if (c->phase_events) ROBO_HIP_CHECK(hipEventRecord(c->events[20], c->stream));
     ROBO_TRY(gp_build_gram(g, theta, mean_c));
     if (c->phase_events) ROBO_HIP_CHECK(hipEventRecord(c->events[21], c->stream));
@@ -358,8 +351,8 @@ int32_t robo_gp_grad_loglik(robo_gp* g, const double* theta, double mean_c, doub
 // grow the batch workspace to hold S samples at the current n_pad
 static int batch_ensure(robo_gp* g, int S) {
     if (g->b_cap >= S && g->b_npad == g->n_pad) return ROBO_OK;
-    hipFree(g->d_bK); hipFree(g->d_bLinv); hipFree(g->d_bXs); hipFree(g->d_bism); hipFree(g->d_bout);
-    hipFree(g->d_bsp); hipFree(g->d_bfail); hipFree(g->d_bllpart);
+    hipFree(g->d_bK); hipFree(g->d_bLinv); hipFree(g->d_bXs); hipFree(g->d_bout);
+    hipFree(g->d_bsp); hipFree(g->d_bfail); hipFree(g->d_bllpart);   // d_bism lives in d_bsp's block
     if (g->h_bstage) hipHostFree(g->h_bstage);
     g->d_bK = g->d_bLinv = g->d_bXs = g->d_bism = g->d_bout = g->h_bstage = nullptr;
     g->d_bsp = nullptr; g->d_bfail = nullptr; g->d_bllpart = nullptr;
@@ -369,13 +362,17 @@ static int batch_ensure(robo_gp* g, int S) {
     ROBO_TRY(dev_alloc(&g->d_bLinv, (size_t)S * np * NB));
     ROBO_HIP_CHECK(hipMemset(g->d_bLinv, 0, (size_t)S * np * NB * sizeof(double)));
     ROBO_TRY(dev_alloc(&g->d_bXs, (size_t)S * np * D));
-    ROBO_TRY(dev_alloc(&g->d_bism, (size_t)S * D));
     ROBO_TRY(dev_alloc(&g->d_bout, (size_t)S * 2));
-    ROBO_TRY(dev_alloc(&g->d_bsp, (size_t)S));
+    {   // [S x FitSample | S x D inverse sqrt metrics] in one block: one upload per pass
+        char* blk = nullptr;
+        ROBO_TRY(dev_alloc(&blk, (size_t)S * sizeof(FitSample) + (size_t)S * D * sizeof(double)));
+        g->d_bsp = reinterpret_cast<FitSample*>(blk);
+        g->d_bism = reinterpret_cast<double*>(g->d_bsp + S);
+    }
     ROBO_TRY(dev_alloc(&g->d_bfail, (size_t)S));
     ROBO_TRY(dev_alloc(&g->d_bllpart, (size_t)S * (np / NB) * 2));
-    // pinned staging: [S x FitSample | S x D ism] up, [S x 2 doubles | S ints] down
-    const size_t bytes = (size_t)S * (sizeof(FitSample) + D * sizeof(double) + 2 * sizeof(double) + sizeof(int)) + 64;
+    // pinned staging: [S x FitSample | S x D ism] up, [S x 3 doubles] down (written by the device)
+    const size_t bytes = (size_t)S * (sizeof(FitSample) + D * sizeof(double) + 3 * sizeof(double)) + 64;
     ROBO_HIP_CHECK(hipHostMalloc((void**)&g->h_bstage, bytes, 0));
     g->b_cap = S;
     g->b_npad = g->n_pad;
@@ -400,8 +397,10 @@ static int fit_batch_core(robo_gp* g, const double* thetas, int32_t S, double me
     for (int s0 = 0; s0 < S; s0 += chunk) {
         const int ns = S - s0 < chunk ? S - s0 : chunk;
         ROBO_HIP_CHECK(hipStreamSynchronize(c->stream));   // staging buffer reuse
+        const int cap = g->b_cap;                          // layout of the staging block and of its device twin
         FitSample* hsp = reinterpret_cast<FitSample*>(g->h_bstage);
-        double* hism = reinterpret_cast<double*>(hsp + chunk);
+        double* hism = reinterpret_cast<double*>(hsp + cap);
+        double* hout = hism + (size_t)cap * D;             // [ns][3]: z.z, log det, failure flag
         std::vector<int> status(ns, ROBO_OK);
         for (int s = 0; s < ns; ++s) {
             const int st = theta_to_sample(g, thetas + (size_t)(s0 + s) * P, mean_c, hsp + s, hism + (size_t)s * D);
@@ -411,8 +410,8 @@ static int fit_batch_core(robo_gp* g, const double* thetas, int32_t S, double me
                 theta_to_sample(g, zeros, mean_c, hsp + s, hism + (size_t)s * D);
             }
         }
-        ROBO_HIP_CHECK(hipMemcpyAsync(g->d_bsp, hsp, (size_t)ns * sizeof(FitSample), hipMemcpyHostToDevice, c->stream));
-        ROBO_HIP_CHECK(hipMemcpyAsync(g->d_bism, hism, (size_t)ns * D * sizeof(double), hipMemcpyHostToDevice, c->stream));
+        ROBO_HIP_CHECK(hipMemcpyAsync(g->d_bsp, hsp, (size_t)cap * sizeof(FitSample) + (size_t)ns * D * sizeof(double),
+                                      hipMemcpyHostToDevice, c->stream));
         FitBuffers fb;
         fb.K = g->d_bK; fb.k_stride = np * np;
         fb.Linv = g->d_bLinv; fb.linv_stride = np * NB;
@@ -422,21 +421,17 @@ static int fit_batch_core(robo_gp* g, const double* thetas, int32_t S, double me
         fb.out = g->d_bout;
         fb.ll_part = g->d_bllpart;
         fb.LinvP = nullptr;
-        fb.host_out = nullptr;
+        fb.host_out = hout;
         fb.S = ns;
         ROBO_TRY(launch_scale_inputs(c, g->d_X, g->d_bXs, g->d_bism, g->n, g->n_pad, D, ns, np * D, (size_t)D));
         ROBO_TRY(launch_gram(g, fb));
         ROBO_TRY(launch_potrf(g, fb));   // its tail kernel also reduces the log-likelihood terms into fb.out
-        double* hout = hism + (size_t)chunk * D;
-        int* hfail = reinterpret_cast<int*>(hout + 2 * (size_t)chunk);
-        ROBO_HIP_CHECK(hipMemcpyAsync(hout, g->d_bout, (size_t)ns * 2 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
-        ROBO_HIP_CHECK(hipMemcpyAsync(hfail, g->d_bfail, (size_t)ns * sizeof(int), hipMemcpyDeviceToHost, c->stream));
-        ROBO_HIP_CHECK(hipStreamSynchronize(c->stream));
+        ROBO_HIP_CHECK(hipStreamSynchronize(c->stream));   // the finishing kernel wrote hout (pinned) itself
         for (int s = 0; s < ns; ++s) {
             double ll = -HUGE_VAL;
             if (status[s] == ROBO_OK) {
-                if (hfail[s] != 0) status[s] = ROBO_NOT_POSITIVE_DEFINITE;
-                else ll = -0.5 * (hout[2 * s] + hout[2 * s + 1] + (double)g->n * std::log(2.0 * M_PI));
+                if (hout[3 * s + 2] != 0.0) status[s] = ROBO_NOT_POSITIVE_DEFINITE;
+                else ll = -0.5 * (hout[3 * s] + hout[3 * s + 1] + (double)g->n * std::log(2.0 * M_PI));
             }
             out_loglik[s0 + s] = ll;
             if (out_status) out_status[s0 + s] = status[s];

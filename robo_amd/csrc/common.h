@@ -42,6 +42,12 @@ struct FitSample {
     double mean_c;   // constant prior mean
 };
 
+// one theta as kernel arguments (single-sample fits, gram.hip)
+struct ThetaArgs {
+    FitSample sp;
+    double ism[MAX_DIM];   // 1 / sqrt(metric_d)
+};
+
 void set_error(const char* fmt, ...);
 
 #define ROBO_HIP_CHECK(expr)                                                                       \
@@ -110,7 +116,6 @@ struct robo_gp {
     double* d_Linv;     // (n_pad_max / NB) x NB x NB inverses of the diagonal blocks
     double* d_LinvP;    // the same inverses as packed MFMA A-operand fragments (WP_BLOCK doubles per block, predict.hip)
     double* d_theta;    // inverse sqrt metric (dim) of the current theta
-    double* h_theta;    // pinned staging: [FitSample | inverse sqrt metric (dim)]
     robo::FitSample* d_sp;   // device copy of the current FitSample
     // batch workspace for robo_gp_loglik_batch (lazy, b_cap samples)
     int b_cap, b_npad;
@@ -170,6 +175,8 @@ struct FitBuffers {
     double* host_out;                    // pinned host [3]: z.z, 2 sum log diag, failure flag -- or nullptr
     int S;
 };
+int launch_scale_inputs_theta(robo_ctx* ctx, const double* d_in, double* d_out, const ThetaArgs& ta, int64_t rows_real,
+                              int64_t rows_pad, int dim, double* d_ism_out, FitSample* d_sp_out);
 int launch_gram(robo_gp* gp, const FitBuffers& fb);
 int launch_potrf(robo_gp* gp, const FitBuffers& fb);
 int launch_diag_timeline(robo_gp* gp, long long* d_stamps);

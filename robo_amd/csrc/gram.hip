@@ -37,6 +37,41 @@ __global__ __launch_bounds__(256) void scale_inputs_kernel(const double* __restr
     }
 }
 
+// Single-theta fits: the sample (covariance parameters, noise, mean) and the inverse square-root metrics arrive as
+// KERNEL ARGUMENTS (2.1 KB by value) instead of through a pinned staging buffer and a host-to-device copy launch --
+// the copy alone was ~10 % of a fit at BO-typical N <= 100.  Block 0 leaves device copies for the kernels that follow
+// (gram: FitSample; posterior: candidate scaling by the same metrics).
+__global__ __launch_bounds__(256) void scale_inputs_theta_kernel(const double* __restrict__ in, double* __restrict__ out,
+                                                                 const ThetaArgs ta, long long rows_real,
+                                                                 long long rows_pad, int dim,
+                                                                 double* __restrict__ ism_out,
+                                                                 FitSample* __restrict__ sp_out) {
+    if (blockIdx.x == 0) {
+        for (int d = threadIdx.x; d < dim; d += blockDim.x) ism_out[d] = ta.ism[d];
+        if (threadIdx.x == 0) *sp_out = ta.sp;
+    }
+    const long long total = rows_pad * dim;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (long long)gridDim.x * blockDim.x) {
+        const long long r = i / dim;
+        const int d = (int)(i - r * dim);
+        const long long src = r < rows_real ? r : 0;
+        out[i] = rows_real > 0 ? in[src * dim + d] * ta.ism[d] : 0.0;
+    }
+}
+
+int launch_scale_inputs_theta(robo_ctx* ctx, const double* d_in, double* d_out, const ThetaArgs& ta, int64_t rows_real,
+                              int64_t rows_pad, int dim, double* d_ism_out, FitSample* d_sp_out) {
+    const long long total = (long long)rows_pad * dim;
+    int blocks = (int)((total + 255) / 256);
+    if (blocks > 4096) blocks = 4096;
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(scale_inputs_theta_kernel, dim3(blocks), dim3(256), 0, ctx->stream, d_in, d_out, ta,
+                       (long long)rows_real, (long long)rows_pad, dim, d_ism_out, d_sp_out);
+    ROBO_LAUNCH_CHECK();
+    return ROBO_OK;
+}
+
 // cov[a][b] = k(Xi[i0 + ty*4 + a], Xj[j0 + tx*4 + b]) ; Xi/Xj row-major (rows, dim), pre-scaled
 template <class T, int KIND>
 __device__ __forceinline__ void pair_cov(const CovParams& cp, const double* __restrict__ Xi,

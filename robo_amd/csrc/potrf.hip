@@ -704,7 +704,7 @@ __global__ __launch_bounds__(256) void potrf_inverse_kernel(const double* __rest
 }
 
 // (z.z, 2 sum log L_ii) of every sample from the per-block partials, added in block order (a fixed summation order);
-// with host_out (pinned, device-visible; single-sample fits) the result and the failure flag go straight to the host.
+// with host_out (pinned, device-visible; [S][3]) the result and the failure flag go straight to the host.
 // A launch of its own: handing the partials over INSIDE the tail kernel (agent-scope release + arrival counter) was
 // measured at +16 us -- the release writes back an L2 full of the factorisation's dirty lines (r02z).
 __global__ __launch_bounds__(64) void loglik_finish_kernel(const double* __restrict__ ll_part, int nbk,
@@ -721,9 +721,9 @@ __global__ __launch_bounds__(64) void loglik_finish_kernel(const double* __restr
     out[2 * smp] = sq;
     out[2 * smp + 1] = 2.0 * sl;
     if (host_out) {
-        host_out[0] = sq;
-        host_out[1] = 2.0 * sl;
-        host_out[2] = (double)fail[smp];
+        host_out[3 * smp] = sq;
+        host_out[3 * smp + 1] = 2.0 * sl;
+        host_out[3 * smp + 2] = (double)fail[smp];
     }
 }
 
