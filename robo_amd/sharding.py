@@ -17,9 +17,12 @@ import numpy as np
 
 def dist_info():
     """(torch.distributed module or None, rank, world_size) of the initialised default process group"""
-    try:
-        import torch.distributed as dist
-    except Exception:       # torch is plumbing for multi-GPU runs only; single-GPU use never needs it
+    # torch is plumbing for multi-GPU runs only: a process group can only have been initialised by code that already
+    # imported torch.distributed, so a single-process run never pays the ~1 s import (it used to, on the first
+    # maximize() of every BO run)
+    import sys
+    dist = sys.modules.get("torch.distributed")
+    if dist is None:
         return None, 0, 1
     if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
         return dist, dist.get_rank(), dist.get_world_size()
