@@ -60,10 +60,10 @@ def reduce_argmax(pairs):
 
 def allgather_argmax(local_max, local_global_index, device=None):
     """Exchange the per-shard incumbents (16 B per rank) -> global (max, argmax)."""
+    if dist_info()[2] == 1:
+        return float(local_max), int(local_global_index)
     import torch
     import torch.distributed as dist
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
-        return float(local_max), int(local_global_index)
     world = dist.get_world_size()
     dev = device if device is not None else ("cuda" if dist.get_backend() == "nccl" else "cpu")
     # the index travels as an exact float64 (< 2^53) next to the value: one 16-byte message
@@ -76,10 +76,10 @@ def allgather_argmax(local_max, local_global_index, device=None):
 
 def allgather_ordered_sum(partial_sum, device=None):
     """Sum per-rank partial acquisition sums in rank order (deterministic on every rank)."""
+    if dist_info()[2] == 1:
+        return np.asarray(partial_sum, dtype=np.float64)
     import torch
     import torch.distributed as dist
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
-        return np.asarray(partial_sum, dtype=np.float64)
     world = dist.get_world_size()
     dev = device if device is not None else ("cuda" if dist.get_backend() == "nccl" else "cpu")
     mine = torch.as_tensor(np.ascontiguousarray(partial_sum, dtype=np.float64)).to(dev)
@@ -93,10 +93,10 @@ def allgather_ordered_sum(partial_sum, device=None):
 
 def allgather_rows(row, device=None):
     """every rank contributes one fp64 row (D,) -> (world, D), identical on every rank"""
+    if dist_info()[2] == 1:
+        return np.asarray(row, dtype=np.float64)[None, :]
     import torch
     import torch.distributed as dist
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
-        return np.asarray(row, dtype=np.float64)[None, :]
     world = dist.get_world_size()
     dev = device if device is not None else ("cuda" if dist.get_backend() == "nccl" else "cpu")
     mine = torch.as_tensor(np.ascontiguousarray(row, dtype=np.float64)).to(dev)
