@@ -270,6 +270,7 @@ static FitBuffers own_buffers(robo_gp* g) {
     fb.ll_part = g->d_llpart;
     fb.LinvP = g->d_LinvP;
     fb.host_out = g->ctx->h_pinned;
+    fb.want_inverse = true;
     fb.S = 1;
     return fb;
 }
@@ -422,6 +423,7 @@ static int fit_batch_core(robo_gp* g, const double* thetas, int32_t S, double me
         fb.ll_part = g->d_bllpart;
         fb.LinvP = nullptr;
         fb.host_out = hout;
+        fb.want_inverse = (bool)keep;      // likelihoods only: the posterior's inverse blocks are not formed
         fb.S = ns;
         ROBO_TRY(launch_scale_inputs(c, g->d_X, g->d_bXs, g->d_bism, g->n, g->n_pad, D, ns, np * D, (size_t)D));
         ROBO_TRY(launch_gram(g, fb));

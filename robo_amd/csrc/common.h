@@ -172,7 +172,8 @@ struct FitBuffers {
     double* out;                         // [S][2]: z.z, 2 sum log diag
     double* ll_part;                     // [S][n_pad/128][2] per-block partial sums of the log-likelihood terms
     double* LinvP;                       // packed inverse fragments of the GP's own factor, or nullptr (batch workspace)
-    double* host_out;                    // pinned host [3]: z.z, 2 sum log diag, failure flag -- or nullptr
+    double* host_out;                    // pinned host [S][3]: z.z, 2 sum log diag, failure flag -- or nullptr
+    bool want_inverse;                   // false: log-likelihood only (no explicit inverse blocks, no fragments)
     int S;
 };
 int launch_scale_inputs_theta(robo_ctx* ctx, const double* d_in, double* d_out, const ThetaArgs& ta, int64_t rows_real,
