@@ -466,10 +466,12 @@ __device__ __forceinline__ void diag_writeback(const DiagSmem& m, double* __rest
 
 __global__ __launch_bounds__(256) void potrf_diag_kernel(double* __restrict__ K, size_t k_stride, int ld, int k,
                                                          int n_real, double* __restrict__ Linv, size_t linv_stride,
-                                                         int* __restrict__ fail, long long* __restrict__ dbg) {
+                                                         int* __restrict__ fail, long long* __restrict__ dbg,
+                                                         double* __restrict__ ll_out, double* __restrict__ ll_host) {
     __shared__ double smem[DIAG_SMEM_DOUBLES];
     const DiagSmem m = diag_carve(smem);
     const int tid = threadIdx.x;
+    const int smp = blockIdx.x;
     K += (size_t)blockIdx.x * k_stride;           // batch coordinate
     Linv += (size_t)blockIdx.x * linv_stride;
     fail += blockIdx.x;
@@ -486,6 +488,42 @@ __global__ __launch_bounds__(256) void potrf_diag_kernel(double* __restrict__ K,
 
     diag128_factor_invert(m.sL, m.sW, m.sT, m.sRd, m.sCol, k * NB, n_real, fail, dbg);
 
+    if (ll_out) {
+        // Likelihood evaluation of a one-block problem (N < 128, the usual size of a BO run): the whole factor is in
+        // LDS, so (z.z, 2 sum log L_ii, failure flag) leave from here -- no write-back, no tail and finishing launches.
+        // Same operations in the same order as potrf_inverse_kernel + loglik_finish_kernel on one block.
+        __syncthreads();
+        double q = 0.0, lg = 0.0;
+        if (tid < NB && tid < n_real) {
+            const double zi = m.sL[blk_off(n_real >> 4, tid >> 4) + bidx(n_real & 15, tid & 15)];
+            q = zi * zi;
+            lg = log(m.sL[blk_off(tid >> 4, tid >> 4) + bidx(tid & 15, tid & 15)]);
+        }
+        for (int o = 32; o > 0; o >>= 1) {
+            q += __shfl_xor(q, o);
+            lg += __shfl_xor(lg, o);
+        }
+        __syncthreads();
+        double* red = m.sW;
+        if ((tid & 63) == 0 && tid < NB) {
+            red[tid >> 6] = q;
+            red[2 + (tid >> 6)] = lg;
+        }
+        __syncthreads();
+        if (tid == 0) {
+            double sq = 0.0, sl = 0.0;
+            sq += red[0] + red[1];
+            sl += red[2] + red[3];
+            ll_out[2 * smp] = sq;
+            ll_out[2 * smp + 1] = 2.0 * sl;
+            if (ll_host) {
+                ll_host[3 * smp] = sq;
+                ll_host[3 * smp + 1] = 2.0 * sl;
+                ll_host[3 * smp + 2] = (double)*fail;
+            }
+        }
+        return;
+    }
     diag_writeback(m, Kd, ld, Linv + (size_t)k * NB * NB);
     if (dbg && tid == 0) dbg[12] = clock64();
 }
@@ -1048,7 +1086,7 @@ int launch_potrf(robo_gp* gp, const FitBuffers& fb) {
     const bool fused = S <= 2 && allow_fused;
 #define ROBO_DIAG(KK)                                                                                          \
     hipLaunchKernelGGL(potrf_diag_kernel, dim3(S), dim3(256), 0, ctx->stream, fb.K, fb.k_stride, ld, (KK), gp->n, \
-                       fb.Linv, fb.linv_stride, fb.fail, (long long*)nullptr)
+                       fb.Linv, fb.linv_stride, fb.fail, (long long*)nullptr, (double*)nullptr, (double*)nullptr)
 #define ROBO_PANEL(KK)                                                                                         \
     hipLaunchKernelGGL(potrf_panel_kernel, dim3((nb - (KK)-1) * 2, S), dim3(256), 0, ctx->stream, fb.K,        \
                        fb.k_stride, ld, (KK), (const double*)fb.Linv, fb.linv_stride, (long long*)nullptr)
@@ -1062,6 +1100,13 @@ int launch_potrf(robo_gp* gp, const FitBuffers& fb) {
         if ((TILES) * S >= 96) ROBO_STEP(4, false, (TILES), BASE, KOP, DEPTH, FIRST, 0);                          \
         else if ((TILES) > 0) ROBO_STEP(1, false, (TILES)*4, BASE, KOP, DEPTH, FIRST, 0);                         \
     } while (0)
+    if (nb == 1 && !fb.want_inverse) {
+        // one block, likelihood only: factor and reduce in one launch
+        hipLaunchKernelGGL(potrf_diag_kernel, dim3(S), dim3(256), 0, ctx->stream, fb.K, fb.k_stride, ld, 0, gp->n, fb.Linv,
+                           fb.linv_stride, fb.fail, (long long*)nullptr, fb.out, fb.host_out);
+        ROBO_LAUNCH_CHECK();
+        return ROBO_OK;
+    }
     // test knobs (tests/: the emulator reaches the persistent multi-tile path at small N through them)
     const char* e_tm4 = getenv("ROBO_POTRF_TM4_MIN");
     const char* e_wg = getenv("ROBO_POTRF_MAX_WG");
@@ -1118,7 +1163,7 @@ int launch_potrf(robo_gp* gp, const FitBuffers& fb) {
 // one instrumented diagonal-block kernel on panel 0 of the current gram matrix
 int launch_diag_timeline(robo_gp* gp, long long* d_stamps) {
     hipLaunchKernelGGL(potrf_diag_kernel, dim3(1), dim3(256), 0, gp->ctx->stream, gp->d_K, (size_t)0, gp->n_pad, 0,
-                       gp->n, gp->d_Linv, (size_t)0, gp->ctx->d_fail, d_stamps);
+                       gp->n, gp->d_Linv, (size_t)0, gp->ctx->d_fail, d_stamps, (double*)nullptr, (double*)nullptr);
     // ... and the panel solve below it (stamps 16..19: start, operands in LDS, chain done, stored)
     const int nb = gp->n_pad / NB;
     if (nb > 1)
