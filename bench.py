@@ -247,6 +247,20 @@ def run_headline(args, D_, _lib, sharding):
         return sharding.allgather_argmax(mx, am + rank * M)
 
     elapsed_pcie, _, _ = timed_steps(D_, ctx, step_pcie, max(2, args.steps // 2), 1)
+    # small candidate batches on the same fitted GP (the reference's default RandomSampling draws 500 candidates): latency,
+    # not throughput -- the 16/32-candidate block-row step
+    small_ms = {}
+    if rank == 0:
+        for m_small in (500, 8192):
+            cs = _lib.Candidates(ctx, np.random.RandomState(11).rand(m_small, D))
+            gp.acq(args.acq, 0.0, eta, cs, want_values=False)
+            ts = []
+            for _ in range(5):
+                t0 = time.perf_counter()
+                gp.acq(args.acq, 0.0, eta, cs, want_values=False)
+                ts.append((time.perf_counter() - t0) * 1e3)
+            small_ms[str(m_small)] = float(np.min(ts))
+            cs.close()
     pcie_steps = max(2, args.steps // 2)
 
     out = None
@@ -304,6 +318,7 @@ def run_headline(args, D_, _lib, sharding):
                          "frac_of_mfma_peak": N ** 3 / 3.0 / (chol_ms * 1e-3) / 1e12 / FP64_MFMA_PEAK_TFLOPS},
             "gp_fit_batched": {"thetas": S_half, "ms_total": batch_ms, "ms_per_theta": batch_ms / S_half},
             "gp_grad_loglik_ms": {"total_incl_fit": grad_ms, "after_factorisation": grad_dev_ms},
+            "small_batch_latency_ms": small_ms,
             "argmax": list(best), "roofline": roof, "device": ctx.name,
         }
         if world == 1 and not args.no_cpu_baseline:
