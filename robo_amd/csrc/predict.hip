@@ -267,9 +267,10 @@ __global__ __launch_bounds__(256, 2) void trsm_step_gen_kernel(const double* __r
 // v.z reductions are redone from an LDS copy of the result in exactly its order -- so both give the same bits.
 // MB = candidate blocks of 16 per workgroup: 2 (32 candidates), or 1 (16 candidates: twice the workgroups, used while
 // that still means at most two per CU -- two short chains per CU overlap where one leaves the matrix pipe idle)
-template <int MB> constexpr int small_stage() { return (NB + 16 * MB) * LDS_LD; }   // staging stage: L tile | V tile
-template <int MB> constexpr int small_smem_doubles() {   // T image + result image, or the two staging stages
-    return 2 * MB * NB * 16 > 2 * small_stage<MB>() ? 2 * MB * NB * 16 : 2 * small_stage<MB>();
+// DK = k-tiles of 16 per staging stage (2: one barrier per 32 contraction steps, but one workgroup per CU)
+template <int MB, int DK> constexpr int small_stage() { return DK * (NB + 16 * MB) * LDS_LD; }   // DK x (L tile | V tile)
+template <int MB, int DK> constexpr int small_smem_doubles() {   // T image + result image, or the two staging stages
+    return 2 * MB * NB * 16 > 2 * small_stage<MB, DK>() ? 2 * MB * NB * 16 : 2 * small_stage<MB, DK>();
 }
 
 template <int MB>
@@ -342,48 +343,68 @@ __device__ __forceinline__ void gen_cross_tile_s(const CovParams& cp, const doub
 }
 
 // acc -= A[128 rows, 0:kend] * B[16 MB rows, 0:kend]^T, wave w on rows 32 w .. 32 w + 31
-template <int MB>
+template <int MB, int SMALL_DK>
 __device__ __forceinline__ void gemm_s(const double* __restrict__ A, int lda, const double* __restrict__ B, int ldb,
                                        int kend, AccS<MB>& acc, double* smem) {
-    constexpr int SA = NB * LDS_LD, SC = 16 * MB, SMALL_STAGE = small_stage<MB>();
-    const int nk = kend / BK, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    if (nk <= 0) return;
-    Tile4 ra = tile_load_regs<128>(A, lda, 0);
-    Tile4 rb = tile_load_regs<SC>(B, ldb, 0);
-    tile_store_lds<128>(smem, ra);
-    tile_store_lds<SC>(smem + SA, rb);
+    // With 8 (MB = 1) or 16 MFMAs per wave and k-tile the loop is bound by the barrier -> LDS store -> fragment read
+    // round trip per stage, not by the matrix pipe (per-launch trace: 1850 cycles per k-tile for 1024 of MFMA), so a
+    // stage holds SMALL_DK k-tiles: with 2, half the round trips (M <= 2048 at N = 4096: 3.08 -> 2.54 ms) at 83-92 KB
+    // of LDS, i.e. one workgroup per CU -- the launcher uses 1 where two workgroups per CU are needed.
+    constexpr int SA = NB * LDS_LD, SC = 16 * MB, SUB = (NB + SC) * LDS_LD, SMALL_STAGE = small_stage<MB, SMALL_DK>();
+    const int nst = kend / (BK * SMALL_DK), lane = threadIdx.x & 63, wave = threadIdx.x >> 6;   // kend = 128 i
+    if (nst <= 0) return;
+    Tile4 ra[SMALL_DK], rb[SMALL_DK];
+#pragma unroll
+    for (int u = 0; u < SMALL_DK; ++u) {
+        ra[u] = tile_load_regs<128>(A, lda, u * BK);
+        rb[u] = tile_load_regs<SC>(B, ldb, u * BK);
+    }
+#pragma unroll
+    for (int u = 0; u < SMALL_DK; ++u) {
+        tile_store_lds<128>(smem + u * SUB, ra[u]);
+        tile_store_lds<SC>(smem + u * SUB + SA, rb[u]);
+    }
     __syncthreads();
-    for (int kt = 0; kt < nk; ++kt) {
-        const double* cur = smem + (kt & 1) * SMALL_STAGE;
-        double* nxt = smem + ((kt + 1) & 1) * SMALL_STAGE;
-        const bool more = kt + 1 < nk;
+    for (int st = 0; st < nst; ++st) {
+        const double* cur = smem + (st & 1) * SMALL_STAGE;
+        double* nxt = smem + ((st + 1) & 1) * SMALL_STAGE;
+        const bool more = st + 1 < nst;
         if (more) {
-            ra = tile_load_regs<128>(A, lda, (kt + 1) * BK);
-            rb = tile_load_regs<SC>(B, ldb, (kt + 1) * BK);
+#pragma unroll
+            for (int u = 0; u < SMALL_DK; ++u) {
+                ra[u] = tile_load_regs<128>(A, lda, ((st + 1) * SMALL_DK + u) * BK);
+                rb[u] = tile_load_regs<SC>(B, ldb, ((st + 1) * SMALL_DK + u) * BK);
+            }
         }
-        const double* pa = cur + (wave * 32 + (lane & 15)) * LDS_LD + (lane >> 4);
-        const double* pb = cur + SA + (lane & 15) * LDS_LD + (lane >> 4);
 #pragma unroll
-        for (int kk = 0; kk < BK / 4; ++kk) {
-            double a[2], b[MB];
+        for (int u = 0; u < SMALL_DK; ++u) {
+            const double* pa = cur + u * SUB + (wave * 32 + (lane & 15)) * LDS_LD + (lane >> 4);
+            const double* pb = cur + u * SUB + SA + (lane & 15) * LDS_LD + (lane >> 4);
 #pragma unroll
-            for (int rbl = 0; rbl < 2; ++rbl) a[rbl] = pa[rbl * 16 * LDS_LD + kk * 4];
+            for (int kk = 0; kk < BK / 4; ++kk) {
+                double a[2], b[MB];
 #pragma unroll
-            for (int mb = 0; mb < MB; ++mb) b[mb] = -pb[mb * 16 * LDS_LD + kk * 4];
+                for (int rbl = 0; rbl < 2; ++rbl) a[rbl] = pa[rbl * 16 * LDS_LD + kk * 4];
 #pragma unroll
-            for (int rbl = 0; rbl < 2; ++rbl)
+                for (int mb = 0; mb < MB; ++mb) b[mb] = -pb[mb * 16 * LDS_LD + kk * 4];
 #pragma unroll
-                for (int mb = 0; mb < MB; ++mb) acc.t[rbl][mb] = mfma_f64(a[rbl], b[mb], acc.t[rbl][mb]);
+                for (int rbl = 0; rbl < 2; ++rbl)
+#pragma unroll
+                    for (int mb = 0; mb < MB; ++mb) acc.t[rbl][mb] = mfma_f64(a[rbl], b[mb], acc.t[rbl][mb]);
+            }
         }
         if (more) {
-            tile_store_lds<128>(nxt, ra);
-            tile_store_lds<SC>(nxt + SA, rb);
+#pragma unroll
+            for (int u = 0; u < SMALL_DK; ++u) {
+                tile_store_lds<128>(nxt + u * SUB, ra[u]);
+                tile_store_lds<SC>(nxt + u * SUB + SA, rb[u]);
+            }
         }
         __syncthreads();
     }
 }
 
-template <int KIND, int MB>
+template <int KIND, int MB, int DK>
 __global__ __launch_bounds__(256) void trsm_step_small_kernel(const double* __restrict__ Xcs,
                                                               const double* __restrict__ Xs, double* __restrict__ V,
                                                               int ldv, const double* __restrict__ L, int ld,
@@ -391,14 +412,14 @@ __global__ __launch_bounds__(256) void trsm_step_small_kernel(const double* __re
                                                               double* __restrict__ q, double* __restrict__ mu,
                                                               long long c0, CovParams cp) {
     constexpr int SC = 16 * MB;
-    __shared__ double smem[small_smem_doubles<MB>()];
+    __shared__ double smem[small_smem_doubles<MB, DK>()];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = lane >> 4, nn = lane & 15;
     double* Vrow = V + (size_t)blockIdx.x * SC * ldv;
     const long long cw = c0 + (long long)blockIdx.x * SC;
     const int n_valid = n - i * NB;
     AccS<MB> acc;
     gen_cross_tile_s<KIND, MB>(cp, Xcs + (size_t)cw * cp.dim, Xs + (size_t)i * NB * cp.dim, n_valid, smem, acc);
-    if (i > 0) gemm_s(L + (size_t)i * NB * ld, ld, Vrow, ldv, i * NB, acc, smem);
+    if (i > 0) gemm_s<MB, DK>(L + (size_t)i * NB * ld, ld, Vrow, ldv, i * NB, acc, smem);
     // ---- T^T -> LDS: sT[mb][row][16]
     double* sT = smem;
     double* sO = smem + MB * NB * 16;
@@ -563,22 +584,25 @@ int launch_predict_fused(robo_gp* gp, robo_cand* cand, int64_t c0, int64_t cn) {
         const char* e = getenv("ROBO_TRSM_SMALL_MAX");
         const int64_t small_max = e ? atoll(e) : 16384;
         if (cn <= small_max) {
-            // 16 candidates per workgroup while that is at most two workgroups per CU, 32 beyond
-            const char* e_narrow = getenv("ROBO_TRSM_SMALL_NARROW");   // test knob: force either width
-            const bool narrow = e_narrow ? atoi(e_narrow) != 0 : cn / 16 <= 2 * (int64_t)gp->ctx->num_cu;
+            // 16 candidates per workgroup while that is at most one workgroup per CU, 32 beyond; two k-tiles per
+            // staging stage (83-92 KB of LDS) while one workgroup per CU covers the batch
+            const char* e_narrow = getenv("ROBO_TRSM_SMALL_NARROW");   // test knob: 0 / 1 force the width
+            const int64_t ncu = gp->ctx->num_cu;
+            const bool narrow = e_narrow ? atoi(e_narrow) != 0 : cn / 16 <= ncu;
+            const char* e_deep = getenv("ROBO_TRSM_SMALL_DEEP");       // test knob: 0 / 1 force the stage depth
+            const bool deep = e_deep ? atoi(e_deep) != 0 : cn / (narrow ? 16 : 32) <= ncu;
             const dim3 sgrid((unsigned)(cn / (narrow ? 16 : 32)));
+#define ROBO_SMALL_LAUNCH(KIND, MB, DK)                                                                        \
+    hipLaunchKernelGGL((trsm_step_small_kernel<KIND, MB, DK>), sgrid, dim3(256), 0, gp->ctx->stream,           \
+                       (const double*)cand->d_Xcs, (const double*)gp->d_Xs, cand->d_V, gp->n_pad,             \
+                       (const double*)gp->d_K, gp->n_pad, (const double*)gp->d_LinvP, i, gp->n, cand->d_q,     \
+                       cand->d_mu, (long long)c0, gp->cov)
 #define ROBO_SMALL_CALL(KIND)                                                                                  \
     do {                                                                                                       \
-        if (narrow)                                                                                            \
-            hipLaunchKernelGGL((trsm_step_small_kernel<KIND, 1>), sgrid, dim3(256), 0, gp->ctx->stream,        \
-                               (const double*)cand->d_Xcs, (const double*)gp->d_Xs, cand->d_V, gp->n_pad,     \
-                               (const double*)gp->d_K, gp->n_pad, (const double*)gp->d_LinvP, i, gp->n,        \
-                               cand->d_q, cand->d_mu, (long long)c0, gp->cov);                                 \
-        else                                                                                                   \
-            hipLaunchKernelGGL((trsm_step_small_kernel<KIND, 2>), sgrid, dim3(256), 0, gp->ctx->stream,        \
-                               (const double*)cand->d_Xcs, (const double*)gp->d_Xs, cand->d_V, gp->n_pad,     \
-                               (const double*)gp->d_K, gp->n_pad, (const double*)gp->d_LinvP, i, gp->n,        \
-                               cand->d_q, cand->d_mu, (long long)c0, gp->cov);                                 \
+        if (narrow && deep) ROBO_SMALL_LAUNCH(KIND, 1, 2);                                                     \
+        else if (narrow) ROBO_SMALL_LAUNCH(KIND, 1, 1);                                                        \
+        else if (deep) ROBO_SMALL_LAUNCH(KIND, 2, 2);                                                          \
+        else ROBO_SMALL_LAUNCH(KIND, 2, 1);                                                                    \
     } while (0)
             for (int i = 0; i < nbk; ++i) {
                 if (gp->kind == ROBO_KERNEL_MATERN52_ARD) ROBO_SMALL_CALL(ROBO_KERNEL_MATERN52_ARD);
@@ -586,6 +610,7 @@ int launch_predict_fused(robo_gp* gp, robo_cand* cand, int64_t c0, int64_t cn) {
                 else ROBO_SMALL_CALL(ROBO_KERNEL_FABOLAS);
             }
 #undef ROBO_SMALL_CALL
+#undef ROBO_SMALL_LAUNCH
             ROBO_LAUNCH_CHECK();
             return ROBO_OK;
         }

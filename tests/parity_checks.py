@@ -776,13 +776,16 @@ def check_small_and_large_tiles_agree(ctx, monkeypatch, cases=(("matern52", 300,
         _, mx_l, am_l, _ = g.acq("ei", 0.0, float(y.min()), Xc)
         monkeypatch.setenv("ROBO_TRSM_SMALL_MAX", "1000000")
         for narrow in ("0", "1"):          # 32 and 16 candidates per workgroup
-            monkeypatch.setenv("ROBO_TRSM_SMALL_NARROW", narrow)
-            mu_s, var_s = g.predict(Xc)
-            _, mx_s, am_s, _ = g.acq("ei", 0.0, float(y.min()), Xc)
-            np.testing.assert_array_equal(mu_s, mu_l)
-            np.testing.assert_array_equal(var_s, var_l)
-            assert (mx_s, am_s) == (mx_l, am_l)
+            for deep in ("0", "1"):        # one and two k-tiles per staging stage
+                monkeypatch.setenv("ROBO_TRSM_SMALL_NARROW", narrow)
+                monkeypatch.setenv("ROBO_TRSM_SMALL_DEEP", deep)
+                mu_s, var_s = g.predict(Xc)
+                _, mx_s, am_s, _ = g.acq("ei", 0.0, float(y.min()), Xc)
+                np.testing.assert_array_equal(mu_s, mu_l)
+                np.testing.assert_array_equal(var_s, var_l)
+                assert (mx_s, am_s) == (mx_l, am_l)
         monkeypatch.delenv("ROBO_TRSM_SMALL_NARROW")
+        monkeypatch.delenv("ROBO_TRSM_SMALL_DEEP")
         monkeypatch.delenv("ROBO_TRSM_SMALL_MAX")
         g.close()
 
