@@ -259,6 +259,11 @@ static int theta_to_sample(const robo_gp* g, const double* theta, double mean_c,
     return ROBO_OK;
 }
 
+static unsigned long long next_fit_gen() {
+    static unsigned long long gen = 0;
+    return ++gen;
+}
+
 static FitBuffers own_buffers(robo_gp* g) {
     FitBuffers fb;
     fb.K = g->d_K; fb.k_stride = 0;
@@ -321,6 +326,7 @@ int32_t robo_gp_fit(robo_gp* g, const double* theta, double mean_c, double* out_
     const double quad = hp[0], logdet = hp[1];
     g->loglik = -0.5 * (quad + logdet + (double)g->n * std::log(2.0 * M_PI));
     g->fitted = true;
+    g->fit_gen = next_fit_gen();
     if (out_loglik) *out_loglik = g->loglik;
     if (out_fail_col) *out_fail_col = -1;
     return ROBO_OK;
@@ -514,6 +520,7 @@ int32_t robo_gp_fit_batch(robo_gp* const* gps, int32_t S, const double* thetas, 
             g->mean_c = mean_c;
             g->loglik = out_loglik[s0 + s];
             g->fitted = true;
+            g->fit_gen = next_fit_gen();
         }
         ROBO_HIP_CHECK(hipStreamSynchronize(c->stream));
         return ROBO_OK;
@@ -598,6 +605,7 @@ int32_t robo_cand_set_points(robo_cand* k, const double* Xc, int64_t m) {
         return ROBO_BAD_SHAPE;
     }
     ROBO_HIP_CHECK(hipSetDevice(k->ctx->device));
+    k->solved_gen = 0;
     ROBO_HIP_CHECK(hipMemcpyAsync(k->d_Xc, Xc, (size_t)m * k->dim * sizeof(double), hipMemcpyHostToDevice, k->ctx->stream));
     ROBO_HIP_CHECK(hipStreamSynchronize(k->ctx->stream));   // the caller's buffer is only borrowed for the call
     return ROBO_OK;
@@ -742,6 +750,7 @@ static int predict_core(robo_gp* g, robo_cand* k, bool single_chunk,
         return ROBO_BAD_SHAPE;
     }
     ROBO_HIP_CHECK(hipSetDevice(g->ctx->device));
+    k->solved_gen = 0;
     ROBO_TRY(cand_ensure_workspace(k, g->n_pad, single_chunk));
     ROBO_TRY(launch_scale_inputs(g->ctx, k->d_Xc, k->d_Xcs, g->d_theta, k->m, k->m_pad, g->dim));
     // event slots 24..27 bracket the phases of the LAST chunk (bench.py reads them after a sync):
@@ -1116,7 +1125,13 @@ int32_t robo_ig_eval_cand(robo_gp* g, robo_cand* k, robo_cand* rep, int32_t npts
     const int nb = (int)rep->m;
     ROBO_TRY(ig_check(nb, npts));
     const int kf = round_up(nb * nb, 16);
-    ROBO_TRY(predict_core(g, rep, true));                       // V of the representer points
+    // V of the representer points: kept across calls while the factor and the points stay the same (the reference
+    // does its representer-point work once per update(), information_gain.py:127-167, not per compute())
+    if (!(rep->solved_gen != 0 && rep->solved_gp == g && rep->solved_gen == g->fit_gen)) {
+        ROBO_TRY(predict_core(g, rep, true));
+        rep->solved_gp = g;
+        rep->solved_gen = g->fit_gen;
+    }
     ROBO_TRY(cand_ensure_workspace(k, g->n_pad, false));
     ROBO_TRY(ig_ensure(k, kf));
     ROBO_TRY(ig_upload(k, nb, npts, kf, logP, lmb, W, dlogPdMu, dlogPdSigma, dlogPdMudMu));

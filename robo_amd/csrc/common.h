@@ -104,6 +104,7 @@ struct robo_gp {
     int n_pad;      // round_up(n + 1, NB): row n is the augmented (y - mean) row, rest identity
     int n_pad_max;
     bool has_data, fitted;
+    unsigned long long fit_gen;   // process-wide serial number of the factor this handle holds (0: none)
     bool fp32_gram;     // mixed precision: covariance entries evaluated in fp32 (BASELINE config 5)
     robo::CovParams cov;   // kind, dim, amp, blr_a, blr_b of the current theta
     double amp, noise, mean_c;
@@ -138,6 +139,8 @@ struct robo_cand {
     int64_t chunk;      // candidates per workspace pass (multiple of NB)
     int ldv;            // n_pad the workspace was sized for
     size_t v_bytes;
+    const robo_gp* solved_gp;        // d_V holds L^-1 k_* of ALL the points for this factor (entropy search keeps
+    unsigned long long solved_gen;   // the representer points' solve across compute() calls); 0 = not valid
     double* d_q;        // (m_pad) sum_n V^2
     double* d_mu;       // (m_pad) V . z
     double* d_mean;     // (m_pad) transformed mean

@@ -91,6 +91,24 @@ def _check_ig(ctx, **kw):
     # (3) the moments entry point (any model) gives the same numbers
     vals2 = _lib.ig_from_moments(ctx, S, var, d["ep"], d["sn2"])
     np.testing.assert_allclose(vals2, vals, rtol=1e-12, atol=1e-14)
+    # (4) the representer points' solve is kept across calls on the same factor and redone after a refit or new points
+    vals3, _, _ = _lib.ig_eval(d["g"], cand, rep, d["ep"], d["sn2"])          # served from the kept solve
+    np.testing.assert_array_equal(vals3, vals)
+    theta2 = d["ogp"].theta.copy()
+    theta2[1] += 0.3
+    d["g"].fit(theta2, d["ogp"].mean)
+    vals4, _, _ = _lib.ig_eval(d["g"], cand, rep, d["ep"], d["sn2"])          # new factor: must not reuse
+    rep_fresh = _lib.Candidates(ctx, d["zb"])
+    vals5, _, _ = _lib.ig_eval(d["g"], cand, rep_fresh, d["ep"], d["sn2"])
+    np.testing.assert_array_equal(vals4, vals5)
+    assert np.max(np.abs(vals4 - vals)) > 0
+    rep.set_points(d["zb"][::-1].copy())                                     # new points in the same handle
+    rep_rev = _lib.Candidates(ctx, d["zb"][::-1].copy())
+    vals6, _, _ = _lib.ig_eval(d["g"], cand, rep, d["ep"], d["sn2"])
+    vals7, _, _ = _lib.ig_eval(d["g"], cand, rep_rev, d["ep"], d["sn2"])
+    np.testing.assert_array_equal(vals6, vals7)
+    rep_fresh.close()
+    rep_rev.close()
     cand.close()
     rep.close()
     d["g"].close()
