@@ -178,6 +178,7 @@ int32_t robo_gp_destroy(robo_gp* g) {
     if (!g) return ROBO_OK;
     hipSetDevice(g->ctx->device);
     hipStreamSynchronize(g->ctx->stream);
+    robo_cand_destroy(g->host_cand);
     hipFree(g->d_X);
     hipFree(g->d_Xs);
     hipFree(g->d_y);
@@ -818,6 +819,24 @@ int32_t robo_gp_predict_mixture_cand(robo_gp* const* gps, int32_t S, robo_cand* 
     return ROBO_OK;
 }
 
+// The candidate handle behind the host-array entry points (robo_gp_predict, robo_acq_eval).  Small batches -- the
+// reference's 500 random candidates per iteration, the 1 x D calls of its single-point maximisers -- come back with
+// the same size over and over: their handle (a dozen device allocations) is kept with the GP and only re-uploaded
+// (0.14 -> ~0.08 ms per call at N <= 100).  Larger batches are created and destroyed per call as before.
+static int host_cand(robo_gp* g, const double* Xc, int64_t m, robo_cand** out, bool* kept) {
+    *kept = m <= 16384;
+    if (!*kept) return robo_cand_create(g->ctx, Xc, m, g->dim, out);
+    if (g->host_cand && g->host_cand->m == m) {
+        ROBO_TRY(robo_cand_set_points(g->host_cand, Xc, m));
+    } else {
+        robo_cand_destroy(g->host_cand);
+        g->host_cand = nullptr;
+        ROBO_TRY(robo_cand_create(g->ctx, Xc, m, g->dim, &g->host_cand));
+    }
+    *out = g->host_cand;
+    return ROBO_OK;
+}
+
 int32_t robo_gp_predict(robo_gp* g, const double* Xc, int64_t m, double* out_mean, double* out_var) {
     if (!g) return ROBO_BAD_ARGUMENT;
     if (!g->fitted) {
@@ -825,9 +844,10 @@ int32_t robo_gp_predict(robo_gp* g, const double* Xc, int64_t m, double* out_mea
         return ROBO_NOT_FITTED;
     }
     robo_cand* k = nullptr;
-    ROBO_TRY(robo_cand_create(g->ctx, Xc, m, g->dim, &k));
+    bool kept = false;
+    ROBO_TRY(host_cand(g, Xc, m, &k, &kept));
     const int st = robo_gp_predict_cand(g, k, out_mean, out_var);
-    robo_cand_destroy(k);
+    if (!kept) robo_cand_destroy(k);
     return st;
 }
 
@@ -974,9 +994,10 @@ int32_t robo_acq_eval(robo_gp* g, int32_t acq_kind, double par, double eta, cons
         return ROBO_NOT_FITTED;
     }
     robo_cand* k = nullptr;
-    ROBO_TRY(robo_cand_create(g->ctx, Xc, m, g->dim, &k));
+    bool kept = false;
+    ROBO_TRY(host_cand(g, Xc, m, &k, &kept));
     const int st = robo_acq_eval_cand(g, acq_kind, par, eta, k, out_acq, out_max, out_argmax, out_flags);
-    robo_cand_destroy(k);
+    if (!kept) robo_cand_destroy(k);
     return st;
 }
 

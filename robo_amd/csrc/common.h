@@ -105,6 +105,7 @@ struct robo_gp {
     int n_pad_max;
     bool has_data, fitted;
     unsigned long long fit_gen;   // process-wide serial number of the factor this handle holds (0: none)
+    struct robo_cand* host_cand;  // candidate handle behind the host-array entry points, kept between calls of one size
     bool fp32_gram;     // mixed precision: covariance entries evaluated in fp32 (BASELINE config 5)
     robo::CovParams cov;   // kind, dim, amp, blr_a, blr_b of the current theta
     double amp, noise, mean_c;
