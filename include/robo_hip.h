@@ -164,7 +164,10 @@ int32_t robo_cand_get_point(robo_cand* cand, int64_t index, double* out_x); /* o
 
 /* ---- posterior: replaces george.GP.predict (gaussian_process.py:280-294) ------------ */
 /* mean (m,), var (m,): diagonal only; var floored at DBL_EPSILON after the output
- * transform, exactly gaussian_process.py:282-294.  Either output may be NULL.               */
+ * transform, exactly gaussian_process.py:282-294.  Either output may be NULL.
+ * The host-array forms (robo_gp_predict, robo_acq_eval) keep the candidate handle they build inside the
+ * robo_gp between calls of one batch size <= 16384 (the reference's 500 candidates per iteration, the 1 x D
+ * calls of its single-point maximisers): a repeated call only re-uploads the points.                       */
 int32_t robo_gp_predict_cand(robo_gp* gp, robo_cand* cand, double* out_mean, double* out_var);
 int32_t robo_gp_predict(robo_gp* gp, const double* Xc, int64_t m, double* out_mean, double* out_var);
 /* GaussianProcessMCMC.predict (gaussian_process_mcmc.py:205-249): mixture over S fitted GPs,
