@@ -349,10 +349,11 @@ int32_t robo_gp_grad_loglik(robo_gp* g, const double* theta, double mean_c, doub
     }
     // event slots 28 -> 29: everything after the factorisation (W^T, A, the reductions)
     ROBO_HIP_CHECK(hipEventRecord(c->events[28], c->stream));
-    ROBO_TRY(launch_grad_loglik(g, g->d_gV, g->d_gA, g->d_galpha, g->d_gpart, g->d_gout));
+    double* hg = c->h_pinned + 8;          // P <= MAX_DIM + 3 doubles behind the fit's three result slots
+    ROBO_TRY(launch_grad_loglik(g, g->d_gV, g->d_gA, g->d_galpha, g->d_gpart, g->d_gout, hg));
     ROBO_HIP_CHECK(hipEventRecord(c->events[29], c->stream));
-    ROBO_HIP_CHECK(hipMemcpyAsync(out_grad, g->d_gout, (size_t)P * sizeof(double), hipMemcpyDeviceToHost, c->stream));
     ROBO_HIP_CHECK(hipStreamSynchronize(c->stream));
+    memcpy(out_grad, hg, (size_t)P * sizeof(double));
     return ROBO_OK;
 }
 

@@ -189,7 +189,8 @@ int launch_cross_gram(robo_gp* gp, robo_cand* cand, int64_t c0, int64_t cn);
 int launch_trsm(robo_gp* gp, robo_cand* cand, int64_t c0, int64_t cn);
 int launch_predict_fused(robo_gp* gp, robo_cand* cand, int64_t c0, int64_t cn);
 int launch_pack_linv(robo_gp* gp);
-int launch_grad_loglik(robo_gp* gp, double* d_V, double* d_A, double* d_alpha, double* d_part, double* d_out);
+int launch_grad_loglik(robo_gp* gp, double* d_V, double* d_A, double* d_alpha, double* d_part, double* d_out,
+                       double* h_out);
 int launch_post(robo_gp* gp, robo_cand* cand, int64_t c0, int64_t cn);
 int launch_cross_grad(robo_gp* gp, const double* d_Xcs, double* d_V, int64_t c_first, int64_t c_count, int64_t rows_pad);
 int launch_predgrad_post(robo_gp* gp, const double* d_V, const double* d_q, const double* d_mu, const double* d_Xcs,

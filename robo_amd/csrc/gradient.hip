@@ -288,7 +288,7 @@ __global__ __launch_bounds__(256) void grad_reduce_kernel(const double* __restri
 
 // out[p] = 0.5 sum_tiles part[p][tile]   (fixed order: strided per thread, then a tree)
 __global__ __launch_bounds__(256) void grad_final_kernel(const double* __restrict__ part, int ntiles,
-                                                         double* __restrict__ out) {
+                                                         double* __restrict__ out, double* __restrict__ out_host) {
     __shared__ double s[256];
     const double* row = part + (size_t)blockIdx.x * ntiles;
     double a = 0.0;
@@ -299,12 +299,16 @@ __global__ __launch_bounds__(256) void grad_final_kernel(const double* __restric
         if ((int)threadIdx.x < o) s[threadIdx.x] += s[threadIdx.x + o];
         __syncthreads();
     }
-    if (threadIdx.x == 0) out[blockIdx.x] = 0.5 * s[0];
+    if (threadIdx.x == 0) {
+        out[blockIdx.x] = 0.5 * s[0];
+        if (out_host) out_host[blockIdx.x] = 0.5 * s[0];   // pinned, device-visible: no copy launch for P doubles
+    }
 }
 
 // d_V, d_A: (n_pad x n_pad) workspaces (d_A doubles as W during the inversion); d_alpha: n_pad;
 // d_part: P x tiles64; d_out: P.  Asynchronous on the context's stream.
-int launch_grad_loglik(robo_gp* gp, double* d_V, double* d_A, double* d_alpha, double* d_part, double* d_out) {
+int launch_grad_loglik(robo_gp* gp, double* d_V, double* d_A, double* d_alpha, double* d_part, double* d_out,
+                       double* h_out) {
     hipStream_t st = gp->ctx->stream;
     const int n = gp->n, n_pad = gp->n_pad, nbk = (n + NB - 1) / NB;
     double* d_W = d_A;   // dead before kinv_tile_kernel writes A
@@ -328,7 +332,7 @@ int launch_grad_loglik(robo_gp* gp, double* d_V, double* d_A, double* d_alpha, d
     else if (gp->kind == ROBO_KERNEL_RBF_ARD) ROBO_GRAD_CALL(ROBO_KERNEL_RBF_ARD);
     else ROBO_GRAD_CALL(ROBO_KERNEL_FABOLAS);
 #undef ROBO_GRAD_CALL
-    hipLaunchKernelGGL(grad_final_kernel, dim3(P), dim3(256), 0, st, (const double*)d_part, ntiles, d_out);
+    hipLaunchKernelGGL(grad_final_kernel, dim3(P), dim3(256), 0, st, (const double*)d_part, ntiles, d_out, h_out);
     ROBO_LAUNCH_CHECK();
     return ROBO_OK;
 }
