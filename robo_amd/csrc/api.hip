@@ -586,6 +586,7 @@ static int cand_alloc(robo_ctx* ctx, int64_t m, int32_t dim, robo_cand** out) {
     ROBO_TRY(dev_alloc(&k->d_part_val, (size_t)k->n_part + 1));
     ROBO_TRY(dev_alloc(&k->d_part_idx, (size_t)k->n_part + 1));
     ROBO_TRY(dev_alloc(&k->d_flags, 4));
+    ROBO_HIP_CHECK(hipMemset(k->d_flags, 0, 4 * sizeof(unsigned)));   // cleared again by every read-back
     *out = k;
     return ROBO_OK;
 }
@@ -958,9 +959,7 @@ static int acq_read_back(robo_cand* k, const double* d_vec, double* out_vec, dou
                          uint32_t* out_flags) {
     robo_ctx* c = k->ctx;
     double* hp = c->h_pinned;
-    ROBO_HIP_CHECK(hipMemcpyAsync(hp, k->d_part_val + k->n_part, sizeof(double), hipMemcpyDeviceToHost, c->stream));
-    ROBO_HIP_CHECK(hipMemcpyAsync(hp + 1, k->d_part_idx + k->n_part, sizeof(long long), hipMemcpyDeviceToHost, c->stream));
-    ROBO_HIP_CHECK(hipMemcpyAsync(hp + 2, k->d_flags, sizeof(unsigned), hipMemcpyDeviceToHost, c->stream));
+    ROBO_TRY(launch_report_best(k, hp));   // (max, argmax, flags) -> pinned memory; clears the flag word
     if (out_vec)
         ROBO_HIP_CHECK(hipMemcpyAsync(out_vec, d_vec, (size_t)k->m * sizeof(double), hipMemcpyDeviceToHost, c->stream));
     ROBO_HIP_CHECK(hipStreamSynchronize(c->stream));
@@ -982,7 +981,6 @@ int32_t robo_acq_eval_cand(robo_gp* g, int32_t acq_kind, double par, double eta,
                            double* out_max, int64_t* out_argmax, uint32_t* out_flags) {
     ROBO_TRY(check_acq_kind(acq_kind));
     ROBO_TRY(predict_core(g, k, false));
-    ROBO_HIP_CHECK(hipMemsetAsync(k->d_flags, 0, sizeof(unsigned), g->ctx->stream));
     ROBO_TRY(launch_acq(g->ctx, k, acq_kind, par, eta, false, false));
     return acq_read_back(k, k->d_acq, out_acq, out_max, out_argmax, out_flags);
 }
@@ -1007,7 +1005,6 @@ static int acq_accumulate(robo_gp* const* gps, int32_t S, int32_t acq_kind, doub
     if (!gps || S < 1 || !k || !etas) return ROBO_BAD_ARGUMENT;
     ROBO_TRY(check_acq_kind(acq_kind));
     ROBO_HIP_CHECK(hipSetDevice(k->ctx->device));
-    ROBO_HIP_CHECK(hipMemsetAsync(k->d_flags, 0, sizeof(unsigned), k->ctx->stream));
     for (int s = 0; s < S; ++s) {
         ROBO_TRY(predict_core(gps[s], k, false));
         ROBO_TRY(launch_acq(k->ctx, k, acq_kind, par, etas[s], true, s == 0));
@@ -1040,7 +1037,6 @@ int32_t robo_acq_eval_moments(robo_ctx* ctx, int32_t acq_kind, double par, doubl
     int st = ROBO_OK;
     hipError_t e = hipMemcpyAsync(k->d_mean, mean, (size_t)m * sizeof(double), hipMemcpyHostToDevice, ctx->stream);
     if (e == hipSuccess) e = hipMemcpyAsync(k->d_var, var, (size_t)m * sizeof(double), hipMemcpyHostToDevice, ctx->stream);
-    if (e == hipSuccess) e = hipMemsetAsync(k->d_flags, 0, sizeof(unsigned), ctx->stream);
     if (e != hipSuccess) {
         set_error("robo_acq_eval_moments upload failed: %s", hipGetErrorString(e));
         st = ROBO_RUNTIME_ERROR;
@@ -1164,7 +1160,6 @@ int32_t robo_ig_eval_cand(robo_gp* g, robo_cand* k, robo_cand* rep, int32_t npts
         ROBO_TRY(launch_ig_dh(g->ctx, k->d_S, k->d_var, k->d_F, k->d_Q, k->d_G, k->d_igc, c0, cn, k->m, nb, npts, kf,
                               sn2, H, k->d_acq_sum));
     }
-    ROBO_HIP_CHECK(hipMemsetAsync(k->d_flags, 0, sizeof(unsigned), g->ctx->stream));
     ROBO_TRY(launch_argmax(k, k->d_acq_sum, 1.0));
     return acq_read_back(k, k->d_acq, out_dh, out_max, out_argmax, nullptr);
 }

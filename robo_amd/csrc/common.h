@@ -198,6 +198,7 @@ int launch_predgrad_post(robo_gp* gp, const double* d_V, const double* d_q, cons
                          double* d_dvar);
 int launch_acq(robo_ctx* ctx, robo_cand* cand, int acq_kind, double par, double eta, bool accumulate, bool first);
 int launch_argmax(robo_cand* cand, const double* d_vals, double scale);
+int launch_report_best(robo_cand* cand, double* h_pinned);
 int launch_cov(robo_gp* gp, robo_cand* cand, double* d_cov);
 int launch_mixture(robo_cand* cand, int S);
 int launch_cross_cov(robo_gp* gp, robo_cand* cand, robo_cand* rep, int64_t c0, int64_t cn, double* d_S);
