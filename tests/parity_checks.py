@@ -789,3 +789,38 @@ def check_small_and_large_tiles_agree(ctx, monkeypatch, cases=(("matern52", 300,
         monkeypatch.delenv("ROBO_TRSM_SMALL_MAX")
         g.close()
 
+
+def check_host_array_handle_reuse(ctx):
+    """the host-array entry points keep their candidate handle inside the GP between calls of one batch size: results
+    must not depend on what the handle held before (other sizes, other points, a refit in between)"""
+    rs = np.random.RandomState(17)
+    N, D = 150, 4
+    X = rs.rand(N, D)
+    y = np.sin(3 * X.sum(axis=1))
+    theta = np.concatenate([[0.0], np.full(D, np.log(0.5)), [np.log(1e-2)]])
+    theta2 = theta.copy()
+    theta2[1:1 + D] += 0.4
+    g = _lib.DeviceGP(ctx, "matern52", N, D)
+    g.set_data(X, y)
+    g.fit(theta, 0.0)
+
+    def fresh(th, Xc):
+        h = _lib.DeviceGP(ctx, "matern52", N, D)
+        h.set_data(X, y)
+        h.fit(th, 0.0)
+        out = h.predict(Xc), h.acq("ei", 0.0, float(y.min()), Xc)
+        h.close()
+        return out
+
+    A, B, C_ = rs.rand(50, D), rs.rand(70, D), rs.rand(50, D)
+    for th, Xc in ((theta, A), (theta, B), (theta, C_), (theta2, C_), (theta2, A), (theta, rs.rand(1, D))):
+        g.fit(th, 0.0)
+        (mu_f, var_f), (val_f, mx_f, am_f, fl_f) = fresh(th, Xc)
+        mu, var = g.predict(Xc)
+        val, mx, am, fl = g.acq("ei", 0.0, float(y.min()), Xc)
+        np.testing.assert_array_equal(mu, mu_f)
+        np.testing.assert_array_equal(var, var_f)
+        np.testing.assert_array_equal(val, val_f)
+        assert (mx, am, fl) == (mx_f, am_f, fl_f)
+    g.close()
+

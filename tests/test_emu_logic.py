@@ -182,3 +182,7 @@ def test_phase_events(emu_ctx):
 def test_small_and_large_candidate_tiles_agree(emu_ctx, monkeypatch):
     P.check_small_and_large_tiles_agree(emu_ctx, monkeypatch)
 
+
+def test_host_array_handle_reuse(emu_ctx):
+    P.check_host_array_handle_reuse(emu_ctx)
+
