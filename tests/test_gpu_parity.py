@@ -396,3 +396,7 @@ def test_phase_events(ctx):
 def test_small_and_large_candidate_tiles_agree(ctx, monkeypatch):
     P.check_small_and_large_tiles_agree(ctx, monkeypatch)
 
+
+
+def test_host_array_handle_reuse(ctx):
+    P.check_host_array_handle_reuse(ctx)
