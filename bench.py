@@ -18,7 +18,8 @@ roofline; the default, and what the driver runs, is the headline):
     c2   GP Matern-5/2 N=1024 D=8, 65 536 candidates, EI                          (candidate shard)
     c3   50 hyper-parameter samples, N=2048 D=16, marginal LogEI over 65 536      (SAMPLE shard, 13/13/12/12 at 4)
     c4   Fabolas kernel N=4096 D=10+1, information gain per unit cost, 8192/GPU   (candidate shard)
-    c5   N=8192 D=64, LCB, 2^17 Sobol candidates per GPU, fp32 K-build            (candidate shard)
+    c5   N=8192 D=64, LCB, 2^17 Sobol candidates per GPU, fp32 K-build            (candidate shard;
+         --m 1048576: the whole 2^20-candidate set on one GPU, 70 GB solve workspace in one pass)
 """
 import argparse
 import json
@@ -444,7 +445,8 @@ def run_c5(args, D_, _lib, sharding):
     N, D, M = args.n, args.d, args.m
     # one workspace pass for the whole shard (131 072 x 8320 doubles = 8.7 GB of the 288 GB): the HIP-event slots
     # bracket the solve of ONE pass, and the roofline below prices all M rows against it
-    os.environ.setdefault("ROBO_WS_BYTES", str(12 << 30))
+    n_pad = (N + 1 + 127) // 128 * 128
+    os.environ.setdefault("ROBO_WS_BYTES", str(max(12 << 30, min(M * n_pad * 8 + (1 << 20), 160 << 30))))
     X, y, theta, _ = synthetic(N, D, 1, 0)
     gp = _lib.DeviceGP(ctx, "matern52", N, D)
     gp.set_precision(True)

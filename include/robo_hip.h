@@ -160,6 +160,10 @@ int32_t robo_cand_create_random(robo_ctx* ctx, int64_t m, int32_t dim, uint64_t 
 int32_t robo_cand_create_sobol(robo_ctx* ctx, int64_t m, int32_t dim, const uint64_t* sv, const uint64_t* shift,
                                int32_t bits, uint64_t first_index, robo_cand** out);
 int32_t robo_cand_get_points(robo_cand* cand, double* out_Xc);
+/* candidates per pass of the solve workspace of the LAST posterior evaluated on this handle (a multiple of 128; the
+ * whole padded batch when it fits ROBO_WS_BYTES, default 6 GiB); 0 before the first evaluation.  Diagnostics: lets a
+ * caller (tests) see that a batch was evaluated in several passes.                                              */
+int32_t robo_cand_workspace_chunk(robo_cand* cand, int64_t* out_chunk);
 int32_t robo_cand_get_point(robo_cand* cand, int64_t index, double* out_x); /* one row: the winner */
 
 /* ---- posterior: replaces george.GP.predict (gaussian_process.py:280-294) ------------ */

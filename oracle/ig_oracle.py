@@ -51,3 +51,33 @@ def dh_fun(v, sigma_x_rep, sn2, logP, lmb, dlogPdMu, dlogPdSigma, dlogPdMudMu, W
     if np.isnan(dH) or dH == np.inf:
         dH = -sys.float_info.max
     return dH
+
+
+def innovation_inputs(ogp, X_test, zb, chunk=2048):
+    """The two posterior quantities ``innovations`` (information_gain.py:253-272) reads for every candidate x,
+    from an :class:`oracle.gp_oracle.OracleGP` -- the oracle's OWN numbers, nothing from the device:
+
+      v[c]     = ``model.predict(x)[1]``                      (:255; diagonal, floored at eps)
+      S[c, b]  = ``model.predict_variance(rep, x)[b, 0]``     (:263 -> gaussian_process.py:243-248: the last row
+                 of the full covariance of [rep; x], floored at eps -- negative covariances included, :290-294)
+
+    The reference forms one (Nb+1) x (Nb+1) covariance per candidate through ``gp.predict``
+    (K** - K* K^-1 K*^T); the same entries are taken here from V = L^-1 K*^T, chunked over candidates:
+    S = k(x, rep) - V_x^T V_rep.  Inputs in the caller's space (normalised like ``predict`` does)."""
+    from oracle import gp_oracle as O
+    import scipy.linalg as sla
+    eps = float(np.finfo(np.float64).eps)
+    norm = (lambda X: O.zero_one_normalization(X, ogp.lower, ogp.upper)[0]) if ogp.normalize_input else (lambda X: X)
+    scale = ogp.y_std ** 2 if ogp.normalize_output else 1.0
+    th_k = ogp.theta[:-1]
+    Zn = norm(np.asarray(zb, dtype=np.float64))
+    Vz = sla.solve_triangular(ogp.L, O.kernel_matrix(ogp.kind, th_k, ogp.X, Zn), lower=True, check_finite=False)
+    M = X_test.shape[0]
+    v = np.empty(M)
+    S = np.empty((M, Zn.shape[0]))
+    for s in range(0, M, chunk):
+        Xn = norm(np.asarray(X_test[s:s + chunk], dtype=np.float64))
+        Vx = sla.solve_triangular(ogp.L, O.kernel_matrix(ogp.kind, th_k, ogp.X, Xn), lower=True, check_finite=False)
+        v[s:s + chunk] = (O.kernel_diag(ogp.kind, th_k, Xn) - np.sum(Vx * Vx, axis=0)) * scale
+        S[s:s + chunk] = (O.kernel_matrix(ogp.kind, th_k, Xn, Zn) - Vx.T @ Vz) * scale
+    return np.clip(v, eps, np.inf), np.clip(S, eps, np.inf)

@@ -24,7 +24,7 @@ static size_t workspace_bytes() {
     const char* e = getenv("ROBO_WS_BYTES");
     if (e && *e) {
         const double v = atof(e);
-        if (v >= 1e6) return (size_t)v;
+        if (v >= 1.0) return (size_t)v;   // callers round down to whole 128-candidate blocks, at least one
     }
     return (size_t)6 << 30;
 }
@@ -681,6 +681,12 @@ int32_t robo_cand_get_point(robo_cand* k, int64_t index, double* out_x) {
     ROBO_HIP_CHECK(hipMemcpyAsync(out_x, k->d_Xc + (size_t)index * k->dim, (size_t)k->dim * sizeof(double),
                                   hipMemcpyDeviceToHost, k->ctx->stream));
     ROBO_HIP_CHECK(hipStreamSynchronize(k->ctx->stream));
+    return ROBO_OK;
+}
+
+int32_t robo_cand_workspace_chunk(robo_cand* k, int64_t* out_chunk) {
+    if (!k || !out_chunk) return ROBO_BAD_ARGUMENT;
+    *out_chunk = k->chunk;
     return ROBO_OK;
 }
 

@@ -12,14 +12,9 @@ from robo_amd.priors import DefaultPrior
 from robo_amd.solver import BayesianOptimization
 
 
-def entropy_search(objective_function, lower, upper, num_iterations=30, maximizer="random", model="gp_mcmc",
-                   X_init=None, Y_init=None, n_init=3, output_path=None, rng=None, n_candidates=500,
-                   chain_length=200, burnin_steps=100, n_representer=50, n_outcomes=400):
-    assert upper.shape[0] == lower.shape[0], "Dimension miss match"
-    assert np.all(lower < upper), "Lower bound >= upper bound"
-    assert n_init <= num_iterations, "Number of initial design point has to be <= than the number of iterations"
-    if rng is None:
-        rng = np.random.RandomState(np.random.randint(0, 10000))
+def build_entropy_search(lower, upper, maximizer="random", model="gp_mcmc", rng=None, n_candidates=500,
+                         chain_length=200, burnin_steps=100, n_representer=50, n_outcomes=400):
+    """the objects robo/fmin/entropy_search.py:69-121 wires together -> (model, acquisition function, maximiser)"""
     n_dims = lower.shape[0]
     kernel = 2 * Matern52Kernel(np.ones([n_dims]), ndim=n_dims)
     prior = DefaultPrior(len(kernel) + 1)
@@ -41,6 +36,19 @@ def entropy_search(objective_function, lower, upper, num_iterations=30, maximize
         raise ValueError("%s is not a valid function to maximize the acquisition function (robo_amd: 'random')"
                          % maximizer)
     max_func = RandomSampling(acquisition_func, lower, upper, n_samples=n_candidates, rng=rng)
+    return gp, acquisition_func, max_func
+
+
+def entropy_search(objective_function, lower, upper, num_iterations=30, maximizer="random", model="gp_mcmc",
+                   X_init=None, Y_init=None, n_init=3, output_path=None, rng=None, n_candidates=500,
+                   chain_length=200, burnin_steps=100, n_representer=50, n_outcomes=400):
+    assert upper.shape[0] == lower.shape[0], "Dimension miss match"
+    assert np.all(lower < upper), "Lower bound >= upper bound"
+    assert n_init <= num_iterations, "Number of initial design point has to be <= than the number of iterations"
+    if rng is None:
+        rng = np.random.RandomState(np.random.randint(0, 10000))
+    gp, acquisition_func, max_func = build_entropy_search(lower, upper, maximizer, model, rng, n_candidates,
+                                                          chain_length, burnin_steps, n_representer, n_outcomes)
     bo = BayesianOptimization(objective_function, lower, upper, acquisition_func, gp, max_func,
                               initial_design=init_latin_hypercube_sampling, initial_points=n_init, rng=rng,
                               output_path=output_path)

@@ -28,25 +28,11 @@ def retransform(s_transform, s_min, s_max):
     return int(np.rint(2 ** (s_transform * (np.log2(s_max) - np.log2(s_min)) + np.log2(s_min))))
 
 
-def fabolas(objective_function, lower, upper, s_min, s_max, n_init=40, num_iterations=100, subsets=[256, 128, 64],
-            inc_estimation="mean", burnin=100, chain_length=100, n_hypers=12, output_path=None, rng=None,
-            n_candidates=500, n_representer=50, n_outcomes=400):
-    """objective_function(x, s) -> (validation error, cost); returns the reference's result dict."""
-    time_start = time.time()
-    if rng is None:
-        rng = np.random.RandomState(np.random.randint(0, 10000))
+def build_fabolas(lower, upper, burnin=100, chain_length=100, n_hypers=12, rng=None, n_candidates=500,
+                  n_representer=50, n_outcomes=400):
+    """the objects robo/fmin/fabolas.py:99-199 wires together -> (objective model, cost model, acquisition
+    function, maximiser)"""
     n_dims = lower.shape[0]
-    time_func_eval, time_overhead, incumbents, runtime = [], [], [], []
-    X, y, c = [], [], []
-
-    def _dump(it):
-        if output_path is not None:
-            data = {"optimization_overhead": time_overhead[it], "runtime": runtime[it],
-                    "incumbent": np.asarray(incumbents[it]).tolist(), "time_func_eval": time_func_eval[it],
-                    "iteration": it}
-            with open(os.path.join(output_path, "fabolas_iter_%d.json" % it), "w") as fh:
-                json.dump(data, fh)
-
     kernel = FabolasKernel(n_dims + 1, metric=0.01, log_a=0.1, log_b=0.1, amp=1.0)
     if n_hypers < 2 * len(kernel):
         n_hypers = 3 * len(kernel)
@@ -68,6 +54,30 @@ def fabolas(objective_function, lower, upper, s_min, s_max, n_init=40, num_itera
                                     is_env_variable=is_env, n_representer=n_representer, Np=n_outcomes, rng=rng)
     acquisition_func = MarginalizationGPMCMC(ig)
     maximizer = RandomSampling(acquisition_func, extend_lower, extend_upper, n_samples=n_candidates)
+    return model_objective, model_cost, acquisition_func, maximizer
+
+
+def fabolas(objective_function, lower, upper, s_min, s_max, n_init=40, num_iterations=100, subsets=[256, 128, 64],
+            inc_estimation="mean", burnin=100, chain_length=100, n_hypers=12, output_path=None, rng=None,
+            n_candidates=500, n_representer=50, n_outcomes=400):
+    """objective_function(x, s) -> (validation error, cost); returns the reference's result dict."""
+    time_start = time.time()
+    if rng is None:
+        rng = np.random.RandomState(np.random.randint(0, 10000))
+    n_dims = lower.shape[0]
+    time_func_eval, time_overhead, incumbents, runtime = [], [], [], []
+    X, y, c = [], [], []
+
+    def _dump(it):
+        if output_path is not None:
+            data = {"optimization_overhead": time_overhead[it], "runtime": runtime[it],
+                    "incumbent": np.asarray(incumbents[it]).tolist(), "time_func_eval": time_func_eval[it],
+                    "iteration": it}
+            with open(os.path.join(output_path, "fabolas_iter_%d.json" % it), "w") as fh:
+                json.dump(data, fh)
+
+    model_objective, model_cost, acquisition_func, maximizer = build_fabolas(
+        lower, upper, burnin, chain_length, n_hypers, rng, n_candidates, n_representer, n_outcomes)
 
     x_init = init_latin_hypercube_sampling(lower, upper, n_init, rng)
     for it in range(n_init):

@@ -401,8 +401,139 @@ def make_branin(R, seed=3, n_iter=30):
     _save("ref_branin", **out)
 
 
+# ------------------------------------------------------------------------------------------------
+# (6) the other two front ends: robo.fmin.entropy_search (model="gp") and robo.fmin.fabolas, first
+#     model-based iterations, everything their loops decide logged for a replay (tests/ref_checks.py)
+# ------------------------------------------------------------------------------------------------
+def _rng_state():
+    st = np.random.get_state()
+    return dict(keys=st[1].copy(), pos=st[2], has_gauss=st[3], cached=st[4])
+
+
+def es_objective(x):
+    """a 2-d objective on [-5, 10] x [0, 15] (Branin / 50: the scale entropy_search's default priors expect)"""
+    return branin(x) / 50.0
+
+
+def make_entropy_search(R, seed=5, n_iter=9):
+    """robo/fmin/entropy_search.py:20-131 with model="gp": GaussianProcess (DefaultPrior, L-BFGS-B) +
+    InformationGain(sampling_acquisition=EI, Nb=50, Np=400) + RandomSampling(500), run by the reference's own
+    BayesianOptimization loop.  Logged per model-based iteration: the hyper-parameters its optimiser found, the
+    representer points its (OS-entropy seeded) emcee sampler drew, the global RNG state right before
+    RandomSampling.maximize, and what it chose."""
+    _placeholder_optional_models()
+    from robo.fmin import entropy_search as fmin_es
+    from robo.maximizers.random_sampling import RandomSampling
+    GP, IG = R.GaussianProcess, R.InformationGain
+    log_t, log_r, log_m = [], [], []
+    o_train, o_rep, o_max = GP.train, IG.sample_representer_points, RandomSampling.maximize
+
+    def train(self, X, y, do_optimize=True):
+        o_train(self, X, y, do_optimize)
+        log_t.append(dict(n=X.shape[0], hypers=np.array(self.hypers, dtype=np.float64), noise=float(self.noise)))
+
+    def rep(self):
+        o_rep(self)
+        log_r.append(dict(zb=np.array(self.zb), lmb=np.array(self.lmb)))
+
+    def maximize(self):
+        st = _rng_state()
+        x = o_max(self)
+        st["x"] = np.array(x)
+        log_m.append(st)
+        return x
+
+    GP.train, IG.sample_representer_points, RandomSampling.maximize = train, rep, maximize
+    try:
+        lo, hi = np.array([-5.0, 0.0]), np.array([10.0, 15.0])
+        np.random.seed(seed)
+        res = fmin_es(es_objective, lo, hi, num_iterations=n_iter, n_init=3, maximizer="random", model="gp",
+                      rng=np.random.RandomState(seed))
+    finally:
+        GP.train, IG.sample_representer_points, RandomSampling.maximize = o_train, o_rep, o_max
+    assert len(log_t) == len(log_r) == len(log_m) == n_iter - 3
+    _save("ref_entropy_search", X=np.array(res["X"]), y=np.array(res["y"]), seed=seed,
+          n=np.array([l["n"] for l in log_t]), hypers=np.array([l["hypers"] for l in log_t]),
+          noise=np.array([l["noise"] for l in log_t]), zb=np.array([l["zb"] for l in log_r]),
+          lmb=np.array([l["lmb"] for l in log_r]), x_new=np.array([l["x"] for l in log_m]),
+          rng_keys=np.array([l["keys"] for l in log_m]), rng_pos=np.array([l["pos"] for l in log_m]),
+          rng_has_gauss=np.array([l["has_gauss"] for l in log_m]), rng_cached=np.array([l["cached"] for l in log_m]),
+          incumbents=np.array(res["incumbents"]), incumbent_values=np.array(res["incumbent_values"]))
+
+
+def fabolas_objective(x, s):
+    """(validation error, cost) of a configuration x in [0,1]^2 on s data points: error falls, cost grows with s"""
+    err = 0.1 + (x[0] - 0.3) ** 2 + 0.5 * (x[1] - 0.6) ** 2 + 2.0 / np.sqrt(s)
+    return float(err), float(0.05 + s / 400.0 * (1.0 + x[0]))
+
+
+def make_fabolas_frontend(R, seed=6, n_init=3, subsets=(64, 16), n_model_based=3):
+    """robo/fmin/fabolas.py:31-312 as shipped: two FabolasGPMCMC models (EnvPrior, emcee), InformationGainPerUnitCost
+    (EI proposal, 50 representer points) marginalised over the hyper-parameter samples, RandomSampling(500) on the
+    extended box, projected incumbent.  Logged per model-based iteration: both models' hyper-parameter samples,
+    every estimator's representer points, the incumbent estimate, the global RNG state before maximize, the choice."""
+    _placeholder_optional_models()
+    import robo.fmin                                  # noqa: F401
+    ref_fab = sys.modules["robo.fmin.fabolas"]        # (the package attribute of that name is the function)
+    from robo.maximizers.random_sampling import RandomSampling
+    MC, IGC = R.FabolasGPMCMC, R.InformationGainPerUnitCost
+    log_t, log_r, log_m, log_i = [], [], [], []
+    o_train, o_rep, o_max, o_inc = MC.train, IGC.sample_representer_points, RandomSampling.maximize, \
+        ref_fab.projected_incumbent_estimation
+
+    def train(self, X, y, do_optimize=True, **kw):
+        o_train(self, X, y, do_optimize, **kw)
+        log_t.append(dict(n=X.shape[0], hypers=np.array(self.hypers, dtype=np.float64)))
+
+    def rep(self):
+        o_rep(self)
+        log_r.append(dict(zb=np.array(self.zb), lmb=np.array(self.lmb)))
+
+    def maximize(self):
+        st = _rng_state()
+        x = o_max(self)
+        st["x"] = np.array(x)
+        log_m.append(st)
+        return x
+
+    def inc(model, X, proj_value=1):
+        a, b = o_inc(model, X, proj_value)
+        log_i.append((np.array(a), float(b)))
+        return a, b
+
+    MC.train, IGC.sample_representer_points, RandomSampling.maximize = train, rep, maximize
+    ref_fab.projected_incumbent_estimation = inc
+    n0 = n_init * len(subsets)
+    try:
+        np.random.seed(seed)
+        res = ref_fab.fabolas(fabolas_objective, np.zeros(2), np.ones(2), s_min=10, s_max=1000, n_init=n_init,
+                              num_iterations=n0 + n_model_based, subsets=list(subsets), burnin=20, chain_length=10,
+                              n_hypers=12, rng=np.random.RandomState(seed))
+    finally:
+        MC.train, IGC.sample_representer_points, RandomSampling.maximize = o_train, o_rep, o_max
+        ref_fab.projected_incumbent_estimation = o_inc
+    S = log_t[0]["hypers"].shape[0]
+    assert len(log_t) == 2 * n_model_based + 1 and len(log_m) == n_model_based and len(log_r) == S * n_model_based
+    out = dict(X=np.array(res["X"]), y=np.log(np.array(res["y"])), c=np.array(res["c"]), seed=seed, S=S, n0=n0,
+               x_opt=np.array(res["x_opt"]))
+    for it in range(n_model_based):
+        out["hypers_obj_%d" % it] = log_t[2 * it]["hypers"]
+        out["hypers_cost_%d" % it] = log_t[2 * it + 1]["hypers"]
+        out["zb_%d" % it] = np.array([l["zb"] for l in log_r[S * it:S * (it + 1)]])
+        out["lmb_%d" % it] = np.array([l["lmb"] for l in log_r[S * it:S * (it + 1)]])
+        out["inc_%d" % it], out["inc_val_%d" % it] = log_i[it]
+        m = log_m[it]
+        out["x_new_%d" % it] = m["x"]
+        out["rng_keys_%d" % it], out["rng_pos_%d" % it] = m["keys"], m["pos"]
+        out["rng_has_gauss_%d" % it], out["rng_cached_%d" % it] = m["has_gauss"], m["cached"]
+    out["hypers_final"] = log_t[-1]["hypers"]
+    out["inc_final"], out["inc_val_final"] = log_i[-1]
+    _save("ref_fabolas_frontend", **out)
+
+
 MAKERS = dict(gp=make_gp, mcmc=make_mcmc, fabolas=make_fabolas, infogain=make_infogain,
-              infogain_config4=make_infogain_config4, branin=make_branin)
+              infogain_config4=make_infogain_config4, branin=make_branin,
+              entropy_search=make_entropy_search, fabolas_frontend=make_fabolas_frontend)
 
 if __name__ == "__main__":
     R = reference()

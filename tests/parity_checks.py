@@ -824,3 +824,46 @@ def check_host_array_handle_reuse(ctx):
         assert (mx, am, fl) == (mx_f, am_f, fl_f)
     g.close()
 
+
+
+def check_chunked_workspace(ctx, monkeypatch, N, D, M, ws_blocks, kind="matern52"):
+    """Candidate batches larger than the solve workspace (ROBO_WS_BYTES) are evaluated in passes of whole
+    128-candidate blocks: posterior, acquisition values and argmax must equal the single-pass results bit for bit,
+    and the oracle's within the stated tolerances."""
+    from _tol import MU_ATOL, MU_RTOL, VAR_ATOL_REL_AMP
+    rs = np.random.RandomState(N + M)
+    X = rs.rand(N, D)
+    y = np.sinc(X * 10 - 5).sum(axis=1)
+    theta = np.concatenate([[0.2], np.log(0.25 * D) + 0.2 * rs.randn(D), [np.log(1e-3)]])
+    Xc = rs.rand(M, D)
+    ogp = O.OracleGP(kind, theta, lower=np.zeros(D), upper=np.ones(D))
+    ogp.train(X, y)
+    g = _lib.DeviceGP(ctx, kind, N, D)
+    g.set_data(X, y)
+    g.fit(theta, ogp.mean)
+    eta = float(y.min())
+    monkeypatch.delenv("ROBO_WS_BYTES", raising=False)
+    mu1, var1 = g.predict(Xc)
+    v1, mx1, am1, _ = g.acq("ei", 0.0, eta, Xc)
+    n_pad = (N + 1 + 127) // 128 * 128
+    monkeypatch.setenv("ROBO_WS_BYTES", str(ws_blocks * 128 * n_pad * 8))
+    cand = _lib.Candidates(ctx, Xc)                 # a fresh handle: its workspace is sized under the limit
+    mu2, var2 = g.predict(cand)
+    v2, mx2, am2, _ = g.acq("ei", 0.0, eta, cand)
+    n_pass = -(-((M + 127) // 128) // ws_blocks)
+    assert n_pass >= 2, n_pass
+    assert cand.chunk() == ws_blocks * 128, (cand.chunk(), ws_blocks)
+    cand.close()
+    monkeypatch.delenv("ROBO_WS_BYTES")
+    np.testing.assert_array_equal(mu1, mu2)
+    np.testing.assert_array_equal(var1, var2)
+    np.testing.assert_array_equal(v1, v2)
+    assert am1 == am2 and mx1 == mx2
+    mu_o, var_o = ogp.predict(Xc, diag_only=True)
+    np.testing.assert_allclose(mu2, mu_o, rtol=MU_RTOL, atol=MU_ATOL)
+    np.testing.assert_allclose(var2, var_o, rtol=0, atol=VAR_ATOL_REL_AMP * np.exp(theta[0]))
+    ei_o = O.ei(mu_o, var_o, eta)
+    want, srt = int(np.argmax(ei_o)), np.sort(ei_o)
+    assert am2 == want or srt[-1] - srt[-2] <= 1e-7 * abs(ei_o[want]), (am2, want)
+    g.close()
+    return n_pass

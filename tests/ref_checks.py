@@ -381,3 +381,102 @@ def check_ref_branin_free_run(device=None):
     while same < 30 and np.array_equal(Xm[same], gold["X"][same]):
         same += 1
     return same, float(res["f_opt"]), float(gold["f_opt"])
+
+
+# ------------------------------------------------------------------------------------------------
+# (6) the other two front ends replayed: robo/fmin/entropy_search.py:20-131 (model="gp") and
+#     robo/fmin/fabolas.py:31-312, objects wired by robo_amd's own front-end builders
+# ------------------------------------------------------------------------------------------------
+def _set_global_rng(gold, sfx):
+    np.random.set_state(("MT19937", gold["rng_keys" + sfx], int(gold["rng_pos" + sfx]),
+                         int(gold["rng_has_gauss" + sfx]), float(gold["rng_cached" + sfx])))
+
+
+def check_ref_entropy_search_replay(device=None):
+    """At every model-based iteration of the reference's own entropy_search run: same data so far, the
+    hyper-parameters its L-BFGS-B found, the representer points its emcee sampler drew (seeded from OS entropy
+    there: inputs), the global RNG state it had before RandomSampling.maximize -> robo_amd's GaussianProcess +
+    InformationGain + RandomSampling (as robo_amd.fmin.entropy_search wires them) must choose the SAME candidate,
+    bit for bit, i.e. the same argmax over the 500 information gains."""
+    from robo_amd.fmin.entropy_search import build_entropy_search
+    gold = load("ref_entropy_search")
+    lo, hi = np.array([-5.0, 0.0]), np.array([10.0, 15.0])
+    X, y = gold["X"], gold["y"]
+    np.testing.assert_array_equal(y, np.array([G.es_objective(x) for x in X]))
+    gp, acq, rs = build_entropy_search(lo, hi, "random", "gp", np.random.RandomState(0))
+    if device is not None:
+        gp.device = device
+    for it, n in enumerate(gold["n"]):
+        h = gold["hypers"][it]
+        gp.kernel.set_parameter_vector(h[:-1])
+        gp.noise = np.exp(h[-1])
+        gp.train(X[:n], y[:n], do_optimize=False)
+        np.testing.assert_allclose(gp.noise, gold["noise"][it], rtol=1e-12)
+
+        def pinned(zb=gold["zb"][it], lmb=gold["lmb"][it]):
+            acq.sampling_acquisition.update(acq.model)
+            acq.zb, acq.lmb = zb.copy(), lmb.copy()
+
+        acq.sample_representer_points = pinned
+        acq.update(gp)
+        np.random.set_state(("MT19937", gold["rng_keys"][it], int(gold["rng_pos"][it]),
+                             int(gold["rng_has_gauss"][it]), float(gold["rng_cached"][it])))
+        x_new = rs.maximize()
+        np.testing.assert_array_equal(x_new, gold["x_new"][it], err_msg="iteration %d (n=%d)" % (it, n))
+        np.testing.assert_array_equal(x_new, X[n])
+        inc, inc_val = gp.get_incumbent()
+        np.testing.assert_allclose(inc, gold["incumbents"][n - 1], rtol=1e-13)      # best of the first n points
+        np.testing.assert_allclose(inc_val, gold["incumbent_values"][n - 1], rtol=1e-13)
+    return len(gold["n"])
+
+
+def check_ref_fabolas_replay(device=None, n_iter=None):
+    """The same for robo.fmin.fabolas: per model-based iteration both models' hyper-parameter samples, every
+    estimator's representer points and the global RNG state are the reference run's; the projected incumbent
+    (fabolas.py:225-227) and the candidate RandomSampling picks on the information gain per unit cost,
+    marginalised over the 12 samples, must be the reference's."""
+    from robo_amd.acquisition_functions import InformationGainPerUnitCost
+    from robo_amd.fmin.fabolas import build_fabolas
+    from robo_amd.util.incumbent_estimation import projected_incumbent_estimation
+    gold = load("ref_fabolas_frontend")
+    X, y, c, n0, S = gold["X"], gold["y"], gold["c"], int(gold["n0"]), int(gold["S"])
+    m_obj, m_cost, acq, rs = build_fabolas(np.zeros(2), np.ones(2), burnin=20, chain_length=10, n_hypers=12,
+                                           rng=np.random.RandomState(0))
+    assert m_obj.n_hypers == S
+    if device is not None:
+        m_obj.device = m_cost.device = device
+    state = {}
+
+    def pinned(self):
+        self.sampling_acquisition.update(self.model)
+        i = [k for k, mdl in enumerate(m_obj.models) if mdl is self.model][0]
+        self.zb, self.lmb = state["zb"][i].copy(), state["lmb"][i].copy()
+
+    orig = InformationGainPerUnitCost.sample_representer_points
+    InformationGainPerUnitCost.sample_representer_points = pinned
+    try:
+        n_all = X.shape[0] - n0
+        for it in range(n_all if n_iter is None else min(n_iter, n_all)):
+            n = n0 + it
+            m_obj.hypers = [h for h in gold["hypers_obj_%d" % it]]
+            m_cost.hypers = [h for h in gold["hypers_cost_%d" % it]]
+            m_obj.train(X[:n], y[:n], do_optimize=False)
+            m_cost.train(X[:n], c[:n], do_optimize=False)
+            inc, inc_val = projected_incumbent_estimation(m_obj, X[:n, :-1], proj_value=1)
+            np.testing.assert_allclose(inc, gold["inc_%d" % it], rtol=1e-13)
+            np.testing.assert_allclose(inc_val, float(gold["inc_val_%d" % it]), rtol=1e-7, atol=1e-9)
+            state["zb"], state["lmb"] = gold["zb_%d" % it], gold["lmb_%d" % it]
+            acq.update(m_obj, m_cost)
+            assert len(acq.estimators) == S
+            _set_global_rng(gold, "_%d" % it)
+            x_new = rs.maximize()
+            np.testing.assert_array_equal(x_new, gold["x_new_%d" % it], err_msg="iteration %d" % it)
+            np.testing.assert_array_equal(x_new, X[n])
+        m_obj.hypers = [h for h in gold["hypers_final"]]
+        m_obj.train(X, y, do_optimize=False)
+        inc, inc_val = projected_incumbent_estimation(m_obj, X[:, :-1], proj_value=1)
+        np.testing.assert_allclose(inc[:-1], gold["x_opt"], rtol=1e-13)
+        np.testing.assert_allclose(inc_val, float(gold["inc_val_final"]), rtol=1e-7, atol=1e-9)
+    finally:
+        InformationGainPerUnitCost.sample_representer_points = orig
+    return n_all if n_iter is None else min(n_iter, n_all)

@@ -100,22 +100,8 @@ def test_fp32_gram_mixed_precision(emu_ctx):
 
 def test_chunked_workspace_equals_single_pass(emu_ctx, monkeypatch):
     """candidate batches larger than the solve workspace are processed in chunks"""
-    from make_golden import golden_inputs
-    from oracle import gp_oracle as O
-    inp = golden_inputs("small_matern")
-    ogp = P.oracle_gp(inp)
-    g = P.device_gp(emu_ctx, ogp, inp)
-    g.fit(inp["theta"], ogp.mean)
-    Xc = np.random.RandomState(0).rand(700, 3)
-    mu1, var1 = g.predict(Xc)
-    monkeypatch.setenv("ROBO_WS_BYTES", str(2 * 128 * 128 * 8))   # two 128-candidate blocks per pass
-    mu2, var2 = g.predict(Xc)
-    np.testing.assert_array_equal(mu1, mu2)
-    np.testing.assert_array_equal(var1, var2)
-    _, _, am1, _ = g.acq("ei", 0.0, float(ogp.y.min()), Xc)
-    monkeypatch.delenv("ROBO_WS_BYTES")
-    _, _, am2, _ = g.acq("ei", 0.0, float(ogp.y.min()), Xc)
-    assert am1 == am2
+    P.check_chunked_workspace(emu_ctx, monkeypatch, N=150, D=3, M=700, ws_blocks=2)
+
 
 
 def test_multi_panel_factorisation(emu_ctx):

@@ -75,19 +75,27 @@ def _check_ig(ctx, **kw):
     d = _setup(ctx, **kw)
     cand = _lib.Candidates(ctx, d["Xc"])
     rep = _lib.Candidates(ctx, d["zb"])
-    # (1) cross-covariances vs the oracle's full covariance (clipped at eps like the reference)
+    # (1) cross-covariances and variances of EVERY candidate vs the oracle's own (clipped at eps like the reference)
     S = _lib.cross_cov(d["g"], cand, rep)
-    both = np.concatenate([d["zb"], d["Xc"][:20]])
-    _, cov = d["ogp"].predict(both, full_cov=True)
-    Nb = d["zb"].shape[0]
-    np.testing.assert_allclose(S[:20], cov[Nb:, :Nb], rtol=0, atol=1e-9)
-    # (2) information gain vs the NumPy restatement fed with the device's own (v, s)
-    vals, mx, am = _lib.ig_eval(d["g"], cand, rep, d["ep"], d["sn2"])
     _, var = d["g"].predict(cand)
-    ref = np.array([IG.dh_fun(var[c], S[c][:, None], d["sn2"], d["logP"], d["lmb"], d["dMu"], d["dSig"], d["dMM"],
+    var_o, S_o = IG.innovation_inputs(d["ogp"], d["Xc"], d["zb"])
+    amp = float(np.max(O.kernel_diag(d["ogp"].kind, d["ogp"].theta[:-1], d["Xc"][:8])))
+    np.testing.assert_allclose(S, S_o, rtol=0, atol=1e-9 * amp)
+    np.testing.assert_allclose(var, var_o, rtol=0, atol=1e-9 * amp)
+    # (2) information gain of every candidate vs the NumPy restatement fed with the ORACLE's (v, s): nothing the
+    # device computed enters the expected values
+    vals, mx, am = _lib.ig_eval(d["g"], cand, rep, d["ep"], d["sn2"])
+    ref = np.array([IG.dh_fun(var_o[c], S_o[c][:, None], d["sn2"], d["logP"], d["lmb"], d["dMu"], d["dSig"], d["dMM"],
                               d["W"]) for c in range(d["Xc"].shape[0])])
-    np.testing.assert_allclose(vals, ref, rtol=1e-8, atol=1e-10)
-    assert am == int(np.argmax(vals)) and am == int(np.argmax(ref))
+    np.testing.assert_allclose(vals, ref, rtol=1e-6, atol=1e-6 * np.abs(ref).max())
+    want = int(np.argmax(ref))
+    srt = np.sort(ref)
+    assert am == int(np.argmax(vals)) and (am == want or srt[-1] - srt[-2] <= 1e-6 * abs(ref[want])), (am, want)
+    assert mx == vals[am]
+    # (2b) the entropy algebra alone (same restatement on the device's own (v, s)): tighter, not a parity claim
+    alg = np.array([IG.dh_fun(var[c], S[c][:, None], d["sn2"], d["logP"], d["lmb"], d["dMu"], d["dSig"], d["dMM"],
+                              d["W"]) for c in range(0, d["Xc"].shape[0], 7)])
+    np.testing.assert_allclose(vals[::7], alg, rtol=1e-8, atol=1e-10)
     # (3) the moments entry point (any model) gives the same numbers
     vals2 = _lib.ig_from_moments(ctx, S, var, d["ep"], d["sn2"])
     np.testing.assert_allclose(vals2, vals, rtol=1e-12, atol=1e-14)

@@ -63,6 +63,14 @@ def test_branin_replay_emulated(emu):
     R.check_ref_branin_replay()
 
 
+def test_entropy_search_replay_emulated(emu):
+    assert R.check_ref_entropy_search_replay() == 6
+
+
+def test_fabolas_replay_emulated(emu):
+    assert R.check_ref_fabolas_replay(n_iter=1) == 1         # host logic; all three iterations run on the MI355X
+
+
 # ---- MI355X ---------------------------------------------------------------------------------------------
 @pytest.mark.gpu
 @pytest.mark.parametrize("name", ["ref_gp_matern", "ref_gp_rbf_nout", "ref_gp_headline_shape"])
@@ -115,3 +123,15 @@ def test_branin_free_run(gpu):
     # finite-difference L-BFGS-B; after the first diverging optimiser run the two are different random searches
     assert same >= 8
     assert f_mine - 0.397887 <= 1.0
+
+
+@pytest.mark.gpu
+def test_entropy_search_trajectory_replay(gpu):
+    """robo.fmin.entropy_search's own run (model="gp"): same choice at all 6 model-based iterations"""
+    assert R.check_ref_entropy_search_replay() == 6
+
+
+@pytest.mark.gpu
+def test_fabolas_trajectory_replay(gpu):
+    """robo.fmin.fabolas's own run: projected incumbents and the choice at all 3 model-based iterations"""
+    assert R.check_ref_fabolas_replay() == 3
