@@ -284,7 +284,7 @@ def run_headline(args, D_, _lib, sharding):
                 traffic, traffic_src = tj["bytes_per_launch"], tj.get("commit")
         except Exception:
             pass
-        roof = roofline_trsm(ctx, N, M, trsm_ms, traffic=traffic)
+        roof = roofline_trsm(ctx, N, M, trsm_ms, kernel=cand.solve_kernel(), traffic=traffic)
         roof["traffic_measured_at_commit"] = traffic_src
         roof["mfma_f64_microbench"] = mb
         if clock_peak:
@@ -302,12 +302,16 @@ def run_headline(args, D_, _lib, sharding):
                        "n_train": N, "dim": D, "candidates_per_gpu": M, "acquisition": args.acq,
                        "parallelism": "candidate-shard x%d, replicated fit" % world},
             "algorithmic_tflops_whole_step": value * flops_ei(N, D) / 1e12,
+            # `value` is the resident-input rate (the bench contract: inputs in HBM when the timed region starts); SURVEY
+            # 8(d)'s host-buffer definition of an "EI eval" is this block
             "pcie_inclusive": {"value": world * M * pcie_steps / elapsed_pcie, "unit": "EI evals/s",
                                "ms_per_step": elapsed_pcie / pcie_steps * 1e3,
                                "what": "SURVEY 8(d) definition: H2D of the %d x %d candidate batch (pageable host memory, "
                                        "into an existing handle) + evaluation + D2H of (max, argmax)" % (M, D)},
-            "gp_fit_ms": float(np.min(fit_ms)),
-            "gp_fit_incl_h2d_ms": float(np.min(fit_h2d)),
+            # GP-fit = robo_gp_fit wall time for one theta INCLUDING the H2D of X, y, theta and the D2H of
+            # the log-likelihood; the data-resident refit (what an MCMC / L-BFGS loop pays per theta) next to it
+            "gp_fit_ms": float(np.min(fit_h2d)),
+            "gp_fit_data_resident_ms": float(np.min(fit_ms)),
             "gp_fit_phases_ms": {"gram": gram_ms, "cholesky": chol_ms, "loglik": ll_ms},
             "gp_fit_frac_of_mfma_peak": (N ** 3 / 3.0 + N * (N + 1) / 2.0 * (3 * D + 16) + 2.0 * N * N)
             / (float(np.min(fit_ms)) * 1e-3) / 1e12 / FP64_MFMA_PEAK_TFLOPS,
@@ -358,7 +362,7 @@ def run_c3(args, D_, _lib, sharding):
         return None
     ms = elapsed / args.steps * 1e3
     # elapsed_ms(25, 26) brackets the LAST sample's solve of a step
-    roof = roofline_trsm(ctx, N, M, trsm_ms)
+    roof = roofline_trsm(ctx, N, M, trsm_ms, kernel=cand.solve_kernel())
     return {"metric": METRIC, "value": S * M * args.steps / elapsed, "unit": "LogEI sample-evals/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": True,
             "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
@@ -431,8 +435,11 @@ def run_c4(args, D_, _lib, sharding):
                                    "cost (Nb=50, Np=400, objective + cost GP), %d candidates per GPU" % M,
                        "n_train": N, "dim": D, "candidates_per_gpu": M, "acquisition": "information_gain_per_unit_cost",
                        "parallelism": "candidate-shard x%d, replicated fits" % world},
-            "argmax": list(best), "roofline": roofline_trsm(ctx, N, M, trsm_ms), "device": ctx.name,
-            "note": "roofline: the block-row solve of the LAST posterior of a step (the cost model's)"}
+            "argmax": list(best),
+            "roofline": roofline_trsm(ctx, N, M, trsm_ms, kernel=cand_cost.solve_kernel()),
+            "device": ctx.name,
+            "note": "roofline: the block-row solve of the LAST posterior of a step (the cost model's); at this batch "
+                    "size the step is latency-bound, not MFMA-bound (see small_batch_latency_ms of the headline line)"}
 
 
 # ----------------------------------------------------------------------------------------------------
@@ -477,7 +484,7 @@ def run_c5(args, D_, _lib, sharding):
                        "n_train": N, "dim": D, "candidates_per_gpu": M, "acquisition": "lcb",
                        "parallelism": "candidate-shard x%d, replicated fit" % world},
             "gp_fit_ms": fit_ms, "algorithmic_tflops_whole_step": world * M * flops_ei(N, D) / (ms * 1e-3) / 1e12,
-            "argmax": list(best), "roofline": roofline_trsm(ctx, N, M, trsm_ms, kernel="trsm_step_kernel"),
+            "argmax": list(best), "roofline": roofline_trsm(ctx, N, M, trsm_ms, passes=-(-M // cand.chunk()), kernel=cand.solve_kernel()),
             "device": ctx.name}
 
 

@@ -164,6 +164,9 @@ int32_t robo_cand_get_points(robo_cand* cand, double* out_Xc);
  * whole padded batch when it fits ROBO_WS_BYTES, default 6 GiB); 0 before the first evaluation.  Diagnostics: lets a
  * caller (tests) see that a batch was evaluated in several passes.                                              */
 int32_t robo_cand_workspace_chunk(robo_cand* cand, int64_t* out_chunk);
+/* name of the kernel that ran the solve of the last posterior on this handle ("" before the first): the library picks
+ * it from the batch size and precision; bench.py labels its roofline block with it.  Diagnostics.                */
+int32_t robo_cand_last_solve_kernel(robo_cand* cand, char* buf, int32_t buf_len);
 int32_t robo_cand_get_point(robo_cand* cand, int64_t index, double* out_x); /* one row: the winner */
 
 /* ---- posterior: replaces george.GP.predict (gaussian_process.py:280-294) ------------ */

@@ -31,7 +31,7 @@ SYMBOLS = [
     "robo_gp_set_precision", "robo_theta_size",
     "robo_gp_fit", "robo_gp_loglik_batch", "robo_gp_fit_batch", "robo_gp_grad_loglik", "robo_gp_get_factor", "robo_gp_get_gram",
     "robo_cand_create", "robo_cand_destroy", "robo_cand_set_points", "robo_cand_create_uniform", "robo_cand_get_points",
-    "robo_cand_create_random", "robo_cand_create_sobol", "robo_cand_get_point", "robo_cand_workspace_chunk",
+    "robo_cand_create_random", "robo_cand_create_sobol", "robo_cand_get_point", "robo_cand_workspace_chunk", "robo_cand_last_solve_kernel",
     "robo_gp_predict_cand", "robo_gp_predict", "robo_gp_predict_cov", "robo_gp_predict_grad", "robo_gp_predict_mixture_cand",
     "robo_acq_eval_cand", "robo_acq_eval", "robo_acq_eval_moments", "robo_acq_eval_marginal_cand", "robo_acq_eval_sum_cand",
     "robo_ig_eval_cand", "robo_ig_eval_moments", "robo_gp_cross_cov",
@@ -126,6 +126,7 @@ def lib():
         "robo_cand_create_sobol": [vp, i64, i32, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), i32, C.c_uint64, pp],
         "robo_cand_get_point": [vp, i64, _dp],
         "robo_cand_workspace_chunk": [vp, C.POINTER(i64)],
+        "robo_cand_last_solve_kernel": [vp, C.c_char_p, i32],
         "robo_gp_predict_cand": [vp, vp, _dp, _dp],
         "robo_gp_predict": [vp, _dp, i64, _dp, _dp],
         "robo_gp_predict_cov": [vp, _dp, i64, _dp, _dp],
@@ -336,6 +337,12 @@ class Candidates(object):
         n = C.c_int64(0)
         check(lib().robo_cand_workspace_chunk(self._h, C.byref(n)))
         return int(n.value)
+
+    def solve_kernel(self):
+        """name of the kernel that ran the solve of the last posterior evaluated on this handle"""
+        buf = C.create_string_buffer(64)
+        check(lib().robo_cand_last_solve_kernel(self._h, buf, 64))
+        return buf.value.decode()
 
     def points(self):
         out = np.empty((self.m, self.dim))

@@ -690,6 +690,12 @@ int32_t robo_cand_workspace_chunk(robo_cand* k, int64_t* out_chunk) {
     return ROBO_OK;
 }
 
+int32_t robo_cand_last_solve_kernel(robo_cand* k, char* buf, int32_t buf_len) {
+    if (!k || !buf || buf_len < 1) return ROBO_BAD_ARGUMENT;
+    snprintf(buf, (size_t)buf_len, "%s", k->solve_kernel ? k->solve_kernel : "");
+    return ROBO_OK;
+}
+
 int32_t robo_cand_get_points(robo_cand* k, double* out_Xc) {
     if (!k || !out_Xc) return ROBO_BAD_ARGUMENT;
     ROBO_HIP_CHECK(hipMemcpyAsync(out_Xc, k->d_Xc, (size_t)k->m * k->dim * sizeof(double), hipMemcpyDeviceToHost,

@@ -138,6 +138,7 @@ struct robo_cand {
     double* d_Xcs;      // (m_pad, dim) scaled for the GP being evaluated
     double* d_V;        // (chunk, ldv) cross-gram -> L^-1 k_* in place
     int64_t chunk;      // candidates per workspace pass (multiple of NB)
+    const char* solve_kernel;   // name of the kernel that ran the last posterior's solve (diagnostics: bench labels)
     int ldv;            // n_pad the workspace was sized for
     size_t v_bytes;
     const robo_gp* solved_gp;        // d_V holds L^-1 k_* of ALL the points for this factor (entropy search keeps

@@ -567,6 +567,7 @@ int launch_trsm(robo_gp* gp, robo_cand* cand, int64_t c0, int64_t cn) {
     // identity padding (n % 128 == 0) solves to zeros and is skipped (its V columns stay the
     // zeros cross_gram_kernel wrote)
     const int nbk = (gp->n + NB - 1) / NB;
+    cand->solve_kernel = "trsm_step_kernel";
     for (int i = 0; i < nbk; ++i) {
         hipLaunchKernelGGL(trsm_step_kernel, dim3((unsigned)(cn / NB)), dim3(256), 0, gp->ctx->stream, cand->d_V,
                            gp->n_pad, (const double*)gp->d_K, gp->n_pad, (const double*)gp->d_LinvP, i, gp->n,
@@ -592,6 +593,7 @@ int launch_predict_fused(robo_gp* gp, robo_cand* cand, int64_t c0, int64_t cn) {
             const char* e_deep = getenv("ROBO_TRSM_SMALL_DEEP");       // test knob: 0 / 1 force the stage depth
             const bool deep = e_deep ? atoi(e_deep) != 0 : cn / (narrow ? 16 : 32) <= ncu;
             const dim3 sgrid((unsigned)(cn / (narrow ? 16 : 32)));
+            cand->solve_kernel = "trsm_step_small_kernel";
 #define ROBO_SMALL_LAUNCH(KIND, MB, DK)                                                                        \
     hipLaunchKernelGGL((trsm_step_small_kernel<KIND, MB, DK>), sgrid, dim3(256), 0, gp->ctx->stream,           \
                        (const double*)cand->d_Xcs, (const double*)gp->d_Xs, cand->d_V, gp->n_pad,             \
@@ -620,6 +622,7 @@ int launch_predict_fused(robo_gp* gp, robo_cand* cand, int64_t c0, int64_t cn) {
                        (const double*)cand->d_Xcs, (const double*)gp->d_Xs, cand->d_V, gp->n_pad,             \
                        (const double*)gp->d_K, gp->n_pad, (const double*)gp->d_LinvP, i,                      \
                        (i + rows < nbk ? i + rows : nbk), gp->n, cand->d_q, cand->d_mu, (long long)c0, gp->cov)
+    cand->solve_kernel = "trsm_step_gen_kernel";
     static const int rows = [] {
         const char* e = getenv("ROBO_TRSM_ROWS");
         const int r = e ? atoi(e) : 1;

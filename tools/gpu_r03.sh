@@ -1,0 +1,48 @@
+#!/bin/bash
+# One GPU-box session of round 3.  usage: tools/gpu_r03.sh <tag> [tests] [bench] [configs] [prof] [pmc] [fit] [small]
+TAG=${1:-r03}; shift
+OUT=gpurun_out/$TAG; mkdir -p $OUT; export TMPDIR=/tmp
+cd "$(dirname "$0")/.."
+for what in "$@"; do case $what in
+tests)
+  timeout 1500 python -m pytest tests -m gpu -q -x --durations=15 > $OUT/pytest_gpu.log 2>&1; echo "pytest rc=$?" >> $OUT/summary.txt
+  tail -30 $OUT/pytest_gpu.log >> $OUT/summary.txt ;;
+smoke)
+  timeout 300 python __graft_entry__.py smoke > $OUT/smoke.txt 2>&1; echo "smoke rc=$?" >> $OUT/summary.txt ;;
+bench)
+  timeout 600 python bench.py --gpus 1 > $OUT/bench.json 2> $OUT/bench.err; echo "bench rc=$?" >> $OUT/summary.txt
+  python - <<PY >> $OUT/summary.txt 2>&1
+import json; d=json.load(open('$OUT/bench.json'))
+print('value', d['value'], 'ms', d['ms_per_step'], 'frac', d['roofline']['frac'], 'fit', d['gp_fit_ms'], d.get('gp_fit_data_resident_ms'), d['gp_fit_phases_ms'], 'k1', d['k_assembly'], 'small', d['small_batch_latency_ms'], 'batched', d['gp_fit_batched'])
+PY
+  ;;
+configs)
+  : > $OUT/configs.jsonl
+  for c in c2 c3 c4 c5; do
+    timeout 600 python bench.py --gpus 1 --config $c --no-cpu-baseline >> $OUT/configs.jsonl 2>> $OUT/configs.err; echo "$c rc=$?" >> $OUT/summary.txt
+  done
+  timeout 900 python bench.py --gpus 1 --config c5 --m 1048576 --steps 2 --warmup 1 --no-cpu-baseline >> $OUT/configs.jsonl 2>> $OUT/configs.err; echo "c5 full rc=$?" >> $OUT/summary.txt
+  cut -c1-300 $OUT/configs.jsonl >> $OUT/summary.txt ;;
+prof)
+  timeout 900 rocprofv3 --kernel-trace --stats -d $OUT/prof -o bench -- python bench.py --gpus 1 --no-cpu-baseline > $OUT/prof_bench.json 2> $OUT/prof.err; echo "rocprof rc=$?" >> $OUT/summary.txt
+  python tools/rocpd_stats.py $OUT/prof/bench_results.db > $OUT/bench_kernel_stats.csv 2>> $OUT/prof.err
+  find $OUT/prof -size +20M -delete
+  head -16 $OUT/bench_kernel_stats.csv >> $OUT/summary.txt ;;
+pmc)
+  for C in FETCH_SIZE WRITE_SIZE "SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE"; do
+    name=$(echo $C | tr ' ' '_')
+    timeout 600 rocprofv3 --kernel-trace --pmc $C -d $OUT/pmc/$name -o pmc -- python bench.py --gpus 1 --steps 1 --warmup 0 --no-cpu-baseline > $OUT/pmc_$name.json 2> $OUT/pmc_$name.err
+    echo "pmc $C rc=$?" >> $OUT/summary.txt
+  done
+  python tools/rocpd_pmc.py $OUT/pmc > $OUT/pmc_summary.txt 2>&1
+  find $OUT/pmc -size +30M -delete
+  grep -i "trsm_step\|potrf_step\|gram_kernel\|potrf_panel" $OUT/pmc_summary.txt | head -24 >> $OUT/summary.txt ;;
+fit)
+  python tools/diag_timeline.py > $OUT/diag_timeline.txt 2>&1
+  timeout 600 bash tools/gpu_fit_trace.sh $TAG > $OUT/fit_trace.log 2>&1
+  cat $OUT/diag_timeline.txt >> $OUT/summary.txt; tail -3 $OUT/fit_trace.txt >> $OUT/summary.txt 2>/dev/null ;;
+small)
+  timeout 300 python tools/small_m_timing.py > $OUT/small_m.txt 2>&1; cat $OUT/small_m.txt >> $OUT/summary.txt ;;
+*) echo "unknown step $what" >> $OUT/summary.txt ;;
+esac; done
+cat $OUT/summary.txt
