@@ -26,6 +26,7 @@ FLAG_ZERO_SIGMA, FLAG_NEGATIVE_EI, FLAG_NAN = 1, 2, 4
 SYMBOLS = [
     "robo_device_count", "robo_ctx_create", "robo_ctx_destroy", "robo_ctx_synchronize",
     "robo_ctx_device_name", "robo_ctx_event_record", "robo_ctx_event_elapsed_ms", "robo_ctx_set_phase_events",
+    "robo_ctx_set_tuning",
     "robo_last_error_string", "robo_version_string",
     "robo_gp_create", "robo_gp_destroy", "robo_gp_set_data", "robo_gp_set_output_transform",
     "robo_gp_set_precision", "robo_theta_size",
@@ -105,6 +106,7 @@ def lib():
         "robo_ctx_event_record": [vp, i32],
         "robo_ctx_event_elapsed_ms": [vp, i32, i32, C.POINTER(C.c_float)],
         "robo_ctx_set_phase_events": [vp, i32],
+        "robo_ctx_set_tuning": [vp, C.c_char_p, i64],
         "robo_gp_create": [vp, i32, i32, i32, pp],
         "robo_gp_destroy": [vp],
         "robo_gp_set_data": [vp, _dp, _dp, i32],
@@ -245,6 +247,12 @@ class Context(object):
     def set_phase_events(self, on):
         """record event slots 19..23 around the phases of robo_gp_fit (off by default)"""
         check(lib().robo_ctx_set_phase_events(self._h, 1 if on else 0))
+
+    def set_tuning(self, key, value=None):
+        """kernel-variant / workspace knobs of this context (include/robo_hip.h); value None restores the default,
+        key "env" re-reads the ROBO_* environment variables"""
+        v = -(2 ** 63) if value is None else int(value)
+        check(lib().robo_ctx_set_tuning(self._h, key.encode(), v))
 
     def selftest_mfma_layout(self):
         e = C.c_double(0)

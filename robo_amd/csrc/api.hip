@@ -1,6 +1,7 @@
 // C ABI of librobo_hip.so (see include/robo_hip.h for the contract and the reference call
 // sites each entry point replaces).  Host-side orchestration only: every number is
 // produced by the kernels in gram.hip / potrf.hip / predict.hip / acq.hip.
+#include <cctype>
 #include <cmath>
 #include <cstdarg>
 #include <cstdlib>
@@ -20,20 +21,46 @@ void set_error(const char* fmt, ...) {
     va_end(ap);
 }
 
-static size_t workspace_bytes() {
-    const char* e = getenv("ROBO_WS_BYTES");
-    if (e && *e) {
-        const double v = atof(e);
-        if (v >= 1.0) return (size_t)v;   // callers round down to whole 128-candidate blocks, at least one
-    }
-    return (size_t)6 << 30;
+// ---- tuning knobs: environment -> context, once (robo_ctx_create); robo_ctx_set_tuning afterwards -------------------
+struct TuneKey {
+    const char* name;          // robo_ctx_set_tuning key; the environment variable is ROBO_<NAME in upper case>
+    long long Tuning::*ll;
+    int Tuning::*i;
+    long long dflt;
+};
+static const TuneKey TUNE_KEYS[] = {
+    {"ws_bytes", &Tuning::ws_bytes, nullptr, (long long)6 << 30},
+    {"trsm_small_max", &Tuning::trsm_small_max, nullptr, 16384},
+    {"trsm_small_narrow", nullptr, &Tuning::trsm_small_narrow, -1},
+    {"trsm_small_deep", nullptr, &Tuning::trsm_small_deep, -1},
+    {"trsm_rows", nullptr, &Tuning::trsm_rows, 1},
+    {"predict_stepwise", nullptr, &Tuning::predict_stepwise, 0},
+    {"winv_max", &Tuning::winv_max, nullptr, 16384},
+    {"winv_min_blocks", nullptr, &Tuning::winv_min_blocks, 4},
+    {"potrf_fused", nullptr, &Tuning::potrf_fused, 1},
+    {"potrf_tm4_min", nullptr, &Tuning::potrf_tm4_min, 96},
+    {"potrf_max_wg", nullptr, &Tuning::potrf_max_wg, 0},
+    {"potrf_group", nullptr, &Tuning::potrf_group, 4},
+};
+
+static void tune_set(Tuning* t, const TuneKey& k, long long v) {
+    if (k.ll) t->*(k.ll) = v;
+    else t->*(k.i) = (int)v;
 }
 
-// ROBO_PREDICT_STEPWISE=1 selects the step-wise (one launch per block row) posterior for A/B runs
-static bool stepwise_predict() {
-    const char* e = getenv("ROBO_PREDICT_STEPWISE");
-    return e && *e == '1';
+void tuning_from_env(Tuning* t) {
+    for (const TuneKey& k : TUNE_KEYS) {
+        char env[64] = "ROBO_";
+        size_t o = strlen(env);
+        for (const char* p = k.name; *p && o + 1 < sizeof(env); ++p) env[o++] = (char)toupper((unsigned char)*p);
+        env[o] = 0;
+        const char* e = getenv(env);
+        tune_set(t, k, (e && *e) ? (long long)atof(e) : k.dflt);
+    }
+    if (t->ws_bytes < 1) t->ws_bytes = (long long)6 << 30;   // callers round down to whole 128-candidate blocks
 }
+
+static size_t workspace_bytes(const robo_ctx* c) { return (size_t)c->tune.ws_bytes; }
 
 template <class T>
 static int dev_alloc(T** p, size_t count) {
@@ -81,6 +108,7 @@ int32_t robo_ctx_create(int32_t device, void* hip_stream, robo_ctx** out) {
         const char* e = getenv("ROBO_PHASE_EVENTS");
         c->phase_events = e && atoi(e) != 0;
     }
+    tuning_from_env(&c->tune);   // the only place the tuning variables are read
     hipDeviceProp_t prop;
     ROBO_HIP_CHECK(hipGetDeviceProperties(&prop, device));
     snprintf(c->name, sizeof(c->name), "%s (%s)", prop.name, prop.gcnArchName);
@@ -128,6 +156,22 @@ int32_t robo_ctx_set_phase_events(robo_ctx* c, int32_t on) {
     return ROBO_OK;
 }
 
+int32_t robo_ctx_set_tuning(robo_ctx* c, const char* key, int64_t value) {
+    if (!c || !key) return ROBO_BAD_ARGUMENT;
+    if (strcmp(key, "env") == 0) {          // re-read every ROBO_<NAME> variable
+        tuning_from_env(&c->tune);
+        return ROBO_OK;
+    }
+    for (const TuneKey& k : TUNE_KEYS)
+        if (strcmp(key, k.name) == 0) {
+            tune_set(&c->tune, k, value == INT64_MIN ? k.dflt : (long long)value);
+            if (c->tune.ws_bytes < 1) c->tune.ws_bytes = (long long)6 << 30;
+            return ROBO_OK;
+        }
+    set_error("robo_ctx_set_tuning: unknown key '%s'", key);
+    return ROBO_BAD_ARGUMENT;
+}
+
 int32_t robo_ctx_event_elapsed_ms(robo_ctx* c, int32_t a, int32_t b, float* out_ms) {
     if (a < 0 || a >= 32 || b < 0 || b >= 32 || !out_ms) return ROBO_BAD_ARGUMENT;
     ROBO_HIP_CHECK(hipEventSynchronize(c->events[b]));
@@ -167,7 +211,7 @@ int32_t robo_gp_create(robo_ctx* ctx, int32_t kind, int32_t n_max, int32_t dim, 
     // the strictly upper 16x16 sub-blocks of every inverted diagonal block are zero and never written
     ROBO_HIP_CHECK(hipMemset(g->d_Linv, 0, np * NB * sizeof(double)));
     ROBO_TRY(dev_alloc(&g->d_LinvP, (np / NB) * WP_BLOCK));
-    ROBO_TRY(dev_alloc(&g->d_llpart, (np / NB) * 2));
+    ROBO_TRY(dev_alloc(&g->d_llpart, (np / NB) * 4));
     ROBO_TRY(dev_alloc(&g->d_theta, (size_t)dim + 8 + sizeof(FitSample) / sizeof(double)));
     g->d_sp = reinterpret_cast<FitSample*>(g->d_theta + dim + 8);
     *out = g;
@@ -188,6 +232,9 @@ int32_t robo_gp_destroy(robo_gp* g) {
     hipFree(g->d_llpart);
     hipFree(g->d_bllpart);
     hipFree(g->d_theta);
+    hipFree(g->d_Winv);
+    hipFree(g->d_wunits);
+    hipFree(g->d_wprefix);
     hipFree(g->d_gV);
     hipFree(g->d_gA);
     hipFree(g->d_galpha);
@@ -325,6 +372,8 @@ int32_t robo_gp_fit(robo_gp* g, const double* theta, double mean_c, double* out_
         return ROBO_NOT_POSITIVE_DEFINITE;
     }
     const double quad = hp[0], logdet = hp[1];
+    g->diag_min = hp[3];
+    g->diag_max = hp[4];
     g->loglik = -0.5 * (quad + logdet + (double)g->n * std::log(2.0 * M_PI));
     g->fitted = true;
     g->fit_gen = next_fit_gen();
@@ -339,9 +388,9 @@ int32_t robo_gp_grad_loglik(robo_gp* g, const double* theta, double mean_c, doub
     ROBO_TRY(robo_gp_fit(g, theta, mean_c, out_loglik, out_fail_col));
     robo_ctx* c = g->ctx;
     const int P = robo_theta_size(g->kind, g->dim);
-    if (!g->d_gV) {
+    if (!g->d_gV) ROBO_TRY(dev_alloc(&g->d_gV, (size_t)g->n_pad_max * g->n_pad_max));   // (shared with winv_ensure)
+    if (!g->d_gA) {
         const size_t np = (size_t)g->n_pad_max, t64 = (np + 63) / 64;
-        ROBO_TRY(dev_alloc(&g->d_gV, np * np));
         ROBO_TRY(dev_alloc(&g->d_gA, np * np));
         ROBO_TRY(dev_alloc(&g->d_galpha, np));
         ROBO_TRY(dev_alloc(&g->d_gpart, (size_t)P * (t64 * (t64 + 1) / 2)));
@@ -379,9 +428,9 @@ static int batch_ensure(robo_gp* g, int S) {
         g->d_bism = reinterpret_cast<double*>(g->d_bsp + S);
     }
     ROBO_TRY(dev_alloc(&g->d_bfail, (size_t)S));
-    ROBO_TRY(dev_alloc(&g->d_bllpart, (size_t)S * (np / NB) * 2));
-    // pinned staging: [S x FitSample | S x D ism] up, [S x 3 doubles] down (written by the device)
-    const size_t bytes = (size_t)S * (sizeof(FitSample) + D * sizeof(double) + 3 * sizeof(double)) + 64;
+    ROBO_TRY(dev_alloc(&g->d_bllpart, (size_t)S * (np / NB) * 4));
+    // pinned staging: [S x FitSample | S x D ism] up, [S x 5 doubles] down (written by the device)
+    const size_t bytes = (size_t)S * (sizeof(FitSample) + D * sizeof(double) + 5 * sizeof(double)) + 64;
     ROBO_HIP_CHECK(hipHostMalloc((void**)&g->h_bstage, bytes, 0));
     g->b_cap = S;
     g->b_npad = g->n_pad;
@@ -399,7 +448,7 @@ static int fit_batch_core(robo_gp* g, const double* thetas, int32_t S, double me
     ROBO_HIP_CHECK(hipSetDevice(c->device));
     // bound the workspace: sub-batches of at most `chunk` samples (S * n_pad^2 doubles each)
     size_t per = np * np * sizeof(double) + np * (NB + (size_t)D) * sizeof(double);
-    int chunk = (int)(workspace_bytes() / per);
+    int chunk = (int)(workspace_bytes(c) / per);
     if (chunk < 1) chunk = 1;
     if (chunk > S) chunk = S;
     ROBO_TRY(batch_ensure(g, chunk));
@@ -409,7 +458,7 @@ static int fit_batch_core(robo_gp* g, const double* thetas, int32_t S, double me
         const int cap = g->b_cap;                          // layout of the staging block and of its device twin
         FitSample* hsp = reinterpret_cast<FitSample*>(g->h_bstage);
         double* hism = reinterpret_cast<double*>(hsp + cap);
-        double* hout = hism + (size_t)cap * D;             // [ns][3]: z.z, log det, failure flag
+        double* hout = hism + (size_t)cap * D;             // [ns][5]: z.z, log det, failure flag, min / max L_ii
         std::vector<int> status(ns, ROBO_OK);
         for (int s = 0; s < ns; ++s) {
             const int st = theta_to_sample(g, thetas + (size_t)(s0 + s) * P, mean_c, hsp + s, hism + (size_t)s * D);
@@ -440,8 +489,8 @@ static int fit_batch_core(robo_gp* g, const double* thetas, int32_t S, double me
         for (int s = 0; s < ns; ++s) {
             double ll = -HUGE_VAL;
             if (status[s] == ROBO_OK) {
-                if (hout[3 * s + 2] != 0.0) status[s] = ROBO_NOT_POSITIVE_DEFINITE;
-                else ll = -0.5 * (hout[3 * s] + hout[3 * s + 1] + (double)g->n * std::log(2.0 * M_PI));
+                if (hout[5 * s + 2] != 0.0) status[s] = ROBO_NOT_POSITIVE_DEFINITE;
+                else ll = -0.5 * (hout[5 * s] + hout[5 * s + 1] + (double)g->n * std::log(2.0 * M_PI));
             }
             out_loglik[s0 + s] = ll;
             if (out_status) out_status[s0 + s] = status[s];
@@ -492,9 +541,13 @@ int32_t robo_gp_fit_batch(robo_gp* const* gps, int32_t S, const double* thetas, 
     const size_t np = (size_t)g0->n_pad;
     const int P = robo_theta_size(g0->kind, D);
     auto keep = [&](int s0, int ns, const int* status) -> int {
+        const double* hout = reinterpret_cast<const double*>(reinterpret_cast<const FitSample*>(g0->h_bstage) + g0->b_cap) +
+                             (size_t)g0->b_cap * D;      // the batch's [ns][5] result block (fit_batch_core)
         for (int s = 0; s < ns; ++s) {
             if (status[s] != ROBO_OK) continue;
             robo_gp* g = gps[s0 + s];
+            g->diag_min = hout[5 * s + 3];
+            g->diag_max = hout[5 * s + 4];
             if (g != g0) {   // every handle ends up self-contained: same training data as gps[0]
                 ROBO_HIP_CHECK(hipMemcpyAsync(g->d_X, g0->d_X, (size_t)n * D * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
                 ROBO_HIP_CHECK(hipMemcpyAsync(g->d_y, g0->d_y, (size_t)n * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
@@ -724,6 +777,9 @@ int32_t robo_cand_destroy(robo_cand* k) {
     hipFree(k->d_Q);
     hipFree(k->d_G);
     hipFree(k->d_igc);
+    hipFree(k->d_Ks);
+    hipFree(k->d_P);
+    hipFree(k->d_qpart);
     hipFree(k->d_part_val);
     hipFree(k->d_part_idx);
     hipFree(k->d_flags);
@@ -734,7 +790,7 @@ int32_t robo_cand_destroy(robo_cand* k) {
 // size the (chunk x n_pad) solve workspace for this GP; grows, never shrinks
 static int cand_ensure_workspace(robo_cand* k, int n_pad, bool single_chunk) {
     const size_t row = (size_t)n_pad * sizeof(double);
-    int64_t chunk = (int64_t)(workspace_bytes() / row) / NB * NB;
+    int64_t chunk = (int64_t)(workspace_bytes(k->ctx) / row) / NB * NB;
     if (chunk < NB) chunk = NB;
     if (chunk > k->m_pad || single_chunk) chunk = k->m_pad;
     const size_t need = (size_t)chunk * row;
@@ -752,8 +808,19 @@ static int cand_ensure_workspace(robo_cand* k, int n_pad, bool single_chunk) {
 
 // K4 + K5: fills cand->d_mean / d_var (asynchronous).  after_chunk(c0, cn), if given, runs while
 // the chunk's V = L^-1 K*^T is still in the workspace (cross-covariances for entropy search).
+// Small batches on a well-conditioned factor go through the explicit inverse W = L^-1 (winv.hip): one triangular
+// product instead of n / 128 dependent block-row launches.  The bound on max L_ii / min L_ii keeps W's forward error
+// (~eps cond(L)) three orders of magnitude inside the stated tolerances; beyond it the substitution stays.
+static bool use_winv(const robo_gp* g, const robo_cand* k) {
+    const Tuning& t = g->ctx->tune;
+    if (g->fp32_gram || t.predict_stepwise || t.winv_max <= 0) return false;
+    if (k->m_pad > t.winv_max || (g->n + NB - 1) / NB < t.winv_min_blocks) return false;
+    return g->diag_min > 0.0 && g->diag_max <= 1.0e4 * g->diag_min;
+}
+
+// need_v: the caller consumes V = L^-1 K_*^T itself (cross-covariances, full covariance), not only its reductions
 static int predict_core(robo_gp* g, robo_cand* k, bool single_chunk,
-                        const std::function<int(int64_t, int64_t)>& after_chunk = nullptr) {
+                        const std::function<int(int64_t, int64_t)>& after_chunk = nullptr, bool need_v = false) {
     if (!g || !k) return ROBO_BAD_ARGUMENT;
     if (!g->fitted) {
         set_error("Model has to be trained first!");
@@ -767,27 +834,35 @@ static int predict_core(robo_gp* g, robo_cand* k, bool single_chunk,
     ROBO_HIP_CHECK(hipSetDevice(g->ctx->device));
     k->solved_gen = 0;
     ROBO_TRY(cand_ensure_workspace(k, g->n_pad, single_chunk));
+    const bool winv = use_winv(g, k);
+    if (winv) ROBO_TRY(winv_ensure(g));
     ROBO_TRY(launch_scale_inputs(g->ctx, k->d_Xc, k->d_Xcs, g->d_theta, k->m, k->m_pad, g->dim));
     // event slots 24..27 bracket the phases of the LAST chunk (bench.py reads them after a sync):
     //   24 -> 25 cross-gram, 25 -> 26 triangular solve (the MFMA kernel), 26 -> 27 post
+    // (small batches are latency-bound and four event packets cost several microseconds: recorded for them only when
+    // the phase events are switched on, robo_ctx_set_phase_events)
     hipStream_t st = g->ctx->stream;
+    const bool ev = g->ctx->phase_events || k->m_pad > 16384;
     for (int64_t c0 = 0; c0 < k->m_pad; c0 += k->chunk) {
         const int64_t cn = k->m_pad - c0 < k->chunk ? k->m_pad - c0 : k->chunk;
-        ROBO_HIP_CHECK(hipEventRecord(g->ctx->events[24], st));
-        if (g->fp32_gram || stepwise_predict()) {
+        if (ev) ROBO_HIP_CHECK(hipEventRecord(g->ctx->events[24], st));
+        if (winv) {
+            if (ev) ROBO_HIP_CHECK(hipEventRecord(g->ctx->events[25], st));
+            ROBO_TRY(launch_predict_winv(g, k, c0, cn, need_v || (bool)after_chunk));
+        } else if (g->fp32_gram || g->ctx->tune.predict_stepwise) {
             // mixed precision (fp32 covariance entries) keeps the two-pass form
             ROBO_TRY(launch_cross_gram(g, k, c0, cn));
-            ROBO_HIP_CHECK(hipEventRecord(g->ctx->events[25], st));
+            if (ev) ROBO_HIP_CHECK(hipEventRecord(g->ctx->events[25], st));
             ROBO_TRY(launch_trsm(g, k, c0, cn));
         } else {
-            ROBO_HIP_CHECK(hipEventRecord(g->ctx->events[25], st));
+            if (ev) ROBO_HIP_CHECK(hipEventRecord(g->ctx->events[25], st));
             ROBO_TRY(launch_predict_fused(g, k, c0, cn));
         }
-        ROBO_HIP_CHECK(hipEventRecord(g->ctx->events[26], st));
+        if (ev) ROBO_HIP_CHECK(hipEventRecord(g->ctx->events[26], st));
         if (after_chunk) ROBO_TRY(after_chunk(c0, cn));
     }
     ROBO_TRY(launch_post(g, k, 0, k->m_pad));
-    ROBO_HIP_CHECK(hipEventRecord(g->ctx->events[27], st));
+    if (ev) ROBO_HIP_CHECK(hipEventRecord(g->ctx->events[27], st));
     return ROBO_OK;
 }
 
@@ -879,7 +954,7 @@ int32_t robo_gp_predict_grad(robo_gp* g, const double* Xc, int64_t m, double* ou
     ROBO_TRY(robo_cand_create(c, Xc, m, D, &kc));
     // candidates per pass: D + 1 workspace rows each, rows padded to the 128-row solve tile
     const size_t row_bytes = (size_t)g->n_pad * sizeof(double);
-    int64_t per = (int64_t)(workspace_bytes() / row_bytes / NB * NB) / E;
+    int64_t per = (int64_t)(workspace_bytes(c) / row_bytes / NB * NB) / E;
     if (per < 1) per = 1;
     if (per > m) per = m;
     const int64_t rows_pad = round_up64(per * E, NB);
@@ -932,7 +1007,7 @@ int32_t robo_gp_predict_cov(robo_gp* g, const double* Xc, int64_t m, double* out
     }
     robo_cand* k = nullptr;
     ROBO_TRY(robo_cand_create(g->ctx, Xc, m, g->dim, &k));
-    int st = predict_core(g, k, true);
+    int st = predict_core(g, k, true, nullptr, true);
     double* d_cov = nullptr;
     if (st == ROBO_OK && hipMalloc((void**)&d_cov, (size_t)m * m * sizeof(double)) != hipSuccess) {
         set_error("hipMalloc of the %lld x %lld covariance failed", (long long)m, (long long)m);
@@ -1136,7 +1211,7 @@ int32_t robo_gp_cross_cov(robo_gp* g, robo_cand* k, robo_cand* rep, double* out_
         set_error("cross-covariance reference set limited to 64 points (got %lld)", (long long)rep->m);
         return ROBO_BAD_SHAPE;
     }
-    ROBO_TRY(predict_core(g, rep, true));
+    ROBO_TRY(predict_core(g, rep, true, nullptr, true));
     ROBO_TRY(cand_ensure_workspace(k, g->n_pad, false));
     ROBO_TRY(ig_ensure(k, 16));
     ROBO_TRY(predict_core(g, k, false, [&](int64_t c0, int64_t cn) { return launch_cross_cov(g, k, rep, c0, cn, k->d_S); }));
@@ -1158,7 +1233,7 @@ int32_t robo_ig_eval_cand(robo_gp* g, robo_cand* k, robo_cand* rep, int32_t npts
     // V of the representer points: kept across calls while the factor and the points stay the same (the reference
     // does its representer-point work once per update(), information_gain.py:127-167, not per compute())
     if (!(rep->solved_gen != 0 && rep->solved_gp == g && rep->solved_gen == g->fit_gen)) {
-        ROBO_TRY(predict_core(g, rep, true));
+        ROBO_TRY(predict_core(g, rep, true, nullptr, true));
         rep->solved_gp = g;
         rep->solved_gen = g->fit_gen;
     }

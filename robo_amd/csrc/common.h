@@ -74,6 +74,24 @@ static inline int64_t round_up64(int64_t x, int64_t m) { return (x + m - 1) / m 
 }  // namespace robo
 
 // ---- handle layouts --------------------------------------------------------------------
+namespace robo {
+// Tuning knobs of a context: read ONCE from the environment when the context is created (ROBO_<NAME>), changed
+// afterwards only through robo_ctx_set_tuning -- nothing on the hot path calls getenv.  -1 = automatic.
+struct Tuning {
+    long long ws_bytes;          // solve workspace per candidate handle (default 6 GiB)
+    long long trsm_small_max;    // batches <= this use the 16/32-candidate block-row step
+    int trsm_small_narrow;       // -1 auto, 0 / 1 force 32 / 16 candidates per workgroup
+    int trsm_small_deep;         // -1 auto, 0 / 1 force 1 / 2 k-tiles per staging stage
+    int trsm_rows;               // block rows per launch of the 128-candidate step
+    int predict_stepwise;        // 1: cross-gram in memory + trsm_step_kernel (A/B)
+    long long winv_max;          // batches <= this (and >= winv_min_blocks block rows) go through W = L^-1 (0: never)
+    int winv_min_blocks;
+    int potrf_fused;             // 0: never fuse the next diagonal block into the trailing update
+    int potrf_tm4_min, potrf_max_wg, potrf_group;
+};
+void tuning_from_env(Tuning* t);
+}  // namespace robo
+
 struct robo_ctx {
     int device;
     hipStream_t stream;
@@ -82,6 +100,7 @@ struct robo_ctx {
     bool phase_events;   // record the internal phase events of robo_gp_fit (robo_ctx_set_phase_events, default off)
     char name[256];
     int num_cu;
+    robo::Tuning tune;
     // scratch shared by every call on this context
     double* d_scalars;   // [8]: quad, logdet, ...
     int* d_fail;         // first failing column + 1, or 0
@@ -127,6 +146,13 @@ struct robo_gp {
     double *d_llpart, *d_bllpart;   // log-likelihood partials of the tail kernel (own factor / batch workspace)
     // workspace of robo_gp_grad_loglik (lazy, sized for n_pad_max): W^T, A = alpha alpha^T - K^-1, ...
     double *d_gV, *d_gA, *d_galpha, *d_gpart, *d_gout;
+    // explicit inverse factor W = L^-1 for small candidate batches (winv.hip): lazy, rebuilt when the factor changes
+    double* d_Winv;                 // (n_pad_max, n_pad_max) row-major, lower block triangle valid
+    unsigned long long winv_gen;    // fit_gen the inverse was built for (0: none)
+    int* d_wunits;                  // unit table of the triangular product for winv_nbk block rows (int4 per unit)
+    int* d_wprefix;                 // first canonical unit of every block row (winv_nbk + 1 entries)
+    int winv_nbk, winv_units, winv_kc;
+    double diag_min, diag_max;      // extreme diagonal entries of L over the training rows (0, 0: unknown)
 };
 
 struct robo_cand {
@@ -156,6 +182,10 @@ struct robo_cand {
     double* d_mu_all;   // (s_cap, m_pad) per-sample means/variances for the GP-MCMC mixture (lazy)
     double* d_var_all;
     int s_cap;
+    // explicit-inverse path (winv.hip), lazy: cross-gram K_* (chunk x n_pad), per-unit product tiles, per-block-row
+    // partial sums of |v|^2 and v.z
+    double *d_Ks, *d_P, *d_qpart;
+    size_t ks_bytes, p_bytes, qpart_bytes;
     double* d_part_val; // per-block argmax partials
     long long* d_part_idx;
     unsigned* d_flags;
@@ -175,9 +205,9 @@ struct FitBuffers {
     const FitSample* sp;                 // [S]
     int* fail;                           // [S]
     double* out;                         // [S][2]: z.z, 2 sum log diag
-    double* ll_part;                     // [S][n_pad/128][2] per-block partial sums of the log-likelihood terms
+    double* ll_part;                     // [S][n_pad/128][4] per block: z.z and sum log L_ii shares, min / max L_ii
     double* LinvP;                       // packed inverse fragments of the GP's own factor, or nullptr (batch workspace)
-    double* host_out;                    // pinned host [S][3]: z.z, 2 sum log diag, failure flag -- or nullptr
+    double* host_out;                    // pinned host [S][5]: z.z, 2 sum log diag, failure flag, min / max L_ii -- or nullptr
     bool want_inverse;                   // false: log-likelihood only (no explicit inverse blocks, no fragments)
     int S;
 };
@@ -186,12 +216,16 @@ int launch_scale_inputs_theta(robo_ctx* ctx, const double* d_in, double* d_out, 
 int launch_gram(robo_gp* gp, const FitBuffers& fb);
 int launch_potrf(robo_gp* gp, const FitBuffers& fb);
 int launch_diag_timeline(robo_gp* gp, long long* d_stamps);
-int launch_cross_gram(robo_gp* gp, robo_cand* cand, int64_t c0, int64_t cn);
+int launch_cross_gram(robo_gp* gp, robo_cand* cand, int64_t c0, int64_t cn, double* d_out = nullptr);
+// posterior of a chunk through W = L^-1 (winv.hip): fills cand->d_q / d_mu (and d_V when store_v)
+int winv_ensure(robo_gp* gp);
+int launch_predict_winv(robo_gp* gp, robo_cand* cand, int64_t c0, int64_t cn, bool store_v);
 int launch_trsm(robo_gp* gp, robo_cand* cand, int64_t c0, int64_t cn);
 int launch_predict_fused(robo_gp* gp, robo_cand* cand, int64_t c0, int64_t cn);
 int launch_pack_linv(robo_gp* gp);
 int launch_grad_loglik(robo_gp* gp, double* d_V, double* d_A, double* d_alpha, double* d_part, double* d_out,
                        double* h_out);
+int launch_triinv(robo_gp* gp, double* d_W, double* d_V);   // W = L^-1 (and V = W^T) of the current factor
 int launch_post(robo_gp* gp, robo_cand* cand, int64_t c0, int64_t cn);
 int launch_cross_grad(robo_gp* gp, const double* d_Xcs, double* d_V, int64_t c_first, int64_t c_count, int64_t rows_pad);
 int launch_predgrad_post(robo_gp* gp, const double* d_V, const double* d_q, const double* d_mu, const double* d_Xcs,

@@ -307,17 +307,29 @@ __global__ __launch_bounds__(256) void grad_final_kernel(const double* __restric
 
 // d_V, d_A: (n_pad x n_pad) workspaces (d_A doubles as W during the inversion); d_alpha: n_pad;
 // d_part: P x tiles64; d_out: P.  Asynchronous on the context's stream.
-int launch_grad_loglik(robo_gp* gp, double* d_V, double* d_A, double* d_alpha, double* d_part, double* d_out,
-                       double* h_out) {
+// W = L^-1 (lower block triangle of d_W; its strictly upper blocks hold scratch) and V = W^T of the current factor
+int launch_triinv(robo_gp* gp, double* d_W, double* d_V) {
     hipStream_t st = gp->ctx->stream;
     const int n = gp->n, n_pad = gp->n_pad, nbk = (n + NB - 1) / NB;
-    double* d_W = d_A;   // dead before kinv_tile_kernel writes A
     hipLaunchKernelGGL(triinv_base_kernel, dim3(nbk), dim3(256), 0, st, (const double*)gp->d_Linv, n, d_W, d_V, n_pad);
     for (int sb = 1; sb < nbk; sb *= 2) {
         const dim3 grid((unsigned)(sb * sb), (unsigned)((nbk + 2 * sb - 1) / (2 * sb)));
         for (int phase = 0; phase < 2; ++phase)
             hipLaunchKernelGGL(triinv_kernel, grid, dim3(256), 0, st, phase, sb, nbk, n, (const double*)gp->d_K, d_W, d_V,
                                n_pad);
+    }
+    ROBO_LAUNCH_CHECK();
+    return ROBO_OK;
+}
+
+int launch_grad_loglik(robo_gp* gp, double* d_V, double* d_A, double* d_alpha, double* d_part, double* d_out,
+                       double* h_out) {
+    hipStream_t st = gp->ctx->stream;
+    const int n = gp->n, n_pad = gp->n_pad, nbk = (n + NB - 1) / NB;
+    double* d_W = d_A;   // dead before kinv_tile_kernel writes A
+    {
+        const int s = launch_triinv(gp, d_W, d_V);
+        if (s != ROBO_OK) return s;
     }
     hipLaunchKernelGGL(alpha_kernel, dim3((nbk * NB + 3) / 4), dim3(256), 0, st, (const double*)d_V, n_pad,
                        (const double*)(gp->d_K + (size_t)n * n_pad), n, nbk * NB, d_alpha);

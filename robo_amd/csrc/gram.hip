@@ -310,12 +310,13 @@ int launch_gram(robo_gp* gp, const FitBuffers& fb) {
     return ROBO_OK;
 }
 
-int launch_cross_gram(robo_gp* gp, robo_cand* cand, int64_t c0, int64_t cn) {
-    // cn is a multiple of NB (=2*GT)
+int launch_cross_gram(robo_gp* gp, robo_cand* cand, int64_t c0, int64_t cn, double* d_out) {
+    // cn is a multiple of NB (=2*GT); d_out: (cn x n_pad) destination, the solve workspace by default
     const dim3 grid(gp->n_pad / GT, (unsigned)(cn / GT));
+    if (!d_out) d_out = cand->d_V;
 #define ROBO_CROSS_CALL(TYPE, KIND)                                                                             \
     hipLaunchKernelGGL((cross_gram_kernel<TYPE, KIND>), grid, dim3(256), 0, gp->ctx->stream,                    \
-                       (const double*)cand->d_Xcs, (const double*)gp->d_Xs, cand->d_V, (long long)c0, gp->n,    \
+                       (const double*)cand->d_Xcs, (const double*)gp->d_Xs, d_out, (long long)c0, gp->n,        \
                        gp->n_pad, gp->cov)
     ROBO_DISPATCH_COV(gp->fp32_gram, gp->kind, ROBO_CROSS_CALL);
 #undef ROBO_CROSS_CALL

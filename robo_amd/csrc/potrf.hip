@@ -493,21 +493,27 @@ __global__ __launch_bounds__(256) void potrf_diag_kernel(double* __restrict__ K,
         // LDS, so (z.z, 2 sum log L_ii, failure flag) leave from here -- no write-back, no tail and finishing launches.
         // Same operations in the same order as potrf_inverse_kernel + loglik_finish_kernel on one block.
         __syncthreads();
-        double q = 0.0, lg = 0.0;
+        double q = 0.0, lg = 0.0, dmin = __builtin_huge_val(), dmax = 0.0;
         if (tid < NB && tid < n_real) {
             const double zi = m.sL[blk_off(n_real >> 4, tid >> 4) + bidx(n_real & 15, tid & 15)];
             q = zi * zi;
-            lg = log(m.sL[blk_off(tid >> 4, tid >> 4) + bidx(tid & 15, tid & 15)]);
+            const double d = m.sL[blk_off(tid >> 4, tid >> 4) + bidx(tid & 15, tid & 15)];
+            lg = log(d);
+            dmin = dmax = d;
         }
         for (int o = 32; o > 0; o >>= 1) {
             q += __shfl_xor(q, o);
             lg += __shfl_xor(lg, o);
+            dmin = fmin(dmin, __shfl_xor(dmin, o));
+            dmax = fmax(dmax, __shfl_xor(dmax, o));
         }
         __syncthreads();
         double* red = m.sW;
         if ((tid & 63) == 0 && tid < NB) {
             red[tid >> 6] = q;
             red[2 + (tid >> 6)] = lg;
+            red[4 + (tid >> 6)] = dmin;
+            red[6 + (tid >> 6)] = dmax;
         }
         __syncthreads();
         if (tid == 0) {
@@ -517,9 +523,11 @@ __global__ __launch_bounds__(256) void potrf_diag_kernel(double* __restrict__ K,
             ll_out[2 * smp] = sq;
             ll_out[2 * smp + 1] = 2.0 * sl;
             if (ll_host) {
-                ll_host[3 * smp] = sq;
-                ll_host[3 * smp + 1] = 2.0 * sl;
-                ll_host[3 * smp + 2] = (double)*fail;
+                ll_host[5 * smp] = sq;
+                ll_host[5 * smp + 1] = 2.0 * sl;
+                ll_host[5 * smp + 2] = (double)*fail;
+                ll_host[5 * smp + 3] = fmin(red[4], red[5]);
+                ll_host[5 * smp + 4] = fmax(red[6], red[7]);
             }
         }
         return;
@@ -648,26 +656,34 @@ __global__ __launch_bounds__(256) void potrf_inverse_kernel(const double* __rest
         // BO-typical N < 128 the inverse was 20 of the 47 us of a batched pass
         const double* Ks = K + (size_t)blockIdx.y * k_stride;
         const int kb = blockIdx.x, t = threadIdx.x, r = kb * NB + t;
-        double q = 0.0, lg = 0.0;
+        double q = 0.0, lg = 0.0, dmin = __builtin_huge_val(), dmax = 0.0;
         if (t < NB && r < n_real) {
             const double zi = Ks[(size_t)n_real * ld + r];
             q = zi * zi;
-            lg = log(Ks[(size_t)r * ld + r]);
+            const double d = Ks[(size_t)r * ld + r];
+            lg = log(d);
+            dmin = dmax = d;
         }
         for (int o = 32; o > 0; o >>= 1) {
             q += __shfl_xor(q, o);
             lg += __shfl_xor(lg, o);
+            dmin = fmin(dmin, __shfl_xor(dmin, o));
+            dmax = fmax(dmax, __shfl_xor(dmax, o));
         }
         double* red = smem;
         if ((t & 63) == 0 && t < NB) {
             red[t >> 6] = q;
             red[2 + (t >> 6)] = lg;
+            red[4 + (t >> 6)] = dmin;
+            red[6 + (t >> 6)] = dmax;
         }
         __syncthreads();
         if (t == 0) {
-            double* part = ll_part + ((size_t)blockIdx.y * gridDim.x + kb) * 2;
+            double* part = ll_part + ((size_t)blockIdx.y * gridDim.x + kb) * 4;
             part[0] = red[0] + red[1];
             part[1] = red[2] + red[3];
+            part[2] = fmin(red[4], red[5]);
+            part[3] = fmax(red[6], red[7]);
         }
         return;
     }
@@ -744,34 +760,43 @@ __global__ __launch_bounds__(256) void potrf_inverse_kernel(const double* __rest
     }
     // ---- log-likelihood terms of rows 128 k .. 128 k + 127 (rows >= n_real: augmented row / padding, no share)
     {
-        double q = 0.0, lg = 0.0;
+        double q = 0.0, lg = 0.0, dmin = __builtin_huge_val(), dmax = 0.0;
         const int r = k * NB + tid;
         if (tid < NB && r < n_real) {
             const double zi = K[(size_t)n_real * ld + r];
             q = zi * zi;
-            lg = log(sL[blk_off(tid >> 4, tid >> 4) + bidx(tid & 15, tid & 15)]);
+            const double d = sL[blk_off(tid >> 4, tid >> 4) + bidx(tid & 15, tid & 15)];
+            lg = log(d);
+            dmin = dmax = d;
         }
         for (int o = 32; o > 0; o >>= 1) {
             q += __shfl_xor(q, o);
             lg += __shfl_xor(lg, o);
+            dmin = fmin(dmin, __shfl_xor(dmin, o));
+            dmax = fmax(dmax, __shfl_xor(dmax, o));
         }
         __syncthreads();            // sW / the counters are dead: reuse the scratch
         double* red = smem + 2 * NBLK * BLK;
         if (lane == 0 && wave < 2) {
             red[wave] = q;
             red[2 + wave] = lg;
+            red[4 + wave] = dmin;
+            red[6 + wave] = dmax;
         }
         __syncthreads();
         if (tid == 0) {
-            double* part = ll_part + ((size_t)blockIdx.y * gridDim.x + k) * 2;
+            double* part = ll_part + ((size_t)blockIdx.y * gridDim.x + k) * 4;
             part[0] = red[0] + red[1];
             part[1] = red[2] + red[3];
+            part[2] = fmin(red[4], red[5]);
+            part[3] = fmax(red[6], red[7]);
         }
     }
 }
 
 // (z.z, 2 sum log L_ii) of every sample from the per-block partials, added in block order (a fixed summation order);
-// with host_out (pinned, device-visible; [S][3]) the result and the failure flag go straight to the host.
+// with host_out (pinned, device-visible; [S][5]) the result, the failure flag and the extreme diagonal entries go
+// straight to the host.
 // A launch of its own: handing the partials over INSIDE the tail kernel (agent-scope release + arrival counter) was
 // measured at +16 us -- the release writes back an L2 full of the factorisation's dirty lines (r02z).
 __global__ __launch_bounds__(64) void loglik_finish_kernel(const double* __restrict__ ll_part, int nbk,
@@ -779,18 +804,22 @@ __global__ __launch_bounds__(64) void loglik_finish_kernel(const double* __restr
                                                            double* __restrict__ host_out) {
     const int smp = blockIdx.x;
     if (threadIdx.x != 0) return;
-    const double* part = ll_part + (size_t)smp * nbk * 2;
-    double sq = 0.0, sl = 0.0;
+    const double* part = ll_part + (size_t)smp * nbk * 4;
+    double sq = 0.0, sl = 0.0, dmin = __builtin_huge_val(), dmax = 0.0;
     for (int b = 0; b < nbk; ++b) {
-        sq += part[2 * b];
-        sl += part[2 * b + 1];
+        sq += part[4 * b];
+        sl += part[4 * b + 1];
+        dmin = fmin(dmin, part[4 * b + 2]);
+        dmax = fmax(dmax, part[4 * b + 3]);
     }
     out[2 * smp] = sq;
     out[2 * smp + 1] = 2.0 * sl;
     if (host_out) {
-        host_out[3 * smp] = sq;
-        host_out[3 * smp + 1] = 2.0 * sl;
-        host_out[3 * smp + 2] = (double)fail[smp];
+        host_out[5 * smp] = sq;
+        host_out[5 * smp + 1] = 2.0 * sl;
+        host_out[5 * smp + 2] = (double)fail[smp];
+        host_out[5 * smp + 3] = dmin;      // extreme diagonal entries of L over the training rows (conditioning
+        host_out[5 * smp + 4] = dmax;      // estimate for the explicit-inverse posterior, api.hip use_winv)
     }
 }
 
@@ -1082,8 +1111,8 @@ int launch_potrf(robo_gp* gp, const FitBuffers& fb) {
     robo_ctx* ctx = gp->ctx;
     const int ld = gp->n_pad, nb = gp->n_pad / NB, S = fb.S;
     // fb.fail[0 .. S) was zeroed by the gram kernel (launch_gram always precedes this)
-    static const bool allow_fused = [] { const char* e = getenv("ROBO_POTRF_FUSED"); return !e || atoi(e) != 0; }();
-    const bool fused = S <= 2 && allow_fused;
+    const Tuning& tune = ctx->tune;
+    const bool fused = S <= 2 && tune.potrf_fused != 0;
 #define ROBO_DIAG(KK)                                                                                          \
     hipLaunchKernelGGL(potrf_diag_kernel, dim3(S), dim3(256), 0, ctx->stream, fb.K, fb.k_stride, ld, (KK), gp->n, \
                        fb.Linv, fb.linv_stride, fb.fail, (long long*)nullptr, (double*)nullptr, (double*)nullptr)
@@ -1108,9 +1137,7 @@ int launch_potrf(robo_gp* gp, const FitBuffers& fb) {
         return ROBO_OK;
     }
     // test knobs (tests/: the emulator reaches the persistent multi-tile path at small N through them)
-    const char* e_tm4 = getenv("ROBO_POTRF_TM4_MIN");
-    const char* e_wg = getenv("ROBO_POTRF_MAX_WG");
-    const int tm4_min = e_tm4 ? atoi(e_tm4) : 96, wg_cap = e_wg ? atoi(e_wg) : 0;
+    const int tm4_min = tune.potrf_tm4_min, wg_cap = tune.potrf_max_wg;
     const int max_wg = wg_cap >= 2 ? wg_cap : ctx->num_cu;
     if (fused) {
         // single theta: trailing update of step k + diagonal block k+1 (workgroup 0) in one launch
@@ -1130,11 +1157,8 @@ int launch_potrf(robo_gp* gp, const FitBuffers& fb) {
         // factored (left-looking, one update of growing depth), and the rest of the trailing matrix
         // receives all G panels in ONE (128 G)-deep update -- 1/G of the C traffic.  Bitwise the same
         // factor: every element still accumulates its products in ascending k on top of the stored value.
-        static const int G = [] {
-            const char* e = getenv("ROBO_POTRF_GROUP");
-            const int g = e ? atoi(e) : 4;   // measured, 27 thetas at N = 4096 (ms per theta): G=1 0.668, 2 0.596, 4 0.574, 6 0.566
-            return g < 1 ? 1 : (g > 8 ? 8 : g);
-        }();
+        // measured, 27 thetas at N = 4096 (ms per theta): G=1 0.668, 2 0.596, 4 0.574, 6 0.566
+        const int G = tune.potrf_group < 1 ? 1 : (tune.potrf_group > 8 ? 8 : tune.potrf_group);
         for (int k0 = 0; k0 < nb; k0 += G) {
             const int g = nb - k0 < G ? nb - k0 : G;          // panels in this group
             for (int kk = k0; kk < k0 + g; ++kk) {

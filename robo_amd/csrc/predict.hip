@@ -581,17 +581,14 @@ int launch_trsm(robo_gp* gp, robo_cand* cand, int64_t c0, int64_t cn) {
 int launch_predict_fused(robo_gp* gp, robo_cand* cand, int64_t c0, int64_t cn) {
     const int nbk = (gp->n + NB - 1) / NB;
     const dim3 grid((unsigned)(cn / NB));
+    const Tuning& tune = gp->ctx->tune;
     {   // batches that leave most CUs without a 128-candidate workgroup: 32 candidates per workgroup
-        const char* e = getenv("ROBO_TRSM_SMALL_MAX");
-        const int64_t small_max = e ? atoll(e) : 16384;
-        if (cn <= small_max) {
+        if (cn <= tune.trsm_small_max) {
             // 16 candidates per workgroup while that is at most one workgroup per CU, 32 beyond; two k-tiles per
-            // staging stage (83-92 KB of LDS) while one workgroup per CU covers the batch
-            const char* e_narrow = getenv("ROBO_TRSM_SMALL_NARROW");   // test knob: 0 / 1 force the width
+            // staging stage (83-92 KB of LDS) while one workgroup per CU covers the batch (the knobs force either)
             const int64_t ncu = gp->ctx->num_cu;
-            const bool narrow = e_narrow ? atoi(e_narrow) != 0 : cn / 16 <= ncu;
-            const char* e_deep = getenv("ROBO_TRSM_SMALL_DEEP");       // test knob: 0 / 1 force the stage depth
-            const bool deep = e_deep ? atoi(e_deep) != 0 : cn / (narrow ? 16 : 32) <= ncu;
+            const bool narrow = tune.trsm_small_narrow >= 0 ? tune.trsm_small_narrow != 0 : cn / 16 <= ncu;
+            const bool deep = tune.trsm_small_deep >= 0 ? tune.trsm_small_deep != 0 : cn / (narrow ? 16 : 32) <= ncu;
             const dim3 sgrid((unsigned)(cn / (narrow ? 16 : 32)));
             cand->solve_kernel = "trsm_step_small_kernel";
 #define ROBO_SMALL_LAUNCH(KIND, MB, DK)                                                                        \
@@ -623,11 +620,7 @@ int launch_predict_fused(robo_gp* gp, robo_cand* cand, int64_t c0, int64_t cn) {
                        (const double*)gp->d_K, gp->n_pad, (const double*)gp->d_LinvP, i,                      \
                        (i + rows < nbk ? i + rows : nbk), gp->n, cand->d_q, cand->d_mu, (long long)c0, gp->cov)
     cand->solve_kernel = "trsm_step_gen_kernel";
-    static const int rows = [] {
-        const char* e = getenv("ROBO_TRSM_ROWS");
-        const int r = e ? atoi(e) : 1;
-        return r < 1 ? 1 : r;
-    }();
+    const int rows = tune.trsm_rows < 1 ? 1 : tune.trsm_rows;
     for (int i = 0; i < nbk; i += rows) {
         if (gp->kind == ROBO_KERNEL_MATERN52_ARD) ROBO_STEP_CALL(ROBO_KERNEL_MATERN52_ARD);
         else if (gp->kind == ROBO_KERNEL_RBF_ARD) ROBO_STEP_CALL(ROBO_KERNEL_RBF_ARD);

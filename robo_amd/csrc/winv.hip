@@ -1,0 +1,188 @@
+// Posterior of SMALL candidate batches through the explicit inverse factor W = L^-1.
+//
+// Replaces, for batches of at most a few thousand candidates, the same reference lines as predict.hip
+// (george.GP.predict's  Kxs K^-1 Kxs^T  and  Kxs alpha,  robo/models/gaussian_process.py:280-286) -- what
+// robo/maximizers/random_sampling.py:9,42 actually asks for is 500 candidates per call, the single-point maximisers
+// ask for one, entropy search for 50 representer points.
+//
+// The block-row solve of predict.hip is a chain of n/128 dependent launches however few candidates there are
+// (2.5 ms at N = 4096 for 1 .. 2048 candidates): forward substitution orders the block rows.  With W = L^-1
+// (triinv_kernel of gradient.hip, once per factor, lazily) there is no order:
+//       V = K_* W^T,     V[c][j] = sum_{k <= j} K_*[c][k] W[j][k],     q_c = |V_c|^2,  mu_c = V_c . z
+// is ONE lower-triangular product.  Work units are (128 candidates) x (128 columns j) x (a chunk of KC 128-blocks of
+// the contraction index k): the triangle makes block row j cost (j + 1) block products, so without the split over k
+// a 500-candidate batch would be bound by the last block row of each candidate tile (32 products on one workgroup);
+// with it the batch is ~320 units of at most 8 products, launched heaviest first.
+//   winv_gemm_kernel     one unit: 128 x 128 x (128 KC) fp64 MFMA product (gemm_f64.h) -> its own tile of P
+//   winv_reduce_kernel   per (candidate tile, block row): the unit tiles added IN CHUNK ORDER -> V tile (stored only
+//                        for callers that consume V: entropy search, full covariance), |v|^2 and v.z of its 128 columns
+//   winv_finish_kernel   per candidate: the block rows' partial sums added in block-row order -> q, mu
+// The association of every V entry is therefore fixed by (n_pad, KC) alone: values do not depend on the batch size, the
+// workspace chunking or the launch order (bit-identical across them; they differ from the block-row solve's by
+// rounding, ~1e-13 relative -- same tolerances against the oracle).
+//
+// Numerics: W carries a forward error of ~eps cond(L) (the block-row solve: eps cond of a 128-block), so the caller
+// (api.hip) takes this path only while max L_ii / min L_ii stays below a bound and keeps the substitution otherwise.
+#include <algorithm>
+#include <vector>
+
+#include "common.h"
+#include "gemm_f64.h"
+
+namespace robo {
+
+__global__ __launch_bounds__(256, 2) void winv_gemm_kernel(const double* __restrict__ Ks, int ldk,
+                                                           const double* __restrict__ W, int ldw,
+                                                           const int4* __restrict__ units, int n_units,
+                                                           double* __restrict__ P) {
+    __shared__ double smem[GEMM_SMEM_DOUBLES];
+    const int ct = blockIdx.x;
+    const int4 u = units[blockIdx.y];            // (block row j, first k-block, end k-block, canonical unit id)
+    Acc acc;
+    acc_zero(acc);
+    gemm_nt_128<false>(Ks + (size_t)ct * NB * ldk, ldk, W + (size_t)u.x * NB * ldw, ldw, u.y * NB, u.z * NB, acc, smem);
+    double* out = P + ((size_t)ct * n_units + u.w) * (NB * NB);
+#pragma unroll
+    for (int tm = 0; tm < 4; ++tm)
+#pragma unroll
+        for (int tn = 0; tn < 4; ++tn)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) out[acc_row(tm, r) * NB + acc_col(tn)] = acc.t[tm][tn][r];
+}
+
+// tile (candidate tile ct, block row j): wave w owns rows w, w + 4, ..; lane l the columns 2 l, 2 l + 1
+template <bool STORE_V>
+__global__ __launch_bounds__(256) void winv_reduce_kernel(const double* __restrict__ P, const int* __restrict__ prefix,
+                                                          int n_units, const double* __restrict__ z, int n,
+                                                          double* __restrict__ V, int ldv, double* __restrict__ qpart,
+                                                          double* __restrict__ mupart, long long rows) {
+    const int j = blockIdx.x, ct = blockIdx.y;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int u0 = prefix[j], nch = prefix[j + 1] - u0;
+    const double* base = P + ((size_t)ct * n_units + u0) * (NB * NB) + 2 * lane;
+    const int col = j * NB + 2 * lane;
+    const bool ok0 = col < n, ok1 = col + 1 < n;
+    const double z0 = ok0 ? z[col] : 0.0, z1 = ok1 ? z[col + 1] : 0.0;
+    for (int i = 0; i < NB / 4; ++i) {
+        const int row = wave + 4 * i;
+        double2 s = *reinterpret_cast<const double2*>(base + row * NB);
+        for (int ch = 1; ch < nch; ++ch) {
+            const double2 t = *reinterpret_cast<const double2*>(base + (size_t)ch * (NB * NB) + row * NB);
+            s.x += t.x;
+            s.y += t.y;
+        }
+        s.x = ok0 ? s.x : 0.0;
+        s.y = ok1 ? s.y : 0.0;
+        const long long c = (long long)ct * NB + row;
+        if (STORE_V) *reinterpret_cast<double2*>(V + (size_t)c * ldv + col) = s;
+        double q = fma(s.y, s.y, s.x * s.x), m = fma(s.y, z1, s.x * z0);
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            q += __shfl_xor(q, o);
+            m += __shfl_xor(m, o);
+        }
+        if (lane == 0) {
+            qpart[(size_t)j * rows + c] = q;
+            mupart[(size_t)j * rows + c] = m;
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void winv_finish_kernel(const double* __restrict__ qpart,
+                                                          const double* __restrict__ mupart, int nbk, long long rows,
+                                                          double* __restrict__ q, double* __restrict__ mu) {
+    const long long c = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= rows) return;
+    double a = 0.0, b = 0.0;
+    for (int j = 0; j < nbk; ++j) {
+        a += qpart[(size_t)j * rows + c];
+        b += mupart[(size_t)j * rows + c];
+    }
+    q[c] = a;
+    mu[c] = b;
+}
+
+// contraction blocks per unit: fixed by the number of block rows of the factor (and by nothing else)
+static int winv_kc(int nbk) { return nbk >= 16 ? 8 : (nbk >= 8 ? 4 : 2); }
+
+// W of the current factor + the unit table for its number of block rows
+int winv_ensure(robo_gp* gp) {
+    hipStream_t st = gp->ctx->stream;
+    const size_t np = (size_t)gp->n_pad_max;
+    if (!gp->d_Winv) {
+        ROBO_HIP_CHECK(hipMalloc((void**)&gp->d_Winv, np * np * sizeof(double)));
+        gp->winv_gen = 0;
+    }
+    if (!gp->d_gV) ROBO_HIP_CHECK(hipMalloc((void**)&gp->d_gV, np * np * sizeof(double)));   // W^T, scratch of the build
+    const int nbk = (gp->n + NB - 1) / NB;
+    if (gp->winv_nbk != nbk) {
+        const int kc = winv_kc(nbk);
+        std::vector<int> prefix(nbk + 1, 0);
+        std::vector<int4> units;
+        for (int j = 0; j < nbk; ++j) {
+            prefix[j] = (int)units.size();
+            for (int k0 = 0; k0 <= j; k0 += kc) units.push_back(make_int4(j, k0, std::min(k0 + kc, j + 1), (int)units.size()));
+        }
+        prefix[nbk] = (int)units.size();
+        // launch order: heaviest first (stable: ties keep the canonical order)
+        std::stable_sort(units.begin(), units.end(), [](const int4& a, const int4& b) { return a.z - a.y > b.z - b.y; });
+        if (gp->d_wunits) ROBO_HIP_CHECK(hipFree(gp->d_wunits));
+        if (gp->d_wprefix) ROBO_HIP_CHECK(hipFree(gp->d_wprefix));
+        gp->d_wunits = gp->d_wprefix = nullptr;
+        gp->winv_nbk = 0;
+        ROBO_HIP_CHECK(hipMalloc((void**)&gp->d_wunits, units.size() * sizeof(int4)));
+        ROBO_HIP_CHECK(hipMalloc((void**)&gp->d_wprefix, prefix.size() * sizeof(int)));
+        ROBO_HIP_CHECK(hipMemcpyAsync(gp->d_wunits, units.data(), units.size() * sizeof(int4), hipMemcpyHostToDevice, st));
+        ROBO_HIP_CHECK(hipMemcpyAsync(gp->d_wprefix, prefix.data(), prefix.size() * sizeof(int), hipMemcpyHostToDevice, st));
+        ROBO_HIP_CHECK(hipStreamSynchronize(st));   // the staging vectors die with this scope
+        gp->winv_nbk = nbk;
+        gp->winv_units = (int)units.size();
+        gp->winv_kc = kc;
+    }
+    if (gp->winv_gen != gp->fit_gen) {
+        const int s = launch_triinv(gp, gp->d_Winv, gp->d_gV);
+        if (s != ROBO_OK) return s;
+        gp->winv_gen = gp->fit_gen;
+    }
+    return ROBO_OK;
+}
+
+static int grow(double** p, size_t* have, size_t need) {
+    if (*have >= need) return ROBO_OK;
+    if (*p) ROBO_HIP_CHECK(hipFree(*p));
+    *p = nullptr;
+    *have = 0;
+    ROBO_HIP_CHECK(hipMalloc((void**)p, need));
+    *have = need;
+    return ROBO_OK;
+}
+
+int launch_predict_winv(robo_gp* gp, robo_cand* cand, int64_t c0, int64_t cn, bool store_v) {
+    hipStream_t st = gp->ctx->stream;
+    const int n_pad = gp->n_pad, nbk = gp->winv_nbk, nu = gp->winv_units;
+    const unsigned cts = (unsigned)(cn / NB);
+    int s = grow(&cand->d_Ks, &cand->ks_bytes, (size_t)cn * n_pad * sizeof(double));
+    if (s == ROBO_OK) s = grow(&cand->d_P, &cand->p_bytes, (size_t)cts * nu * NB * NB * sizeof(double));
+    if (s == ROBO_OK) s = grow(&cand->d_qpart, &cand->qpart_bytes, (size_t)2 * nbk * cn * sizeof(double));
+    if (s != ROBO_OK) return s;
+    double* qpart = cand->d_qpart;
+    double* mupart = cand->d_qpart + (size_t)nbk * cn;
+    s = launch_cross_gram(gp, cand, c0, cn, cand->d_Ks);
+    if (s != ROBO_OK) return s;
+    cand->solve_kernel = "winv_gemm_kernel";
+    hipLaunchKernelGGL(winv_gemm_kernel, dim3(cts, (unsigned)nu), dim3(256), 0, st, (const double*)cand->d_Ks, n_pad,
+                       (const double*)gp->d_Winv, n_pad, (const int4*)gp->d_wunits, nu, cand->d_P);
+    const double* z = gp->d_K + (size_t)gp->n * n_pad;
+    if (store_v)
+        hipLaunchKernelGGL(winv_reduce_kernel<true>, dim3((unsigned)nbk, cts), dim3(256), 0, st, (const double*)cand->d_P,
+                           (const int*)gp->d_wprefix, nu, z, gp->n, cand->d_V, n_pad, qpart, mupart, (long long)cn);
+    else
+        hipLaunchKernelGGL(winv_reduce_kernel<false>, dim3((unsigned)nbk, cts), dim3(256), 0, st, (const double*)cand->d_P,
+                           (const int*)gp->d_wprefix, nu, z, gp->n, cand->d_V, n_pad, qpart, mupart, (long long)cn);
+    hipLaunchKernelGGL(winv_finish_kernel, dim3((unsigned)((cn + 255) / 256)), dim3(256), 0, st, (const double*)qpart,
+                       (const double*)mupart, nbk, (long long)cn, cand->d_q + c0, cand->d_mu + c0);
+    ROBO_LAUNCH_CHECK();
+    return ROBO_OK;
+}
+
+}  // namespace robo

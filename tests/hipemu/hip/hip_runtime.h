@@ -52,6 +52,8 @@ typedef double v4d_emu __attribute__((vector_size(32)));
 
 struct alignas(16) double2 { double x, y; };
 static inline double2 make_double2(double x, double y) { double2 r; r.x = x; r.y = y; return r; }
+struct alignas(16) int4 { int x, y, z, w; };
+static inline int4 make_int4(int x, int y, int z, int w) { int4 r; r.x = x; r.y = y; r.z = z; r.w = w; return r; }
 
 namespace hipemu {
 struct Lane {

@@ -771,22 +771,24 @@ def check_small_and_large_tiles_agree(ctx, monkeypatch, cases=(("matern52", 300,
         g.set_data(X, y)
         g.fit(theta, float(y.mean()))
         Xc = rs.rand(M, D)
-        monkeypatch.setenv("ROBO_TRSM_SMALL_MAX", "0")
-        mu_l, var_l = g.predict(Xc)
-        _, mx_l, am_l, _ = g.acq("ei", 0.0, float(y.min()), Xc)
-        monkeypatch.setenv("ROBO_TRSM_SMALL_MAX", "1000000")
-        for narrow in ("0", "1"):          # 32 and 16 candidates per workgroup
-            for deep in ("0", "1"):        # one and two k-tiles per staging stage
-                monkeypatch.setenv("ROBO_TRSM_SMALL_NARROW", narrow)
-                monkeypatch.setenv("ROBO_TRSM_SMALL_DEEP", deep)
-                mu_s, var_s = g.predict(Xc)
-                _, mx_s, am_s, _ = g.acq("ei", 0.0, float(y.min()), Xc)
-                np.testing.assert_array_equal(mu_s, mu_l)
-                np.testing.assert_array_equal(var_s, var_l)
-                assert (mx_s, am_s) == (mx_l, am_l)
-        monkeypatch.delenv("ROBO_TRSM_SMALL_NARROW")
-        monkeypatch.delenv("ROBO_TRSM_SMALL_DEEP")
-        monkeypatch.delenv("ROBO_TRSM_SMALL_MAX")
+        try:
+            ctx.set_tuning("winv_max", 0)           # the block-row substitution only (not the explicit-inverse path)
+            ctx.set_tuning("trsm_small_max", 0)
+            mu_l, var_l = g.predict(Xc)
+            _, mx_l, am_l, _ = g.acq("ei", 0.0, float(y.min()), Xc)
+            ctx.set_tuning("trsm_small_max", 1000000)
+            for narrow in (0, 1):          # 32 and 16 candidates per workgroup
+                for deep in (0, 1):        # one and two k-tiles per staging stage
+                    ctx.set_tuning("trsm_small_narrow", narrow)
+                    ctx.set_tuning("trsm_small_deep", deep)
+                    mu_s, var_s = g.predict(Xc)
+                    _, mx_s, am_s, _ = g.acq("ei", 0.0, float(y.min()), Xc)
+                    np.testing.assert_array_equal(mu_s, mu_l)
+                    np.testing.assert_array_equal(var_s, var_l)
+                    assert (mx_s, am_s) == (mx_l, am_l)
+        finally:
+            for key in ("trsm_small_narrow", "trsm_small_deep", "trsm_small_max", "winv_max"):
+                ctx.set_tuning(key, None)
         g.close()
 
 
@@ -827,7 +829,7 @@ def check_host_array_handle_reuse(ctx):
 
 
 def check_chunked_workspace(ctx, monkeypatch, N, D, M, ws_blocks, kind="matern52"):
-    """Candidate batches larger than the solve workspace (ROBO_WS_BYTES) are evaluated in passes of whole
+    """Candidate batches larger than the solve workspace (tuning key ws_bytes) are evaluated in passes of whole
     128-candidate blocks: posterior, acquisition values and argmax must equal the single-pass results bit for bit,
     and the oracle's within the stated tolerances."""
     from _tol import MU_ATOL, MU_RTOL, VAR_ATOL_REL_AMP
@@ -842,11 +844,11 @@ def check_chunked_workspace(ctx, monkeypatch, N, D, M, ws_blocks, kind="matern52
     g.set_data(X, y)
     g.fit(theta, ogp.mean)
     eta = float(y.min())
-    monkeypatch.delenv("ROBO_WS_BYTES", raising=False)
+    ctx.set_tuning("ws_bytes", None)
     mu1, var1 = g.predict(Xc)
     v1, mx1, am1, _ = g.acq("ei", 0.0, eta, Xc)
     n_pad = (N + 1 + 127) // 128 * 128
-    monkeypatch.setenv("ROBO_WS_BYTES", str(ws_blocks * 128 * n_pad * 8))
+    ctx.set_tuning("ws_bytes", ws_blocks * 128 * n_pad * 8)
     cand = _lib.Candidates(ctx, Xc)                 # a fresh handle: its workspace is sized under the limit
     mu2, var2 = g.predict(cand)
     v2, mx2, am2, _ = g.acq("ei", 0.0, eta, cand)
@@ -854,7 +856,7 @@ def check_chunked_workspace(ctx, monkeypatch, N, D, M, ws_blocks, kind="matern52
     assert n_pass >= 2, n_pass
     assert cand.chunk() == ws_blocks * 128, (cand.chunk(), ws_blocks)
     cand.close()
-    monkeypatch.delenv("ROBO_WS_BYTES")
+    ctx.set_tuning("ws_bytes", None)
     np.testing.assert_array_equal(mu1, mu2)
     np.testing.assert_array_equal(var1, var2)
     np.testing.assert_array_equal(v1, v2)
@@ -867,3 +869,94 @@ def check_chunked_workspace(ctx, monkeypatch, N, D, M, ws_blocks, kind="matern52
     assert am2 == want or srt[-1] - srt[-2] <= 1e-7 * abs(ei_o[want]), (am2, want)
     g.close()
     return n_pass
+
+
+def check_winv_path(ctx, cases=(("matern52", 300, 5, 700), ("fabolas", 280, 4, 130), ("rbf", 1100, 3, 40))):
+    """Small batches through the explicit inverse factor W = L^-1 (winv.hip) against the oracle at the stated
+    tolerances and against the block-row substitution (rounding-level agreement, same argmax); values independent of
+    the workspace chunking (bit for bit); full covariance and cross-covariances (callers that consume V itself);
+    a refit rebuilds W; an ill-conditioned factor stays on the substitution."""
+    from _tol import MU_ATOL, MU_RTOL, VAR_ATOL_REL_AMP
+    rs = np.random.RandomState(43)
+    try:
+        ctx.set_tuning("winv_min_blocks", 2)
+        for kind, N, D, M in cases:
+            X = rs.rand(N, D)
+            y = np.sin(3 * X.sum(axis=1))
+            P = O.n_kernel_params(kind, D) + 1
+            theta = np.zeros(P)
+            theta[1:1 + D if kind != "fabolas" else D] = np.log(0.4 * D)
+            theta[-1] = np.log(1e-2)
+            ogp = O.OracleGP(kind, theta, normalize_input=False)
+            ogp.train(X, y)
+            g = _lib.DeviceGP(ctx, kind, N, D)
+            g.set_data(X, y)
+            g.fit(theta, ogp.mean)
+            Xc = rs.rand(M, D)
+            eta = float(y.min())
+            amp = float(np.max(O.kernel_diag(kind, theta[:-1], Xc)))
+            ctx.set_tuning("winv_max", 0)
+            mu_b, var_b = g.predict(Xc)
+            _, _, am_b, _ = g.acq("ei", 0.0, eta, Xc)
+            ctx.set_tuning("winv_max", None)
+            cand = _lib.Candidates(ctx, Xc)
+            mu_w, var_w = g.predict(cand)
+            assert cand.solve_kernel() == "winv_gemm_kernel"
+            vals, mx, am_w, _ = g.acq("ei", 0.0, eta, cand)
+            mu_o, var_o = ogp.predict(Xc, diag_only=True)
+            np.testing.assert_allclose(mu_w, mu_o, rtol=MU_RTOL, atol=MU_ATOL)
+            np.testing.assert_allclose(var_w, var_o, rtol=0, atol=VAR_ATOL_REL_AMP * amp)
+            np.testing.assert_allclose(mu_w, mu_b, rtol=0, atol=1e-11 * max(1.0, np.abs(mu_b).max()))
+            np.testing.assert_allclose(var_w, var_b, rtol=0, atol=1e-11 * amp)
+            ei_o = O.ei(mu_o, var_o, eta)
+            want, srt = int(np.argmax(ei_o)), np.sort(ei_o)
+            assert am_w == int(np.argmax(vals)) and (am_w == want or srt[-1] - srt[-2] <= 1e-7 * abs(ei_o[want]))
+            assert am_w == am_b or srt[-1] - srt[-2] <= 1e-7 * abs(ei_o[want])
+            # chunked passes: same bits
+            n_pad = (N + 1 + 127) // 128 * 128
+            ctx.set_tuning("ws_bytes", 2 * 128 * n_pad * 8)
+            c2 = _lib.Candidates(ctx, Xc)
+            mu_c, var_c = g.predict(c2)
+            assert c2.solve_kernel() == "winv_gemm_kernel" and (M <= 256 or c2.chunk() == 256)
+            c2.close()
+            ctx.set_tuning("ws_bytes", None)
+            np.testing.assert_array_equal(mu_c, mu_w)
+            np.testing.assert_array_equal(var_c, var_w)
+            # consumers of V itself
+            mu33, cov = g.predict_cov(Xc[:33])
+            _, cov_o = ogp.predict(Xc[:33], full_cov=True)
+            np.testing.assert_allclose(np.clip(cov, np.finfo(float).eps, np.inf), cov_o, rtol=0,
+                                       atol=VAR_ATOL_REL_AMP * amp)      # (the class clips like the reference; the ABI does not)
+            rep = _lib.Candidates(ctx, Xc[40:52] if M > 52 else Xc[:12])
+            S = _lib.cross_cov(g, cand, rep)
+            from oracle import ig_oracle as IG
+            _, S_o = IG.innovation_inputs(ogp, Xc, Xc[40:52] if M > 52 else Xc[:12])
+            np.testing.assert_allclose(S, S_o, rtol=0, atol=1e-9 * amp)
+            rep.close()
+            # a refit at another theta rebuilds W
+            theta2 = theta.copy()
+            theta2[1] += 0.4
+            o2 = O.OracleGP(kind, theta2, normalize_input=False)
+            o2.train(X, y)
+            g.fit(theta2, o2.mean)
+            mu2, var2 = g.predict(cand)
+            m2o, v2o = o2.predict(Xc, diag_only=True)
+            np.testing.assert_allclose(mu2, m2o, rtol=MU_RTOL, atol=MU_ATOL)
+            np.testing.assert_allclose(var2, v2o, rtol=0, atol=VAR_ATOL_REL_AMP * amp)
+            cand.close()
+            g.close()
+        # conditioning guard: noise 1e-10 on a dense 1-d design -> diagonal ratio beyond the bound -> substitution
+        X = rs.rand(300, 1)
+        y = np.sin(4 * X.sum(axis=1))
+        theta = np.array([0.0, np.log(0.3 ** 2), np.log(1e-10)])
+        g = _lib.DeviceGP(ctx, "matern52", 300, 1)
+        g.set_data(X, y)
+        g.fit(theta, float(y.mean()))
+        cand = _lib.Candidates(ctx, rs.rand(100, 1))
+        g.predict(cand)
+        assert cand.solve_kernel() != "winv_gemm_kernel", cand.solve_kernel()
+        cand.close()
+        g.close()
+    finally:
+        for key in ("winv_min_blocks", "winv_max", "ws_bytes"):
+            ctx.set_tuning(key, None)

@@ -139,12 +139,16 @@ def test_persistent_tile_updates(emu_ctx, monkeypatch):
     g.set_data(X, y)
     g.fit(theta, ogp.mean)
     L_ref = g.factor().copy()
-    monkeypatch.setenv("ROBO_POTRF_TM4_MIN", "1")
-    for cap in ("4", "3", "64"):          # 3 / 2 tile workgroups sharing 9 tiles; one tile each
-        monkeypatch.setenv("ROBO_POTRF_MAX_WG", cap)
-        ll = g.fit(theta, ogp.mean)
-        np.testing.assert_allclose(ll, ogp.loglikelihood(theta), rtol=1e-10)
-        np.testing.assert_array_equal(g.factor(), L_ref)
+    try:
+        emu_ctx.set_tuning("potrf_tm4_min", 1)
+        for cap in (4, 3, 64):          # 3 / 2 tile workgroups sharing 9 tiles; one tile each
+            emu_ctx.set_tuning("potrf_max_wg", cap)
+            ll = g.fit(theta, ogp.mean)
+            np.testing.assert_allclose(ll, ogp.loglikelihood(theta), rtol=1e-10)
+            np.testing.assert_array_equal(g.factor(), L_ref)
+    finally:
+        emu_ctx.set_tuning("potrf_tm4_min", None)
+        emu_ctx.set_tuning("potrf_max_wg", None)
     np.testing.assert_allclose(L_ref, ogp.L, rtol=0, atol=1e-11)
     g.close()
 
@@ -172,3 +176,8 @@ def test_small_and_large_candidate_tiles_agree(emu_ctx, monkeypatch):
 def test_host_array_handle_reuse(emu_ctx):
     P.check_host_array_handle_reuse(emu_ctx)
 
+
+
+def test_winv_small_batch_path(emu_ctx):
+    """the explicit-inverse posterior for small batches (winv.hip): index arithmetic, unit table, chunk order"""
+    P.check_winv_path(emu_ctx, cases=(("matern52", 300, 5, 300), ("fabolas", 280, 4, 130)))

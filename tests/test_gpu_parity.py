@@ -418,5 +418,12 @@ def test_chunked_workspace_equals_single_pass(ctx, monkeypatch):
     assert P.check_chunked_workspace(ctx, monkeypatch, N=2048, D=16, M=40000, ws_blocks=64) == 5
 
 
+def test_winv_small_batch_path(ctx):
+    """small batches through the explicit inverse factor: oracle tolerances, rounding-level agreement with the
+    substitution, chunk invariance, V consumers, refit, conditioning guard -- incl. the headline factor"""
+    P.check_winv_path(ctx)
+    P.check_winv_path(ctx, cases=(("matern52", 4096, 16, 500), ("matern52", 2000, 8, 8192)))
+
+
 def test_host_array_handle_reuse(ctx):
     P.check_host_array_handle_reuse(ctx)

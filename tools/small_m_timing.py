@@ -1,20 +1,37 @@
-"""posterior + EI latency for small candidate batches at the headline GP (N=4096, D=16): 32- vs 128-candidate step"""
+"""posterior + EI latency for small candidate batches at the headline GP (N=4096, D=16): the block-row substitution
+(128- and 32-candidate steps) vs the explicit-inverse path (winv.hip); also a few smaller factors"""
 import os, sys, time, numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from robo_amd import _lib
-N, D = 4096, 16
 ctx = _lib.Context(0)
-X = np.random.RandomState(0).rand(N, D); y = np.sinc(X * 10 - 5).sum(axis=1); y = (y - y.mean()) / y.std()
-theta = np.concatenate([[0.0], np.full(D, np.log(0.25 * D)), [np.log(1e-3)]])
-g = _lib.DeviceGP(ctx, "matern52", N, D); g.set_data(X, y); g.fit(theta, 0.0)
-for M in (128, 500, 2048, 8192, 16384, 32768):
-    cand = _lib.Candidates(ctx, np.random.RandomState(1).rand(M, D))
-    out = []
-    for small in ("0", "1000000"):
-        os.environ["ROBO_TRSM_SMALL_MAX"] = small
-        g.acq("ei", 0.0, float(y.min()), cand, want_values=False)
-        ts = []
-        for _ in range(5):
-            t0 = time.perf_counter(); g.acq("ei", 0.0, float(y.min()), cand, want_values=False); ts.append((time.perf_counter() - t0) * 1e3)
-        out.append(min(ts))
-    print("M=%6d: 128-candidate step %.3f ms, 32-candidate step %.3f ms" % (M, out[0], out[1]))
+
+
+def best(f, reps=5):
+    f()
+    ts = []
+    for _ in range(reps):
+        t0 = time.perf_counter(); f(); ts.append((time.perf_counter() - t0) * 1e3)
+    return min(ts)
+
+
+for N, D in ((4096, 16), (2048, 16), (1000, 8), (500, 4)):
+    X = np.random.RandomState(0).rand(N, D); y = np.sinc(X * 10 - 5).sum(axis=1); y = (y - y.mean()) / y.std()
+    theta = np.concatenate([[0.0], np.full(D, np.log(0.25 * D)), [np.log(1e-3)]])
+    g = _lib.DeviceGP(ctx, "matern52", N, D); g.set_data(X, y); g.fit(theta, 0.0)
+    eta = float(y.min())
+    t0 = time.perf_counter(); g.acq("ei", 0.0, eta, np.random.rand(500, D), want_values=False)
+    print("N=%d: first 500-candidate call after the fit (builds W): %.3f ms" % (N, (time.perf_counter() - t0) * 1e3))
+    for M in ((1, 128, 500, 2048, 8192, 16384, 32768) if N == 4096 else (500, 8192)):
+        cand = _lib.Candidates(ctx, np.random.RandomState(1).rand(M, D))
+        out = []
+        for winv, small in ((0, 0), (0, 1000000), (1 << 30, 1000000)):
+            ctx.set_tuning("winv_max", winv); ctx.set_tuning("winv_min_blocks", 1); ctx.set_tuning("trsm_small_max", small)
+            out.append(best(lambda: g.acq("ei", 0.0, eta, cand, want_values=False)))
+        kern = cand.solve_kernel()
+        for k in ("winv_max", "winv_min_blocks", "trsm_small_max"):
+            ctx.set_tuning(k, None)
+        dflt = best(lambda: g.acq("ei", 0.0, eta, cand, want_values=False))
+        print("N=%5d M=%6d: 128-cand step %.3f ms, 32-cand step %.3f ms, explicit inverse %.3f ms (%s); default policy %.3f ms (%s)"
+              % (N, M, out[0], out[1], out[2], kern, dflt, cand.solve_kernel()))
+        cand.close()
+    g.close()
