@@ -85,7 +85,7 @@ int32_t robo_ctx_set_phase_events(robo_ctx* ctx, int32_t on);
  * ROBO_<KEY in upper case>), and changed afterwards only through this call; value INT64_MIN restores the default, key
  * "env" re-reads all variables.  Keys: ws_bytes (solve workspace per candidate handle, default 6 GiB),
  * winv_max / winv_min_blocks (batches of at most winv_max candidates on a factor of at least winv_min_blocks 128-row
- * blocks are evaluated through the explicit inverse factor, winv.hip; default 16384 / 4; 0 = never),
+ * blocks are evaluated through the explicit inverse factor, winv.hip; default 32768 / 6, measured r03b; 0 = never),
  * trsm_small_max, trsm_small_narrow, trsm_small_deep, trsm_rows, predict_stepwise, potrf_fused, potrf_tm4_min,
  * potrf_max_wg, potrf_group (kernel-variant selection; A/B runs and tests).                                     */
 int32_t robo_ctx_set_tuning(robo_ctx* ctx, const char* key, int64_t value);

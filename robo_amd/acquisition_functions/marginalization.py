@@ -86,6 +86,11 @@ class MarginalizationGPMCMC(BaseAcquisitionFunction):
         b, e = self._shard()
         est = self.estimators[b:e]
         S = len(self.estimators)
+        if isinstance(X_test, _lib.Candidates):
+            # a device-generated batch lives in the normalised space of ITS maximiser's model; the sample shard
+            # evaluates host coordinates (every rank must see the same points): bring them back once
+            X_test = self._host_points(X_test)
+        negative_ei = False
         if est and isinstance(self.acquisition_func, ClosedFormAcquisition) and \
                 all(isinstance(getattr(x.model, "gp", None), _lib.DeviceGP) and x.model.is_trained for x in est):
             models = [x.model for x in est]
@@ -96,14 +101,26 @@ class MarginalizationGPMCMC(BaseAcquisitionFunction):
                                                       np.array([x._eta(None) for x in est]), cand, reduce="sum")
             finally:
                 cand.close()
-            if est[0].kind == "ei" and flags & _lib.FLAG_NEGATIVE_EI:
-                raise ValueError
+            negative_ei = est[0].kind == "ei" and bool(flags & _lib.FLAG_NEGATIVE_EI)
         else:
             part = np.zeros(X_test.shape[0])
             for x in est:
                 part = part + np.asarray(x.compute(X_test), dtype=np.float64).reshape(-1)
-        total = sharding.allgather_ordered_sum(part)
-        return total / S
+        # the guard of ei.py:86-88 travels WITH the partial sums (one extra entry): raising on one rank before the
+        # collective would leave the others waiting in it
+        total = sharding.allgather_ordered_sum(np.append(part, 1.0 if negative_ei else 0.0))
+        if total[-1] > 0:
+            raise ValueError
+        return total[:-1] / S
+
+    def _host_points(self, cand):
+        """coordinates of a device candidate batch in the caller's input space"""
+        m0 = self.estimators[0].model
+        P = cand.points()
+        lower, upper = np.asarray(m0.lower, dtype=np.float64), np.asarray(m0.upper, dtype=np.float64)
+        if hasattr(m0, "normalize") and not getattr(m0, "normalize_input", False):
+            raise TypeError("device-generated candidates are not supported with Fabolas sub-models")
+        return lower + (upper - lower) * P
 
     def _native_eval(self, X_test, want_values):
         est = self.estimators
@@ -140,6 +157,8 @@ class MarginalizationGPMCMC(BaseAcquisitionFunction):
                     return vals
             else:
                 return vals
+        if isinstance(X_test, _lib.Candidates):
+            X_test = self._host_points(X_test)       # host loop below: the reference's per-estimator evaluation
         acquisition_values = np.zeros([len(self.model.models), X_test.shape[0]])
         for i in range(len(self.model.models)):
             acquisition_values[i] = self.estimators[i].compute(X_test, derivative=derivative)

@@ -35,8 +35,8 @@ static const TuneKey TUNE_KEYS[] = {
     {"trsm_small_deep", nullptr, &Tuning::trsm_small_deep, -1},
     {"trsm_rows", nullptr, &Tuning::trsm_rows, 1},
     {"predict_stepwise", nullptr, &Tuning::predict_stepwise, 0},
-    {"winv_max", &Tuning::winv_max, nullptr, 16384},
-    {"winv_min_blocks", nullptr, &Tuning::winv_min_blocks, 4},
+    {"winv_max", &Tuning::winv_max, nullptr, 32768},
+    {"winv_min_blocks", nullptr, &Tuning::winv_min_blocks, 6},
     {"potrf_fused", nullptr, &Tuning::potrf_fused, 1},
     {"potrf_tm4_min", nullptr, &Tuning::potrf_tm4_min, 96},
     {"potrf_max_wg", nullptr, &Tuning::potrf_max_wg, 0},
@@ -957,6 +957,8 @@ int32_t robo_gp_predict_grad(robo_gp* g, const double* Xc, int64_t m, double* ou
     int64_t per = (int64_t)(workspace_bytes(c) / row_bytes / NB * NB) / E;
     if (per < 1) per = 1;
     if (per > m) per = m;
+    // cross_grad_kernel and predgrad_post_kernel put (a multiple of) the candidate index on grid.y / grid.x
+    if (per + NB > 65535) per = 65535 - NB;
     const int64_t rows_pad = round_up64(per * E, NB);
     robo_cand* ws = nullptr;   // the pseudo-row solve workspace
     double *d_dm = nullptr, *d_dv = nullptr;
@@ -1041,6 +1043,14 @@ static int check_acq_kind(int kind) {
     return ROBO_OK;
 }
 
+// The flag word of a candidate handle is OR-ed into by the acquisition kernels and cleared by the read-back's report
+// kernel.  An error return between the two (a later sample's posterior failing, a launch failure) would leave stale
+// ZERO_SIGMA / NEGATIVE_EI bits in a handle that lives on (kept host-array handles, representer points): clear them.
+static int clear_flags_on_error(robo_cand* k, int status) {
+    if (status != ROBO_OK && k && k->d_flags) hipMemsetAsync(k->d_flags, 0, 4 * sizeof(unsigned), k->ctx->stream);
+    return status;
+}
+
 // D2H of (max, argmax, flags) [+ the acquisition vector] and the one synchronisation of the call
 static int acq_read_back(robo_cand* k, const double* d_vec, double* out_vec, double* out_max, int64_t* out_argmax,
                          uint32_t* out_flags) {
@@ -1068,8 +1078,8 @@ int32_t robo_acq_eval_cand(robo_gp* g, int32_t acq_kind, double par, double eta,
                            double* out_max, int64_t* out_argmax, uint32_t* out_flags) {
     ROBO_TRY(check_acq_kind(acq_kind));
     ROBO_TRY(predict_core(g, k, false));
-    ROBO_TRY(launch_acq(g->ctx, k, acq_kind, par, eta, false, false));
-    return acq_read_back(k, k->d_acq, out_acq, out_max, out_argmax, out_flags);
+    ROBO_TRY(clear_flags_on_error(k, launch_acq(g->ctx, k, acq_kind, par, eta, false, false)));
+    return clear_flags_on_error(k, acq_read_back(k, k->d_acq, out_acq, out_max, out_argmax, out_flags));
 }
 
 int32_t robo_acq_eval(robo_gp* g, int32_t acq_kind, double par, double eta, const double* Xc, int64_t m,
@@ -1093,8 +1103,8 @@ static int acq_accumulate(robo_gp* const* gps, int32_t S, int32_t acq_kind, doub
     ROBO_TRY(check_acq_kind(acq_kind));
     ROBO_HIP_CHECK(hipSetDevice(k->ctx->device));
     for (int s = 0; s < S; ++s) {
-        ROBO_TRY(predict_core(gps[s], k, false));
-        ROBO_TRY(launch_acq(k->ctx, k, acq_kind, par, etas[s], true, s == 0));
+        ROBO_TRY(clear_flags_on_error(k, predict_core(gps[s], k, false)));
+        ROBO_TRY(clear_flags_on_error(k, launch_acq(k->ctx, k, acq_kind, par, etas[s], true, s == 0)));
     }
     return ROBO_OK;
 }
@@ -1103,15 +1113,15 @@ int32_t robo_acq_eval_marginal_cand(robo_gp* const* gps, int32_t S, int32_t acq_
                                     robo_cand* k, double* out_acq, double* out_max, int64_t* out_argmax,
                                     uint32_t* out_flags) {
     ROBO_TRY(acq_accumulate(gps, S, acq_kind, par, etas, k));
-    ROBO_TRY(launch_argmax(k, k->d_acq_sum, (double)S));
-    return acq_read_back(k, k->d_acq, out_acq, out_max, out_argmax, out_flags);
+    ROBO_TRY(clear_flags_on_error(k, launch_argmax(k, k->d_acq_sum, (double)S)));
+    return clear_flags_on_error(k, acq_read_back(k, k->d_acq, out_acq, out_max, out_argmax, out_flags));
 }
 
 int32_t robo_acq_eval_sum_cand(robo_gp* const* gps, int32_t S, int32_t acq_kind, double par, const double* etas,
                                robo_cand* k, double* out_acq_sum, uint32_t* out_flags) {
     ROBO_TRY(acq_accumulate(gps, S, acq_kind, par, etas, k));
-    ROBO_TRY(launch_argmax(k, k->d_acq_sum, 1.0));
-    return acq_read_back(k, k->d_acq_sum, out_acq_sum, nullptr, nullptr, out_flags);
+    ROBO_TRY(clear_flags_on_error(k, launch_argmax(k, k->d_acq_sum, 1.0)));
+    return clear_flags_on_error(k, acq_read_back(k, k->d_acq_sum, out_acq_sum, nullptr, nullptr, out_flags));
 }
 
 int32_t robo_acq_eval_moments(robo_ctx* ctx, int32_t acq_kind, double par, double eta, const double* mean,

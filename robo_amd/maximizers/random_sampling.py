@@ -28,9 +28,14 @@ class BaseMaximizer(object):
 
 class RandomSampling(BaseMaximizer):
 
-    def __init__(self, objective_function, lower, upper, n_samples=500, rng=None, device_argmax=True):
+    def __init__(self, objective_function, lower, upper, n_samples=500, rng=None, device_argmax=True, shard=False):
         self.n_samples = n_samples
         self.device_argmax = device_argmax
+        # shard=True (explicit opt-in, like GaussianProcessMCMC.sample_shard): with one process per GPU every rank
+        # evaluates its slice of the SAME candidate matrix and the per-shard incumbents are exchanged.  All ranks
+        # must then run the same BO loop with the same seeds and call maximize() in lock step; that the candidate
+        # matrices agree is checked before the exchange.  An initialised process group alone does NOT switch this on.
+        self.shard = shard
         super(RandomSampling, self).__init__(objective_function, lower, upper, rng)
 
     def candidates(self):
@@ -46,10 +51,13 @@ class RandomSampling(BaseMaximizer):
 
     def maximize(self):
         X = self.candidates()
-        from robo_amd import sharding
-        if sharding.dist_info()[2] > 1:
-            # one process per GPU: same seeds, hence the same X, on every rank; each evaluates its slice
-            return X[sharding.sharded_argmax(self.objective_func, X)]
+        if self.shard:
+            from robo_amd import sharding
+            if sharding.dist_info()[2] > 1:
+                # one process per GPU: same seeds, hence the same X, on every rank; each evaluates its slice
+                sharding.assert_replicated("RandomSampling candidates", [X.shape[0], X.shape[1], float(X.sum()),
+                                                                         float(X[0, 0]), float(X[-1, -1])])
+                return X[sharding.sharded_argmax(self.objective_func, X)]
         if self.device_argmax and hasattr(self.objective_func, "argmax"):
             return X[self.objective_func.argmax(X)]
         y = self.objective_func(X)
@@ -67,9 +75,13 @@ class DeviceRandomSampling(BaseMaximizer):
     space; the random stream is Philox, so the sequence differs from the reference's NumPy one.
     """
 
-    def __init__(self, objective_function, lower, upper, n_samples=65536, rng=None):
+    def __init__(self, objective_function, lower, upper, n_samples=65536, rng=None, shard=False):
         super(DeviceRandomSampling, self).__init__(objective_function, lower, upper, rng)
         self.n_samples = int(n_samples)
+        # shard=True: explicit opt-in to the candidate shard (see RandomSampling); rank r then draws rows [b, e) of the
+        # recipe from ITS OWN Philox stream (seed + 7919 r), so the sharded candidate set is a different (equally
+        # distributed) sample than the single-process one
+        self.shard = shard
 
     def maximize(self):
         from robo_amd import _lib
@@ -84,7 +96,10 @@ class DeviceRandomSampling(BaseMaximizer):
         scale = 0.1 / (upper - lower)
         seed = int(self.rng.randint(0, 2 ** 31 - 1))
         from robo_amd import sharding
-        _, rank, world = sharding.dist_info()
+        _, rank, world = sharding.dist_info() if self.shard else (None, 0, 1)
+        if world > 1:
+            sharding.assert_replicated("DeviceRandomSampling (n_samples, seed, incumbent)",
+                                       [self.n_samples, seed] + [float(v) for v in loc])
         # candidate shard (one process per GPU, same rng seed everywhere): rank r generates and evaluates rows
         # [b, e) of the recipe -- its own Philox stream, the 70 % / 30 % split kept globally -- and only the
         # per-shard incumbent (16 B) and the winning point (D doubles) are exchanged
@@ -114,10 +129,11 @@ class DeviceSobolSampling(BaseMaximizer):
     evaluates its own contiguous slice and only the per-shard incumbent and the winning point are exchanged.
     Not in the reference (which has no Sobol sampler); same maximiser protocol as RandomSampling."""
 
-    def __init__(self, objective_function, lower, upper, n_samples=2 ** 16, seed=0, rng=None):
+    def __init__(self, objective_function, lower, upper, n_samples=2 ** 16, seed=0, rng=None, shard=False):
         super(DeviceSobolSampling, self).__init__(objective_function, lower, upper, rng)
         self.n_samples = int(n_samples)
         self.seed = seed
+        self.shard = shard      # explicit opt-in to the candidate shard (slices of ONE sequence: same result as unsharded)
 
     def maximize(self):
         from scipy.stats import qmc
@@ -128,7 +144,9 @@ class DeviceSobolSampling(BaseMaximizer):
         if not getattr(sub, "normalize_input", False) or not hasattr(sub, "gp"):
             raise TypeError("DeviceSobolSampling needs a robo_amd GP model with normalize_input=True")
         lower, upper = np.asarray(sub.lower, dtype=np.float64), np.asarray(sub.upper, dtype=np.float64)
-        _, rank, world = sharding.dist_info()
+        _, rank, world = sharding.dist_info() if self.shard else (None, 0, 1)
+        if world > 1:
+            sharding.assert_replicated("DeviceSobolSampling (n_samples, seed)", [self.n_samples, int(self.seed)])
         b, e = sharding.shard_range(self.n_samples, rank, world)
         eng = qmc.Sobol(d=lower.shape[0], scramble=True, seed=self.seed)
         cand = _lib.Candidates(sub.gp.ctx, m=max(e - b, 1), sobol=eng, first=b)

@@ -211,16 +211,25 @@ class GaussianProcessMCMC(BaseModel):
             from robo_amd import sharding
             _, rank, world = sharding.dist_info()
             if world > 1:
-                # mixture from per-rank partial sums (3 M doubles per rank): mean_s mu_s and
-                # var_s(mu_s) + mean_s var_s with var_s(mu) = mean(mu^2) - mean(mu)^2
+                # mixture from per-rank partial sums in TWO exchanges, like np.var's two passes
+                # (gaussian_process_mcmc.py:239): first (sum mu_s, sum var_s) -> the mixture mean m, then
+                # sum (mu_s - m)^2.  The one-pass form mean(mu^2) - mean(mu)^2 cancels catastrophically when
+                # |mu| is large against the spread of the mu_s (normalize_output=False).
                 b, e = sharding.shard_range(len(self.models), rank, world)
-                part = np.zeros((3, X_test.shape[0]))
+                S = len(self.models)
+                mus = []
+                part = np.zeros((2, X_test.shape[0]))
                 for model in self.models[b:e]:
                     mu_s, var_s = model.predict(X_test)
-                    part += np.stack((mu_s, mu_s * mu_s, var_s))
-                tot = sharding.allgather_ordered_sum(part) / len(self.models)
-                v = (tot[1] - tot[0] * tot[0]) + tot[2]
-                return tot[0], np.clip(v, np.finfo(v.dtype).eps, np.inf)
+                    mus.append(mu_s)
+                    part += np.stack((mu_s, var_s))
+                tot = sharding.allgather_ordered_sum(part) / S
+                m = tot[0]
+                dev2 = np.zeros(X_test.shape[0])
+                for mu_s in mus:
+                    dev2 += (mu_s - m) ** 2
+                v = sharding.allgather_ordered_sum(dev2) / S + tot[1]
+                return m, np.clip(v, np.finfo(v.dtype).eps, np.inf)
         gps = [getattr(m, "gp", None) for m in self.models]
         if all(isinstance(g, _lib.DeviceGP) for g in gps) and all(m.is_trained for m in self.models):
             # all samples live on the device: S posteriors on one candidate upload + mixture kernel

@@ -105,6 +105,19 @@ def allgather_rows(row, device=None):
     return np.stack([t.cpu().numpy() for t in out])
 
 
+def assert_replicated(what, values):
+    """Every rank passes the same small vector of numbers, or ALL ranks raise: the check in front of a sharded
+    maximisation (ranks that drifted apart -- other seeds, another number of maximize() calls -- would otherwise
+    dead-lock in the exchange or score a point against another rank's model)."""
+    _, rank, world = dist_info()
+    if world == 1:
+        return
+    rows = allgather_rows(np.asarray(values, dtype=np.float64))
+    if not all(np.array_equal(rows[0], r, equal_nan=True) for r in rows[1:]):
+        raise RuntimeError("%s differ across ranks (rank %d of %d holds %r): sharded maximisation needs identical "
+                           "seeds and call sequences on every rank" % (what, rank, world, list(values)))
+
+
 def sharded_argmax(acq, X):
     """Candidate shard of one acquisition maximisation (SURVEY.md 8e axis 1): every rank evaluates its contiguous
     slice of the SAME candidate matrix X against its own replica of the model and the per-shard incumbents are

@@ -109,13 +109,13 @@ def _class_worker(rank, world, port, out_dir):
     gp.train(X, y, do_optimize=False)
     acq = A.EI(gp)
     np.random.seed(21)
-    x_sharded = RandomSampling(acq, lo, hi, n_samples=203, rng=np.random.RandomState(8)).maximize()
+    x_sharded = RandomSampling(acq, lo, hi, n_samples=203, rng=np.random.RandomState(8), shard=True).maximize()
     np.random.seed(21)
     cands = RandomSampling(acq, lo, hi, n_samples=203, rng=np.random.RandomState(8)).candidates()
     np.testing.assert_array_equal(x_sharded, cands[int(np.argmax(acq.compute(cands)))])
     assert sharding.sharded_argmax(acq, Xc) == int(np.argmax(acq.compute(Xc)))
     # device-generated candidates: per-rank Philox shards, the winner's point travels to every rank
-    x_dev = DeviceRandomSampling(acq, lo, hi, n_samples=1001, rng=np.random.RandomState(9)).maximize()
+    x_dev = DeviceRandomSampling(acq, lo, hi, n_samples=1001, rng=np.random.RandomState(9), shard=True).maximize()
     assert np.all(x_dev >= lo) and np.all(x_dev <= hi)
     np.save(os.path.join(out_dir, "xdev_%d.npy" % rank), x_dev)
     # ... and it is the best point of the union of the shards, re-evaluated here on one rank
@@ -135,12 +135,34 @@ def _class_worker(rank, world, port, out_dir):
     # Sobol candidates: per-rank slices of ONE sequence -> exactly the single-process winner
     from robo_amd.maximizers import DeviceSobolSampling
     from scipy.stats import qmc
-    x_sob = DeviceSobolSampling(acq, lo, hi, n_samples=513, seed=4).maximize()
+    x_sob = DeviceSobolSampling(acq, lo, hi, n_samples=513, seed=4, shard=True).maximize()
     import warnings
     with warnings.catch_warnings():
         warnings.simplefilter("ignore")
         pts = lo + (hi - lo) * qmc.Sobol(d=D, scramble=True, seed=4).random(513)
     np.testing.assert_array_equal(x_sob, pts[int(np.argmax(acq.compute(pts)))])
+    # without the explicit opt-in a process group changes nothing: every rank maximises over all candidates itself
+    np.random.seed(21)
+    x_plain = RandomSampling(acq, lo, hi, n_samples=203, rng=np.random.RandomState(8)).maximize()
+    np.testing.assert_array_equal(x_plain, x_sharded)
+    # ranks that drifted apart (different seeds) are caught before the exchange, on every rank
+    import pytest
+    with pytest.raises(RuntimeError, match="differ across ranks"):
+        np.random.seed(100 + rank)
+        RandomSampling(acq, lo, hi, n_samples=203, rng=np.random.RandomState(8), shard=True).maximize()
+    with pytest.raises(RuntimeError, match="differ across ranks"):
+        DeviceSobolSampling(acq, lo, hi, n_samples=513, seed=4 + rank, shard=True).maximize()
+    # large offsets between the per-sample means: the two-pass variance of the sharded mixture stays accurate
+    big = mcmc(True)
+    for i, mdl in enumerate(big.models):
+        if mdl.is_trained:
+            mdl.gp.set_output_transform(1.0e8 + i, 1.0)       # mu_s -> mu_s + 1e8 + s
+    for i, mdl in enumerate(full.models):
+        mdl.gp.set_output_transform(1.0e8 + i, 1.0)
+    m_ref, v_ref = full.predict(Xc)
+    m_sh, v_sh = big.predict(Xc)
+    np.testing.assert_allclose(m_sh, m_ref, rtol=1e-13)
+    np.testing.assert_allclose(v_sh, v_ref, rtol=1e-9)
     dist.barrier()
     dist.destroy_process_group()
 
