@@ -126,6 +126,19 @@ class Dist(object):
                                     device_id=torch.device("cuda", self.local_rank))
             self.dist = dist
 
+    def make_comm(self, _lib, ctx):
+        """the library's own communicator (robo_amd/csrc/comm.hip: RCCL all-gathers on the library's stream) for the
+        exchanges of the data path; torch.distributed only carries its 128-byte id (and the timing barrier)"""
+        if self.dist is None:
+            return None
+        box = [_lib.Comm.create_id() if self.rank == 0 else None]
+        if self.world > 1:
+            self.dist.broadcast_object_list(box, src=0)
+        self.comm = _lib.Comm(ctx, self.rank, self.world, box[0])
+        from robo_amd import sharding
+        sharding._comm = self.comm        # the module-level helpers (allgather_argmax ...) use this communicator too
+        return self.comm
+
     def barrier(self, ctx):
         ctx.synchronize()
         if self.dist is not None:
@@ -150,6 +163,9 @@ class Dist(object):
             os.write(self.out_fd, line)
 
     def close(self):
+        if getattr(self, "comm", None) is not None:
+            from robo_amd import sharding
+            sharding.close_comm()
         if self.dist is not None:
             self.dist.barrier()
             self.dist.destroy_process_group()
@@ -195,6 +211,16 @@ def run_headline(args, D_, _lib, sharding):
     gp = _lib.DeviceGP(ctx, "matern52", N, D)
     gp.set_data(X, y)
     cand = _lib.Candidates(ctx, Xc)          # candidates resident in HBM before the timed region
+    comm = D_.make_comm(_lib, ctx)
+
+    def evaluate():
+        """one pass over this rank's candidates -> the global (max, argmax): with a communicator posterior, EI, local
+        argmax, the all-gather of the per-rank incumbents and the cross-rank tie-break are ONE library call"""
+        if comm is not None:
+            _, mx, am, _, _ = comm.acq_sharded(gp, args.acq, 0.0, eta, cand, rank * M)
+            return mx, am
+        _, mx, am, _ = gp.acq(args.acq, 0.0, eta, cand, want_values=False)
+        return mx, am
 
     # ---- GP fit (replicated on every rank) ------------------------------------------------
     fit_ms, fit_phase, fit_ev_ms = [], [], []
@@ -235,8 +261,7 @@ def run_headline(args, D_, _lib, sharding):
     gp.fit(theta, mean_c)          # the batch call leaves the GP unfitted
 
     def step():
-        _, mx, am, _ = gp.acq(args.acq, 0.0, eta, cand, want_values=False)
-        return sharding.allgather_argmax(mx, am + rank * M)
+        return evaluate()
 
     elapsed, best, trsm_ms = timed_steps(D_, ctx, step, args.steps, args.warmup)
 
@@ -244,8 +269,7 @@ def run_headline(args, D_, _lib, sharding):
     # handle, D2H of the result) -- reported next to `value`, which is the resident-input rate
     def step_pcie():
         cand.set_points(Xc)
-        _, mx, am, _ = gp.acq(args.acq, 0.0, eta, cand, want_values=False)
-        return sharding.allgather_argmax(mx, am + rank * M)
+        return evaluate()
 
     elapsed_pcie, _, _ = timed_steps(D_, ctx, step_pcie, max(2, args.steps // 2), 1)
     # small candidate batches on the same fitted GP (the reference's default RandomSampling draws 500 candidates): latency,
@@ -363,15 +387,19 @@ def run_c3(args, D_, _lib, sharding):
     cand = _lib.Candidates(ctx, Xc)
     etas = np.full(e - b, eta)
     fit_s = []
+    comm = D_.make_comm(_lib, ctx)
 
     def step():
         t0 = time.perf_counter()
         _, st = _lib.fit_batch(gps, thetas[b:e], mean_c)          # S_r factorisations in one batched pass
         assert np.all(st == _lib.OK)
         fit_s.append(time.perf_counter() - t0)
-        part, _, _, _ = _lib.acq_marginal(gps, "log_ei", 0.0, etas, cand, reduce="sum")
-        total = sharding.allgather_ordered_sum(part) / S          # 512 KB per rank
-        return float(total.max()), int(np.argmax(total))
+        if comm is not None:
+            # partial sums stay on the device: RCCL all-gather (512 KB per rank), rank-ordered sum, argmax in the library
+            _, mx, am, _ = comm.acq_marginal_sharded(gps, S, "log_ei", 0.0, etas, cand, want_values=False)
+        else:
+            _, mx, am, _ = _lib.acq_marginal(gps, "log_ei", 0.0, etas, cand, want_values=False)
+        return float(mx), int(am)
 
     elapsed, best, trsm_ms = timed_steps(D_, ctx, step, args.steps, args.warmup)
     if rank != 0:
@@ -432,6 +460,7 @@ def run_c4(args, D_, _lib, sharding):
     ep = _lib.EPState(logP, lmb, W, dMu, dSig, dMM)
     cand, cand_cost, rep = _lib.Candidates(ctx, Xc), _lib.Candidates(ctx, Xc_cost), _lib.Candidates(ctx, zb)
     sn2 = float(np.exp(theta[-1]))
+    D_.make_comm(_lib, ctx)
     ctx.set_phase_events(True)          # batches <= 16384 record the solve's event pair only on request
 
     def step():
@@ -486,9 +515,14 @@ def run_c5(args, D_, _lib, sharding):
     # (bit-identical to qmc.Sobol(d, scramble=True, seed=0).random_base2(20)[rank * M : (rank + 1) * M])
     cand = _lib.Candidates(ctx, m=M, sobol=qmc.Sobol(d=D, scramble=True, seed=0), first=rank * M)
 
+    comm = D_.make_comm(_lib, ctx)
+
     def step():
+        if comm is not None:
+            _, mx, am, _, _ = comm.acq_sharded(gp, "lcb", 1.0, 0.0, cand, rank * M)
+            return mx, am
         _, mx, am, _ = gp.acq("lcb", 1.0, 0.0, cand, want_values=False)
-        return sharding.allgather_argmax(mx, am + rank * M)
+        return mx, am
 
     elapsed, best, trsm_ms = timed_steps(D_, ctx, step, args.steps, args.warmup)
     if rank != 0:

@@ -249,6 +249,40 @@ int32_t robo_ig_eval_moments(robo_ctx* ctx, int64_t m, int32_t nb, int32_t n_out
  * predict(full_cov=True) -> predict_variance path (gaussian_process.py:243-246,290-294)            */
 int32_t robo_gp_cross_cov(robo_gp* gp, robo_cand* cand, robo_cand* ref, double* out_cov);
 
+/* ---- multi-GPU: one process per GPU, RCCL over xGMI (SURVEY.md 8b "robo_comm_init + _sharded variants", 8e) -------
+ * The reference is single-process; these entry points shard its two independent axes -- the candidate batch of
+ * RandomSampling.maximize (robo/maximizers/random_sampling.py:42-50) and the hyper-parameter samples of
+ * MarginalizationGPMCMC.compute (robo/acquisition_functions/marginalization.py:115-121) -- and run the one small
+ * exchange each of them needs as an RCCL all-gather on the context's stream, device pointers on both sides.  Every
+ * rank holds its own replica of the fitted GP(s) (the fit is deterministic).  librccl.so is loaded on first use.
+ * COLLECTIVE: every rank of the communicator must make the same call; a rank whose local half fails still takes
+ * part in the exchange (as an empty shard) and then returns its error.                                            */
+typedef struct robo_comm robo_comm;
+#define ROBO_COMM_ID_BYTES 128
+/* rank 0 creates the id (ncclGetUniqueId); every rank must receive the same 128 bytes out of band (a file, a TCP
+ * store, MPI, torch.distributed.broadcast_object_list ...) before robo_comm_init                                  */
+int32_t robo_comm_create_id(void* out_id);
+int32_t robo_comm_init(robo_ctx* ctx, int32_t rank, int32_t world, const void* id, robo_comm** out);
+int32_t robo_comm_destroy(robo_comm* comm);
+int32_t robo_comm_info(robo_comm* comm, int32_t* out_rank, int32_t* out_world);
+/* all-gather of `count` host doubles per rank -> recv (world x count), rank-major: the winning point of a
+ * device-generated shard, consistency checks, timings -- the few-hundred-byte side channel                         */
+int32_t robo_comm_allgather(robo_comm* comm, const double* send, int64_t count, double* recv);
+/* candidate shard: robo_acq_eval_cand on this rank's candidates (global index of candidate c = global_offset + c),
+ * then the all-gather of the per-rank incumbents (24 B per rank) and np.argmax's tie-break across them on the device.
+ * out_max / out_argmax: the GLOBAL maximum and its global index, identical on every rank; out_owner_rank: the rank
+ * whose shard holds it; out_flags: OR over all ranks; out_acq (nullable): this rank's m values.                    */
+int32_t robo_acq_eval_cand_sharded(robo_comm* comm, robo_gp* gp, int32_t acq_kind, double par, double eta,
+                                   robo_cand* cand, int64_t global_offset, double* out_acq, double* out_max,
+                                   int64_t* out_argmax, int32_t* out_owner_rank, uint32_t* out_flags);
+/* sample shard: this rank's S_local fitted GPs (S_total over all ranks; S_local may be 0) on ALL candidates; the
+ * per-rank partial sums are all-gathered (m doubles per rank) and added in rank order on the device, divided by
+ * S_total, argmax.  Outputs as robo_acq_eval_marginal_cand, identical on every rank; equal to the single-process
+ * sample-order accumulation up to fp64 re-association (partial sums are formed per shard).                         */
+int32_t robo_acq_eval_marginal_cand_sharded(robo_comm* comm, robo_gp* const* gps, int32_t S_local, int32_t S_total,
+                                            int32_t acq_kind, double par, const double* etas, robo_cand* cand,
+                                            double* out_acq, double* out_max, int64_t* out_argmax,
+                                            uint32_t* out_flags);
 
 #ifdef __cplusplus
 }

@@ -36,7 +36,10 @@ SYMBOLS = [
     "robo_gp_predict_cand", "robo_gp_predict", "robo_gp_predict_cov", "robo_gp_predict_grad", "robo_gp_predict_mixture_cand",
     "robo_acq_eval_cand", "robo_acq_eval", "robo_acq_eval_moments", "robo_acq_eval_marginal_cand", "robo_acq_eval_sum_cand",
     "robo_ig_eval_cand", "robo_ig_eval_moments", "robo_gp_cross_cov",
+    "robo_comm_create_id", "robo_comm_init", "robo_comm_destroy", "robo_comm_info", "robo_comm_allgather",
+    "robo_acq_eval_cand_sharded", "robo_acq_eval_marginal_cand_sharded",
 ]
+COMM_ID_BYTES = 128
 # include/robo_hip_diag.h (librobo_hip_diag.so: tests, bench.py's roofline block, tools/)
 DIAG_SYMBOLS = [
     "robo_selftest_mfma_layout", "robo_microbench_mfma_f64", "robo_microbench_mfma_f64_detail", "robo_microbench_gemm_f64",
@@ -143,6 +146,15 @@ def lib():
         "robo_ig_eval_cand": [vp, vp, vp, i32, dbl, _dp, _dp, _dp, _dp, _dp, _dp, _dp, _dp, C.POINTER(i64)],
         "robo_ig_eval_moments": [vp, i64, i32, i32, dbl, _dp, _dp, _dp, _dp, _dp, _dp, _dp, _dp, _dp],
         "robo_gp_cross_cov": [vp, vp, vp, _dp],
+        "robo_comm_create_id": [C.c_char_p],
+        "robo_comm_init": [vp, i32, i32, C.c_char_p, pp],
+        "robo_comm_destroy": [vp],
+        "robo_comm_info": [vp, C.POINTER(i32), C.POINTER(i32)],
+        "robo_comm_allgather": [vp, _dp, i64, _dp],
+        "robo_acq_eval_cand_sharded": [vp, vp, i32, dbl, dbl, vp, i64, _dp, _dp, C.POINTER(i64), C.POINTER(i32),
+                                       C.POINTER(C.c_uint32)],
+        "robo_acq_eval_marginal_cand_sharded": [vp, pp, i32, i32, i32, dbl, _dp, vp, _dp, _dp, C.POINTER(i64),
+                                                C.POINTER(C.c_uint32)],
     }
     for name, args in sig.items():
         fn = getattr(L, name)
@@ -490,6 +502,58 @@ class DeviceGP(object):
             out = np.empty(m) if want_values else None
             check(lib().robo_acq_eval(self._h, ACQ_KINDS[kind], float(par), float(eta), _arr(Xc), m,
                                       _arr(out) if want_values else None, C.byref(mx), C.byref(am), C.byref(fl)))
+        return out, mx.value, am.value, fl.value
+
+
+class Comm(object):
+    """robo_comm: this process's rank in a one-process-per-GPU job; the exchanges of the candidate / sample shards run
+    inside the library as RCCL all-gathers on the context's stream (include/robo_hip.h).  Every method is COLLECTIVE."""
+
+    @staticmethod
+    def create_id():
+        """rank 0: the 128-byte id every rank must be given (out of band) before constructing its Comm"""
+        buf = C.create_string_buffer(COMM_ID_BYTES)
+        check(lib().robo_comm_create_id(buf))
+        return bytes(buf.raw)
+
+    def __init__(self, ctx, rank, world, comm_id):
+        assert len(comm_id) == COMM_ID_BYTES
+        self.ctx, self.rank, self.world = ctx, int(rank), int(world)
+        self._h = C.c_void_p()
+        check(lib().robo_comm_init(ctx._h, self.rank, self.world, bytes(comm_id), C.byref(self._h)))
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h:
+            lib().robo_comm_destroy(self._h)
+            self._h = None
+
+    def allgather(self, values):
+        """values: (count,) host doubles -> (world, count), identical on every rank"""
+        v = _f64(np.asarray(values, dtype=np.float64).reshape(-1))
+        out = np.empty((self.world, v.shape[0]))
+        check(lib().robo_comm_allgather(self._h, _arr(v), v.shape[0], _arr(out)))
+        return out
+
+    def acq_sharded(self, gp, kind, par, eta, cand, global_offset, want_values=False):
+        """candidate shard -> (this rank's values or None, GLOBAL max, GLOBAL argmax, owner rank, flags OR-ed)"""
+        out = np.empty(cand.m) if want_values else None
+        mx, am, own, fl = C.c_double(0), C.c_int64(0), C.c_int32(0), C.c_uint32(0)
+        check(lib().robo_acq_eval_cand_sharded(self._h, gp._h, ACQ_KINDS[kind], float(par), float(eta), cand._h,
+                                               int(global_offset), _arr(out) if want_values else None, C.byref(mx),
+                                               C.byref(am), C.byref(own), C.byref(fl)))
+        return out, mx.value, am.value, own.value, fl.value
+
+    def acq_marginal_sharded(self, gps, s_total, kind, par, etas, cand, want_values=True):
+        """sample shard: this rank's fitted GPs (possibly none) -> (mean over ALL s_total samples or None, max,
+        argmax, flags), identical on every rank"""
+        S = len(gps)
+        arr = (C.c_void_p * max(S, 1))(*[g._h for g in gps])
+        etas = _f64(np.asarray(etas, dtype=np.float64).reshape(-1)) if S else np.zeros(1)
+        out = np.empty(cand.m) if want_values else None
+        mx, am, fl = C.c_double(0), C.c_int64(0), C.c_uint32(0)
+        check(lib().robo_acq_eval_marginal_cand_sharded(self._h, arr, S, int(s_total), ACQ_KINDS[kind], float(par),
+                                                        _arr(etas), cand._h, _arr(out) if want_values else None,
+                                                        C.byref(mx), C.byref(am), C.byref(fl)))
         return out, mx.value, am.value, fl.value
 
 

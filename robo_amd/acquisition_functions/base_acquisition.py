@@ -92,6 +92,38 @@ class ClosedFormAcquisition(BaseAcquisitionFunction):
             return int(am)
         return int(np.argmax(self.compute(X, eta=eta)))
 
+    def argmax_sharded(self, comm, X_slice, global_offset):
+        """Candidate shard (robo_amd.sharding.sharded_argmax): this rank's slice of the candidate matrix, whose first
+        row has global index ``global_offset`` -> the GLOBAL np.argmax index, identical on every rank.  Posterior,
+        acquisition, local argmax, the RCCL all-gather of the per-rank incumbents and the cross-rank tie-break are one
+        library call (robo_acq_eval_cand_sharded); the reference's EI guards act on the flags OR-ed over all ranks,
+        i.e. exactly as they would on the unsharded batch."""
+        eta = self._eta(None)
+        if not self._is_native():
+            from robo_amd import sharding
+            vals = np.asarray(self.compute(X_slice), dtype=np.float64).reshape(-1)
+            if vals.shape[0] != X_slice.shape[0]:
+                vals = np.zeros(X_slice.shape[0])
+            j = int(np.argmax(vals))
+            return sharding.allgather_argmax(float(vals[j]), global_offset + j)[1]
+        model = self.model
+        if not model.is_trained:
+            raise Exception('Model has to be trained first!')
+        model._materialise()
+        norm = model.normalize if hasattr(model, "normalize") else model._normalised
+        cand = _lib.Candidates(model.gp.ctx, norm(X_slice))
+        try:
+            _, mx, am, _, flags = comm.acq_sharded(model.gp, self.kind, self.par, eta, cand, global_offset)
+        finally:
+            cand.close()
+        self.last_max, self.last_argmax = mx, am
+        if self.kind == "ei":
+            if flags & _lib.FLAG_ZERO_SIGMA:
+                return 0
+            if flags & _lib.FLAG_NEGATIVE_EI:
+                raise ValueError
+        return int(am)
+
     def _moment_gradients(self, X):
         """(mean, var, d mean / d x (M, D), d var / d x (M, D)) from ``model.predictive_gradients`` -- the
         protocol of ei.py:80-85 / pi.py:65-71 / lcb.py:66-68 (GPy shapes: dmdx (M, D, 1), dvdx (M, D))."""

@@ -90,28 +90,37 @@ class MarginalizationGPMCMC(BaseAcquisitionFunction):
             # a device-generated batch lives in the normalised space of ITS maximiser's model; the sample shard
             # evaluates host coordinates (every rank must see the same points): bring them back once
             X_test = self._host_points(X_test)
-        negative_ei = False
-        if est and isinstance(self.acquisition_func, ClosedFormAcquisition) and \
-                all(isinstance(getattr(x.model, "gp", None), _lib.DeviceGP) and x.model.is_trained for x in est):
-            models = [x.model for x in est]
-            norm = models[0].normalize if hasattr(models[0], "normalize") else models[0]._normalised
-            cand = _lib.Candidates(models[0].gp.ctx, norm(X_test))
+        comm = sharding.comm()
+        # which exchange runs must not depend on the rank: decided from the CLASSES of all estimators' models
+        fused = isinstance(self.acquisition_func, ClosedFormAcquisition) and \
+            all(hasattr(x.model, "acquisition") and hasattr(x.model, "gp") for x in self.estimators)
+        if fused:
+            # partial sums on the device, all-gathered and added in rank order inside the library
+            # (robo_acq_eval_marginal_cand_sharded); a rank without samples (S < world) takes part with an empty sum
+            for x in est:
+                if not x.model.is_trained:
+                    raise Exception('Model has to be trained first!')
+                x.model._materialise()
+            ref = est[0] if est else self.estimators[0]
+            if est:
+                m0 = ref.model
+                Xn = (m0.normalize if hasattr(m0, "normalize") else m0._normalised)(X_test)
+            else:
+                Xn = np.zeros_like(np.asarray(X_test, dtype=np.float64))      # never evaluated: no local sample
+            cand = _lib.Candidates(comm.ctx, Xn)
             try:
-                part, _, _, flags = _lib.acq_marginal([m.gp for m in models], est[0].kind, est[0].par,
-                                                      np.array([x._eta(None) for x in est]), cand, reduce="sum")
+                vals, mx, am, flags = comm.acq_marginal_sharded([x.model.gp for x in est], S, ref.kind, ref.par,
+                                                                [x._eta(None) for x in est], cand)
             finally:
                 cand.close()
-            negative_ei = est[0].kind == "ei" and bool(flags & _lib.FLAG_NEGATIVE_EI)
-        else:
-            part = np.zeros(X_test.shape[0])
-            for x in est:
-                part = part + np.asarray(x.compute(X_test), dtype=np.float64).reshape(-1)
-        # the guard of ei.py:86-88 travels WITH the partial sums (one extra entry): raising on one rank before the
-        # collective would leave the others waiting in it
-        total = sharding.allgather_ordered_sum(np.append(part, 1.0 if negative_ei else 0.0))
-        if total[-1] > 0:
-            raise ValueError
-        return total[:-1] / S
+            self.last_max, self.last_argmax = mx, am
+            if ref.kind == "ei" and flags & _lib.FLAG_NEGATIVE_EI:
+                raise ValueError                      # the flags are OR-ed over all ranks: every rank raises
+            return vals
+        part = np.zeros(X_test.shape[0])
+        for x in est:
+            part = part + np.asarray(x.compute(X_test), dtype=np.float64).reshape(-1)
+        return sharding.allgather_ordered_sum(part) / S
 
     def _host_points(self, cand):
         """coordinates of a device candidate batch in the caller's input space"""

@@ -1299,3 +1299,20 @@ int32_t robo_ig_eval_moments(robo_ctx* ctx, int64_t m, int32_t nb, int32_t npts,
 
 // ---------------------------------------------------------------------------------------
 }  // extern "C"
+
+// the local halves of the sharded entry points (comm.hip)
+namespace robo {
+int api_acq_local(robo_gp* g, int kind, double par, double eta, robo_cand* k) {
+    ROBO_TRY(check_acq_kind(kind));
+    ROBO_TRY(predict_core(g, k, false));
+    return clear_flags_on_error(k, launch_acq(g->ctx, k, kind, par, eta, false, false));
+}
+int api_acq_accumulate(robo_gp* const* gps, int S, int kind, double par, const double* etas, robo_cand* k) {
+    return acq_accumulate(gps, S, kind, par, etas, k);
+}
+int api_acq_read_back(robo_cand* k, const double* d_vec, double* out_vec, double* out_max, int64_t* out_argmax,
+                      uint32_t* out_flags) {
+    return acq_read_back(k, d_vec, out_vec, out_max, out_argmax, out_flags);
+}
+int api_clear_flags(robo_cand* k, int status) { return clear_flags_on_error(k, status); }
+}  // namespace robo

@@ -1,32 +1,75 @@
 """Multi-GPU sharding of the two independent axes of the hot path.
 
-One process per GPU (torch.distributed; backend "nccl" is RCCL over xGMI on ROCm, "gloo"
-in the CPU tests).  No data-path collective: every rank holds a full replica of the fitted
-GP (the fit is deterministic, so running it on every rank is cheaper than broadcasting L)
-and evaluates its own contiguous shard.  The only exchanges are
+One process per GPU.  No data-path collective: every rank holds a full replica of the fitted GP (the fit is
+deterministic, so running it on every rank is cheaper than broadcasting L) and evaluates its own contiguous shard.
+The exchanges run INSIDE librobo_hip.so (robo_amd/csrc/comm.hip: RCCL all-gathers on the library's stream, device
+pointers on both sides) through a :class:`robo_amd._lib.Comm`:
 
-* candidate shard:  all-gather of one (max, global index) pair per rank, then the same
-  np.argmax tie-break on every rank (lowest global index, NaN maximal);
-* sample shard:     all-gather of the per-rank partial sums of M acquisition values and a
-  RANK-ORDERED local sum: deterministic and identical on every rank (an all-reduce SUM
-  guarantees neither).  It equals the single-GPU sample-order accumulation of
+* candidate shard:  all-gather of one (max, global index, flags) triple per rank, then the np.argmax tie-break
+  (lowest global index, NaN maximal) -- ``robo_acq_eval_cand_sharded``;
+* sample shard:     all-gather of the per-rank partial sums of M acquisition values and a RANK-ORDERED sum:
+  deterministic and identical on every rank (an all-reduce SUM guarantees neither) --
+  ``robo_acq_eval_marginal_cand_sharded``.  It equals the single-GPU sample-order accumulation of
   MarginalizationGPMCMC.compute up to fp64 re-association (partial sums are formed per shard).
+
+The communicator needs one 128-byte id on every rank.  ``init_comm`` takes it from the caller (any launcher);
+without that call, a process whose ``torch.distributed`` default group is initialised gets its communicator on first
+use, the id travelling through ``broadcast_object_list`` -- torch is then rendezvous plumbing only, nothing of the
+data path touches it.
 """
 import numpy as np
 
+_comm = None            # this process's library communicator (robo_amd._lib.Comm)
 
-def dist_info():
-    """(torch.distributed module or None, rank, world_size) of the initialised default process group"""
-    # torch is plumbing for multi-GPU runs only: a process group can only have been initialised by code that already
-    # imported torch.distributed, so a single-process run never pays the ~1 s import (it used to, on the first
-    # maximize() of every BO run)
+
+def init_comm(rank, world, comm_id, ctx=None):
+    """Join the job: rank in [0, world), comm_id = the bytes rank 0 got from ``robo_amd._lib.Comm.create_id()``."""
+    global _comm
+    from robo_amd import _lib
+    if _comm is not None:
+        _comm.close()
+    _comm = _lib.Comm(ctx if ctx is not None else _lib.default_context(), rank, world, comm_id)
+    return _comm
+
+
+def close_comm():
+    global _comm
+    if _comm is not None:
+        _comm.close()
+        _comm = None
+
+
+def _torch_group():
+    """(rank, world) of an initialised torch.distributed default group, else None -- without importing torch: a
+    group can only have been initialised by code that already imported torch.distributed"""
     import sys
     dist = sys.modules.get("torch.distributed")
-    if dist is None:
+    if dist is None or not (dist.is_available() and dist.is_initialized()):
+        return None
+    return dist.get_rank(), dist.get_world_size()
+
+
+def comm():
+    """the library communicator of this process, or None in a single-process run"""
+    global _comm
+    if _comm is not None:
+        return _comm if _comm.world > 1 else None
+    tg = _torch_group()
+    if tg is None or tg[1] == 1:
+        return None
+    import torch.distributed as dist
+    from robo_amd import _lib
+    box = [_lib.Comm.create_id() if tg[0] == 0 else None]
+    dist.broadcast_object_list(box, src=0)              # rendezvous only: 128 bytes, once per process
+    return init_comm(tg[0], tg[1], box[0])
+
+
+def dist_info():
+    """(communicator or None, rank, world_size)"""
+    c = comm()
+    if c is None:
         return None, 0, 1
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
-        return dist, dist.get_rank(), dist.get_world_size()
-    return None, 0, 1
+    return c, c.rank, c.world
 
 
 def shard_range(n_items, rank, world):
@@ -58,75 +101,64 @@ def reduce_argmax(pairs):
     return best
 
 
-def allgather_argmax(local_max, local_global_index, device=None):
-    """Exchange the per-shard incumbents (16 B per rank) -> global (max, argmax)."""
-    if dist_info()[2] == 1:
+def allgather_argmax(local_max, local_global_index):
+    """Exchange the per-shard incumbents of values computed OUTSIDE the fused entry point (any acquisition function,
+    e.g. the information gain) -> global (max, argmax).  The index travels as an exact float64 (< 2^53)."""
+    c = comm()
+    if c is None:
         return float(local_max), int(local_global_index)
-    import torch
-    import torch.distributed as dist
-    world = dist.get_world_size()
-    dev = device if device is not None else ("cuda" if dist.get_backend() == "nccl" else "cpu")
-    # the index travels as an exact float64 (< 2^53) next to the value: one 16-byte message
-    mine = torch.tensor([float(local_max), float(local_global_index)], dtype=torch.float64, device=dev)
-    out = [torch.empty_like(mine) for _ in range(world)]
-    dist.all_gather(out, mine)
-    pairs = [(float(t[0].item()), int(t[1].item())) for t in out]
-    return reduce_argmax(pairs)
+    rows = c.allgather([float(local_max), float(local_global_index)])
+    return reduce_argmax((float(r[0]), int(r[1])) for r in rows)
 
 
-def allgather_ordered_sum(partial_sum, device=None):
-    """Sum per-rank partial acquisition sums in rank order (deterministic on every rank)."""
-    if dist_info()[2] == 1:
-        return np.asarray(partial_sum, dtype=np.float64)
-    import torch
-    import torch.distributed as dist
-    world = dist.get_world_size()
-    dev = device if device is not None else ("cuda" if dist.get_backend() == "nccl" else "cpu")
-    mine = torch.as_tensor(np.ascontiguousarray(partial_sum, dtype=np.float64)).to(dev)
-    out = [torch.empty_like(mine) for _ in range(world)]
-    dist.all_gather(out, mine)
-    total = out[0].clone()
-    for t in out[1:]:
-        total += t
-    return total.cpu().numpy()
+def allgather_ordered_sum(partial_sum):
+    """Sum per-rank partial vectors in rank order (deterministic on every rank) -- the generic form for quantities
+    that are not acquisition sums (the mixture posterior of GaussianProcessMCMC.predict)."""
+    c = comm()
+    part = np.ascontiguousarray(partial_sum, dtype=np.float64)
+    if c is None:
+        return part
+    rows = c.allgather(part.reshape(-1))
+    total = rows[0].copy()
+    for r in rows[1:]:
+        total += r
+    return total.reshape(part.shape)
 
 
-def allgather_rows(row, device=None):
+def allgather_rows(row):
     """every rank contributes one fp64 row (D,) -> (world, D), identical on every rank"""
-    if dist_info()[2] == 1:
+    c = comm()
+    if c is None:
         return np.asarray(row, dtype=np.float64)[None, :]
-    import torch
-    import torch.distributed as dist
-    world = dist.get_world_size()
-    dev = device if device is not None else ("cuda" if dist.get_backend() == "nccl" else "cpu")
-    mine = torch.as_tensor(np.ascontiguousarray(row, dtype=np.float64)).to(dev)
-    out = [torch.empty_like(mine) for _ in range(world)]
-    dist.all_gather(out, mine)
-    return np.stack([t.cpu().numpy() for t in out])
+    return c.allgather(row)
 
 
 def assert_replicated(what, values):
     """Every rank passes the same small vector of numbers, or ALL ranks raise: the check in front of a sharded
     maximisation (ranks that drifted apart -- other seeds, another number of maximize() calls -- would otherwise
     dead-lock in the exchange or score a point against another rank's model)."""
-    _, rank, world = dist_info()
-    if world == 1:
+    c = comm()
+    if c is None:
         return
     rows = allgather_rows(np.asarray(values, dtype=np.float64))
     if not all(np.array_equal(rows[0], r, equal_nan=True) for r in rows[1:]):
         raise RuntimeError("%s differ across ranks (rank %d of %d holds %r): sharded maximisation needs identical "
-                           "seeds and call sequences on every rank" % (what, rank, world, list(values)))
+                           "seeds and call sequences on every rank" % (what, c.rank, c.world, list(values)))
 
 
 def sharded_argmax(acq, X):
     """Candidate shard of one acquisition maximisation (SURVEY.md 8e axis 1): every rank evaluates its contiguous
     slice of the SAME candidate matrix X against its own replica of the model and the per-shard incumbents are
-    exchanged (16 B per rank).  Returns the global np.argmax index, identical on every rank and identical to the
-    single-process result (values are computed per candidate, so sharding does not change them)."""
-    _, rank, world = dist_info()
+    exchanged.  Returns the global np.argmax index, identical on every rank and identical to the single-process
+    result (values are computed per candidate, so sharding does not change them).  Closed-form acquisitions on a
+    device GP go through the fused entry point (posterior, acquisition, local argmax, RCCL all-gather and the
+    cross-rank tie-break in one library call)."""
+    c, rank, world = dist_info()
     if world == 1:
         return int(acq.argmax(X)) if hasattr(acq, "argmax") else int(np.argmax(acq(X)))
     b, e = shard_range(X.shape[0], rank, world)
+    if hasattr(acq, "argmax_sharded") and e > b:
+        return acq.argmax_sharded(c, X[b:e], b)
     if e > b:
         vals = np.asarray(acq(X[b:e]), dtype=np.float64).reshape(-1)
         if vals.shape[0] != e - b:          # EI's whole-batch collapse to [[0]] (ei.py:72-74): every value is 0

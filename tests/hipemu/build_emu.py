@@ -33,5 +33,18 @@ def build(force=False):
     return OUT
 
 
+FAKE_RCCL = os.path.join(HERE, "_build", "libfake_rccl.so")
+
+
+def build_fake_rccl(force=False):
+    """the shared-memory stand-in for librccl.so (fake_rccl.cpp): ROBO_RCCL_LIB points comm.hip at it"""
+    src = os.path.join(HERE, "fake_rccl.cpp")
+    if not force and os.path.exists(FAKE_RCCL) and os.path.getmtime(src) <= os.path.getmtime(FAKE_RCCL):
+        return FAKE_RCCL
+    os.makedirs(os.path.dirname(FAKE_RCCL), exist_ok=True)
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", src, "-o", FAKE_RCCL, "-lrt", "-pthread"])
+    return FAKE_RCCL
+
+
 if __name__ == "__main__":
     print(build(force=True))

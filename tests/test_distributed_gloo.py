@@ -1,4 +1,6 @@
-"""The N > 1 exchange steps of the sharded hot path on CPU: world_size 2, gloo backend."""
+"""The N > 1 exchange steps of the sharded hot path on CPU, world_size 2: the library's own collective entry points
+(robo_amd/csrc/comm.hip) through the interpreter build, with tests/hipemu/fake_rccl.cpp standing in for librccl.so
+(ROBO_RCCL_LIB) and torch.distributed (gloo) doing what it does in a real job -- the rendezvous of the 128-byte id."""
 import os
 import socket
 
@@ -18,11 +20,25 @@ def _free_port():
     return p
 
 
+def _emu_setup():
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    sys.path.insert(0, os.path.join(here, "hipemu"))
+    import build_emu
+    from robo_amd import _lib
+    os.environ["ROBO_RCCL_LIB"] = build_emu.build_fake_rccl()
+    _lib.use_library(build_emu.build())
+    return _lib
+
+
 def _worker(rank, world, port, out_dir):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
+    _lib = _emu_setup()
     from robo_amd import sharding
+    c, r, w = sharding.dist_info()               # the library communicator, id broadcast through the process group
+    assert isinstance(c, _lib.Comm) and (r, w) == (rank, world)
     # candidate shard: global acquisition vector with a tie across the shard boundary and a NaN case
     M = 1000
     y = np.random.RandomState(5).randint(0, 50, size=M).astype(float)
@@ -42,16 +58,60 @@ def _worker(rank, world, port, out_dir):
     total = sharding.allgather_ordered_sum(acq[sb:se].sum(axis=0))
     np.testing.assert_allclose(total, acq.sum(axis=0), rtol=1e-14)
     np.save(os.path.join(out_dir, "total_%d.npy" % rank), total)
+    # the fused entry points on device handles: candidate shard and sample shard against the single-rank calls
+    from oracle import gp_oracle as O
+    rs = np.random.RandomState(3)
+    N, D, Mc = 150, 3, 701
+    X = rs.rand(N, D)
+    yy = np.sin(3 * X.sum(axis=1))
+    Xc = rs.rand(Mc, D)
+    thetas = np.array([[0.1, np.log(0.5), np.log(0.7), np.log(0.9), np.log(1e-2)]]) + 0.2 * rs.randn(5, 5)
+    ctx = c.ctx
+    gps = [_lib.DeviceGP(ctx, "matern52", N, D) for _ in range(5)]
+    gps[0].set_data(X, yy)
+    _, st = _lib.fit_batch(gps, thetas, float(yy.mean()))
+    assert np.all(st == _lib.OK)
+    eta = float(yy.min())
+    full = _lib.Candidates(ctx, Xc)
+    v_ref, mx_ref, am_ref, fl_ref = gps[0].acq("ei", 0.0, eta, full)
+    b, e = sharding.shard_range(Mc, rank, world)
+    mine = _lib.Candidates(ctx, Xc[b:e])
+    v, mx, am, owner, fl = c.acq_sharded(gps[0], "ei", 0.0, eta, mine, b, want_values=True)
+    np.testing.assert_array_equal(v, v_ref[b:e])
+    assert (mx, am, fl) == (mx_ref, am_ref, fl_ref) and owner == (0 if am_ref < sharding.shard_range(Mc, 0, world)[1] else 1)
+    vm_ref, mxm_ref, amm_ref, _ = _lib.acq_marginal(gps, "log_ei", 0.0, np.full(5, eta), full)
+    sb, se = sharding.shard_range(5, rank, world)
+    vm, mxm, amm, _ = c.acq_marginal_sharded(gps[sb:se], 5, "log_ei", 0.0, np.full(se - sb, eta), full)
+    np.testing.assert_allclose(vm, vm_ref, rtol=1e-13, atol=1e-15)
+    assert amm == amm_ref
+    np.save(os.path.join(out_dir, "marg_%d.npy" % rank), vm)
+    # a rank without samples (S < world) takes part with an empty partial sum
+    vm1, _, amm1, _ = c.acq_marginal_sharded(gps[:1] if rank == 0 else [], 1, "log_ei", 0.0, [eta], full)
+    v1, _, am1, _ = gps[0].acq("log_ei", 0.0, eta, full)
+    np.testing.assert_array_equal(vm1, v1)
+    assert amm1 == am1
+    # a rank whose local half fails still joins the exchange, then reports its error
+    unfitted = _lib.DeviceGP(ctx, "matern52", N, D)
+    raised = False
+    try:
+        c.acq_sharded(unfitted if rank == 1 else gps[0], "ei", 0.0, eta, mine, b)
+    except Exception:
+        raised = True
+    assert raised == (rank == 1)
+    for h in gps + [full, mine, unfitted]:
+        h.close()
     dist.barrier()
+    sharding.close_comm()
     dist.destroy_process_group()
 
 
 def test_sharded_exchange_world2(tmp_path):
     port = _free_port()
     mp.spawn(_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
-    a = np.load(tmp_path / "total_0.npy")
-    b = np.load(tmp_path / "total_1.npy")
-    np.testing.assert_array_equal(a, b)        # bit-identical on both ranks
+    for name in ("total", "marg"):
+        a = np.load(tmp_path / ("%s_0.npy" % name))
+        b = np.load(tmp_path / ("%s_1.npy" % name))
+        np.testing.assert_array_equal(a, b)        # bit-identical on both ranks
 
 
 def _class_worker(rank, world, port, out_dir):
@@ -60,11 +120,8 @@ def _class_worker(rank, world, port, out_dir):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    here = os.path.dirname(os.path.abspath(__file__))
-    sys.path.insert(0, os.path.join(here, "hipemu"))
-    import build_emu
-    from robo_amd import _lib, sharding
-    _lib.use_library(build_emu.build())
+    _lib = _emu_setup()
+    from robo_amd import sharding
     from robo_amd import acquisition_functions as A
     from robo_amd.kernels import Matern52Kernel
     from robo_amd.maximizers import DeviceRandomSampling, RandomSampling
@@ -164,6 +221,7 @@ def _class_worker(rank, world, port, out_dir):
     np.testing.assert_allclose(m_sh, m_ref, rtol=1e-13)
     np.testing.assert_allclose(v_sh, v_ref, rtol=1e-9)
     dist.barrier()
+    sharding.close_comm()
     dist.destroy_process_group()
 
 

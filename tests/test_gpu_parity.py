@@ -425,5 +425,36 @@ def test_winv_small_batch_path(ctx):
     P.check_winv_path(ctx, cases=(("matern52", 4096, 16, 500), ("matern52", 2000, 8, 8192)))
 
 
+def test_comm_one_rank_rccl(ctx):
+    """the collective entry points on the real librccl.so with a one-rank communicator (this lease has one GPU): same
+    results as the single-process calls; the world_size-2 semantics are covered on CPU (tests/test_distributed_gloo.py,
+    shared-memory stand-in for RCCL)"""
+    assert "ROBO_RCCL_LIB" not in os.environ
+    comm = _lib.Comm(ctx, 0, 1, _lib.Comm.create_id())
+    rs = np.random.RandomState(3)
+    N, D, Mc = 700, 5, 3001
+    X = rs.rand(N, D)
+    y = np.sin(3 * X.sum(axis=1))
+    thetas = np.concatenate([[0.1], np.full(D, np.log(0.3 * D)), [np.log(1e-2)]])[None, :] + 0.2 * rs.randn(4, D + 2)
+    gps = [_lib.DeviceGP(ctx, "matern52", N, D) for _ in range(4)]
+    gps[0].set_data(X, y)
+    _, st = _lib.fit_batch(gps, thetas, float(y.mean()))
+    assert np.all(st == _lib.OK)
+    cand = _lib.Candidates(ctx, rs.rand(Mc, D))
+    eta = float(y.min())
+    np.testing.assert_array_equal(comm.allgather([1.5, -2.0, 7.0]), [[1.5, -2.0, 7.0]])
+    v_ref, mx_ref, am_ref, fl_ref = gps[0].acq("ei", 0.0, eta, cand)
+    v, mx, am, owner, fl = comm.acq_sharded(gps[0], "ei", 0.0, eta, cand, 1000, want_values=True)
+    np.testing.assert_array_equal(v, v_ref)
+    assert (mx, am, owner, fl) == (mx_ref, am_ref + 1000, 0, fl_ref)
+    vm_ref, mxm, amm, _ = _lib.acq_marginal(gps, "log_ei", 0.0, np.full(4, eta), cand)
+    vm, mxs, ams, _ = comm.acq_marginal_sharded(gps, 4, "log_ei", 0.0, np.full(4, eta), cand)
+    np.testing.assert_array_equal(vm, vm_ref)
+    assert (mxs, ams) == (mxm, amm)
+    comm.close()
+    for h in gps + [cand]:
+        h.close()
+
+
 def test_host_array_handle_reuse(ctx):
     P.check_host_array_handle_reuse(ctx)

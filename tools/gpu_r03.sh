@@ -23,6 +23,10 @@ configs)
   done
   timeout 900 python bench.py --gpus 1 --config c5 --m 1048576 --steps 2 --warmup 1 --no-cpu-baseline >> $OUT/configs.jsonl 2>> $OUT/configs.err; echo "c5 full rc=$?" >> $OUT/summary.txt
   cut -c1-300 $OUT/configs.jsonl >> $OUT/summary.txt ;;
+dist)
+  ROBO_BENCH_FORCE_DIST=1 timeout 600 python bench.py --gpus 1 --no-cpu-baseline > $OUT/forcedist.json 2> $OUT/forcedist.err; echo "forcedist rc=$?" >> $OUT/summary.txt
+  ROBO_BENCH_FORCE_DIST=1 timeout 600 python bench.py --gpus 1 --config c3 --no-cpu-baseline > $OUT/forcedist_c3.json 2>> $OUT/forcedist.err; echo "forcedist c3 rc=$?" >> $OUT/summary.txt
+  cut -c1-200 $OUT/forcedist.json $OUT/forcedist_c3.json >> $OUT/summary.txt; tail -3 $OUT/forcedist.err >> $OUT/summary.txt ;;
 prof)
   timeout 900 rocprofv3 --kernel-trace --stats -d $OUT/prof -o bench -- python bench.py --gpus 1 --no-cpu-baseline > $OUT/prof_bench.json 2> $OUT/prof.err; echo "rocprof rc=$?" >> $OUT/summary.txt
   python tools/rocpd_stats.py $OUT/prof/bench_results.db > $OUT/bench_kernel_stats.csv 2>> $OUT/prof.err
