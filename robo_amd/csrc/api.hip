@@ -41,6 +41,7 @@ static const TuneKey TUNE_KEYS[] = {
     {"potrf_tm4_min", nullptr, &Tuning::potrf_tm4_min, 96},
     {"potrf_max_wg", nullptr, &Tuning::potrf_max_wg, 0},
     {"potrf_group", nullptr, &Tuning::potrf_group, 4},
+    {"gram_persistent", nullptr, &Tuning::gram_persistent, 0},
 };
 
 static void tune_set(Tuning* t, const TuneKey& k, long long v) {

@@ -46,8 +46,10 @@ static Rccl* rccl() {
     if (api.handle) return &api;
     const char* name = getenv("ROBO_RCCL_LIB");       // (not a hot path: once per process)
     if (!name || !*name) name = "librccl.so";
-    void* h = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
-    if (!h && strcmp(name, "librccl.so") == 0) h = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+    // RTLD_LOCAL: a process that also runs torch.distributed has torch's own bundled librccl.so loaded; the five
+    // symbols are taken from THIS handle and nothing is interposed
+    void* h = dlopen(name, RTLD_NOW | RTLD_LOCAL);
+    if (!h && strcmp(name, "librccl.so") == 0) h = dlopen("librccl.so.1", RTLD_NOW | RTLD_LOCAL);
     if (!h) {
         set_error("cannot load %s: %s", name, dlerror());
         return nullptr;

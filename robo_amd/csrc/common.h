@@ -88,6 +88,7 @@ struct Tuning {
     int winv_min_blocks;
     int potrf_fused;             // 0: never fuse the next diagonal block into the trailing update
     int potrf_tm4_min, potrf_max_wg, potrf_group;
+    int gram_persistent;         // K1: persistent workgroups per CU; 0 (default, faster: r03d) = one workgroup per tile
 };
 void tuning_from_env(Tuning* t);
 }  // namespace robo

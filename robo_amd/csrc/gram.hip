@@ -45,10 +45,14 @@ __global__ __launch_bounds__(256) void scale_inputs_theta_kernel(const double* _
                                                                  const ThetaArgs ta, long long rows_real,
                                                                  long long rows_pad, int dim,
                                                                  double* __restrict__ ism_out,
-                                                                 FitSample* __restrict__ sp_out) {
+                                                                 FitSample* __restrict__ sp_out,
+                                                                 int* __restrict__ tile_counter) {
     if (blockIdx.x == 0) {
         for (int d = threadIdx.x; d < dim; d += blockDim.x) ism_out[d] = ta.ism[d];
-        if (threadIdx.x == 0) *sp_out = ta.sp;
+        if (threadIdx.x == 0) {
+            *sp_out = ta.sp;
+            *tile_counter = 0;     // the persistent gram kernel's tile hand-out starts at 0 (no memset launch)
+        }
     }
     const long long total = rows_pad * dim;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
@@ -62,12 +66,13 @@ __global__ __launch_bounds__(256) void scale_inputs_theta_kernel(const double* _
 
 int launch_scale_inputs_theta(robo_ctx* ctx, const double* d_in, double* d_out, const ThetaArgs& ta, int64_t rows_real,
                               int64_t rows_pad, int dim, double* d_ism_out, FitSample* d_sp_out) {
+    int* d_counter = ctx->d_fail + 2;     // d_fail[0]: failure flag; [2]: tile counter of gram_persistent_kernel
     const long long total = (long long)rows_pad * dim;
     int blocks = (int)((total + 255) / 256);
     if (blocks > 4096) blocks = 4096;
     if (blocks < 1) blocks = 1;
     hipLaunchKernelGGL(scale_inputs_theta_kernel, dim3(blocks), dim3(256), 0, ctx->stream, d_in, d_out, ta,
-                       (long long)rows_real, (long long)rows_pad, dim, d_ism_out, d_sp_out);
+                       (long long)rows_real, (long long)rows_pad, dim, d_ism_out, d_sp_out, d_counter);
     ROBO_LAUNCH_CHECK();
     return ROBO_OK;
 }
@@ -245,6 +250,181 @@ __global__ __launch_bounds__(256, 6) void gram_kernel(const double* __restrict__
     }
 }
 
+
+// ---- K1, single theta, fp64 stationary kernels: PERSISTENT workgroups -------------------------------------------------
+// gram_kernel above launches one short workgroup per 64 x 64 tile (2211 at N = 4096): every resident workgroup goes
+// through  load coordinates -> barrier -> 16 LDS-fed distance passes -> sqrt / exp -> store  in the same phase at the
+// same time, the dispatcher has 8844 waves to start, and the fp64 VALU -- the bounding resource, 69 instructions per
+// pair -- was busy for less than half of the kernel's 76k cycles (r02 PMC and ablations).  Here WPC
+// workgroups per CU stay for the whole kernel and take tiles from an atomic counter (heaviest-first is irrelevant: all
+// tiles cost the same); the NEXT tile's coordinates are requested before the current tile's math and land in registers
+// while it runs (double-buffered LDS images), stores drain behind the following tile.  Same arithmetic per entry as
+// gram_kernel<double, KIND> (pair_cov_dot): bit-identical K.
+// MEASURED SLOWER (r03d, MI355X, N = 4096 D = 16): 42.0 us with 3..8 workgroups per CU, 54 us with one, against 34.5 us
+// for gram_kernel (N = 8192 D = 64: 195 vs 185 us; N = 2048: 23 vs 17.5 us).  The kernel is bound by its fp64 VALU work
+// (69 instructions per pair = 15.8 us at 100 % issue), not by phase alignment or dispatch: at 122 VGPRs only four waves
+// per SIMD are resident instead of six, and that costs more than the prefetch hides.  Kept as an option (tuning key
+// gram_persistent = workgroups per CU, default 0 = off) with its equality test; see DESIGN.md section 4.
+struct TileRegs {
+    double v[8];    // 64 rows x 16 dims of the i block (0..3) and of the j block (4..7): thread t holds [row (t + 256 e) >> 4][d = t & 15]
+};
+
+__device__ __forceinline__ TileRegs tile_coords_load(const double* __restrict__ X, long long i0, long long j0, int dim,
+                                                     int d0) {
+    const int t = threadIdx.x, d = t & 15;
+    const bool ok = d0 + d < dim;
+    TileRegs r;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const int row = (t + e * 256) >> 4;
+        r.v[e] = ok ? X[(i0 + row) * dim + d0 + d] : 0.0;
+        r.v[4 + e] = ok ? X[(j0 + row) * dim + d0 + d] : 0.0;
+    }
+    return r;
+}
+
+__device__ __forceinline__ void tile_coords_stage(const TileRegs& r, double* sI, double* sJ) {
+    const int t = threadIdx.x, d = t & 15;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const int row = (t + e * 256) >> 4;
+        sI[d * GLD + row] = r.v[e];
+        sJ[d * GLD + row] = r.v[4 + e];
+    }
+}
+
+template <int KIND>
+__global__ __launch_bounds__(256, 4) void gram_persistent_kernel(const double* __restrict__ Xs,
+                                                                 const double* __restrict__ y, double* __restrict__ K,
+                                                                 int n, int n_pad, const FitSample* __restrict__ sp,
+                                                                 int* __restrict__ fail, int* __restrict__ counter,
+                                                                 int tiles) {
+    __shared__ double sI[2][GD * GLD];
+    __shared__ double sJ[2][GD * GLD];
+    __shared__ double sN[2 * GT];
+    __shared__ int sNext;
+    if (blockIdx.x == 0 && threadIdx.x == 0) fail[0] = 0;
+    const CovParams cp = sp[0].cov;
+    const double noise = sp[0].noise, mean_c = sp[0].mean_c;
+    const int t = threadIdx.x, tx = t & 15, ty = t >> 4, dim = cp.dim;
+    const double* sMine = nullptr;
+    int cur = (int)blockIdx.x;                 // the first gridDim.x tiles are handed out statically
+    if (cur >= tiles) return;
+    int bi, bj;
+    tri_tile(cur, bi, bj);
+    TileRegs regs = tile_coords_load(Xs, (long long)bi * GT, (long long)bj * GT, dim, 0);
+    int buf = 0;
+    for (;;) {
+        const long long i0 = (long long)bi * GT, j0 = (long long)bj * GT;
+        // claim the next tile and request its first coordinate chunk: in flight during this tile's math
+        if (t == 0) sNext = atomicAdd(counter, 1) + (int)gridDim.x;
+        tile_coords_stage(regs, sI[buf], sJ[buf]);
+        __syncthreads();                        // staged coordinates + sNext visible
+        const int nxt = sNext;
+        int nbi = 0, nbj = 0;
+        TileRegs nregs;
+        if (nxt < tiles) {
+            tri_tile(nxt, nbi, nbj);
+            nregs = tile_coords_load(Xs, (long long)nbi * GT, (long long)nbj * GT, dim, 0);
+        }
+        // ---- distances of this tile (pair_cov_dot, chunk by chunk; chunk 0 is already staged)
+        double dot[4][4];
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+            for (int b = 0; b < 4; ++b) dot[a][b] = 0.0;
+        double nrm = 0.0;
+        for (int d0 = 0; d0 < dim; d0 += GD) {
+            double* cI = sI[buf];
+            double* cJ = sJ[buf];
+            if (d0 > 0) {                       // dim > 16: further chunks are staged synchronously
+                __syncthreads();
+                const TileRegs more = tile_coords_load(Xs, i0, j0, dim, d0);
+                tile_coords_stage(more, cI, cJ);
+                __syncthreads();
+            }
+            sMine = t < GT ? cI : cJ;
+            const int dn = dim - d0 < GD ? dim - d0 : GD;
+            if (t < 2 * GT)
+                for (int d = 0; d < dn; ++d) {
+                    const double x = sMine[d * GLD + (t & (GT - 1))];
+                    nrm = fma(x, x, nrm);
+                }
+            for (int d = 0; d < dn; ++d) {
+                double xi[4], xj[4];
+#pragma unroll
+                for (int a = 0; a < 4; ++a) {
+                    xi[a] = cI[d * GLD + ty * 4 + a];
+                    xj[a] = cJ[d * GLD + tx * 4 + a];
+                }
+#pragma unroll
+                for (int a = 0; a < 4; ++a)
+#pragma unroll
+                    for (int b = 0; b < 4; ++b) dot[a][b] = fma(xi[a], xj[b], dot[a][b]);
+            }
+        }
+        __syncthreads();                        // sN of the previous tile fully read
+        if (t < 2 * GT) sN[t] = nrm;
+        __syncthreads();
+        double ni[4], nj[4];
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+            ni[a] = sN[ty * 4 + a];
+            nj[a] = sN[GT + tx * 4 + a];
+        }
+        double cov[4][4];
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {
+                double r2 = fma(-2.0, dot[a][b], ni[a] + nj[b]);
+                r2 = r2 > 0.0 ? r2 : 0.0;
+                if (i0 + ty * 4 + a == j0 + tx * 4 + b) r2 = 0.0;     // the diagonal is exact
+                cov[a][b] = cov_finish<double, KIND>(cp, r2, 0.0);
+            }
+        if (bi != bj && (int)i0 + GT <= n) {
+#pragma unroll
+            for (int a = 0; a < 4; ++a) {
+                double2* dst = reinterpret_cast<double2*>(K + (size_t)(i0 + ty * 4 + a) * n_pad + j0 + tx * 4);
+                dst[0] = make_double2(cov[a][0], cov[a][1]);
+                dst[1] = make_double2(cov[a][2], cov[a][3]);
+            }
+        } else {
+#pragma unroll
+            for (int a = 0; a < 4; ++a) {
+                const int gi = (int)i0 + ty * 4 + a;
+                double v[4];
+#pragma unroll
+                for (int b = 0; b < 4; ++b) {
+                    const int gj = (int)j0 + tx * 4 + b;
+                    double val;
+                    if (gi < n && gj < n) {
+                        val = cov[a][b];
+                        if (gi == gj) val += noise;
+                    } else if (gi == gj) {
+                        val = 1.0;
+                    } else if (gi == n && gj < n) {
+                        val = y[gj] - mean_c;
+                    } else if (gj == n && gi < n) {
+                        val = y[gi] - mean_c;
+                    } else {
+                        val = 0.0;
+                    }
+                    v[b] = val;
+                }
+                double2* dst = reinterpret_cast<double2*>(K + (size_t)gi * n_pad + j0 + tx * 4);
+                dst[0] = make_double2(v[0], v[1]);
+                dst[1] = make_double2(v[2], v[3]);
+            }
+        }
+        if (nxt >= tiles) break;
+        regs = nregs;
+        bi = nbi;
+        bj = nbj;
+        buf ^= 1;
+    }
+}
+
 // V[c - c0][j] = k(xc_c, x_j) for j < n, 0 for n <= j < n_pad
 template <class T, int KIND>
 __global__ __launch_bounds__(256) void cross_gram_kernel(const double* __restrict__ Xcs,
@@ -301,6 +481,24 @@ int launch_scale_inputs(robo_ctx* ctx, const double* d_in, double* d_out, const 
 int launch_gram(robo_gp* gp, const FitBuffers& fb) {
     const int T = gp->n_pad / GT;
     const int tiles = T * (T + 1) / 2;
+    const Tuning& tune = gp->ctx->tune;
+    if (fb.S == 1 && fb.K == gp->d_K && !gp->fp32_gram && gp->kind != ROBO_KERNEL_FABOLAS && tune.gram_persistent > 0 &&
+        tiles > gp->ctx->num_cu * 2) {
+        // single theta, fp64, stationary kernel (the headline path): persistent workgroups; the counter was zeroed by
+        // launch_scale_inputs_theta, which always precedes a single-theta gram build
+        const int wpc = tune.gram_persistent;
+        int grid = gp->ctx->num_cu * wpc;
+        if (grid > tiles) grid = tiles;
+        int* counter = gp->ctx->d_fail + 2;
+        if (gp->kind == ROBO_KERNEL_MATERN52_ARD)
+            hipLaunchKernelGGL(gram_persistent_kernel<ROBO_KERNEL_MATERN52_ARD>, dim3(grid), dim3(256), 0, gp->ctx->stream,
+                               fb.Xs, (const double*)gp->d_y, fb.K, gp->n, gp->n_pad, fb.sp, fb.fail, counter, tiles);
+        else
+            hipLaunchKernelGGL(gram_persistent_kernel<ROBO_KERNEL_RBF_ARD>, dim3(grid), dim3(256), 0, gp->ctx->stream,
+                               fb.Xs, (const double*)gp->d_y, fb.K, gp->n, gp->n_pad, fb.sp, fb.fail, counter, tiles);
+        ROBO_LAUNCH_CHECK();
+        return ROBO_OK;
+    }
 #define ROBO_GRAM_CALL(TYPE, KIND)                                                                              \
     hipLaunchKernelGGL((gram_kernel<TYPE, KIND>), dim3(tiles, fb.S), dim3(256), 0, gp->ctx->stream, fb.Xs,      \
                        fb.xs_stride, (const double*)gp->d_y, fb.K, fb.k_stride, gp->n, gp->n_pad, fb.sp, fb.fail)

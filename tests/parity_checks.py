@@ -960,3 +960,28 @@ def check_winv_path(ctx, cases=(("matern52", 300, 5, 700), ("fabolas", 280, 4, 1
     finally:
         for key in ("winv_min_blocks", "winv_max", "ws_bytes"):
             ctx.set_tuning(key, None)
+
+
+def check_gram_variants(ctx, cases=(("matern52", 300, 5), ("rbf", 200, 3))):
+    """K1: the persistent-workgroup gram kernel (tiles from an atomic counter, next tile's coordinates prefetched) and
+    the one-workgroup-per-tile kernel write the same K, bit for bit -- and the oracle's within rtol 1e-13"""
+    rs = np.random.RandomState(47)
+    for kind, N, D in cases:
+        X = rs.rand(N, D)
+        y = np.sin(3 * X.sum(axis=1))
+        theta = np.concatenate([[0.2], np.log(0.3 * D) + 0.2 * rs.randn(D), [np.log(1e-3)]])
+        g = _lib.DeviceGP(ctx, kind, N, D)
+        g.set_data(X, y)
+        try:
+            ctx.set_tuning("gram_persistent", 0)
+            K0 = g.gram(theta)
+            ll0 = g.fit(theta, float(y.mean()))
+            for wpc in (4, 1, 3):
+                ctx.set_tuning("gram_persistent", wpc)
+                np.testing.assert_array_equal(g.gram(theta), K0)
+                assert g.fit(theta, float(y.mean())) == ll0
+        finally:
+            ctx.set_tuning("gram_persistent", None)
+        Ko = O.kernel_matrix(kind, theta[:-1], X) + (np.exp(theta[-1]) + 1.25e-12) * np.eye(N)
+        np.testing.assert_allclose(K0, Ko, rtol=1e-13, atol=1e-15)
+        g.close()

@@ -181,3 +181,7 @@ def test_host_array_handle_reuse(emu_ctx):
 def test_winv_small_batch_path(emu_ctx):
     """the explicit-inverse posterior for small batches (winv.hip): index arithmetic, unit table, chunk order"""
     P.check_winv_path(emu_ctx, cases=(("matern52", 300, 5, 300), ("fabolas", 280, 4, 130)))
+
+
+def test_gram_kernel_variants(emu_ctx):
+    P.check_gram_variants(emu_ctx)

@@ -425,6 +425,11 @@ def test_winv_small_batch_path(ctx):
     P.check_winv_path(ctx, cases=(("matern52", 4096, 16, 500), ("matern52", 2000, 8, 8192)))
 
 
+def test_gram_kernel_variants(ctx):
+    P.check_gram_variants(ctx)
+    P.check_gram_variants(ctx, cases=(("matern52", 4096, 16), ("matern52", 1000, 40)))
+
+
 def test_comm_one_rank_rccl(ctx):
     """the collective entry points on the real librccl.so with a one-rank communicator (this lease has one GPU): same
     results as the single-process calls; the world_size-2 semantics are covered on CPU (tests/test_distributed_gloo.py,
