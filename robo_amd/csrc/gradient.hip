@@ -50,39 +50,47 @@ __global__ __launch_bounds__(256) void triinv_base_kernel(const double* __restri
 //             -> upper triangle of W (rows A, columns C), scratch
 //   phase 1:  X = -C^-1 T        tile (i-block of C, j-block of A):  sum_k W[i][k] T^T[j][k], k in C, k <= i
 //             -> W[C, A] = X,  V[A, C] = X^T (columns >= n zeroed)
+// TM: 32 TM rows of the output tile per workgroup.  The contraction lengths of a level are triangular (1 .. sb blocks), and
+// at the top levels there are no more 128-row tiles than CUs (sb = 16: 256 tiles, the longest 16 blocks deep = 260 us per
+// phase with half of the matrix pipes idle): 32-row sub-tiles give the dispatcher 4x the workgroups to balance
+// (r03: W = L^-1 at N = 4096 1.23 -> ms).  Same k-order per entry, hence the same bits for every TM.
+template <int TM>
 __global__ __launch_bounds__(256, 2) void triinv_kernel(int phase, int sb, int nbk, int n,
                                                         const double* __restrict__ L, double* __restrict__ W,
                                                         double* __restrict__ V, int ld) {
-    __shared__ double smem[GEMM_SMEM_DOUBLES];
+    __shared__ double smem[gemm_smem_doubles<TM>()];
+    constexpr int SPLIT = 4 / TM;
     const int a0 = 2 * (int)blockIdx.y * sb, c0 = a0 + sb;
     int nc = nbk - c0;
     nc = nc > sb ? sb : nc;
     if (nc <= 0) return;
-    const int tj = blockIdx.x % sb, ti = blockIdx.x / sb;   // block inside A, block inside C
+    const int tile = (int)blockIdx.x / SPLIT, h = (int)blockIdx.x % SPLIT;
+    const int tj = tile % sb, ti = tile / sb;   // block inside A, block inside C
     if (ti >= nc) return;
     const size_t rowA = (size_t)(a0 + tj) * NB, rowC = (size_t)(c0 + ti) * NB;
-    Acc acc;
+    const size_t sub = (size_t)h * (32 * TM);    // first row of this workgroup's sub-tile
+    AccT<TM> acc;
     acc_zero(acc);
     if (phase == 0) {
-        gemm_nt_128<false>(V + rowA * ld + (size_t)a0 * NB, ld, L + rowC * ld + (size_t)a0 * NB, ld, tj * NB, sb * NB,
-                           acc, smem);
+        gemm_nt<TM, false>(V + (rowA + sub) * ld + (size_t)a0 * NB, ld, L + rowC * ld + (size_t)a0 * NB, ld, tj * NB,
+                           sb * NB, acc, smem);
 #pragma unroll
-        for (int tm = 0; tm < 4; ++tm)
+        for (int tm = 0; tm < TM; ++tm)
 #pragma unroll
             for (int tn = 0; tn < 4; ++tn)
 #pragma unroll
                 for (int r = 0; r < 4; ++r)
-                    W[(rowA + acc_row(tm, r)) * ld + rowC + acc_col(tn)] = acc.t[tm][tn][r];
+                    W[(rowA + sub + acc_row<TM>(tm, r)) * ld + rowC + acc_col(tn)] = acc.t[tm][tn][r];
     } else {
-        gemm_nt_128<true>(W + rowC * ld + (size_t)c0 * NB, ld, W + rowA * ld + (size_t)c0 * NB, ld, 0, (ti + 1) * NB,
-                          acc, smem);
+        gemm_nt<TM, true>(W + (rowC + sub) * ld + (size_t)c0 * NB, ld, W + rowA * ld + (size_t)c0 * NB, ld, 0,
+                          (ti + 1) * NB, acc, smem);
 #pragma unroll
-        for (int tm = 0; tm < 4; ++tm)
+        for (int tm = 0; tm < TM; ++tm)
 #pragma unroll
             for (int tn = 0; tn < 4; ++tn)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const size_t i = rowC + acc_row(tm, r), j = rowA + acc_col(tn);
+                    const size_t i = rowC + sub + acc_row<TM>(tm, r), j = rowA + acc_col(tn);
                     const double x = acc.t[tm][tn][r];
                     W[i * ld + j] = x;
                     V[j * ld + i] = (int)i < n ? x : 0.0;
@@ -313,10 +321,16 @@ int launch_triinv(robo_gp* gp, double* d_W, double* d_V) {
     const int n = gp->n, n_pad = gp->n_pad, nbk = (n + NB - 1) / NB;
     hipLaunchKernelGGL(triinv_base_kernel, dim3(nbk), dim3(256), 0, st, (const double*)gp->d_Linv, n, d_W, d_V, n_pad);
     for (int sb = 1; sb < nbk; sb *= 2) {
-        const dim3 grid((unsigned)(sb * sb), (unsigned)((nbk + 2 * sb - 1) / (2 * sb)));
-        for (int phase = 0; phase < 2; ++phase)
-            hipLaunchKernelGGL(triinv_kernel, grid, dim3(256), 0, st, phase, sb, nbk, n, (const double*)gp->d_K, d_W, d_V,
-                               n_pad);
+        const unsigned pairs = (unsigned)((nbk + 2 * sb - 1) / (2 * sb));
+        const bool narrow = (long long)sb * sb * pairs <= 2LL * gp->ctx->num_cu;   // too few 128-row tiles to fill the chip
+        for (int phase = 0; phase < 2; ++phase) {
+            if (narrow)
+                hipLaunchKernelGGL(triinv_kernel<1>, dim3((unsigned)(sb * sb * 4), pairs), dim3(256), 0, st, phase, sb, nbk,
+                                   n, (const double*)gp->d_K, d_W, d_V, n_pad);
+            else
+                hipLaunchKernelGGL(triinv_kernel<4>, dim3((unsigned)(sb * sb), pairs), dim3(256), 0, st, phase, sb, nbk, n,
+                                   (const double*)gp->d_K, d_W, d_V, n_pad);
+        }
     }
     ROBO_LAUNCH_CHECK();
     return ROBO_OK;

@@ -83,11 +83,16 @@ __device__ __forceinline__ void pair_cov(const CovParams& cp, const double* __re
                                          const double* __restrict__ Xj, long long i0, long long j0, double* sI,
                                          double* sJ, double (&cov)[4][4]) {
     const int t = threadIdx.x, tx = t & 15, ty = t >> 4, dim = cp.dim;
+    constexpr bool fab = KIND == ROBO_KERNEL_FABOLAS;
     T acc[4][4], uu[4][4];
+    T ss[fab ? 4 : 1][fab ? 4 : 1];      // Fabolas: sum of the per-dimension exponents (matern52_1d_split)
 #pragma unroll
     for (int a = 0; a < 4; ++a)
 #pragma unroll
-        for (int b = 0; b < 4; ++b) cov_init<T, KIND>(cp, acc[a][b], uu[a][b]);
+        for (int b = 0; b < 4; ++b) {
+            cov_init<T, KIND>(cp, acc[a][b], uu[a][b]);
+            if (fab) ss[a][b] = T(0);
+        }
     for (int d0 = 0; d0 < dim; d0 += GD) {
         // stage 64 rows x 16 dims of both blocks, transposed to [d][row]
 #pragma unroll
@@ -107,17 +112,27 @@ __device__ __forceinline__ void pair_cov(const CovParams& cp, const double* __re
                 xi[a] = (T)sI[d * GLD + ty * 4 + a];
                 xj[a] = (T)sJ[d * GLD + tx * 4 + a];
             }
+            if (fab && d0 + d < dim - 1) {
 #pragma unroll
-            for (int a = 0; a < 4; ++a)
+                for (int a = 0; a < 4; ++a)
 #pragma unroll
-                for (int b = 0; b < 4; ++b) cov_step<T, KIND>(cp, d0 + d, xi[a], xj[b], acc[a][b], uu[a][b]);
+                    for (int b = 0; b < 4; ++b) matern52_1d_split(xi[a] - xj[b], acc[a][b], ss[fab ? a : 0][fab ? b : 0]);
+            } else {
+#pragma unroll
+                for (int a = 0; a < 4; ++a)
+#pragma unroll
+                    for (int b = 0; b < 4; ++b) cov_step<T, KIND>(cp, d0 + d, xi[a], xj[b], acc[a][b], uu[a][b]);
+            }
         }
         __syncthreads();
     }
 #pragma unroll
     for (int a = 0; a < 4; ++a)
 #pragma unroll
-        for (int b = 0; b < 4; ++b) cov[a][b] = cov_finish<T, KIND>(cp, acc[a][b], uu[a][b]);
+        for (int b = 0; b < 4; ++b) {
+            if (fab) acc[a][b] *= exp_np(-ss[fab ? a : 0][fab ? b : 0]);
+            cov[a][b] = cov_finish<T, KIND>(cp, acc[a][b], uu[a][b]);
+        }
 }
 
 // fp64 stationary kernels in K1: squared distances through  r2 = |x_i|^2 + |x_j|^2 - 2 x_i . x_j  with the row norms
@@ -190,8 +205,10 @@ __device__ __forceinline__ void pair_cov_dot(const CovParams& cp, const double* 
 // K[i][j] for j-tile <= i-tile.  Rows/cols >= n: row n is the augmented right-hand side
 // (y - mean), the rest identity, so that one Cholesky also yields z = L^-1 (y - mean)
 // as row n of the factor (DESIGN.md "augmented row").
+// (six workgroups per CU = 80 VGPRs; the Fabolas product kernel needs more live values -- one Matern factor per pair and
+// dimension -- and spilled 92 registers under that cap: three per CU for it)
 template <class T, int KIND>
-__global__ __launch_bounds__(256, 6) void gram_kernel(const double* __restrict__ Xs, size_t xs_stride,
+__global__ __launch_bounds__(256, KIND == ROBO_KERNEL_FABOLAS ? 3 : 6) void gram_kernel(const double* __restrict__ Xs, size_t xs_stride,
                                                    const double* __restrict__ y, double* __restrict__ K,
                                                    size_t k_stride, int n, int n_pad,
                                                    const FitSample* __restrict__ sp, int* __restrict__ fail) {

@@ -26,24 +26,27 @@ constexpr int IG_Q2_OFF = 64;   // column offset of the q2 block in the 128-wide
 // s[c][b] = max(eps, y_std^2 (k(x_c, z_b) - v_c . v_zb))  for b < nb, 0 beyond
 // (the clip at eps is the reference's: predict(full_cov=True) clips the WHOLE covariance matrix,
 //  off-diagonals included, gaussian_process.py:290-294, and predict_variance reads it back)
+// TM: 32 TM candidates per workgroup -- a batch of 8192 is only 64 tiles of 128 (0.75 ms of a config-4 step with
+// three quarters of the chip idle, r03e); the k-order of every entry's products is the same, hence the same bits
+template <int TM>
 __global__ __launch_bounds__(256) void cross_cov_kernel(const double* __restrict__ Vc, int ldv,
                                                         const double* __restrict__ Vr, int ldr, int kend,
                                                         const double* __restrict__ Xcs, long long c0,
                                                         const double* __restrict__ Xrs, int nb, CovParams cp,
                                                         double y_std, double* __restrict__ S) {
-    __shared__ double smem[GEMM_SMEM_DOUBLES];
-    const long long r0 = (long long)blockIdx.x * NB;
-    Acc acc;
+    __shared__ double smem[gemm_smem_doubles<TM>()];
+    const long long r0 = (long long)blockIdx.x * (32 * TM);
+    AccT<TM> acc;
     acc_zero(acc);
-    gemm_nt_128<false>(Vc + (size_t)r0 * ldv, ldv, Vr, ldr, 0, kend, acc, smem);
+    gemm_nt<TM, false>(Vc + (size_t)r0 * ldv, ldv, Vr, ldr, 0, kend, acc, smem);
     const double eps = 2.220446049250313e-16;
 #pragma unroll
-    for (int tm = 0; tm < 4; ++tm)
+    for (int tm = 0; tm < TM; ++tm)
 #pragma unroll
         for (int tn = 0; tn < 4; ++tn)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const long long a = r0 + acc_row(tm, r);
+                const long long a = r0 + acc_row<TM>(tm, r);
                 const int b = acc_col(tn);
                 double v = 0.0;
                 if (b < nb) {
@@ -174,10 +177,14 @@ __global__ __launch_bounds__(256) void ig_dh_kernel(const double* __restrict__ S
 }
 
 int launch_cross_cov(robo_gp* gp, robo_cand* cand, robo_cand* rep, int64_t c0, int64_t cn, double* d_S) {
-    hipLaunchKernelGGL(cross_cov_kernel, dim3((unsigned)(cn / NB)), dim3(256), 0, gp->ctx->stream,
-                       (const double*)cand->d_V, gp->n_pad, (const double*)rep->d_V, gp->n_pad,
-                       (gp->n + NB - 1) / NB * NB, (const double*)cand->d_Xcs, (long long)c0,
-                       (const double*)rep->d_Xcs, (int)rep->m, gp->cov, gp->y_std, d_S);
+#define ROBO_CC_CALL(TM)                                                                                         \
+    hipLaunchKernelGGL(cross_cov_kernel<TM>, dim3((unsigned)(cn / (32 * TM))), dim3(256), 0, gp->ctx->stream,  \
+                       (const double*)cand->d_V, gp->n_pad, (const double*)rep->d_V, gp->n_pad,                 \
+                       (gp->n + NB - 1) / NB * NB, (const double*)cand->d_Xcs, (long long)c0,                   \
+                       (const double*)rep->d_Xcs, (int)rep->m, gp->cov, gp->y_std, d_S)
+    if (cn / NB >= 2 * gp->ctx->num_cu) ROBO_CC_CALL(4);
+    else ROBO_CC_CALL(1);
+#undef ROBO_CC_CALL
     ROBO_LAUNCH_CHECK();
     return ROBO_OK;
 }

@@ -80,6 +80,24 @@ __device__ __forceinline__ double matern52_unit<double>(double r2) {
 }
 #endif
 
+// One factor of the Fabolas product kernel, matern52(df^2), in the distance itself: sqrt(5 df^2) = sqrt(5) |df| -- no
+// square root (the v_rsq_f64 + correction sequence was 8 of the ~36 instructions per pair and dimension).  Split form
+// for the tiled gram kernels: the polynomial factor and the exponent separately, so that a pair needs ONE exp over
+// the sum of its exponents instead of one per dimension (another 20 of the 36):
+//     prod_d (1 + s_d + s_d^2 / 3) exp(-s_d)  =  [prod_d (1 + s_d + s_d^2 / 3)] exp(-sum_d s_d),   s_d = sqrt(5) |df_d|
+constexpr double SQRT5 = 2.23606797749978969641;
+template <class T>
+__device__ __forceinline__ T matern52_1d(T df) {
+    const T s = T(SQRT5) * fabs(df);
+    return (T(1) + s + s * s * T(1.0 / 3.0)) * exp_np(-s);
+}
+template <class T>
+__device__ __forceinline__ void matern52_1d_split(T df, T& poly, T& expo) {
+    const T s = T(SQRT5) * fabs(df);
+    poly *= T(1) + s + s * s * T(1.0 / 3.0);
+    expo += s;
+}
+
 // KIND < 0: decided at run time from p.kind (cold paths); otherwise compiled in (the tiled
 // gram kernels are instantiated per kind: a run-time branch in their inner loop cost 2x)
 template <class T, int KIND = -1>
@@ -96,8 +114,7 @@ __device__ __forceinline__ void cov_step(const CovParams& p, int d, T xi, T xj, 
         if (d == p.dim - 1) {
             uu = xi * xj;
         } else {
-            const T df = xi - xj;
-            acc *= matern52_unit(df * df);
+            acc *= matern52_1d(xi - xj);
         }
     } else {
         const T df = xi - xj;

@@ -43,7 +43,7 @@ __global__ __launch_bounds__(256) void cross_grad_kernel(const double* __restric
         double prod = 1.0;
         for (int d = 0; d < D - 1; ++d) {
             const double df = xi[d] - xj[d];
-            prod *= matern52_unit(df * df);
+            prod *= matern52_1d(df);
         }
         const double u = xi[D - 1], up = xj[D - 1];
         const double lin = cp.blr_a + cp.blr_b * u * up;

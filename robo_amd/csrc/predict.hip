@@ -88,7 +88,7 @@ __device__ __forceinline__ void gen_cross_tile_t(const CovParams& cp, const doub
 #pragma unroll
                     for (int mb = 0; mb < 2; ++mb) {
                         const double df = xi[mb] - xj;
-                        if (fab) acc.t[rb][mb][r] *= matern52_unit(df * df);
+                        if (fab) acc.t[rb][mb][r] *= matern52_1d(df);
                         else acc.t[rb][mb][r] = fma(df, df, acc.t[rb][mb][r]);
                     }
                 }
@@ -319,7 +319,7 @@ __device__ __forceinline__ void gen_cross_tile_s(const CovParams& cp, const doub
 #pragma unroll
                     for (int mb = 0; mb < MB; ++mb) {
                         const double df = xi[mb] - xj;
-                        if (fab) acc.t[rbl][mb][r] *= matern52_unit(df * df);
+                        if (fab) acc.t[rbl][mb][r] *= matern52_1d(df);
                         else acc.t[rbl][mb][r] = fma(df, df, acc.t[rbl][mb][r]);
                     }
                 }
