@@ -778,6 +778,7 @@ int32_t robo_cand_destroy(robo_cand* k) {
     hipFree(k->d_Q);
     hipFree(k->d_G);
     hipFree(k->d_igc);
+    free(k->h_igkey);
     hipFree(k->d_Ks);
     hipFree(k->d_P);
     hipFree(k->d_qpart);
@@ -1169,6 +1170,7 @@ static int ig_ensure(robo_cand* k, int kf) {
         hipFree(k->d_G);
         hipFree(k->d_igc);
         k->d_G = k->d_igc = nullptr;
+        if (k->h_igkey) k->h_igkey[0] = -1.0;      // the device copies are gone: no cached EP state
         ROBO_TRY(dev_alloc(&k->d_G, (size_t)NB * kf));
         ROBO_TRY(dev_alloc(&k->d_igc, (size_t)128 + 512 + 64 * 64));
         k->g_cap = (size_t)kf;
@@ -1179,6 +1181,37 @@ static int ig_ensure(robo_cand* k, int kf) {
 // upload the EP state: consts = [logP (64) | lmb (64) | W (npts) | dlogPdMu (nb x nb)], G (128 x kf)
 static int ig_upload(robo_cand* k, int nb, int npts, int kf, const double* logP, const double* lmb, const double* W,
                      const double* dlogPdMu, const double* dlogPdSigma, const double* dlogPdMudMu) {
+    // The EP state changes once per update() of the acquisition function and is then evaluated on batch after batch:
+    // the 2.5 MB re-layout + upload + synchronisation below is skipped when all six arrays equal, bit for bit, the
+    // ones this handle's device copies were made from (0.1 ms of memcmp instead of ~0.5 ms per call at Nb = 50).
+    const int ntri_k = nb * (nb + 1) / 2;
+    const size_t lens[6] = {(size_t)nb, (size_t)nb, (size_t)npts, (size_t)nb * nb, (size_t)nb * ntri_k,
+                            (size_t)nb * nb * nb};
+    const double* srcs[6] = {logP, lmb, W, dlogPdMu, dlogPdSigma, dlogPdMudMu};
+    size_t total = 2;
+    for (size_t l : lens) total += l;
+    if (k->h_igkey && k->igkey_len == total && k->h_igkey[0] == (double)nb && k->h_igkey[1] == (double)npts) {
+        bool same = true;
+        size_t off = 2;
+        for (int a = 0; a < 6 && same; ++a) {
+            same = memcmp(k->h_igkey + off, srcs[a], lens[a] * sizeof(double)) == 0;
+            off += lens[a];
+        }
+        if (same) return ROBO_OK;
+    }
+    if (k->igkey_len != total) {
+        free(k->h_igkey);
+        k->h_igkey = (double*)malloc(total * sizeof(double));
+        k->igkey_len = k->h_igkey ? total : 0;
+    }
+    if (k->h_igkey) {
+        k->h_igkey[0] = -1.0;      // invalid until the upload below has been issued
+        size_t off = 2;
+        for (int a = 0; a < 6; ++a) {
+            memcpy(k->h_igkey + off, srcs[a], lens[a] * sizeof(double));
+            off += lens[a];
+        }
+    }
     std::vector<double> hc((size_t)128 + npts + (size_t)nb * nb, 0.0), hg((size_t)NB * kf, 0.0);
     for (int i = 0; i < nb; ++i) {
         hc[i] = logP[i];
@@ -1199,6 +1232,10 @@ static int ig_upload(robo_cand* k, int nb, int npts, int kf, const double* logP,
     ROBO_HIP_CHECK(hipMemcpyAsync(k->d_igc, hc.data(), hc.size() * sizeof(double), hipMemcpyHostToDevice, st));
     ROBO_HIP_CHECK(hipMemcpyAsync(k->d_G, hg.data(), hg.size() * sizeof(double), hipMemcpyHostToDevice, st));
     ROBO_HIP_CHECK(hipStreamSynchronize(st));   // the staging vectors die with this scope
+    if (k->h_igkey) {
+        k->h_igkey[0] = (double)nb;
+        k->h_igkey[1] = (double)npts;
+    }
     return ROBO_OK;
 }
 

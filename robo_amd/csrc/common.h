@@ -180,6 +180,8 @@ struct robo_cand {
     // features / outputs, EP tensors
     double *d_S, *d_F, *d_Q, *d_G, *d_igc;
     size_t f_cap, q_cap, g_cap;
+    double* h_igkey;    // host copy of the EP state whose device form d_G / d_igc hold (compared in full before an upload
+    size_t igkey_len;   // is skipped: compute() is called many times per update(), information_gain.py:87-125 / :153-167)
     double* d_mu_all;   // (s_cap, m_pad) per-sample means/variances for the GP-MCMC mixture (lazy)
     double* d_var_all;
     int s_cap;

@@ -115,6 +115,22 @@ def _check_ig(ctx, **kw):
     vals6, _, _ = _lib.ig_eval(d["g"], cand, rep, d["ep"], d["sn2"])
     vals7, _, _ = _lib.ig_eval(d["g"], cand, rep_rev, d["ep"], d["sn2"])
     np.testing.assert_array_equal(vals6, vals7)
+    # (5) the EP state's device copy is kept per candidate handle and re-made when ANY of its arrays changes
+    dMM2 = d["dMM"].copy()
+    dMM2[1, 2, 3] += 0.25
+    ep2 = _lib.EPState(d["logP"], d["lmb"], d["W"], d["dMu"], d["dSig"], dMM2)
+    d["g"].fit(d["ogp"].theta, d["ogp"].mean)
+    rep.set_points(d["zb"])
+    v_a, _, _ = _lib.ig_eval(d["g"], cand, rep, d["ep"], d["sn2"])
+    v_b, _, _ = _lib.ig_eval(d["g"], cand, rep, ep2, d["sn2"])
+    v_c, _, _ = _lib.ig_eval(d["g"], cand, rep, d["ep"], d["sn2"])
+    cand_fresh = _lib.Candidates(ctx, d["Xc"])
+    v_d, _, _ = _lib.ig_eval(d["g"], cand_fresh, rep, ep2, d["sn2"])
+    np.testing.assert_array_equal(v_a, vals)
+    np.testing.assert_array_equal(v_c, vals)
+    np.testing.assert_array_equal(v_b, v_d)
+    assert np.max(np.abs(v_b - v_a)) > 0
+    cand_fresh.close()
     rep_fresh.close()
     rep_rev.close()
     cand.close()
