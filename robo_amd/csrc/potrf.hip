@@ -245,25 +245,22 @@ __device__ __forceinline__ int potf2_16_split(double* Ld, double* Wd, double* co
     double p = bcast_lane(a[0], 0);                           // L_00's pivot: group 0, lane 0
 #pragma unroll
     for (int k = 0; k < SB; ++k) {
-        constexpr int dummy = 0;
-        (void)dummy;
         const int pk = k & 1, hk = k >> 1;
+        // (A) the exchange-buffer reads of the deferred update by column k-1 are ISSUED first and consumed last: the
+        // column was published at the end of the previous iteration, so they are a full LDS write -> read round trip
+        // away, and the compiler's own order put the pivot's fma + rsq chain behind the first s_waitcnt on them
+        // (r03 ISA: ~290 cycles per pivot = LDS round trip + rsq chain + hand-over, one after the other).  With the
+        // scheduling barriers the rsq chain of pivot k runs while the reads are in flight.
+        double lprev = 0.0, cv[H];
         if (k > 0) {
-            // deferred update by column k-1 (owner parity pq, buffer (k-1) & 1) of every own column j >= k
             const int pq = (k - 1) & 1, buf = (k - 1) & 1;
-            const double lprev = cb_mult[pq * 4 * SB + buf * SB];
+            lprev = cb_mult[pq * 4 * SB + buf * SB];
             const double* c = cb_col + pq * 4 * SB + buf * SB;
 #pragma unroll
-            for (int h = hk; h < H; ++h) {
-                // h = hk is column k for the lanes of parity pk; for the other parity it is column k+1 (k even) or the
-                // finished column k-1 (k odd), which must not be touched
-                const double m = (pk == 1 && h == hk) ? (par == 1 ? lprev : 0.0) : lprev;
-                a[h] = fma(-m, c[h], a[h]);
-            }
+            for (int h = hk; h < H; ++h) cv[h] = c[h];
         }
-        // the next diagonal entry (columns <= k-1 applied), uniform: lane (row k+1, L group of parity (k+1) & 1)
-        double d1 = 0.0;
-        if (k + 1 < SB) d1 = bcast_lane(a[(k + 1) >> 1], (k + 1) + 32 * ((k + 1) & 1));
+        __builtin_amdgcn_sched_barrier(0);
+        // (B) the pivot
         if (GUARD) {
             if (g0 + k >= n_real) p = 1.0;
             if (!(p > 0.0)) {             // also catches NaN
@@ -272,6 +269,20 @@ __device__ __forceinline__ int potf2_16_split(double* Ld, double* Wd, double* co
             }
         }
         const double ri = pivot_rsqrt(p);
+        __builtin_amdgcn_sched_barrier(0);
+        // (C) deferred update by column k-1 (owner parity pq) of every own column j >= k
+        if (k > 0) {
+#pragma unroll
+            for (int h = hk; h < H; ++h) {
+                // h = hk is column k for the lanes of parity pk; for the other parity it is column k+1 (k even) or the
+                // finished column k-1 (k odd), which must not be touched
+                const double m = (pk == 1 && h == hk) ? (par == 1 ? lprev : 0.0) : lprev;
+                a[h] = fma(-m, cv[h], a[h]);
+            }
+        }
+        // the next diagonal entry (columns <= k-1 applied), uniform: lane (row k+1, L group of parity (k+1) & 1)
+        double d1 = 0.0;
+        if (k + 1 < SB) d1 = bcast_lane(a[(k + 1) >> 1], (k + 1) + 32 * ((k + 1) & 1));
         double lik = a[hk] * ri;                              // meaningful in the lanes of parity pk
         if (GUARD && row == k && !isW) lik = p * ri;
         a[hk] = par == pk ? lik : a[hk];
