@@ -247,6 +247,10 @@ def roofline_trsm(ctx, N, M_rows, trsm_ms_per_step, passes=1, kernel="trsm_step_
     rows N^2 / nb (SURVEY.md 8d's triangular-solve term), duration from HIP events on the library's stream
     (slots 25 -> 26) averaged over the nb launches of a pass"""
     nb = (N + 127) // 128
+    if kernel == "winv_gemm_kernel":
+        # the explicit-inverse path is ONE triangular product per pass; the event pair brackets cross-gram + product +
+        # chunk reduction, priced against the product's algorithmic flops (rows N^2)
+        nb = 1
     avg_launch_ms = trsm_ms_per_step / (nb * passes)
     achieved = (float(M_rows) * N * N / nb) / (avg_launch_ms * 1e-3) / 1e12
     return {"bound": "mfma", "kernel": kernel, "achieved": achieved, "peak": FP64_MFMA_PEAK_TFLOPS,
