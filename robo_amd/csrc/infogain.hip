@@ -76,21 +76,23 @@ __global__ __launch_bounds__(256) void ig_features_kernel(const double* __restri
     }
 }
 
-// C (rows x 128) = A (rows x K) * B (128 x K)^T
+// C (rows x 128) = A (rows x K) * B (128 x K)^T; 32 TM rows per workgroup (TM = 1 while 128-row tiles would leave CUs
+// idle: 8192 candidates are 64 of them; same k-order per entry, same bits)
+template <int TM>
 __global__ __launch_bounds__(256) void gemm_nt_kernel(const double* __restrict__ A, int lda,
                                                       const double* __restrict__ B, int ldb, int K,
                                                       double* __restrict__ C, int ldc) {
-    __shared__ double smem[GEMM_SMEM_DOUBLES];
-    const size_t r0 = (size_t)blockIdx.x * NB;
-    Acc acc;
+    __shared__ double smem[gemm_smem_doubles<TM>()];
+    const size_t r0 = (size_t)blockIdx.x * (32 * TM);
+    AccT<TM> acc;
     acc_zero(acc);
-    gemm_nt_128<false>(A + r0 * lda, lda, B, ldb, 0, K, acc, smem);
+    gemm_nt<TM, false>(A + r0 * lda, lda, B, ldb, 0, K, acc, smem);
 #pragma unroll
-    for (int tm = 0; tm < 4; ++tm)
+    for (int tm = 0; tm < TM; ++tm)
 #pragma unroll
         for (int tn = 0; tn < 4; ++tn)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) C[(r0 + acc_row(tm, r)) * ldc + acc_col(tn)] = acc.t[tm][tn][r];
+            for (int r = 0; r < 4; ++r) C[(r0 + acc_row<TM>(tm, r)) * ldc + acc_col(tn)] = acc.t[tm][tn][r];
 }
 
 // one workgroup per candidate.  consts: [logP (64) | lmb (64) | W (npts) | dlogPdMu (nb x nb)]
@@ -197,8 +199,12 @@ int launch_ig_dh(robo_ctx* ctx, const double* d_S, const double* d_var, double* 
     if (blocks > 16384) blocks = 16384;
     hipLaunchKernelGGL(ig_features_kernel, dim3(blocks), dim3(256), 0, ctx->stream, d_S, (long long)c0, (long long)cn,
                        nb, kf, d_F);
-    hipLaunchKernelGGL(gemm_nt_kernel, dim3((unsigned)(cn / NB)), dim3(256), 0, ctx->stream, (const double*)d_F, kf,
-                       d_G, kf, kf, d_Q, NB);
+    if (cn / NB >= 2 * ctx->num_cu)
+        hipLaunchKernelGGL(gemm_nt_kernel<4>, dim3((unsigned)(cn / NB)), dim3(256), 0, ctx->stream, (const double*)d_F, kf,
+                           d_G, kf, kf, d_Q, NB);
+    else
+        hipLaunchKernelGGL(gemm_nt_kernel<1>, dim3((unsigned)(cn / 32)), dim3(256), 0, ctx->stream, (const double*)d_F, kf,
+                           d_G, kf, kf, d_Q, NB);
     int64_t live = m - c0 < cn ? m - c0 : cn;
     if (live > 0)
         hipLaunchKernelGGL(ig_dh_kernel, dim3((unsigned)live), dim3(256), 0, ctx->stream, d_S, d_var,
