@@ -242,6 +242,16 @@ def timed_steps(D_, ctx, step, steps, warmup):
     return D_.max_over_ranks(time.perf_counter() - t0), last, trsm_ms / steps
 
 
+def config_traffic(config, kernel):
+    """PMC-measured HBM bytes per launch of `kernel` for one of the other configurations (profiles/trsm_traffic_<config>.json,
+    written by tools/gpu_r03.sh pmcconf), or None"""
+    try:
+        tj = json.load(open(os.path.join(ROOT, "profiles", "trsm_traffic_%s.json" % config)))
+        return tj["bytes_per_launch"] if tj["kernel"] in kernel or kernel in tj["kernel"] else None
+    except Exception:
+        return None
+
+
 def roofline_trsm(ctx, N, M_rows, trsm_ms_per_step, passes=1, kernel="trsm_step_gen_kernel", traffic=None):
     """the dominant kernel of every configuration is the block-row solve: algorithmic flops per launch =
     rows N^2 / nb (SURVEY.md 8d's triangular-solve term), duration from HIP events on the library's stream
@@ -385,6 +395,8 @@ def run_headline(args, D_, _lib, sharding):
                 traffic, traffic_src = tj["bytes_per_launch"], tj.get("commit")
         except Exception:
             pass
+        if traffic is None and (N, D) == (1024, 8):
+            traffic = config_traffic("c2", "trsm_step_gen_kernel")
         roof = roofline_trsm(ctx, N, M, trsm_ms, kernel=cand.solve_kernel(), traffic=traffic)
         roof["traffic_measured_at_commit"] = traffic_src
         roof["mfma_f64_microbench"] = mb
@@ -469,7 +481,7 @@ def run_c3(args, D_, _lib, sharding):
         return None
     ms = elapsed / args.steps * 1e3
     # elapsed_ms(25, 26) brackets the LAST sample's solve of a step
-    roof = roofline_trsm(ctx, N, M, trsm_ms, kernel=cand.solve_kernel())
+    roof = roofline_trsm(ctx, N, M, trsm_ms, kernel=cand.solve_kernel(), traffic=config_traffic("c3", cand.solve_kernel()))
     return {"metric": METRIC, "value": S * M * args.steps / elapsed, "unit": "LogEI sample-evals/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": True,
             "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
@@ -548,7 +560,8 @@ def run_c4(args, D_, _lib, sharding):
                        "n_train": N, "dim": D, "candidates_per_gpu": M, "acquisition": "information_gain_per_unit_cost",
                        "parallelism": "candidate-shard x%d, replicated fits" % world},
             "argmax": list(best),
-            "roofline": roofline_trsm(ctx, N, M, trsm_ms, kernel=cand_cost.solve_kernel()),
+            "roofline": roofline_trsm(ctx, N, M, trsm_ms, kernel=cand_cost.solve_kernel(),
+                                      traffic=config_traffic("c4", cand_cost.solve_kernel())),
             "device": ctx.name,
             "note": "roofline: the block-row solve of the LAST posterior of a step (the cost model's); at this batch "
                     "size the step is latency-bound, not MFMA-bound (see small_batch_latency_ms of the headline line)"}
@@ -602,7 +615,8 @@ def run_c5(args, D_, _lib, sharding):
                        "n_train": N, "dim": D, "candidates_per_gpu": M, "acquisition": "lcb",
                        "parallelism": "candidate-shard x%d, replicated fit" % world},
             "gp_fit_ms": fit_ms, "algorithmic_tflops_whole_step": world * M * flops_ei(N, D) / (ms * 1e-3) / 1e12,
-            "argmax": list(best), "roofline": roofline_trsm(ctx, N, M, trsm_ms, passes=-(-M // cand.chunk()), kernel=cand.solve_kernel()),
+            "argmax": list(best), "roofline": roofline_trsm(ctx, N, M, trsm_ms, passes=-(-M // cand.chunk()), kernel=cand.solve_kernel(),
+                                                               traffic=config_traffic("c5", cand.solve_kernel())),
             "device": ctx.name}
 
 

@@ -41,6 +41,19 @@ pmc)
   python tools/rocpd_pmc.py $OUT/pmc > $OUT/pmc_summary.txt 2>&1
   find $OUT/pmc -size +30M -delete
   grep -i "trsm_step\|potrf_step\|gram_kernel\|potrf_panel" $OUT/pmc_summary.txt | head -24 >> $OUT/summary.txt ;;
+pmcconf)
+  # HBM traffic of the dominant kernel of the other configurations: FETCH_SIZE and WRITE_SIZE passes, one step each
+  for cfg in "c2 trsm_step_gen_kernel 1024 8 65536" "c3 trsm_step_gen_kernel 2048 16 65536" "c4 winv_gemm_kernel 4096 11 8192" "c5 trsm_step_kernel 8192 64 131072"; do
+    set -- $cfg
+    for C in FETCH_SIZE WRITE_SIZE; do
+      timeout 600 rocprofv3 --kernel-trace --pmc $C -d $OUT/pmc_$1/$C -o pmc -- python bench.py --gpus 1 --config $1 --steps 1 --warmup 0 --no-cpu-baseline > /dev/null 2> $OUT/pmc_$1_$C.err
+      echo "pmc $1 $C rc=$?" >> $OUT/summary.txt
+    done
+    python tools/rocpd_pmc.py $OUT/pmc_$1 > $OUT/pmc_summary_$1.txt 2>&1
+    python tools/make_traffic_json.py $OUT/pmc_summary_$1.txt $(cat .git_head 2>/dev/null || echo unknown) $2 $1 $3 $4 $5 > $OUT/trsm_traffic_$1.json 2>> $OUT/summary.txt
+    find $OUT/pmc_$1 -size +30M -delete
+    grep bytes_per_launch $OUT/trsm_traffic_$1.json >> $OUT/summary.txt
+  done ;;
 fit)
   python tools/diag_timeline.py > $OUT/diag_timeline.txt 2>&1
   timeout 600 bash tools/gpu_fit_trace.sh $TAG 4096 > $OUT/fit_trace.log 2>&1
