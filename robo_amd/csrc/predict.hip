@@ -49,20 +49,81 @@ struct AccTt {
 
 // K*_i^T into the accumulators: rows = 128 scaled training points (Xt), columns = 128 scaled candidates (Xc);
 // rows >= n_valid are written as 0.  smem: [GD][GXL] for each operand.
+constexpr int GEN_GD = 16, GEN_GXL = NB + 2;     // dimensions per staged chunk, leading dimension of the [d][row] images
+
 template <int KIND>
-__device__ __forceinline__ void gen_cross_tile_t(const CovParams& cp, const double* __restrict__ Xc,
-                                                 const double* __restrict__ Xt, int n_valid, double* smem,
-                                                 AccTt& acc) {
-    constexpr int GD = 16, GXL = NB + 2;
-    double* sC = smem;
-    double* sX = smem + GD * GXL;
-    const int t = threadIdx.x, lane = t & 63, wave = t >> 6, dim = cp.dim;
+__device__ __forceinline__ void gen_tile_init(AccTt& acc) {
     const bool fab = KIND == ROBO_KERNEL_FABOLAS;
 #pragma unroll
     for (int rb = 0; rb < 8; ++rb)
 #pragma unroll
         for (int mb = 0; mb < 2; ++mb) acc.t[rb][mb] = fab ? v4d{1.0, 1.0, 1.0, 1.0} : v4d{0.0, 0.0, 0.0, 0.0};
+}
+
+// one staged chunk of dimensions [d0, d0 + 16): sC / sX hold candidates / training points as [d][row]; `wave` = which 32
+// candidates of the tile this wave owns
+template <int KIND>
+__device__ __forceinline__ void gen_tile_accumulate(const CovParams& cp, const double* sC, const double* sX, int d0,
+                                                    int wave, AccTt& acc) {
+    const int lane = threadIdx.x & 63, dim = cp.dim;
+    const bool fab = KIND == ROBO_KERNEL_FABOLAS;
     const int rbase = lane >> 4, cbase = wave * 32 + (lane & 15);
+    const int dn = dim - d0 < GEN_GD ? dim - d0 : GEN_GD;
+    for (int d = 0; d < dn; ++d) {
+        if (fab && d0 + d == dim - 1) break;   // fidelity column: handled in the finish
+        double xi[2];
+#pragma unroll
+        for (int mb = 0; mb < 2; ++mb) xi[mb] = sC[d * GEN_GXL + cbase + mb * 16];
+#pragma unroll
+        for (int rb = 0; rb < 8; ++rb)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const double xj = sX[d * GEN_GXL + rb * 16 + rbase + 4 * r];
+#pragma unroll
+                for (int mb = 0; mb < 2; ++mb) {
+                    const double df = xi[mb] - xj;
+                    if (fab) acc.t[rb][mb][r] *= matern52_1d(df);
+                    else acc.t[rb][mb][r] = fma(df, df, acc.t[rb][mb][r]);
+                }
+            }
+    }
+}
+
+// covariance function of the accumulated distances; the last staged chunk still holds the fidelity column (dim - 1)
+// for the Fabolas kernel; rows >= n_valid become 0
+template <int KIND>
+__device__ __forceinline__ void gen_tile_finish(const CovParams& cp, const double* sC, const double* sX, int n_valid,
+                                                int wave, AccTt& acc) {
+    const int lane = threadIdx.x & 63, dim = cp.dim;
+    const bool fab = KIND == ROBO_KERNEL_FABOLAS;
+    const int rbase = lane >> 4, cbase = wave * 32 + (lane & 15);
+    const int dl = (dim - 1) % GEN_GD;
+#pragma unroll
+    for (int rb = 0; rb < 8; ++rb)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int row = rb * 16 + rbase + 4 * r;
+#pragma unroll
+            for (int mb = 0; mb < 2; ++mb) {
+                double uu = 0.0;
+                if (fab) uu = sC[dl * GEN_GXL + cbase + mb * 16] * sX[dl * GEN_GXL + row];
+                const double v = cov_finish<double, KIND>(cp, acc.t[rb][mb][r], uu);
+                acc.t[rb][mb][r] = row < n_valid ? v : 0.0;
+            }
+        }
+}
+
+// K*_i^T into the accumulators: rows = 128 scaled training points (Xt), columns = 128 scaled candidates (Xc);
+// rows >= n_valid are written as 0.  smem: [GD][GXL] for each operand.  256 threads.
+template <int KIND>
+__device__ __forceinline__ void gen_cross_tile_t(const CovParams& cp, const double* __restrict__ Xc,
+                                                 const double* __restrict__ Xt, int n_valid, double* smem,
+                                                 AccTt& acc) {
+    constexpr int GD = GEN_GD, GXL = GEN_GXL;
+    double* sC = smem;
+    double* sX = smem + GD * GXL;
+    const int t = threadIdx.x, wave = t >> 6, dim = cp.dim;
+    gen_tile_init<KIND>(acc);
     for (int d0 = 0; d0 < dim; d0 += GD) {
         __syncthreads();   // previous chunk (or previous user of smem) fully consumed
 #pragma unroll
@@ -74,48 +135,15 @@ __device__ __forceinline__ void gen_cross_tile_t(const CovParams& cp, const doub
             sX[d * GXL + row] = ok ? Xt[(size_t)row * dim + d0 + d] : 0.0;
         }
         __syncthreads();
-        const int dn = dim - d0 < GD ? dim - d0 : GD;
-        for (int d = 0; d < dn; ++d) {
-            if (fab && d0 + d == dim - 1) break;   // fidelity column: handled in the finish
-            double xi[2];
-#pragma unroll
-            for (int mb = 0; mb < 2; ++mb) xi[mb] = sC[d * GXL + cbase + mb * 16];
-#pragma unroll
-            for (int rb = 0; rb < 8; ++rb)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const double xj = sX[d * GXL + rb * 16 + rbase + 4 * r];
-#pragma unroll
-                    for (int mb = 0; mb < 2; ++mb) {
-                        const double df = xi[mb] - xj;
-                        if (fab) acc.t[rb][mb][r] *= matern52_1d(df);
-                        else acc.t[rb][mb][r] = fma(df, df, acc.t[rb][mb][r]);
-                    }
-                }
-        }
+        gen_tile_accumulate<KIND>(cp, sC, sX, d0, wave, acc);
     }
-    // finish: covariance function of the accumulated distances; the last staged chunk still holds the fidelity
-    // column (dim - 1) for the Fabolas kernel
-    const int dl = (dim - 1) % GD;
-#pragma unroll
-    for (int rb = 0; rb < 8; ++rb)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int row = rb * 16 + rbase + 4 * r;
-#pragma unroll
-            for (int mb = 0; mb < 2; ++mb) {
-                double uu = 0.0;
-                if (fab) uu = sC[dl * GXL + cbase + mb * 16] * sX[dl * GXL + row];
-                const double v = cov_finish<double, KIND>(cp, acc.t[rb][mb][r], uu);
-                acc.t[rb][mb][r] = row < n_valid ? v : 0.0;
-            }
-        }
+    gen_tile_finish<KIND>(cp, sC, sX, n_valid, wave, acc);
     __syncthreads();   // smem free for the GEMM stages
 }
 
 // acc(8 x 2 tiles per wave) -= A[0:128, k-tile] * B[0:128, k-tile]^T restricted to the wave's 32 B rows
-__device__ __forceinline__ void tile_mfma_t(const double* sA, const double* sB, AccTt& acc) {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+__device__ __forceinline__ void tile_mfma_t(const double* sA, const double* sB, AccTt& acc, int wave) {
+    const int lane = threadIdx.x & 63;
     const double* pa = sA + (lane & 15) * LDS_LD + (lane >> 4);
     const double* pb = sB + (wave * 32 + (lane & 15)) * LDS_LD + (lane >> 4);
 #pragma unroll
@@ -154,7 +182,7 @@ __device__ __forceinline__ void gemm_t(const double* __restrict__ A, int lda, co
             ra = tile_load_regs<128>(A, lda, (kt + 1) * BK);
             rb = tile_load_regs<128>(B, ldb, (kt + 1) * BK);
         }
-        tile_mfma_t(cur, cur + SA, acc);
+        tile_mfma_t(cur, cur + SA, acc, threadIdx.x >> 6);
         if (more) {
             tile_store_lds<128>(nxt, ra);
             tile_store_lds<128>(nxt + SA, rb);
@@ -168,9 +196,9 @@ __device__ __forceinline__ void gemm_t(const double* __restrict__ A, int lda, co
 __device__ __forceinline__ void solve_store_reduce_t(const AccTt& T, const double* __restrict__ Wp,
                                                      const double* __restrict__ z, int n_valid, double* __restrict__ Vt,
                                                      int ldv, double* __restrict__ q, double* __restrict__ mu,
-                                                     bool first) {
+                                                     bool first, int wave) {
     constexpr int PF = 8;   // fragments in flight (L2 hits): 16 MFMAs = 1024 cycles of cover
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = lane >> 4, nn = lane & 15;
+    const int lane = threadIdx.x & 63, g = lane >> 4, nn = lane & 15;
     const double* wp = Wp + lane;
     double wf[PF];
 #pragma unroll
@@ -250,8 +278,170 @@ __global__ __launch_bounds__(256, 2) void trsm_step_gen_kernel(const double* __r
         gen_cross_tile_t<KIND>(cp, Xcs + (size_t)cw * cp.dim, Xs + (size_t)i * NB * cp.dim, n - i * NB, smem, acc);
         if (i > 0) gemm_t(L + (size_t)i * NB * ld, ld, Vrow, ldv, i * NB, acc, smem);
         solve_store_reduce_t(acc, LinvP + (size_t)i * WP_BLOCK, L + (size_t)n * ld + (size_t)i * NB, n - i * NB,
-                             Vrow + (size_t)i * NB, ldv, q + cw, mu + cw, i == 0);
+                             Vrow + (size_t)i * NB, ldv, q + cw, mu + cw, i == 0, threadIdx.x >> 6);
         __syncthreads();   // V_i (global, workgroup scope) before the next block row stages it
+    }
+}
+
+
+// ---- TWO block rows per launch on ONE read of V (r03j..m) -- MEASURED SLOWER, kept as a tested option (tuning key
+// trsm_pair, default 0) -------------------------------------------------------------------------------------------------
+// The block-row step above re-reads, for block row i, the columns < 128 i of V = L^-1 K_*^T that the same workgroup
+// wrote in earlier launches: 33 GB per 65 536-candidate evaluation at N = 4096 (2.2 TB/s of HBM for the whole step).
+// Timing experiments with the one-row kernel (wrong numbers, same arithmetic, same-session A/B, profiles/r03m_*):
+// every workgroup reading the V rows of eight fixed tiles (V served from L2) 16.0 instead of 17.4 ms; pairs / quadruples
+// / octets of neighbouring workgroups reading the same rows (1/2, 1/4, 1/8 of the HBM stream) +2.6 / +3.7 / +4.1 %;
+// V read as if it were stored k-tile-blocked (16 KB contiguous per k-tile instead of 128-byte row pieces) -1.4 %.  So
+// the stream costs ~5 % under a kernel whose matrix pipes are busy 86 % of the time, and half of it is worth +2.6 %.
+// THIS kernel halves it and lost 3 % (3.78 vs 3.90 M evals/s): one workgroup of eight waves per CU instead of two
+// independent ones of four (every k-tile barrier now stops all eight waves of the CU, where two workgroups fill each
+// other's bubbles), and a tail in which half of the waves wait (solve i -> last update of row i+1 -> solve i+1).
+// Here a workgroup of eight waves owns 128 candidates and TWO block rows (i, i + 1): waves 0-3 hold T_i^T, waves 4-7
+// T_{i+1}^T (each wave all 128 rows of its block row for its own 32 candidates, as above), and every staged k-tile of
+// V (columns < 128 i) feeds both -- V is read once per pair of block rows, the launch count halves.  Then
+//   waves 0-3:  V_i = T_i Linv_ii^T, stored;               (waves 4-7 wait)
+//   all waves stage, waves 4-7 multiply:  T_{i+1} -= V_i L[i+1, i]^T   (128 deep; V_i comes back from L2)
+//   waves 4-7:  V_{i+1} = T_{i+1} Linv_{i+1,i+1}^T, stored.
+// Every entry receives the same products in the same (ascending k) order as in the one-row step: same bits.
+constexpr int PAIR_ST = (2 * NB + NB) * LDS_LD;                 // doubles per stage: 256 rows of L | 128 rows of V
+constexpr int PAIR_SMEM_DOUBLES = 2 * PAIR_ST;                  // 110.6 KB: one workgroup (8 waves) per CU
+
+// k-tile loads with 512 threads, every thread active (no masked loads, no zero-filled registers):
+//   256-row operand: thread t takes row t / 2, 8 doubles (half t % 2);  128-row operand: row t / 4, 4 doubles (quarter t % 4)
+struct Tile2 {
+    double2 a, b;
+};
+__device__ __forceinline__ Tile4 tile_load_256(const double* __restrict__ G, int ld, int k0) {
+    const int row = threadIdx.x >> 1, kh = (threadIdx.x & 1) * 8;
+    const double2* p = reinterpret_cast<const double2*>(G + (size_t)row * ld + k0 + kh);
+    Tile4 t;
+    t.a = p[0];
+    t.b = p[1];
+    t.c = p[2];
+    t.d = p[3];
+    return t;
+}
+__device__ __forceinline__ void tile_store_256(double* S, const Tile4 t) {
+    const int row = threadIdx.x >> 1, kh = (threadIdx.x & 1) * 8;
+    double2* p = reinterpret_cast<double2*>(S + row * LDS_LD + kh);
+    p[0] = t.a;
+    p[1] = t.b;
+    p[2] = t.c;
+    p[3] = t.d;
+}
+__device__ __forceinline__ Tile2 tile_load_128q(const double* __restrict__ G, int ld, int k0) {
+    const int row = threadIdx.x >> 2, kq = (threadIdx.x & 3) * 4;
+    const double2* p = reinterpret_cast<const double2*>(G + (size_t)row * ld + k0 + kq);
+    Tile2 t;
+    t.a = p[0];
+    t.b = p[1];
+    return t;
+}
+__device__ __forceinline__ void tile_store_128q(double* S, const Tile2 t) {
+    const int row = threadIdx.x >> 2, kq = (threadIdx.x & 3) * 4;
+    double2* p = reinterpret_cast<double2*>(S + row * LDS_LD + kq);
+    p[0] = t.a;
+    p[1] = t.b;
+}
+
+// acc -= A[this wave's 128 rows, 0:kend] * B[0:128, 0:kend]^T; pipeline of gemm_t with 512 threads.
+// WIDE: A has 256 rows (both block rows; the wave multiplies rows a_row0 ..), else 128 (the last 128 columns of block
+// row i + 1's update, multiplied by half 1 only).  MULTIPLY = false: the same loads, stores and barriers without the
+// products -- the code path of the waves that only help staging (their accumulators are dead by then, and a separate
+// path is what tells the register allocator so).
+template <bool WIDE, bool MULTIPLY>
+__device__ __forceinline__ void gemm_pair(const double* __restrict__ A, int lda, const double* __restrict__ B, int ldb,
+                                          int kend, AccTt* acc, double* smem, int a_row0, int wq) {
+    constexpr int SA = 2 * NB * LDS_LD;
+    const int nk = kend / BK;
+    if (nk <= 0) return;
+    Tile4 ra;
+    Tile2 ra2, rb = tile_load_128q(B, ldb, 0);
+    if (WIDE) ra = tile_load_256(A, lda, 0);
+    else ra2 = tile_load_128q(A, lda, 0);
+    if (WIDE) tile_store_256(smem, ra);
+    else tile_store_128q(smem, ra2);
+    tile_store_128q(smem + SA, rb);
+    __syncthreads();
+#pragma unroll 1   // (the narrow call has a compile-time trip count of 8: fully unrolled it spilled ~1000 registers)
+    for (int kt = 0; kt < nk; ++kt) {
+        double* cur = smem + (kt & 1) * PAIR_ST;
+        double* nxt = smem + ((kt + 1) & 1) * PAIR_ST;
+        const bool more = kt + 1 < nk;
+        if (more) {
+            if (WIDE) ra = tile_load_256(A, lda, (kt + 1) * BK);
+            else ra2 = tile_load_128q(A, lda, (kt + 1) * BK);
+            rb = tile_load_128q(B, ldb, (kt + 1) * BK);
+        }
+        if (MULTIPLY) tile_mfma_t(cur + a_row0 * LDS_LD, cur + SA, *acc, wq);
+        if (more) {
+            if (WIDE) tile_store_256(nxt, ra);
+            else tile_store_128q(nxt, ra2);
+            tile_store_128q(nxt + SA, rb);
+        }
+        __syncthreads();
+    }
+}
+
+template <int KIND>
+__global__ __launch_bounds__(512, 1) void trsm_pair_gen_kernel(const double* __restrict__ Xcs,
+                                                               const double* __restrict__ Xs, double* __restrict__ V,
+                                                               int ldv, const double* __restrict__ L, int ld,
+                                                               const double* __restrict__ LinvP, int i, int n,
+                                                               double* __restrict__ q, double* __restrict__ mu,
+                                                               long long c0, CovParams cp) {
+    __shared__ double smem[PAIR_SMEM_DOUBLES];
+    // (wave-uniform by construction; readfirstlane tells the compiler, so that the two halves' code paths are scalar
+    // branches with disjoint register live ranges instead of exec-masked regions)
+    const int t = threadIdx.x, wave8 = __builtin_amdgcn_readfirstlane(t >> 6), half = wave8 >> 2, wq = wave8 & 3,
+              dim = cp.dim;
+    double* Vrow = V + (size_t)blockIdx.x * NB * ldv;
+    const long long cw = c0 + (long long)blockIdx.x * NB;
+    const int row = i + half;                                   // this wave's block row
+    AccTt acc;
+    {   // ---- both cross-gram tiles: candidates staged once, the two blocks of training points side by side
+        constexpr int GD = GEN_GD, GXL = GEN_GXL;
+        double* sC = smem;
+        double* sX = smem + GD * GXL;                           // [2][GD][GXL]
+        const double* Xc = Xcs + (size_t)cw * dim;
+        const double* Xt = Xs + (size_t)i * NB * dim;           // 256 consecutive training points
+        gen_tile_init<KIND>(acc);
+        for (int d0 = 0; d0 < dim; d0 += GD) {
+            __syncthreads();
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int idx = t + e * 512, r = idx >> 4, d = idx & 15;     // 128 candidates x 16 dims
+                sC[d * GXL + r] = d0 + d < dim ? Xc[(size_t)r * dim + d0 + d] : 0.0;
+            }
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const int idx = t + e * 512, r = idx >> 4, d = idx & 15;     // 256 training points x 16 dims
+                sX[(r >> 7) * GD * GXL + d * GXL + (r & 127)] = d0 + d < dim ? Xt[(size_t)r * dim + d0 + d] : 0.0;
+            }
+            __syncthreads();
+            gen_tile_accumulate<KIND>(cp, sC, sX + half * GD * GXL, d0, wq, acc);
+        }
+        gen_tile_finish<KIND>(cp, sC, sX + half * GD * GXL, n - row * NB, wq, acc);
+        __syncthreads();
+    }
+    // ---- columns < 128 i of V against both block rows of L
+    if (i > 0) gemm_pair<true, true>(L + (size_t)i * NB * ld, ld, Vrow, ldv, i * NB, &acc, smem, half * NB, wq);
+    const double* Ltail = L + (size_t)(i + 1) * NB * ld + (size_t)i * NB;      // L[i+1, i]
+    // ---- the tail.  ONE inlined copy of the solve, reached by half 0 right away and by half 1 after its last update
+    // (two copies made the register allocator spill ~210 registers, a quarter of the accumulators inside the k-loop
+    // above; with one copy whose accumulators die in it: none).  The hardware barrier only counts arrivals, so the two
+    // halves meet at DIFFERENT s_barrier instructions: both execute 1 + 1 + 8 of them.
+    //   half 0:                         solve row i   | B | stage-only loop (1 + 8 barriers)
+    //   half 1:  | B | last 128 columns of row i+1's update (1 + 8 barriers; V_i comes back from L2)   solve row i+1
+    if (half == 1) {
+        __syncthreads();   // V_i and row i's share of q / mu are stored (global, workgroup scope)
+        gemm_pair<false, true>(Ltail, ld, Vrow + (size_t)i * NB, ldv, NB, &acc, smem, 0, wq);
+    }
+    solve_store_reduce_t(acc, LinvP + (size_t)row * WP_BLOCK, L + (size_t)n * ld + (size_t)row * NB, n - row * NB,
+                         Vrow + (size_t)row * NB, ldv, q + cw, mu + cw, row == 0, wq);
+    if (half == 0) {
+        __syncthreads();
+        gemm_pair<false, false>(Ltail, ld, Vrow + (size_t)i * NB, ldv, NB, nullptr, smem, 0, wq);
     }
 }
 
@@ -519,7 +709,7 @@ __global__ __launch_bounds__(256, 2) void trsm_step_kernel(double* __restrict__ 
     }
     if (i > 0) gemm_t(L + (size_t)i * NB * ld, ld, Vrow, ldv, i * NB, acc, smem);
     solve_store_reduce_t(acc, LinvP + (size_t)i * WP_BLOCK, L + (size_t)n * ld + (size_t)i * NB, n - i * NB,
-                         Vrow + (size_t)i * NB, ldv, q + cw, mu + cw, i == 0);
+                         Vrow + (size_t)i * NB, ldv, q + cw, mu + cw, i == 0, threadIdx.x >> 6);
 }
 
 // mean/var from the reductions, with the reference's output transform and variance floor
@@ -621,7 +811,24 @@ int launch_predict_fused(robo_gp* gp, robo_cand* cand, int64_t c0, int64_t cn) {
                        (i + rows < nbk ? i + rows : nbk), gp->n, cand->d_q, cand->d_mu, (long long)c0, gp->cov)
     cand->solve_kernel = "trsm_step_gen_kernel";
     const int rows = tune.trsm_rows < 1 ? 1 : tune.trsm_rows;
-    for (int i = 0; i < nbk; i += rows) {
+    int i_first = 0;
+    if (tune.trsm_pair != 0 && nbk >= 2) {
+        // pairs of block rows on one read of V; an odd last block row takes the one-row step
+        cand->solve_kernel = "trsm_pair_gen_kernel";
+#define ROBO_PAIR_CALL(KIND)                                                                                   \
+    hipLaunchKernelGGL(trsm_pair_gen_kernel<KIND>, grid, dim3(512), 0, gp->ctx->stream,                        \
+                       (const double*)cand->d_Xcs, (const double*)gp->d_Xs, cand->d_V, gp->n_pad,             \
+                       (const double*)gp->d_K, gp->n_pad, (const double*)gp->d_LinvP, i, gp->n, cand->d_q,    \
+                       cand->d_mu, (long long)c0, gp->cov)
+        for (int i = 0; i + 1 < nbk; i += 2) {
+            if (gp->kind == ROBO_KERNEL_MATERN52_ARD) ROBO_PAIR_CALL(ROBO_KERNEL_MATERN52_ARD);
+            else if (gp->kind == ROBO_KERNEL_RBF_ARD) ROBO_PAIR_CALL(ROBO_KERNEL_RBF_ARD);
+            else ROBO_PAIR_CALL(ROBO_KERNEL_FABOLAS);
+        }
+#undef ROBO_PAIR_CALL
+        i_first = nbk & ~1;
+    }
+    for (int i = i_first; i < nbk; i += rows) {
         if (gp->kind == ROBO_KERNEL_MATERN52_ARD) ROBO_STEP_CALL(ROBO_KERNEL_MATERN52_ARD);
         else if (gp->kind == ROBO_KERNEL_RBF_ARD) ROBO_STEP_CALL(ROBO_KERNEL_RBF_ARD);
         else ROBO_STEP_CALL(ROBO_KERNEL_FABOLAS);

@@ -774,8 +774,19 @@ def check_small_and_large_tiles_agree(ctx, monkeypatch, cases=(("matern52", 300,
         try:
             ctx.set_tuning("winv_max", 0)           # the block-row substitution only (not the explicit-inverse path)
             ctx.set_tuning("trsm_small_max", 0)
-            mu_l, var_l = g.predict(Xc)
+            ctx.set_tuning("trsm_pair", 0)          # one block row per launch
+            cl = _lib.Candidates(ctx, Xc)
+            mu_l, var_l = g.predict(cl)
+            assert cl.solve_kernel() == "trsm_step_gen_kernel"
             _, mx_l, am_l, _ = g.acq("ei", 0.0, float(y.min()), Xc)
+            ctx.set_tuning("trsm_pair", 1)          # two block rows per launch on one read of V: same bits
+            mu_p, var_p = g.predict(cl)
+            assert cl.solve_kernel() == "trsm_pair_gen_kernel"
+            _, mx_p, am_p, _ = g.acq("ei", 0.0, float(y.min()), Xc)
+            cl.close()
+            np.testing.assert_array_equal(mu_p, mu_l)
+            np.testing.assert_array_equal(var_p, var_l)
+            assert (mx_p, am_p) == (mx_l, am_l)
             ctx.set_tuning("trsm_small_max", 1000000)
             for narrow in (0, 1):          # 32 and 16 candidates per workgroup
                 for deep in (0, 1):        # one and two k-tiles per staging stage
@@ -787,7 +798,7 @@ def check_small_and_large_tiles_agree(ctx, monkeypatch, cases=(("matern52", 300,
                     np.testing.assert_array_equal(var_s, var_l)
                     assert (mx_s, am_s) == (mx_l, am_l)
         finally:
-            for key in ("trsm_small_narrow", "trsm_small_deep", "trsm_small_max", "winv_max"):
+            for key in ("trsm_small_narrow", "trsm_small_deep", "trsm_small_max", "winv_max", "trsm_pair"):
                 ctx.set_tuning(key, None)
         g.close()
 
