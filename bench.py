@@ -270,6 +270,22 @@ def roofline_trsm(ctx, N, M_rows, trsm_ms_per_step, passes=1, kernel="trsm_step_
             "avg_launch_ms": avg_launch_ms}
 
 
+def clock_under_step(ctx, roof, step, ms_per_step):
+    """shader clock while one more `step` runs (include/robo_hip_diag.h: sampler waves on a second stream), and the fp64
+    peak at THAT clock next to the nominal 2.4 GHz figure `frac` is quoted against.  Information only."""
+    try:
+        ctx.clock_sample_begin(max(200, int(0.75 * ms_per_step * 1e3)))
+        step()
+        ck = ctx.clock_sample_end()
+        pk = FP64_MFMA_PEAK_TFLOPS * ck["mean"] / 2400.0
+        roof["shader_clock_under_kernel"] = {
+            "mhz": ck, "peak_at_that_clock_tflops": pk, "frac_of_peak_at_that_clock": roof["achieved"] / pk,
+            "note": "`frac` is against the nominal 2.4 GHz peak; this block: the clock the part held during one step"}
+    except Exception as e:
+        roof["shader_clock_under_kernel"] = {"error": str(e)[:200]}
+    return roof
+
+
 # ----------------------------------------------------------------------------------------------------
 # headline and config 2: one fitted GP, candidate shard
 # ----------------------------------------------------------------------------------------------------
@@ -404,6 +420,7 @@ def run_headline(args, D_, _lib, sharding):
             roof["gemm_f64_microbench"] = {"lds_core_tflops": g_tf, "shader_mhz_under_load": g_mhz,
                                            "peak_at_that_clock_tflops": clock_peak,
                                            "frac_of_peak_at_that_clock": roof["achieved"] / clock_peak}
+        clock_under_step(ctx, roof, step, ms_per_step)
         k1_bytes = 8.0 * N * (N + 1) / 2 + 8.0 * N * D
         name = "BASELINE headline" if (N, D) == (4096, 16) else "BASELINE config 2" if (N, D) == (1024, 8) else "custom"
         out = {
@@ -482,6 +499,7 @@ def run_c3(args, D_, _lib, sharding):
     ms = elapsed / args.steps * 1e3
     # elapsed_ms(25, 26) brackets the LAST sample's solve of a step
     roof = roofline_trsm(ctx, N, M, trsm_ms, kernel=cand.solve_kernel(), traffic=config_traffic("c3", cand.solve_kernel()))
+    clock_under_step(ctx, roof, step, ms)
     return {"metric": METRIC, "value": S * M * args.steps / elapsed, "unit": "LogEI sample-evals/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": True,
             "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
@@ -560,8 +578,9 @@ def run_c4(args, D_, _lib, sharding):
                        "n_train": N, "dim": D, "candidates_per_gpu": M, "acquisition": "information_gain_per_unit_cost",
                        "parallelism": "candidate-shard x%d, replicated fits" % world},
             "argmax": list(best),
-            "roofline": roofline_trsm(ctx, N, M, trsm_ms, kernel=cand_cost.solve_kernel(),
-                                      traffic=config_traffic("c4", cand_cost.solve_kernel())),
+            "roofline": clock_under_step(ctx, roofline_trsm(ctx, N, M, trsm_ms, kernel=cand_cost.solve_kernel(),
+                                                            traffic=config_traffic("c4", cand_cost.solve_kernel())),
+                                         step, ms),
             "device": ctx.name,
             "note": "roofline: the block-row solve of the LAST posterior of a step (the cost model's); at this batch "
                     "size the step is latency-bound, not MFMA-bound (see small_batch_latency_ms of the headline line)"}
@@ -615,8 +634,10 @@ def run_c5(args, D_, _lib, sharding):
                        "n_train": N, "dim": D, "candidates_per_gpu": M, "acquisition": "lcb",
                        "parallelism": "candidate-shard x%d, replicated fit" % world},
             "gp_fit_ms": fit_ms, "algorithmic_tflops_whole_step": world * M * flops_ei(N, D) / (ms * 1e-3) / 1e12,
-            "argmax": list(best), "roofline": roofline_trsm(ctx, N, M, trsm_ms, passes=-(-M // cand.chunk()), kernel=cand.solve_kernel(),
-                                                               traffic=config_traffic("c5", cand.solve_kernel())),
+            "argmax": list(best),
+            "roofline": clock_under_step(ctx, roofline_trsm(ctx, N, M, trsm_ms, passes=-(-M // cand.chunk()),
+                                                            kernel=cand.solve_kernel(),
+                                                            traffic=config_traffic("c5", cand.solve_kernel())), step, ms),
             "device": ctx.name}
 
 

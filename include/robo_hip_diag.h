@@ -27,6 +27,13 @@ int32_t robo_microbench_mfma_f64_detail(robo_ctx* ctx, int32_t iters, double* ou
 int32_t robo_microbench_gemm_f64(robo_ctx* ctx, int32_t variant, int32_t wgs, int32_t k, int32_t reps,
                                  double* out2);
 
+/* Shader clock while other work runs: _begin launches eight one-wave sampler workgroups on a private stream; each
+ * sleeps through window_us of the 100 MHz wall clock and records the shader cycles that passed.  _end waits for them:
+ * out3 = {mean, min, max} shader MHz.  bench.py brackets one posterior step with it, so that the roofline block can
+ * state the fp64 peak AT THE CLOCK THE KERNEL RAN AT next to the nominal 2.4 GHz figure.                          */
+int32_t robo_diag_clock_sample_begin(robo_ctx* ctx, int32_t window_us);
+int32_t robo_diag_clock_sample_end(robo_ctx* ctx, double* out3);
+
 #ifdef __cplusplus
 }
 #endif

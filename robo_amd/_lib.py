@@ -43,7 +43,7 @@ COMM_ID_BYTES = 128
 # include/robo_hip_diag.h (librobo_hip_diag.so: tests, bench.py's roofline block, tools/)
 DIAG_SYMBOLS = [
     "robo_selftest_mfma_layout", "robo_microbench_mfma_f64", "robo_microbench_mfma_f64_detail", "robo_microbench_gemm_f64",
-    "robo_selftest_diag_timeline",
+    "robo_selftest_diag_timeline", "robo_diag_clock_sample_begin", "robo_diag_clock_sample_end",
 ]
 
 
@@ -186,7 +186,8 @@ def diag():
     for name, args in {"robo_selftest_mfma_layout": [vp, _dp], "robo_microbench_mfma_f64": [vp, i32, _dp],
                        "robo_microbench_mfma_f64_detail": [vp, i32, _dp],
                        "robo_microbench_gemm_f64": [vp, i32, i32, i32, i32, _dp],
-                       "robo_selftest_diag_timeline": [vp, _dp, _dp]}.items():
+                       "robo_selftest_diag_timeline": [vp, _dp, _dp],
+                       "robo_diag_clock_sample_begin": [vp, i32], "robo_diag_clock_sample_end": [vp, _dp]}.items():
         fn = getattr(D, name)
         fn.argtypes = args
         fn.restype = i32
@@ -282,6 +283,15 @@ class Context(object):
         out = np.zeros(2)
         check(diag().robo_microbench_gemm_f64(self._h, int(variant), int(wgs), int(k), int(reps), _arr(out)))
         return float(out[0]), float(out[1])    # TFLOP/s, shader MHz
+
+    def clock_sample_begin(self, window_us):
+        """Shader-clock sampler on a private stream (include/robo_hip_diag.h); measurement only."""
+        check(diag().robo_diag_clock_sample_begin(self._h, int(window_us)))
+
+    def clock_sample_end(self):
+        out = np.zeros(3)
+        check(diag().robo_diag_clock_sample_end(self._h, _arr(out)))
+        return {"mean": float(out[0]), "min": float(out[1]), "max": float(out[2])}
 
     def microbench_mfma_f64(self, iters=2000):
         t = C.c_double(0)

@@ -251,6 +251,8 @@ int launch_sobol(robo_ctx* ctx, double* d_out, int64_t m, int64_t m_pad, int dim
                  const unsigned long long* d_shift, int bits, uint64_t first);
 int launch_mfma_selftest(robo_ctx* ctx, double* out_err);
 int launch_gemm_microbench(robo_ctx* ctx, int variant, int wgs, int K, int reps, double* out_tflops);
+int launch_clock_sampler(robo_ctx* ctx, int window_us);
+int collect_clock_sampler(double* out3);
 int launch_mfma_microbench(robo_ctx* ctx, int iters, double* out_tflops, double* out_cycles_per_mfma,
                            double* out_shader_mhz, double* out_chain);
 }  // namespace robo

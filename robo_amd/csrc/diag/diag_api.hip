@@ -56,4 +56,16 @@ int32_t robo_microbench_mfma_f64_detail(robo_ctx* ctx, int32_t iters, double* ou
     return launch_mfma_microbench(ctx, iters, out3, out3 + 1, out3 + 2, out3 + 3);
 }
 
+int32_t robo_diag_clock_sample_begin(robo_ctx* ctx, int32_t window_us) {
+    if (!ctx) return ROBO_BAD_ARGUMENT;
+    ROBO_HIP_CHECK(hipSetDevice(ctx->device));
+    return launch_clock_sampler(ctx, window_us);
+}
+
+int32_t robo_diag_clock_sample_end(robo_ctx* ctx, double* out3) {
+    if (!ctx || !out3) return ROBO_BAD_ARGUMENT;
+    ROBO_HIP_CHECK(hipSetDevice(ctx->device));
+    return collect_clock_sampler(out3);
+}
+
 }  // extern "C"

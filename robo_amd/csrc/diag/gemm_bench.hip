@@ -185,4 +185,59 @@ int launch_gemm_microbench(robo_ctx* ctx, int variant, int wgs, int K, int reps,
     return ROBO_OK;
 }
 
+// ---- shader clock while ANOTHER kernel runs -------------------------------------------------------------------------
+// The fp64 peak of SURVEY 8(d) (78.6 TFLOP/s) is 32 flop/clk/SIMD at 2.4 GHz; under a chip-wide MFMA + LDS load the
+// part does not hold 2.4 GHz (gemm_lds_bench_kernel above: ~2.05 GHz).  One wave per sampler workgroup sleeps through
+// a window of the 100 MHz wall clock on its own stream and reports shader cycles / wall ticks of that window: launched
+// right before a posterior step on the library stream, it measures the clock the block-row solve actually runs at.
+__global__ __launch_bounds__(64) void clock_sampler_kernel(long long window_ticks, long long* __restrict__ out) {
+    const long long w0 = wall_clock64(), t0 = clock64();
+    long long w;
+    do {
+        __builtin_amdgcn_s_sleep(64);
+        w = wall_clock64();
+    } while (w - w0 < window_ticks);
+    if (threadIdx.x == 0) {
+        out[2 * blockIdx.x] = clock64() - t0;
+        out[2 * blockIdx.x + 1] = w - w0;
+    }
+}
+
+constexpr int SAMPLER_WGS = 8;
+static hipStream_t g_sampler_stream = nullptr;
+static long long* g_sampler_out = nullptr;       // pinned host memory, device-visible
+
+int launch_clock_sampler(robo_ctx* ctx, int window_us) {
+    if (window_us < 1 || window_us > 2000000) return ROBO_BAD_ARGUMENT;
+    if (!g_sampler_stream) ROBO_HIP_CHECK(hipStreamCreateWithFlags(&g_sampler_stream, hipStreamNonBlocking));
+    if (!g_sampler_out) ROBO_HIP_CHECK(hipHostMalloc((void**)&g_sampler_out, 2 * SAMPLER_WGS * sizeof(long long)));
+    for (int i = 0; i < 2 * SAMPLER_WGS; ++i) g_sampler_out[i] = 0;
+    (void)ctx;
+    hipLaunchKernelGGL(clock_sampler_kernel, dim3(SAMPLER_WGS), dim3(64), 0, g_sampler_stream,
+                       (long long)window_us * 100, g_sampler_out);
+    ROBO_LAUNCH_CHECK();
+    return ROBO_OK;
+}
+
+// out3 = {mean, min, max} shader MHz over the sampler workgroups
+int collect_clock_sampler(double* out3) {
+    if (!g_sampler_stream || !g_sampler_out) return ROBO_BAD_ARGUMENT;
+    ROBO_HIP_CHECK(hipStreamSynchronize(g_sampler_stream));
+    double sum = 0.0, lo = 1e30, hi = 0.0;
+    int cnt = 0;
+    for (int i = 0; i < SAMPLER_WGS; ++i) {
+        if (g_sampler_out[2 * i + 1] <= 0) continue;
+        const double mhz = (double)g_sampler_out[2 * i] / ((double)g_sampler_out[2 * i + 1] / 100.0);
+        sum += mhz;
+        lo = mhz < lo ? mhz : lo;
+        hi = mhz > hi ? mhz : hi;
+        ++cnt;
+    }
+    if (cnt == 0) return ROBO_RUNTIME_ERROR;
+    out3[0] = sum / cnt;
+    out3[1] = lo;
+    out3[2] = hi;
+    return ROBO_OK;
+}
+
 }  // namespace robo

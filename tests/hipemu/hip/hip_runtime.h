@@ -172,6 +172,7 @@ static inline v4d_emu __builtin_amdgcn_mfma_f64_16x16x4f64(double a, double b, v
 }
 
 static inline void __builtin_amdgcn_s_setprio(int) {}
+static inline void __builtin_amdgcn_s_sleep(int) {}
 static inline void __builtin_amdgcn_fence(int, const char*) {}
 static inline void __builtin_amdgcn_s_waitcnt(int) {}
 static inline int __builtin_amdgcn_readfirstlane(int v) { return v; }   // only used on wave-uniform values
