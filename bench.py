@@ -176,7 +176,23 @@ class Dist(object):
             box = [_lib.Comm.create_id() if self.rank == 0 else None]
             if self.world > 1:
                 self.dist.broadcast_object_list(box, src=0)
-            comm = _lib.Comm(ctx, self.rank, self.world, box[0])
+            # ncclCommInitRank blocks until every rank has joined: run it on a helper thread with a deadline, so that a
+            # rank that cannot join turns into the fallback below instead of a hung scaling run (bench-only)
+            import threading
+            res = {}
+
+            def _init():
+                try:
+                    res["comm"] = _lib.Comm(ctx, self.rank, self.world, box[0])
+                except Exception as e:   # noqa: BLE001
+                    res["err"] = "%s: %s" % (type(e).__name__, e)
+
+            th = threading.Thread(target=_init, daemon=True)
+            th.start()
+            th.join(float(os.environ.get("ROBO_BENCH_COMM_TIMEOUT", "240")))
+            comm = res.get("comm")
+            if comm is None:
+                err = res.get("err", "communicator setup timed out")
         except Exception as e:           # noqa: BLE001 -- measured anyway, and said so in the JSON line
             comm, err = None, "%s: %s" % (type(e).__name__, e)
         ok = torch.tensor([1.0 if comm is not None else 0.0], device="cuda")

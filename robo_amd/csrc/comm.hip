@@ -262,6 +262,7 @@ int32_t robo_acq_eval_cand_sharded(robo_comm* c, robo_gp* g, int32_t acq_kind, d
         return ROBO_BAD_ARGUMENT;
     }
     hipStream_t st = c->ctx->stream;
+    ROBO_HIP_CHECK(hipSetDevice(c->ctx->device));
     // no early return between here and the collective: a rank that left would leave the others waiting in it
     int status = api_acq_local(g, acq_kind, par, eta, k);
     const bool ok = status == ROBO_OK;
@@ -309,8 +310,10 @@ int32_t robo_acq_eval_marginal_cand_sharded(robo_comm* c, robo_gp* const* gps, i
     hipStream_t st = c->ctx->stream;
     ROBO_HIP_CHECK(hipSetDevice(c->ctx->device));
     const long long m = (long long)k->m;
-    int status = comm_reserve(c, (size_t)m + 1);
-    if (status == ROBO_OK && S_local > 0) status = api_acq_accumulate(gps, S_local, acq_kind, par, etas, k);
+    // (out of device memory for the exchange buffers: nothing to send from -- the one error that leaves before the collective)
+    ROBO_TRY_COMM(comm_reserve(c, (size_t)m + 1));
+    int status = ROBO_OK;
+    if (S_local > 0) status = api_acq_accumulate(gps, S_local, acq_kind, par, etas, k);
     const bool ok = status == ROBO_OK;
     // a failed rank still takes part in the collective (zeros): the others must not hang
     hipLaunchKernelGGL(comm_pack_sum_kernel, dim3((unsigned)((m + 1 + 255) / 256)), dim3(256), 0, st,
