@@ -16,8 +16,10 @@ int32_t robo_selftest_mfma_layout(robo_ctx* ctx, double* out_max_err);
 /* issues `iters` dependent-free MFMA f64 per wave on every CU; returns TFLOP/s               */
 int32_t robo_microbench_mfma_f64(robo_ctx* ctx, int32_t iters, double* out_tflops);
 /* shader-clock offsets of the phase boundaries of one potrf_diag_kernel (panel 0 of the gram
- * matrix at theta): load, potf2(0), sub-panel(0), steps 0..6, inverse, write-back              */
-int32_t robo_selftest_diag_timeline(robo_gp* gp, const double* theta, double* out17);
+ * matrix at theta): load, potf2(0), sub-panel(0), steps 0..6, inverse, write-back [13]; the panel
+ * kernel below it [4]; per interval s = 0..6 of the pivot wave: C1 + C2 done, barrier Bb passed,
+ * potf2(s+1) done [21]                                                                        */
+int32_t robo_selftest_diag_timeline(robo_gp* gp, const double* theta, double* out38);
 /* out3[4] = {full-chip TFLOP/s, shader cycles per MFMA of one wave alone (8 independent
  * accumulators), shader MHz under load, cycles per MFMA in a fully dependent chain}            */
 int32_t robo_microbench_mfma_f64_detail(robo_ctx* ctx, int32_t iters, double* out3);

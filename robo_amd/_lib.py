@@ -464,7 +464,7 @@ class DeviceGP(object):
 
     def diag_timeline(self, theta):
         theta = _f64(theta, (self.n_theta,))
-        out = np.zeros(17)
+        out = np.zeros(38)
         check(diag().robo_selftest_diag_timeline(self._h, _arr(theta), _arr(out)))
         return out
 

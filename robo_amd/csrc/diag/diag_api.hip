@@ -31,15 +31,18 @@ int32_t robo_selftest_diag_timeline(robo_gp* g, const double* theta, double* out
         if (st != ROBO_OK) return st;
     }
     long long* d = nullptr;
-    ROBO_HIP_CHECK(hipMalloc((void**)&d, 24 * sizeof(long long)));
-    ROBO_HIP_CHECK(hipMemsetAsync(d, 0, 24 * sizeof(long long), g->ctx->stream));
+    ROBO_HIP_CHECK(hipMalloc((void**)&d, 56 * sizeof(long long)));
+    ROBO_HIP_CHECK(hipMemsetAsync(d, 0, 56 * sizeof(long long), g->ctx->stream));
     { const int st = launch_diag_timeline(g, d); if (st != ROBO_OK) return st; }
-    long long h[24];
+    long long h[56];
     ROBO_HIP_CHECK(hipMemcpyAsync(h, d, sizeof(h), hipMemcpyDeviceToHost, g->ctx->stream));
     ROBO_HIP_CHECK(hipStreamSynchronize(g->ctx->stream));
     ROBO_HIP_CHECK(hipFree(d));
     for (int i = 0; i < 13; ++i) out13[i] = (double)(h[i] - h[0]);
-    for (int i = 0; i < 4; ++i) out13[13 + i] = (double)(h[16 + i] - h[16]);   // panel kernel (out has 17 entries)
+    for (int i = 0; i < 4; ++i) out13[13 + i] = (double)(h[16 + i] - h[16]);   // panel kernel
+    // per interval s = 0..6 of the pivot wave: C1 + C2 done, through Bb(s), potf2(s+1) done (out has 17 + 21 entries)
+    for (int sb = 0; sb < 7; ++sb)
+        for (int i = 0; i < 3; ++i) out13[17 + 3 * sb + i] = (double)(h[24 + 4 * sb + i] - h[0]);
     return ROBO_OK;
 }
 

@@ -311,12 +311,97 @@ __device__ __forceinline__ int potf2_16_split(double* Ld, double* Wd, double* co
     return fail;
 }
 
-#ifndef ROBO_POTF2_SPLIT
-#define ROBO_POTF2_SPLIT 1      // 0: the two-group version above (A/B builds)
+// ---- rank-1 updates on the matrix pipe, square-root-free (r03t): MEASURED SLOWER, kept as an A/B build ---------------
+// Idea: keep the block in the MFMA ACCUMULATOR layout -- register r of lane l = T[(l >> 4) + 4 r][l & 15] -- in which
+// row k of T is register k >> 2 of the sixteen lanes of group g = k & 3: exactly the lanes that hold k-slice g of BOTH
+// operands of v_mfma_f64_16x16x4_f64 (A[i][g] in lane 16 g + i, B[g][j] in lane 16 g + j).  With the other slices
+// zeroed, the rank-1 update of the whole block by pivot row k is ONE instruction whose operands are already in place:
+// no exchange of the scaled column through LDS.  Elimination runs on the UPPER triangle, row by row (T = transpose of
+// the stored lower block), in LDL^T form so that no square root sits between two pivots:
+//     rinv_k = 1 / p_k;    T[i][j] -= T[k][i] (T[k][j] rinv_k)  for i, j > k;    p_{k+1} = T[k+1][k+1] - T[k][k+1]^2 rinv_k
+// (the last line on the VALU from two broadcasts taken BEFORE the update is issued).  The inverse falls out of a second
+// accumulator: X starts as the identity and receives the same eliminations, X -= w_k (row k of X), w_k = the B operand
+// of the first update.  After the last pivot  L[j][i] = T[i][j] / sqrt(p_i),  W[i][j] = X[i][j] / sqrt(p_i).
+// Correct (emulator suite + MI355X parity suite), and 5.8-6.0k cycles per 16 pivots against 3.8-4.3k for the
+// four-group version (profiles/r03t_diag_timeline_mfma.txt): a VALU instruction (or readlane) that consumes the result
+// of an fp64 MFMA waits ~250 cycles for it (accumulator-to-accumulator chaining is 64), and the operands of update k+1
+// ARE the result of update k -- the matrix pipe cannot sit inside a per-pivot recurrence.
+__device__ __forceinline__ double pivot_rcp(double p) {
+    const double r = __builtin_amdgcn_rcp(p);
+    const double e = fma(-p, r, 1.0);                   // r (1 + e + e^2): third order, like pivot_rsqrt
+    return fma(r * e, 1.0 + e, r);
+}
+
+template <bool GUARD>
+__device__ __forceinline__ int potf2_16_mfma(double* Ld, double* Wd, int lane, int g0, int n_real) {
+    const int col = lane & 15, grp = lane >> 4;
+    v4d t, x;
+    double pj[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int i = grp + 4 * r;
+        t[r] = col >= i ? Ld[bidx(col, i)] : 0.0;       // T[i][col] = stored lower entry [col][i]
+        x[r] = col == i ? 1.0 : 0.0;
+        pj[r] = 1.0;
+    }
+    int fail = 0;
+    double p = bcast_lane(t[0], 0);
+#pragma unroll
+    for (int k = 0; k < SB; ++k) {
+        const int g = k & 3, r = k >> 2;
+        if (GUARD) {
+            if (g0 + k >= n_real) p = 1.0;              // augmented row / identity padding
+            if (!(p > 0.0)) {                           // also catches NaN
+                if (fail == 0) fail = g0 + k + 1;
+                p = 1.0;
+            }
+        }
+        const double nrinv = -pivot_rcp(p);
+        pj[r] = grp == g ? p : pj[r];
+        const double a = (grp == g && col > k) ? t[r] : 0.0;        // row k right of the diagonal, in slice g
+        const double b = a * nrinv;                                  // -w_k
+        const double bx = grp == g ? x[r] : 0.0;                     // row k of X
+        if (k + 1 < SB) {
+            // p_{k+1} from the entries as they are BEFORE this update (row k is final, T[k+1][k+1] has pivots < k)
+            const double u = bcast_lane(t[r], 16 * g + k + 1);
+            const double d = bcast_lane(t[(k + 1) >> 2], 16 * ((k + 1) & 3) + k + 1);
+            p = fma(u * u, nrinv, d);
+        }
+        t = mfma_f64(a, b, t);
+        x = mfma_f64(b, bx, x);
+    }
+    if (!GUARD) {
+        // first non-positive (or non-finite) pivot: every lane of group g holds p_{g + 4 r} in pj[r]
+        int first = SB;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const unsigned long long m = __ballot(!(pj[r] > 0.0 && pj[r] < 1.0e300));
+#pragma unroll
+            for (int g = 3; g >= 0; --g)
+                if (((m >> (16 * g)) & 1ull) != 0ull && 4 * r + g < first) first = 4 * r + g;
+        }
+        if (first < SB) fail = g0 + first + 1;
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int i = grp + 4 * r;
+        const double ri = pivot_rsqrt(pj[r]);
+        const double l = col == i ? pj[r] * ri : t[r] * ri;
+        Ld[bidx(col, i)] = col >= i ? l : 0.0;          // L[col][i]; the upper triangle of the stored block is zero
+        Wd[bidx(i, col)] = x[r] * ri;                   // W[i][col], zero above the diagonal
+    }
+    return fail;
+}
+
+#ifndef ROBO_POTF2
+#define ROBO_POTF2 1            // 1: four lane groups (r02w); 2: rank-1 MFMA version (r03t: slower); 0: two lane groups
 #endif
 // the pivot guard for rows >= n_real only exists in the block(s) that hold the augmented row / padding
 __device__ __forceinline__ int potf2_16(double* Ld, double* Wd, double* colbuf, int lane, int g0, int n_real) {
-#if ROBO_POTF2_SPLIT
+#if ROBO_POTF2 == 2
+    if (g0 + SB <= n_real) return potf2_16_mfma<false>(Ld, Wd, lane, g0, n_real);
+    return potf2_16_mfma<true>(Ld, Wd, lane, g0, n_real);
+#elif ROBO_POTF2 == 1
     if (g0 + SB <= n_real) return potf2_16_split<false>(Ld, Wd, colbuf, lane, g0, n_real);
     return potf2_16_split<true>(Ld, Wd, colbuf, lane, g0, n_real);
 #else
@@ -388,6 +473,7 @@ __device__ __forceinline__ void diag128_factor_invert(double* sL, double* sW, do
 #pragma unroll
             for (int r = 0; r < 4; ++r) P[bidx(lane & 15, (lane >> 4) + 4 * r)] = q[r];   // L = Q^T for the helpers
             wave_lds_fence();
+            if (dbg && tid == 0) dbg[24 + 4 * s] = clock64();     // C1 + C2 done (pivot wave)
         } else {
             // solves of block column s below the pivot wave's own block
             for (int bi = s + 2 + (wave - 1); bi < nsb; bi += 3) {
@@ -400,10 +486,12 @@ __device__ __forceinline__ void diag128_factor_invert(double* sL, double* sW, do
         }
         __syncthreads();                                          // Bb(s): block column s of L is final
         if (dbg && tid == 0 && s == 0) dbg[3] = clock64();
+        if (dbg && tid == 0) dbg[24 + 4 * s + 1] = clock64();     // through Bb(s)
         if (wave == 0) {
             const int f = potf2_16(sL + blk_off(s + 1, s + 1), sW + blk_off(s + 1, s + 1), sCol, lane,
                                    kbase + (s + 1) * SB, n_real);
             if (f != 0 && lane == 0 && *fail == 0) *fail = f;
+            if (dbg && tid == 0) dbg[24 + 4 * s + 2] = clock64() + (long long)(f == 12345678);   // potf2(s+1) done
         } else {
             // Work of the interval, handed out dynamically (an LDS counter per interval; a task is wave-sized):
             // one block of column s+1 (or the next pivot block) receives columns 0..s in one pass.

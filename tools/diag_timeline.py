@@ -18,3 +18,8 @@ for n, v in zip(names, t[:13]):
 prev = 0
 for n, v in zip(["panel start", "operands in LDS", "144-MFMA chain", "stored"], t[13:17]):
     print("%-16s %8.0f cycles  (+%6.0f)" % (n, v, v - prev)); prev = v
+print("pivot wave per interval s (cycles since kernel start): C1+C2 done | through Bb | potf2(s+1) done")
+ba = [t[3 - 1]] + list(t[4:11])        # Ba(0) = stamp 2 ("potf2(0)"), Ba(s+1) = stamps 4+s
+for sb in range(7):
+    c, bb, pf = t[17 + 3 * sb: 20 + 3 * sb]
+    print("s=%d  Ba->C done %5.0f   wait at Bb %5.0f   potf2 %5.0f   wait at Ba %5.0f" % (sb, c - ba[sb], bb - c, pf - bb, ba[sb + 1] - pf))
