@@ -268,6 +268,58 @@ def config_traffic(config, kernel):
         return None
 
 
+def hyper_inference(with_cpu, N=200):
+    """SURVEY 8(a2, a5) / 8(f) rank 1 -- the step BEFORE the posterior, where the fit multiplies: the hyper-parameter
+    inference of ONE Bayesian-optimisation iteration with the reference's defaults (robo/fmin/bayesian_optimization.py:
+    75-100: 2 * ARD Matern-5/2, DefaultPrior, n_hypers = 3 len(kernel) made even, burn-in 100 + chain 200 ensemble steps,
+    i.e. 15 700 likelihoods of the first iteration at D = 16, 10 450 of every later one) at a BO-typical N = 200:
+    robo_amd's GaussianProcessMCMC.train (the whole chain on the device, robo_gp_mcmc_run), wall clock, against the
+    oracle's loglikelihood (the reference's per-walker george fit, restated) on a sample of walkers."""
+    from robo_amd.kernels import Matern52Kernel
+    from robo_amd.priors import DefaultPrior
+    from robo_amd.models.gaussian_process_mcmc import GaussianProcessMCMC
+    D = 16
+    rs = np.random.RandomState(5)
+    X = rs.rand(N, D)
+    y = np.sinc(X * 10 - 5).sum(axis=1)
+    kernel = 2 * Matern52Kernel(np.ones([D]), ndim=D)
+    prior = DefaultPrior(len(kernel) + 1, rng=np.random.RandomState(6))
+    nh = 3 * len(kernel)
+    nh += nh % 2
+    model = GaussianProcessMCMC(kernel, prior=prior, n_hypers=nh, chain_length=200, burnin_steps=100,
+                                normalize_input=True, normalize_output=False, rng=np.random.RandomState(7),
+                                lower=np.zeros(D), upper=np.ones(D))
+    t0 = time.perf_counter()
+    model.train(X, y)
+    first = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    model.train(X, y)                        # burned: chain only -- what every later BO iteration pays
+    later = time.perf_counter() - t0
+    n_first, n_later = nh * (100 + 200 + 2), nh * (200 + 1)
+    out = {"n_train": N, "dim": D, "walkers": nh, "what": "GaussianProcessMCMC.train with the reference's defaults "
+           "(burn-in 100 + chain 200 ensemble steps; later iterations: chain only), incl. the %d per-sample fits" % nh,
+           "first_iteration_ms": first * 1e3, "later_iteration_ms": later * 1e3,
+           "likelihoods_first": n_first, "likelihoods_later": n_later,
+           "likelihoods_per_s": n_later / later}
+    if with_cpu:
+        from oracle import gp_oracle as O
+        hyp = np.asarray(model.hypers)
+        ogp = O.OracleGP("matern52", hyp[0], lower=np.zeros(D), upper=np.ones(D))
+        ogp.train(X, y)
+        ogp.loglikelihood(hyp[0])
+        t0 = time.perf_counter()
+        cnt = 0
+        while time.perf_counter() - t0 < 2.0:
+            ogp.loglikelihood(hyp[cnt % len(hyp)])
+            cnt += 1
+        per = (time.perf_counter() - t0) / cnt
+        out["cpu_port"] = {"ms_per_likelihood": per * 1e3, "likelihoods_timed": cnt,
+                           "later_iteration_ms_at_that_rate": per * n_later * 1e3,
+                           "note": "oracle restatement of gaussian_process_mcmc.py:168-202 (K build + cho_factor + "
+                                   "log-likelihood per walker), single process"}
+    return out
+
+
 def roofline_trsm(ctx, N, M_rows, trsm_ms_per_step, passes=1, kernel="trsm_step_gen_kernel", traffic=None):
     """the dominant kernel of every configuration is the block-row solve: algorithmic flops per launch =
     rows N^2 / nb (SURVEY.md 8d's triangular-solve term), duration from HIP events on the library's stream
@@ -476,6 +528,13 @@ def run_headline(args, D_, _lib, sharding):
             out["exchange"] = D_.exchange
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(N, D, theta, X, y)
+        if world == 1 and (N, D) == (4096, 16):
+            try:
+                out["hyper_inference"] = hyper_inference(not args.no_cpu_baseline)
+                small = hyper_inference(False, N=100)
+                out["hyper_inference"]["n_train_100"] = {k_: small[k_] for k_ in ("later_iteration_ms", "likelihoods_per_s")}
+            except Exception as e:            # noqa: BLE001 -- an extra block; never costs the headline line
+                out["hyper_inference"] = {"error": "%s: %s" % (type(e).__name__, str(e)[:200])}
     return out
 
 

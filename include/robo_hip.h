@@ -132,6 +132,22 @@ int32_t robo_gp_grad_loglik(robo_gp* gp, const double* theta, double mean_c, dou
 int32_t robo_gp_loglik_batch(robo_gp* gp, const double* thetas, int32_t S, double mean_c, double* out_loglik,
                              int32_t* out_status);
 
+/* The hyper-parameter chain of GaussianProcessMCMC.train, resident on the device: replaces
+ *     sampler = emcee.EnsembleSampler(n_hypers, ndim, self.loglikelihood); sampler.run_mcmc(p0, n_steps, rstate0=rng)
+ * (robo/models/gaussian_process_mcmc.py:114-142) INCLUDING emcee 2's stretch move, the prior and the accept test -- one
+ * sequence of launches, no host round trip between half-steps.  lnprob(theta) = log p(y | X, theta) + log prior(theta)
+ * with the reference's protocol (:185-202: any |theta_p| > 20, or a factorisation that fails -> -inf).
+ * prior_kind 0 = none, 1 = robo.priors.default_priors.DefaultPrior with prior_par = {lognormal loc, lognormal sigma,
+ * tophat min, tophat max, horseshoe scale}.  The random numbers of a stretch-move chain do not depend on its state: the
+ * caller draws them in emcee 2's order -- per step and half-ensemble rand(k/2) for z, randint(k/2) for the partners,
+ * rand(k/2) for the accept test -- into u_stretch / partner / u_accept, each [n_steps][2][k/2].
+ * pos (k x P) and lnp (k): in = start positions (lnp evaluated here when eval_start != 0), out = final state;
+ * out_chain (k x n_steps x P), out_lnprob (k x n_steps), out_accepted (k) nullable.  a = 2 in emcee.
+ * ROBO_BAD_ARGUMENT with emcee's message if a log-probability is NaN or the initial one +inf.  Leaves the GP unfitted. */
+int32_t robo_gp_mcmc_run(robo_gp* gp, double mean_c, int32_t prior_kind, const double* prior_par, int32_t n_walkers,
+                         int32_t n_steps, double a, const double* u_stretch, const int32_t* partner,
+                         const double* u_accept, int32_t eval_start, double* pos, double* lnp, double* out_chain,
+                         double* out_lnprob, int64_t* out_accepted);
 /* The per-sample model fits of GaussianProcessMCMC.train (gaussian_process_mcmc.py:149-164: one
  * GaussianProcess per hyper-parameter sample, each a gp.compute on the SAME X, y) as one batched pass
  * that KEEPS the factors: gps[0] holds the training data (robo_gp_set_data); afterwards every gps[s]

@@ -30,7 +30,7 @@ SYMBOLS = [
     "robo_last_error_string", "robo_version_string",
     "robo_gp_create", "robo_gp_destroy", "robo_gp_set_data", "robo_gp_set_output_transform",
     "robo_gp_set_precision", "robo_theta_size",
-    "robo_gp_fit", "robo_gp_loglik_batch", "robo_gp_fit_batch", "robo_gp_grad_loglik", "robo_gp_get_factor", "robo_gp_get_gram",
+    "robo_gp_fit", "robo_gp_loglik_batch", "robo_gp_mcmc_run", "robo_gp_fit_batch", "robo_gp_grad_loglik", "robo_gp_get_factor", "robo_gp_get_gram",
     "robo_cand_create", "robo_cand_destroy", "robo_cand_set_points", "robo_cand_create_uniform", "robo_cand_get_points",
     "robo_cand_create_random", "robo_cand_create_sobol", "robo_cand_get_point", "robo_cand_workspace_chunk", "robo_cand_last_solve_kernel",
     "robo_gp_predict_cand", "robo_gp_predict", "robo_gp_predict_cov", "robo_gp_predict_grad", "robo_gp_predict_mixture_cand",
@@ -119,6 +119,8 @@ def lib():
         "robo_gp_fit": [vp, _dp, dbl, _dp, C.POINTER(i32)],
         "robo_gp_loglik_batch": [vp, _dp, i32, dbl, _dp, C.POINTER(i32)],
         "robo_gp_fit_batch": [pp, i32, _dp, dbl, _dp, C.POINTER(i32)],
+        "robo_gp_mcmc_run": [vp, dbl, i32, _dp, i32, i32, dbl, _dp, C.POINTER(i32), _dp, i32, _dp, _dp, _dp, _dp,
+                             C.POINTER(i64)],
         "robo_gp_grad_loglik": [vp, _dp, dbl, _dp, _dp, C.POINTER(i32)],
         "robo_gp_get_factor": [vp, _dp],
         "robo_gp_get_gram": [vp, _dp, _dp],
@@ -450,6 +452,28 @@ class DeviceGP(object):
         check(lib().robo_gp_loglik_batch(self._h, _arr(thetas), S, float(mean_c), _arr(ll),
                                          st.ctypes.data_as(C.POINTER(C.c_int32))))
         return ll, st
+
+    def mcmc_run(self, mean_c, prior, pos, lnp, n_steps, u_stretch, partner, u_accept, a=2.0):
+        """emcee 2's EnsembleSampler.run_mcmc on the device (robo_gp_mcmc_run): prior = None or (kind, 5 parameters);
+        lnp None = evaluate the start positions.  -> (pos, lnp, chain (k, n_steps, P), lnprob (k, n_steps), accepted (k))"""
+        pos = np.array(pos, dtype=np.float64, order="C")
+        k = pos.shape[0]
+        assert pos.shape == (k, self.n_theta)
+        eval_start = lnp is None
+        lnp = np.zeros(k) if eval_start else np.array(lnp, dtype=np.float64)
+        n_steps = int(n_steps)
+        uz = np.ascontiguousarray(u_stretch, dtype=np.float64).reshape(-1)
+        ua = np.ascontiguousarray(u_accept, dtype=np.float64).reshape(-1)
+        pa = np.ascontiguousarray(partner, dtype=np.int32).reshape(-1)
+        assert uz.size == ua.size == pa.size == n_steps * k
+        chain = np.empty((k, n_steps, self.n_theta))
+        lnps = np.empty((k, n_steps))
+        acc = np.zeros(k, dtype=np.int64)
+        kind, par = (0, np.zeros(5)) if prior is None else (int(prior[0]), _f64(prior[1], (5,)))
+        check(lib().robo_gp_mcmc_run(self._h, float(mean_c), kind, _arr(par), k, n_steps, float(a), _arr(uz),
+                                     pa.ctypes.data_as(C.POINTER(C.c_int32)), _arr(ua), int(eval_start), _arr(pos),
+                                     _arr(lnp), _arr(chain), _arr(lnps), acc.ctypes.data_as(C.POINTER(C.c_int64))))
+        return pos, lnp, chain, lnps, acc
 
     def factor(self):
         out = np.empty((self.n, self.n))

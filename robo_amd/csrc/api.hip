@@ -235,6 +235,7 @@ int32_t robo_gp_destroy(robo_gp* g) {
     hipFree(g->d_bllpart);
     hipFree(g->d_theta);
     hipFree(g->d_Winv);
+    hipFree(g->d_mcmc);
     hipFree(g->d_wunits);
     hipFree(g->d_wprefix);
     hipFree(g->d_gV);
@@ -512,6 +513,126 @@ int32_t robo_gp_loglik_batch(robo_gp* g, const double* thetas, int32_t S, double
     if (S == 0) return ROBO_OK;
     g->fitted = false;   // the GP's own factor is not touched, but the call documents "unfitted after"
     return fit_batch_core(g, thetas, S, mean_c, out_loglik, out_status, nullptr);
+}
+
+// The whole ensemble chain on the device (mcmc.hip): no upload, synchronisation or host arithmetic between two half-steps.
+int32_t robo_gp_mcmc_run(robo_gp* g, double mean_c, int32_t prior_kind, const double* prior_par, int32_t n_walkers,
+                         int32_t n_steps, double a, const double* u_stretch, const int32_t* partner,
+                         const double* u_accept, int32_t eval_start, double* pos, double* lnp, double* out_chain,
+                         double* out_lnprob, int64_t* out_accepted) {
+    if (!g || !pos || !lnp || n_walkers < 2 || (n_walkers & 1) || n_steps < 0 || !(a > 1.0)) return ROBO_BAD_ARGUMENT;
+    if (n_steps > 0 && (!u_stretch || !partner || !u_accept)) return ROBO_BAD_ARGUMENT;
+    if (prior_kind != 0 && (prior_kind != 1 || !prior_par)) {
+        set_error("robo_gp_mcmc_run: prior kind %d (0 = none, 1 = DefaultPrior)", prior_kind);
+        return ROBO_BAD_ARGUMENT;
+    }
+    if (!g->has_data) {
+        set_error("robo_gp_mcmc_run before robo_gp_set_data");
+        return ROBO_NOT_FITTED;
+    }
+    robo_ctx* c = g->ctx;
+    ROBO_HIP_CHECK(hipSetDevice(c->device));
+    const int k = n_walkers, half = k / 2, D = g->dim, P = robo_theta_size(g->kind, D);
+    const size_t np = (size_t)g->n_pad;
+    {   // half an ensemble must fit the batch workspace in one pass (at the sizes of an MCMC fit it always does)
+        const size_t per = np * np * sizeof(double) + np * (NB + (size_t)D) * sizeof(double);
+        if ((size_t)half * per > workspace_bytes(c)) {
+            set_error("robo_gp_mcmc_run: %d walkers of n_pad %zu exceed the batch workspace (ws_bytes)", half, np);
+            return ROBO_BAD_SHAPE;
+        }
+    }
+    g->fitted = false;
+    ROBO_TRY(batch_ensure(g, half));
+    // one scratch block: doubles first, then 64-bit counters, then ints
+    const size_t nr = (size_t)n_steps * k;
+    const size_t n_dbl = (size_t)k * P + k + (size_t)half * P + 2 * (size_t)half + 2 * nr + (size_t)k * n_steps * P + nr;
+    const size_t bytes = n_dbl * sizeof(double) + (size_t)k * sizeof(long long) + (nr + 8) * sizeof(int);
+    if (g->mcmc_bytes < bytes) {
+        if (g->d_mcmc) ROBO_HIP_CHECK(hipFree(g->d_mcmc));
+        g->d_mcmc = nullptr;
+        g->mcmc_bytes = 0;
+        ROBO_HIP_CHECK(hipMalloc((void**)&g->d_mcmc, bytes));
+        g->mcmc_bytes = bytes;
+    }
+    McmcState st;
+    memset(&st, 0, sizeof(st));
+    double* d = reinterpret_cast<double*>(g->d_mcmc);
+    st.d_pos = d; d += (size_t)k * P;
+    st.d_lnp = d; d += k;
+    st.d_q = d; d += (size_t)half * P;
+    st.d_z = d; d += half;
+    st.d_prior = d; d += half;
+    double* d_uz = d; d += nr;
+    double* d_ua = d; d += nr;
+    st.d_chain = d; d += (size_t)k * n_steps * P;
+    st.d_lnprob = d; d += nr;
+    st.d_nacc = reinterpret_cast<long long*>(d);
+    int* di = reinterpret_cast<int*>(st.d_nacc + k);   // [step counter, error flags, 6 spare | partners]
+    st.d_it = di;
+    st.d_err = di + 1;
+    int* d_partner = di + 8;
+    st.d_uz = d_uz; st.d_ua = d_ua; st.d_partner = d_partner;
+    st.k = k; st.P = P; st.D = D; st.kind = g->kind; st.n = g->n; st.n_steps = n_steps; st.ns_eval = half;
+    st.prior_kind = prior_kind; st.a = a; st.mean_c = mean_c;
+    if (prior_kind == 1) for (int i = 0; i < 5; ++i) st.prior_par[i] = prior_par[i];
+    st.d_sp = g->d_bsp; st.d_ism = g->d_bism; st.d_out = g->d_bout; st.d_fail = g->d_bfail;
+    hipStream_t s = c->stream;
+    ROBO_HIP_CHECK(hipMemcpyAsync(st.d_pos, pos, (size_t)k * P * sizeof(double), hipMemcpyHostToDevice, s));
+    if (!eval_start) ROBO_HIP_CHECK(hipMemcpyAsync(st.d_lnp, lnp, (size_t)k * sizeof(double), hipMemcpyHostToDevice, s));
+    if (nr > 0) {
+        ROBO_HIP_CHECK(hipMemcpyAsync(d_uz, u_stretch, nr * sizeof(double), hipMemcpyHostToDevice, s));
+        ROBO_HIP_CHECK(hipMemcpyAsync(d_ua, u_accept, nr * sizeof(double), hipMemcpyHostToDevice, s));
+        ROBO_HIP_CHECK(hipMemcpyAsync(d_partner, partner, nr * sizeof(int), hipMemcpyHostToDevice, s));
+    }
+    ROBO_HIP_CHECK(hipMemsetAsync(st.d_nacc, 0, (size_t)k * sizeof(long long) + 8 * sizeof(int), s));
+    FitBuffers fb;
+    fb.K = g->d_bK; fb.k_stride = np * np;
+    fb.Linv = g->d_bLinv; fb.linv_stride = np * NB;
+    fb.Xs = g->d_bXs; fb.xs_stride = np * D;
+    fb.sp = g->d_bsp;
+    fb.fail = g->d_bfail;
+    fb.out = g->d_bout;
+    fb.ll_part = g->d_bllpart;
+    fb.LinvP = nullptr;
+    fb.host_out = nullptr;             // the likelihood terms are consumed on the device
+    fb.want_inverse = false;
+    fb.S = half;
+    auto half_step = [&](int start, int first, int h) -> int {
+        ROBO_TRY(launch_mcmc_propose(c, st, start, first, h));
+        ROBO_TRY(launch_scale_inputs(c, g->d_X, g->d_bXs, g->d_bism, g->n, g->n_pad, D, half, np * D, (size_t)D));
+        ROBO_TRY(launch_gram(g, fb));
+        ROBO_TRY(launch_potrf(g, fb));
+        return launch_mcmc_accept(c, st, start, first, h);
+    };
+    if (eval_start) {
+        ROBO_TRY(half_step(1, 0, 0));
+        ROBO_TRY(half_step(1, half, 0));
+    }
+    for (int it = 0; it < n_steps; ++it) {
+        ROBO_TRY(half_step(0, 0, 0));
+        ROBO_TRY(half_step(0, 0, 1));
+    }
+    int herr[2] = {0, 0};
+    std::vector<long long> hacc((size_t)k);
+    ROBO_HIP_CHECK(hipMemcpyAsync(pos, st.d_pos, (size_t)k * P * sizeof(double), hipMemcpyDeviceToHost, s));
+    ROBO_HIP_CHECK(hipMemcpyAsync(lnp, st.d_lnp, (size_t)k * sizeof(double), hipMemcpyDeviceToHost, s));
+    if (out_chain && nr > 0)
+        ROBO_HIP_CHECK(hipMemcpyAsync(out_chain, st.d_chain, (size_t)k * n_steps * P * sizeof(double), hipMemcpyDeviceToHost, s));
+    if (out_lnprob && nr > 0)
+        ROBO_HIP_CHECK(hipMemcpyAsync(out_lnprob, st.d_lnprob, nr * sizeof(double), hipMemcpyDeviceToHost, s));
+    ROBO_HIP_CHECK(hipMemcpyAsync(hacc.data(), st.d_nacc, (size_t)k * sizeof(long long), hipMemcpyDeviceToHost, s));
+    ROBO_HIP_CHECK(hipMemcpyAsync(herr, st.d_it, sizeof(herr), hipMemcpyDeviceToHost, s));
+    ROBO_HIP_CHECK(hipStreamSynchronize(s));
+    if (out_accepted) for (int w = 0; w < k; ++w) out_accepted[w] = (int64_t)hacc[(size_t)w];
+    if (herr[1] & 1) {
+        set_error("lnprob returned NaN.");
+        return ROBO_BAD_ARGUMENT;
+    }
+    if (herr[1] & 2) {
+        set_error("The initial lnprob was +inf.");
+        return ROBO_BAD_ARGUMENT;
+    }
+    return ROBO_OK;
 }
 
 int32_t robo_gp_fit_batch(robo_gp* const* gps, int32_t S, const double* thetas, double mean_c, double* out_loglik,

@@ -149,6 +149,8 @@ struct robo_gp {
     // workspace of robo_gp_grad_loglik (lazy, sized for n_pad_max): W^T, A = alpha alpha^T - K^-1, ...
     double *d_gV, *d_gA, *d_galpha, *d_gpart, *d_gout;
     // explicit inverse factor W = L^-1 for small candidate batches (winv.hip): lazy, rebuilt when the factor changes
+    char* d_mcmc;                   // scratch of robo_gp_mcmc_run (one block, lazily grown)
+    size_t mcmc_bytes;
     double* d_Winv;                 // (n_pad_max, n_pad_max) row-major, lower block triangle valid
     unsigned long long winv_gen;    // fit_gen the inverse was built for (0: none)
     int* d_wunits;                  // unit table of the triangular product for winv_nbk block rows (int4 per unit)
@@ -218,6 +220,24 @@ struct FitBuffers {
 int launch_scale_inputs_theta(robo_ctx* ctx, const double* d_in, double* d_out, const ThetaArgs& ta, int64_t rows_real,
                               int64_t rows_pad, int dim, double* d_ism_out, FitSample* d_sp_out);
 int launch_gram(robo_gp* gp, const FitBuffers& fb);
+// the device-resident hyper-parameter chain (mcmc.hip): everything the two kernels around the batched fit need
+struct McmcState {
+    int k, P, D, kind, n, n_steps, ns_eval, prior_kind;
+    double a, mean_c;
+    double prior_par[5];
+    double *d_pos, *d_lnp, *d_q, *d_z, *d_prior;      // (k x P), (k), (k/2 x P), (k/2), (k/2)
+    long long* d_nacc;                                // (k)
+    int *d_it, *d_err;
+    const double *d_uz, *d_ua;                        // (n_steps x 2 x k/2) each, emcee's draw order
+    const int* d_partner;
+    double *d_chain, *d_lnprob;                       // (k x n_steps x P), (k x n_steps); nullable
+    FitSample* d_sp;                                  // the batched fit's inputs / outputs (api.hip batch_ensure)
+    double* d_ism;
+    const double* d_out;
+    const int* d_fail;
+};
+int launch_mcmc_propose(robo_ctx* ctx, const McmcState& st, int start, int first, int h);
+int launch_mcmc_accept(robo_ctx* ctx, const McmcState& st, int start, int first, int h);
 int launch_potrf(robo_gp* gp, const FitBuffers& fb);
 int launch_diag_timeline(robo_gp* gp, long long* d_stamps);
 int launch_cross_gram(robo_gp* gp, robo_cand* cand, int64_t c0, int64_t cn, double* d_out = nullptr);

@@ -102,7 +102,8 @@ class GaussianProcessMCMC(BaseModel):
         gp.set_data(self.X, self.y)
 
         if do_optimize:
-            sampler = EnsembleSampler(self.n_hypers, len(self.kernel) + 1, lnprob_batch=self.loglikelihood_batch)
+            sampler = EnsembleSampler(self.n_hypers, len(self.kernel) + 1, lnprob_batch=self.loglikelihood_batch,
+                                      device_chain=self._device_chain())
             sampler.random_state = self.rng.get_state()
             if not self.burned:
                 if self.prior is None:
@@ -182,6 +183,25 @@ class GaussianProcessMCMC(BaseModel):
         return hasattr(self, "basis_func")
 
     # ---- likelihood ------------------------------------------------------------------------------
+    def _device_chain(self):
+        """The whole ensemble chain on the device (robo_gp_mcmc_run) when the prior is one the library evaluates itself:
+        none, or exactly DefaultPrior (robo/priors/default_priors.py).  Other priors (Fabolas' EnvPrior ...) keep the
+        host sampler around the batched likelihood.  ROBO_MCMC_HOST=1 forces the host sampler (A/B, tests)."""
+        if os.environ.get("ROBO_MCMC_HOST") == "1":
+            return None
+        from robo_amd.priors import DefaultPrior
+        if self.prior is None:
+            prior = None
+        elif type(self.prior) is DefaultPrior:
+            pr = self.prior
+            prior = (1, [pr.ln_prior.mean, pr.ln_prior.sigma, pr.tophat.min, pr.tophat.max, pr.horseshoe.scale])
+        else:
+            return None
+
+        def run(p, lnp, n_steps, u_stretch, partner, u_accept, a):
+            return self.gp.mcmc_run(self.mean, prior, p, lnp, n_steps, u_stretch, partner, u_accept, a)
+        return run
+
     def loglikelihood_batch(self, thetas):
         """log p(y | X, theta) + log prior for a batch (k, P); out-of-bounds / non-PD -> -inf
         (gaussian_process_mcmc.py:185-202)."""

@@ -30,7 +30,7 @@ import numpy as np
 
 class EnsembleSampler(object):
 
-    def __init__(self, nwalkers, dim, lnprob=None, lnprob_batch=None, a=2.0):
+    def __init__(self, nwalkers, dim, lnprob=None, lnprob_batch=None, a=2.0, device_chain=None):
         assert nwalkers % 2 == 0, "The number of walkers must be even."
         assert nwalkers >= 2 * dim, "The number of walkers needs to be at least twice the dimension"
         assert (lnprob is None) != (lnprob_batch is None)
@@ -39,6 +39,9 @@ class EnsembleSampler(object):
             def lnprob_batch(thetas, _f=lnprob):
                 return np.array([_f(t) for t in thetas], dtype=np.float64)
         self._lnprob_batch = lnprob_batch
+        # device_chain(p, lnp | None, N, u_stretch, partner, u_accept, a) -> (p, lnp, chain, lnps, accepted): the whole
+        # run on the device (robo_gp_mcmc_run) with the random numbers drawn HERE, in the order below
+        self._device_chain = device_chain
         self._random = np.random.RandomState()
         self.naccepted = np.zeros(self.k)
         self.iterations = 0
@@ -85,6 +88,8 @@ class EnsembleSampler(object):
             self.random_state = rstate0
         p = np.array(pos0, dtype=np.float64)
         assert p.shape == (self.k, self.dim)
+        if self._device_chain is not None:
+            return self._run_on_device(p, N, lnprob0)
         lnp = self._eval(p) if lnprob0 is None else np.array(lnprob0, dtype=np.float64)
         if np.any(np.isinf(lnp) & (lnp > 0)):
             raise ValueError("The initial lnprob was +inf.")
@@ -110,6 +115,28 @@ class EnsembleSampler(object):
             chain[:, it] = p
             lnps[:, it] = lnp
             self.iterations += 1
+        self._chain = np.concatenate((self._chain, chain), axis=1)
+        self._lnprob = np.concatenate((self._lnprob, lnps), axis=1)
+        return p, lnp, self.random_state
+
+    def _run_on_device(self, p, N, lnprob0):
+        """The same chain with every half-step on the device.  A stretch move's random numbers do not depend on the
+        state of the chain, so they are drawn up front -- per half-step rand (z), randint (partners), rand (accept
+        test), the order of the loop in run_mcmc -- and the stream ends where it would have ended."""
+        half = self.k // 2
+        uz = np.empty((N, 2, half))
+        ua = np.empty((N, 2, half))
+        pa = np.empty((N, 2, half), dtype=np.int32)
+        for it in range(N):
+            for h in range(2):
+                uz[it, h] = self._random.rand(half)
+                pa[it, h] = self._random.randint(half, size=(half,))
+                ua[it, h] = self._random.rand(half)
+        if lnprob0 is not None and np.any(np.isinf(lnprob0) & (np.asarray(lnprob0) > 0)):
+            raise ValueError("The initial lnprob was +inf.")
+        p, lnp, chain, lnps, acc = self._device_chain(p, lnprob0, N, uz, pa, ua, self.a)
+        self.naccepted += acc
+        self.iterations += N
         self._chain = np.concatenate((self._chain, chain), axis=1)
         self._lnprob = np.concatenate((self._lnprob, lnps), axis=1)
         return p, lnp, self.random_state

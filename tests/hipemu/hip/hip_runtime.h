@@ -190,6 +190,12 @@ static inline void __builtin_amdgcn_sched_barrier(int) {}
 // v_rsq_f64 has ~2^-26 relative accuracy on the hardware; the interpreter returns the rounded value
 static inline double __builtin_amdgcn_rsq(double x) { return 1.0 / std::sqrt(x); }
 static inline double __builtin_amdgcn_rcp(double x) { return 1.0 / x; }
+// round-to-nearest arithmetic without contraction (g++ -O2 on x86-64 does not fuse unless -ffp-contract=fast with FMA
+// enabled; volatile keeps the intermediate rounded either way)
+static inline double __dadd_rn(double a, double b) { volatile double r = a + b; return r; }
+static inline double __dsub_rn(double a, double b) { volatile double r = a - b; return r; }
+static inline double __dmul_rn(double a, double b) { volatile double r = a * b; return r; }
+static inline double __ddiv_rn(double a, double b) { volatile double r = a / b; return r; }
 static inline int __ffsll(long long x) { return __builtin_ffsll(x); }
 static inline int __builtin_amdgcn_readlane(int v, int lane) { return hipemu::shfl_any(v, lane); }
 static inline int __double2loint(double x) { uint64_t u; std::memcpy(&u, &x, 8); return (int)(uint32_t)u; }

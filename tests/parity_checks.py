@@ -102,6 +102,110 @@ def check_case(ctx, name, full=True):
     g.close()
 
 
+def check_device_chain(ctx, cases=(("matern52", 150, 3, 10, 14), ("rbf", 40, 2, 8, 10))):
+    """robo_gp_mcmc_run (the whole stretch-move chain on the device) against the host sampler around the batched
+    likelihood with the same RandomState: same accept decisions, positions and log-probabilities to rounding, the random
+    stream ends in the same state; against the CPU oracle's log-probability through the same sampler; walkers outside
+    the reference's |theta| <= 20 bounds and outside the prior's support (-inf); the model class end to end."""
+    from robo_amd.util.ensemble_sampler import EnsembleSampler
+    from robo_amd.priors import DefaultPrior
+    for kind, N, D, k, steps in cases:
+        rs = np.random.RandomState(61)
+        X = rs.rand(N, D)
+        y = np.sin(3 * X.sum(axis=1)) + 0.05 * rs.randn(N)
+        P = D + 2
+        mean = float(np.mean(y))
+        g = _lib.DeviceGP(ctx, kind, N, D)
+        g.set_data(X, y)
+        prior = DefaultPrior(P, rng=np.random.RandomState(62))
+        par = (1, [prior.ln_prior.mean, prior.ln_prior.sigma, prior.tophat.min, prior.tophat.max, prior.horseshoe.scale])
+        p0 = prior.sample_from_prior(k)
+        p0[1, 2] = 23.0          # outside |theta| <= 20: -inf at the start, moves in through a partner
+        p0[2, 1] = 5.0           # outside the tophat: -inf prior
+
+        def lnprob_host(thetas):
+            thetas = np.atleast_2d(thetas)
+            out = np.full(thetas.shape[0], -np.inf)
+            ok = ~np.any((-20 > thetas) + (thetas > 20), axis=1)
+            if np.any(ok):
+                ll, st = g.loglik_batch(thetas[ok], mean)
+                out[ok] = np.where(st == _lib.OK, ll, -np.inf) + prior.lnprob_batch(thetas[ok])
+            return out
+
+        def lnprob_oracle(thetas):
+            out = []
+            for th in np.atleast_2d(thetas):
+                if np.any((-20 > th) + (th > 20)):
+                    out.append(-np.inf)
+                    continue
+                try:
+                    L = O.gp_compute(kind, th, X, np.float64)
+                    out.append(O.gp_log_likelihood(L, y, mean) + prior.lnprob(th))
+                except np.linalg.LinAlgError:
+                    out.append(-np.inf)
+            return np.array(out)
+
+        def run(**kw):
+            smp = EnsembleSampler(k, P, **kw)
+            smp.random_state = np.random.RandomState(63).get_state()
+            pos, lnp, _ = smp.run_mcmc(p0, steps)
+            pos2, lnp2, state = smp.run_mcmc(pos, 3, lnprob0=lnp)       # continue with a given lnprob0
+            return smp.chain, smp.lnprobability, smp.naccepted.copy(), pos2, lnp2, state
+
+        dev = run(lnprob_batch=lnprob_host, device_chain=lambda p, lnp, n, uz, pa, ua, a: g.mcmc_run(mean, par, p, lnp, n, uz, pa, ua, a))
+        host = run(lnprob_batch=lnprob_host)
+        orc = run(lnprob_batch=lnprob_oracle)
+        assert dev[0].shape == (k, steps + 3, P) and np.all(np.isfinite(dev[0]))
+        for ref, tol in ((host, 1e-9), (orc, 1e-7)):
+            np.testing.assert_array_equal(dev[2], ref[2])                       # same accept decisions per walker
+            np.testing.assert_allclose(dev[0], ref[0], rtol=tol, atol=tol)
+            fin = np.isfinite(ref[1])
+            assert np.array_equal(fin, np.isfinite(dev[1]))
+            np.testing.assert_allclose(dev[1][fin], ref[1][fin], rtol=0, atol=1e-7 * max(1.0, np.abs(ref[1][fin]).max()))
+            np.testing.assert_allclose(dev[3], ref[3], rtol=tol, atol=tol)
+        assert dev[2].sum() > 0 and np.isneginf(dev[1][1, 0]) or dev[2][1] > 0   # the out-of-bounds walker started at -inf
+        for a_, b_ in zip(dev[5][1:], host[5][1:]):
+            assert np.array_equal(np.asarray(a_), np.asarray(b_))                # the random stream ends in the same state
+        # no prior
+        d0 = EnsembleSampler(k, P, lnprob_batch=lnprob_host,
+                             device_chain=lambda p, lnp, n, uz, pa, ua, a: g.mcmc_run(mean, None, p, lnp, n, uz, pa, ua, a))
+        d0.random_state = np.random.RandomState(64).get_state()
+        q0 = np.clip(p0, -3, 1.5)
+        d0.run_mcmc(q0, 5)
+
+        def lnprob_noprior(thetas):
+            ll, st = g.loglik_batch(np.atleast_2d(thetas), mean)
+            return np.where(st == _lib.OK, ll, -np.inf)
+        h0 = EnsembleSampler(k, P, lnprob_batch=lnprob_noprior)
+        h0.random_state = np.random.RandomState(64).get_state()
+        h0.run_mcmc(q0, 5)
+        np.testing.assert_allclose(d0.chain, h0.chain, rtol=1e-9, atol=1e-9)
+        np.testing.assert_array_equal(d0.naccepted, h0.naccepted)
+        g.close()
+    # the model class: device chain (default) == host sampler (ROBO_MCMC_HOST=1)
+    from robo_amd.kernels import Matern52Kernel
+    from robo_amd.models.gaussian_process_mcmc import GaussianProcessMCMC
+    rs = np.random.RandomState(65)
+    X = rs.rand(60, 2) * 3 - 1
+    y = np.sin(X[:, 0]) * np.cos(2 * X[:, 1])
+    hyp = {}
+    for mode in ("0", "1"):
+        os.environ["ROBO_MCMC_HOST"] = mode
+        try:
+            kernel = 2 * Matern52Kernel(np.ones([2]), ndim=2)
+            m = GaussianProcessMCMC(kernel, prior=DefaultPrior(len(kernel) + 1, rng=np.random.RandomState(66)),
+                                    n_hypers=8, chain_length=12, burnin_steps=10, rng=np.random.RandomState(67),
+                                    lower=-np.ones(2), upper=2 * np.ones(2), device=None)
+            m.train(X, y)
+            m.train(X, y)                     # burned: chain only, from p0
+            hyp[mode] = (np.array(m.hypers), m.predict(X[:7] + 0.1))
+        finally:
+            os.environ.pop("ROBO_MCMC_HOST", None)
+    np.testing.assert_allclose(hyp["0"][0], hyp["1"][0], rtol=1e-9, atol=1e-9)
+    np.testing.assert_allclose(hyp["0"][1][0], hyp["1"][1][0], rtol=1e-7, atol=1e-9)
+    np.testing.assert_allclose(hyp["0"][1][1], hyp["1"][1][1], rtol=1e-6, atol=1e-10)
+
+
 def check_mcmc_marginal(ctx):
     inp = mcmc_inputs()
     gold = load("mcmc_marginal")

@@ -41,6 +41,10 @@ def test_mcmc_marginal(emu_ctx):
     P.check_mcmc_marginal(emu_ctx)
 
 
+def test_device_resident_chain(emu_ctx):
+    P.check_device_chain(emu_ctx, cases=(("matern52", 150, 3, 10, 6), ("rbf", 40, 2, 8, 5)))
+
+
 def test_elementwise_and_degenerate_branches(emu_ctx):
     P.check_elementwise(emu_ctx)
 
