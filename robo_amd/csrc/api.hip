@@ -597,20 +597,19 @@ int32_t robo_gp_mcmc_run(robo_gp* g, double mean_c, int32_t prior_kind, const do
     fb.host_out = nullptr;             // the likelihood terms are consumed on the device
     fb.want_inverse = false;
     fb.S = half;
-    auto half_step = [&](int start, int first, int h) -> int {
-        ROBO_TRY(launch_mcmc_propose(c, st, start, first, h));
-        ROBO_TRY(launch_scale_inputs(c, g->d_X, g->d_bXs, g->d_bism, g->n, g->n_pad, D, half, np * D, (size_t)D));
+    auto half_step = [&](int start, int first, int h, int it) -> int {
+        ROBO_TRY(launch_mcmc_propose_scale(c, st, start, first, h, it, g->d_X, g->d_bXs, g->n, g->n_pad, np * D));
         ROBO_TRY(launch_gram(g, fb));
         ROBO_TRY(launch_potrf(g, fb));
-        return launch_mcmc_accept(c, st, start, first, h);
+        return launch_mcmc_accept(c, st, start, first, h, it);
     };
     if (eval_start) {
-        ROBO_TRY(half_step(1, 0, 0));
-        ROBO_TRY(half_step(1, half, 0));
+        ROBO_TRY(half_step(1, 0, 0, 0));
+        ROBO_TRY(half_step(1, half, 0, 0));
     }
     for (int it = 0; it < n_steps; ++it) {
-        ROBO_TRY(half_step(0, 0, 0));
-        ROBO_TRY(half_step(0, 0, 1));
+        ROBO_TRY(half_step(0, 0, 0, it));
+        ROBO_TRY(half_step(0, 0, 1, it));
     }
     int herr[2] = {0, 0};
     std::vector<long long> hacc((size_t)k);

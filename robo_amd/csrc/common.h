@@ -236,8 +236,9 @@ struct McmcState {
     const double* d_out;
     const int* d_fail;
 };
-int launch_mcmc_propose(robo_ctx* ctx, const McmcState& st, int start, int first, int h);
-int launch_mcmc_accept(robo_ctx* ctx, const McmcState& st, int start, int first, int h);
+int launch_mcmc_propose_scale(robo_ctx* ctx, const McmcState& st, int start, int first, int h, int it, const double* d_X,
+                              double* d_Xs, int64_t rows_real, int64_t rows_pad, size_t xs_stride);
+int launch_mcmc_accept(robo_ctx* ctx, const McmcState& st, int start, int first, int h, int it);
 int launch_potrf(robo_gp* gp, const FitBuffers& fb);
 int launch_diag_timeline(robo_gp* gp, long long* d_stamps);
 int launch_cross_gram(robo_gp* gp, robo_cand* cand, int64_t c0, int64_t cn, double* d_out = nullptr);

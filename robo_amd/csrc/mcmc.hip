@@ -7,10 +7,10 @@
 // proposal, the prior, the accept test and -- per half-step -- one upload, one synchronisation and ~100 us of Python.
 // At a Bayesian-optimisation-typical N = 200 that host share is more than the device's (r03w: 191 us per half-step,
 // ~85 of them on the device).  Here the whole chain is ONE sequence of launches on the library's stream:
-//   mcmc_propose_kernel   q_w = c_j - z (c_j - s_w) for the walkers of the active half, the reference's bounds
-//                         protocol (any |theta_p| > 20 -> -inf, gaussian_process_mcmc.py:185-190), log prior, and the
-//                         batch fit's inputs (FitSample + inverse square-root metrics) straight into its device buffers
-//   scale / gram / potrf  the batched fit of gram.hip / potrf.hip, unchanged (likelihood terms stay on the device)
+//   mcmc_propose_scale_kernel  q_w = c_j - z (c_j - s_w) for the walkers of the active half, the reference's bounds
+//                         protocol (any |theta_p| > 20 -> -inf, gaussian_process_mcmc.py:185-190), log prior, the batch
+//                         fit's FitSample, and the inputs scaled by the proposal's metrics (scale_inputs_kernel's job)
+//   gram / potrf          the batched fit of gram.hip / potrf.hip, unchanged (likelihood terms stay on the device)
 //   mcmc_accept_kernel    lnp(q) = log-likelihood + log prior, emcee's accept test  (ndim - 1) log z + lnp(q) - lnp(s) >
 //                         log u, walker / log-probability / acceptance-count update, chain record after the second half
 // The random numbers do not depend on the chain, so the caller draws them up front in emcee 2's order (per half-step:
@@ -41,55 +41,87 @@ __device__ __forceinline__ double default_prior_lnprob(const double* th, int P, 
     return lp + hs;
 }
 
-// theta (P) -> the batch fit's per-sample inputs (api.hip theta_to_sample); !ok: the unit kernel (theta = 0), which keeps
-// the slot of a rejected-by-bounds proposal numerically harmless
-__device__ __forceinline__ void theta_to_sample_dev(const double* q, bool ok, int kind, int D, int P, double mean_c,
-                                                    FitSample* sp, double* ism) {
-    const bool fab = kind == ROBO_KERNEL_FABOLAS;
-    const int n_metric = fab ? D - 1 : D;
-    for (int d = 0; d < n_metric; ++d) ism[d] = exp(-0.5 * (ok ? q[1 + d] : 0.0));
-    if (fab) ism[D - 1] = 1.0;
-    sp->cov.kind = kind;
-    sp->cov.dim = D;
-    sp->cov.amp = exp(ok ? q[0] : 0.0);
-    sp->cov.blr_a = fab ? exp(ok ? q[D] : 0.0) : 0.0;
-    sp->cov.blr_b = fab ? exp(ok ? q[D + 1] : 0.0) : 0.0;
-    sp->noise = exp(ok ? q[P - 1] : 0.0) + JITTER;
-    sp->mean_c = mean_c;
-}
-
+// Proposal + input scaling in one launch, grid (blocks over the rows of X, walkers of the half): EVERY block forms its
+// walker's proposal (thread p <-> parameter p), the bounds test and the inverse square-root metrics in LDS, then scales
+// its share of X for the gram kernel (what scale_inputs_kernel does from a metrics array in memory); block 0 of each
+// walker also leaves q, z, the log prior and the batch fit's FitSample behind.  (r03z: as two kernels -- one thread per
+// walker for the proposal -- the proposal alone took 14.6 us of a 54 us half-step at N = 100.)
 // start == 1: the walkers themselves (first evaluation of the start positions), `first`..`first + ns`
-// start == 0: stretch-move proposals of half `h` at step *it
-__global__ __launch_bounds__(256) void mcmc_propose_kernel(McmcState st, int start, int first, int h) {
-    const int ns = start ? st.ns_eval : st.k / 2;
-    const int it = start ? 0 : *st.d_it;
-    for (int w = threadIdx.x; w < ns; w += blockDim.x) {
-        double* q = st.d_q + (size_t)w * st.P;
+// start == 0: stretch-move proposals of half `h` at step `it`
+__global__ __launch_bounds__(256) void mcmc_propose_scale_kernel(McmcState st, int start, int first, int h, int it,
+                                                                 const double* __restrict__ X, double* __restrict__ Xs,
+                                                                 long long rows_real, long long rows_pad,
+                                                                 size_t xs_stride) {
+    __shared__ double sq[MAX_DIM + 8];
+    __shared__ double sism[MAX_DIM];
+    __shared__ double sz;
+    __shared__ int sbad;
+    const int w = blockIdx.y, P = st.P, D = st.D;
+    const int half = st.k / 2;
+    if (threadIdx.x == 0) {
         double z = 1.0;
-        if (start) {
-            for (int p = 0; p < st.P; ++p) q[p] = st.d_pos[(size_t)(first + w) * st.P + p];
-        } else {
-            const int half = st.k / 2;
+        if (!start) {
             const size_t r = ((size_t)it * 2 + h) * half + w;
-            const double* s = st.d_pos + (size_t)(h * half + w) * st.P;
-            const double* c = st.d_pos + (size_t)((1 - h) * half + st.d_partner[r]) * st.P;
             const double t = __dadd_rn(__dmul_rn(st.a - 1.0, st.d_uz[r]), 1.0);
             z = __ddiv_rn(__dmul_rn(t, t), st.a);
-            for (int p = 0; p < st.P; ++p) q[p] = __dsub_rn(c[p], __dmul_rn(z, __dsub_rn(c[p], s[p])));
         }
-        st.d_z[w] = z;
-        bool ok = true;
-        for (int p = 0; p < st.P; ++p) ok = ok && (q[p] >= -20.0 && q[p] <= 20.0);     // also false for NaN / inf
-        double prior = 0.0;
-        if (ok && st.prior_kind == 1) prior = default_prior_lnprob(q, st.P, st.prior_par);
-        st.d_prior[w] = ok ? prior : -__builtin_huge_val();
-        theta_to_sample_dev(q, ok, st.kind, st.D, st.P, st.mean_c, st.d_sp + w, st.d_ism + (size_t)w * st.D);
+        sz = z;
+        sbad = 0;
+    }
+    __syncthreads();
+    bool bad = false;
+    for (int p = threadIdx.x; p < P; p += blockDim.x) {
+        double q;
+        if (start) {
+            q = st.d_pos[(size_t)(first + w) * P + p];
+        } else {
+            const size_t r = ((size_t)it * 2 + h) * half + w;
+            const double s = st.d_pos[(size_t)(h * half + w) * P + p];
+            const double c = st.d_pos[(size_t)((1 - h) * half + st.d_partner[r]) * P + p];
+            q = __dsub_rn(c, __dmul_rn(sz, __dsub_rn(c, s)));
+        }
+        sq[p] = q;
+        bad = bad || !(q >= -20.0 && q <= 20.0);          // also true for NaN / inf
+    }
+    if (bad) sbad = 1;
+    __syncthreads();                                       // sq is complete
+    const bool ok = sbad == 0;
+    const bool fab = st.kind == ROBO_KERNEL_FABOLAS;
+    const int n_metric = fab ? D - 1 : D;
+    for (int d = threadIdx.x; d < D; d += blockDim.x) sism[d] = d < n_metric ? exp(-0.5 * (ok ? sq[1 + d] : 0.0)) : 1.0;
+    __syncthreads();
+    if (blockIdx.x == 0) {
+        for (int p = threadIdx.x; p < P; p += blockDim.x) st.d_q[(size_t)w * P + p] = sq[p];
+        for (int d = threadIdx.x; d < D; d += blockDim.x) st.d_ism[(size_t)w * D + d] = sism[d];
+        if (threadIdx.x == 0) {
+            st.d_z[w] = sz;
+            double prior = 0.0;
+            if (ok && st.prior_kind == 1) prior = default_prior_lnprob(sq, P, st.prior_par);
+            st.d_prior[w] = ok ? prior : -__builtin_huge_val();
+            FitSample sp;
+            sp.cov.kind = st.kind;
+            sp.cov.dim = D;
+            sp.cov.amp = exp(ok ? sq[0] : 0.0);
+            sp.cov.blr_a = fab ? exp(ok ? sq[D] : 0.0) : 0.0;
+            sp.cov.blr_b = fab ? exp(ok ? sq[D + 1] : 0.0) : 0.0;
+            sp.noise = exp(ok ? sq[P - 1] : 0.0) + JITTER;
+            sp.mean_c = st.mean_c;
+            st.d_sp[w] = sp;
+        }
+    }
+    // scale_inputs_kernel's arithmetic: pad rows replicate row 0
+    double* out = Xs + (size_t)w * xs_stride;
+    const long long total = rows_pad * D;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const long long r = i / D;
+        const int d = (int)(i - r * D);
+        const long long src = r < rows_real ? r : 0;
+        out[i] = rows_real > 0 ? X[src * D + d] * sism[d] : 0.0;
     }
 }
 
-__global__ __launch_bounds__(256) void mcmc_accept_kernel(McmcState st, int start, int first, int h) {
+__global__ __launch_bounds__(256) void mcmc_accept_kernel(McmcState st, int start, int first, int h, int it) {
     const int ns = start ? st.ns_eval : st.k / 2;
-    const int it = start ? 0 : *st.d_it;
     const int half = st.k / 2;
     const double cst = (double)st.n * log(2.0 * M_PI);
     for (int w = threadIdx.x; w < ns; w += blockDim.x) {
@@ -117,7 +149,7 @@ __global__ __launch_bounds__(256) void mcmc_accept_kernel(McmcState st, int star
     }
     if (start || h == 0) return;
     __syncthreads();
-    // end of ensemble step `it`: record the chain, advance the step counter
+    // end of ensemble step `it`: record the chain
     if (st.d_chain)
         for (int i = threadIdx.x; i < st.k * st.P; i += blockDim.x) {
             const int w = i / st.P, p = i - w * st.P;
@@ -125,18 +157,22 @@ __global__ __launch_bounds__(256) void mcmc_accept_kernel(McmcState st, int star
         }
     if (st.d_lnprob)
         for (int w = threadIdx.x; w < st.k; w += blockDim.x) st.d_lnprob[(size_t)w * st.n_steps + it] = st.d_lnp[w];
-    __syncthreads();
-    if (threadIdx.x == 0) *st.d_it = it + 1;
 }
 
-int launch_mcmc_propose(robo_ctx* ctx, const McmcState& st, int start, int first, int h) {
-    hipLaunchKernelGGL(mcmc_propose_kernel, dim3(1), dim3(256), 0, ctx->stream, st, start, first, h);
+int launch_mcmc_propose_scale(robo_ctx* ctx, const McmcState& st, int start, int first, int h, int it, const double* d_X,
+                              double* d_Xs, int64_t rows_real, int64_t rows_pad, size_t xs_stride) {
+    const int ns = start ? st.ns_eval : st.k / 2;
+    int blocks = (int)((rows_pad * st.D + 255) / 256);
+    if (blocks > 64) blocks = 64;
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(mcmc_propose_scale_kernel, dim3(blocks, ns), dim3(256), 0, ctx->stream, st, start, first, h, it,
+                       d_X, d_Xs, (long long)rows_real, (long long)rows_pad, xs_stride);
     ROBO_LAUNCH_CHECK();
     return ROBO_OK;
 }
 
-int launch_mcmc_accept(robo_ctx* ctx, const McmcState& st, int start, int first, int h) {
-    hipLaunchKernelGGL(mcmc_accept_kernel, dim3(1), dim3(256), 0, ctx->stream, st, start, first, h);
+int launch_mcmc_accept(robo_ctx* ctx, const McmcState& st, int start, int first, int h, int it) {
+    hipLaunchKernelGGL(mcmc_accept_kernel, dim3(1), dim3(256), 0, ctx->stream, st, start, first, h, it);
     ROBO_LAUNCH_CHECK();
     return ROBO_OK;
 }
