@@ -199,7 +199,11 @@ class GaussianProcessMCMC(BaseModel):
             return None
 
         def run(p, lnp, n_steps, u_stretch, partner, u_accept, a):
-            return self.gp.mcmc_run(self.mean, prior, p, lnp, n_steps, u_stretch, partner, u_accept, a)
+            try:
+                return self.gp.mcmc_run(self.mean, prior, p, lnp, n_steps, u_stretch, partner, u_accept, a)
+            except AssertionError:      # ROBO_BAD_SHAPE: half an ensemble exceeds the batch workspace -> host sampler
+                logger.info("device chain declined (%s); host sampler", _lib.last_error())
+                return None
         return run
 
     def loglikelihood_batch(self, thetas):

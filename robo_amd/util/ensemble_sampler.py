@@ -88,8 +88,13 @@ class EnsembleSampler(object):
             self.random_state = rstate0
         p = np.array(pos0, dtype=np.float64)
         assert p.shape == (self.k, self.dim)
+        draws = None
         if self._device_chain is not None:
-            return self._run_on_device(p, N, lnprob0)
+            done, draws = self._run_on_device(p, N, lnprob0)
+            if done is not None:
+                return done
+            # (the device declined -- e.g. half an ensemble does not fit its batch workspace: the host loop below
+            # consumes the random numbers that were already drawn, in the same order)
         lnp = self._eval(p) if lnprob0 is None else np.array(lnprob0, dtype=np.float64)
         if np.any(np.isinf(lnp) & (lnp > 0)):
             raise ValueError("The initial lnprob was +inf.")
@@ -101,12 +106,14 @@ class EnsembleSampler(object):
             for S0, S1 in ((first, second), (second, first)):
                 s, c = p[S0], p[S1]
                 ns, nc = s.shape[0], c.shape[0]
-                zz = ((self.a - 1.0) * self._random.rand(ns) + 1.0) ** 2.0 / self.a
-                rint = self._random.randint(nc, size=(ns,))
+                hh = 0 if S0 is first else 1
+                u_z = self._random.rand(ns) if draws is None else draws[0][it, hh]
+                zz = ((self.a - 1.0) * u_z + 1.0) ** 2.0 / self.a
+                rint = self._random.randint(nc, size=(ns,)) if draws is None else draws[1][it, hh]
                 q = c[rint] - zz[:, None] * (c[rint] - s)
                 newlnp = self._eval(q)
                 lnpdiff = (self.dim - 1.0) * np.log(zz) + newlnp - lnp[S0]
-                accept = lnpdiff > np.log(self._random.rand(ns))
+                accept = lnpdiff > np.log(self._random.rand(ns) if draws is None else draws[2][it, hh])
                 if np.any(accept):
                     idx = np.arange(self.k)[S0][accept]
                     p[idx] = q[accept]
@@ -134,12 +141,15 @@ class EnsembleSampler(object):
                 ua[it, h] = self._random.rand(half)
         if lnprob0 is not None and np.any(np.isinf(lnprob0) & (np.asarray(lnprob0) > 0)):
             raise ValueError("The initial lnprob was +inf.")
-        p, lnp, chain, lnps, acc = self._device_chain(p, lnprob0, N, uz, pa, ua, self.a)
+        res = self._device_chain(p, lnprob0, N, uz, pa, ua, self.a)
+        if res is None:
+            return None, (uz, pa, ua)
+        p, lnp, chain, lnps, acc = res
         self.naccepted += acc
         self.iterations += N
         self._chain = np.concatenate((self._chain, chain), axis=1)
         self._lnprob = np.concatenate((self._lnprob, lnps), axis=1)
-        return p, lnp, self.random_state
+        return (p, lnp, self.random_state), None
 
     def reset(self):
         self.naccepted[:] = 0

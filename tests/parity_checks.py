@@ -189,8 +189,12 @@ def check_device_chain(ctx, cases=(("matern52", 150, 3, 10, 14), ("rbf", 40, 2, 
     X = rs.rand(60, 2) * 3 - 1
     y = np.sin(X[:, 0]) * np.cos(2 * X[:, 1])
     hyp = {}
-    for mode in ("0", "1"):
-        os.environ["ROBO_MCMC_HOST"] = mode
+    for mode in ("0", "1", "declined"):
+        # "declined": half an ensemble does not fit the batch workspace -> robo_gp_mcmc_run returns ROBO_BAD_SHAPE and the
+        # sampler continues on the host with the random numbers it had already drawn
+        os.environ["ROBO_MCMC_HOST"] = "1" if mode == "1" else "0"
+        if mode == "declined":
+            _lib.default_context().set_tuning("ws_bytes", 200000)
         try:
             kernel = 2 * Matern52Kernel(np.ones([2]), ndim=2)
             m = GaussianProcessMCMC(kernel, prior=DefaultPrior(len(kernel) + 1, rng=np.random.RandomState(66)),
@@ -201,6 +205,8 @@ def check_device_chain(ctx, cases=(("matern52", 150, 3, 10, 14), ("rbf", 40, 2, 
             hyp[mode] = (np.array(m.hypers), m.predict(X[:7] + 0.1))
         finally:
             os.environ.pop("ROBO_MCMC_HOST", None)
+            _lib.default_context().set_tuning("ws_bytes", None)
+    np.testing.assert_array_equal(hyp["declined"][0], hyp["1"][0])
     np.testing.assert_allclose(hyp["0"][0], hyp["1"][0], rtol=1e-9, atol=1e-9)
     np.testing.assert_allclose(hyp["0"][1][0], hyp["1"][1][0], rtol=1e-7, atol=1e-9)
     np.testing.assert_allclose(hyp["0"][1][1], hyp["1"][1][1], rtol=1e-6, atol=1e-10)
