@@ -462,10 +462,9 @@ def test_comm_one_rank_rccl(ctx):
 
 
 def test_host_array_handle_reuse(ctx):
-    P.check_host_array_handle_reuse(ctx)@pytest.mark.gpu
+    P.check_host_array_handle_reuse(ctx)
+
+
 def test_device_resident_chain(ctx):
     P.check_device_chain(ctx)
     P.check_device_chain(ctx, cases=(("matern52", 300, 16, 36, 20),))
-
-
-
