@@ -17,29 +17,9 @@
 // rand for z, randint for the partners, rand for the accept test) -- same stream, same chain as the reference's sampler
 // up to the rounding of exp / log on the device.  q is formed without fused multiply-adds (numpy has none).
 #include "common.h"
+#include "mcmc_dev.h"
 
 namespace robo {
-
-// robo/priors/default_priors.py:7-37 through robo_amd/priors/priors.py: lognormal on theta[0], tophat on the length
-// scales, horseshoe on the noise; par = {lognormal loc, sigma, tophat min, max, horseshoe scale}
-__device__ __forceinline__ double default_prior_lnprob(const double* th, int P, const double* par) {
-    const double ninf = -__builtin_huge_val();
-    const double yv = th[0] - par[0];
-    double lp;
-    if (yv > 0.0) {
-        const double ly = log(yv);
-        lp = -(ly * ly) / (2.0 * par[1] * par[1]) - ly - log(par[1] * sqrt(2.0 * M_PI));
-    } else {
-        lp = ninf;
-    }
-    for (int p = 1; p < P - 1; ++p)
-        if (th[p] < par[2] || th[p] > par[3]) lp = ninf;
-    const double noise = th[P - 1];
-    const double r = par[4] / exp(noise);
-    double hs = log(log(1.0 + 3.0 * (r * r)));
-    if (noise == 0.0) hs = __builtin_huge_val();
-    return lp + hs;
-}
 
 // Proposal + input scaling in one launch, grid (blocks over the rows of X, walkers of the half): EVERY block forms its
 // walker's proposal (thread p <-> parameter p), the bounds test and the inverse square-root metrics in LDS, then scales
@@ -57,39 +37,7 @@ __global__ __launch_bounds__(256) void mcmc_propose_scale_kernel(McmcState st, i
     __shared__ double sz;
     __shared__ int sbad;
     const int w = blockIdx.y, P = st.P, D = st.D;
-    const int half = st.k / 2;
-    if (threadIdx.x == 0) {
-        double z = 1.0;
-        if (!start) {
-            const size_t r = ((size_t)it * 2 + h) * half + w;
-            const double t = __dadd_rn(__dmul_rn(st.a - 1.0, st.d_uz[r]), 1.0);
-            z = __ddiv_rn(__dmul_rn(t, t), st.a);
-        }
-        sz = z;
-        sbad = 0;
-    }
-    __syncthreads();
-    bool bad = false;
-    for (int p = threadIdx.x; p < P; p += blockDim.x) {
-        double q;
-        if (start) {
-            q = st.d_pos[(size_t)(first + w) * P + p];
-        } else {
-            const size_t r = ((size_t)it * 2 + h) * half + w;
-            const double s = st.d_pos[(size_t)(h * half + w) * P + p];
-            const double c = st.d_pos[(size_t)((1 - h) * half + st.d_partner[r]) * P + p];
-            q = __dsub_rn(c, __dmul_rn(sz, __dsub_rn(c, s)));
-        }
-        sq[p] = q;
-        bad = bad || !(q >= -20.0 && q <= 20.0);          // also true for NaN / inf
-    }
-    if (bad) sbad = 1;
-    __syncthreads();                                       // sq is complete
-    const bool ok = sbad == 0;
-    const bool fab = st.kind == ROBO_KERNEL_FABOLAS;
-    const int n_metric = fab ? D - 1 : D;
-    for (int d = threadIdx.x; d < D; d += blockDim.x) sism[d] = d < n_metric ? exp(-0.5 * (ok ? sq[1 + d] : 0.0)) : 1.0;
-    __syncthreads();
+    const bool ok = mcmc_block_proposal(st, start, first, h, it, w, sq, sism, &sz, &sbad);
     if (blockIdx.x == 0) {
         for (int p = threadIdx.x; p < P; p += blockDim.x) st.d_q[(size_t)w * P + p] = sq[p];
         for (int d = threadIdx.x; d < D; d += blockDim.x) st.d_ism[(size_t)w * D + d] = sism[d];
@@ -98,15 +46,7 @@ __global__ __launch_bounds__(256) void mcmc_propose_scale_kernel(McmcState st, i
             double prior = 0.0;
             if (ok && st.prior_kind == 1) prior = default_prior_lnprob(sq, P, st.prior_par);
             st.d_prior[w] = ok ? prior : -__builtin_huge_val();
-            FitSample sp;
-            sp.cov.kind = st.kind;
-            sp.cov.dim = D;
-            sp.cov.amp = exp(ok ? sq[0] : 0.0);
-            sp.cov.blr_a = fab ? exp(ok ? sq[D] : 0.0) : 0.0;
-            sp.cov.blr_b = fab ? exp(ok ? sq[D + 1] : 0.0) : 0.0;
-            sp.noise = exp(ok ? sq[P - 1] : 0.0) + JITTER;
-            sp.mean_c = st.mean_c;
-            st.d_sp[w] = sp;
+            st.d_sp[w] = mcmc_fit_sample(st, sq, ok);
         }
     }
     // scale_inputs_kernel's arithmetic: pad rows replicate row 0
@@ -123,14 +63,8 @@ __global__ __launch_bounds__(256) void mcmc_propose_scale_kernel(McmcState st, i
 __global__ __launch_bounds__(256) void mcmc_accept_kernel(McmcState st, int start, int first, int h, int it) {
     const int ns = start ? st.ns_eval : st.k / 2;
     const int half = st.k / 2;
-    const double cst = (double)st.n * log(2.0 * M_PI);
     for (int w = threadIdx.x; w < ns; w += blockDim.x) {
-        double lp = st.d_prior[w];
-        if (lp > -__builtin_huge_val()) {          // (a +inf prior stays +inf unless the fit fails, as on the host)
-            const double ll = st.d_fail[w] != 0 ? -__builtin_huge_val()
-                                                : -0.5 * (st.d_out[2 * w] + st.d_out[2 * w + 1] + cst);
-            lp = ll + lp;
-        }
+        const double lp = mcmc_lnprob(st.d_prior[w], st.d_fail[w], st.d_out[2 * w], st.d_out[2 * w + 1], st.n);
         if (lp != lp) atomicOr(st.d_err, 1);       // emcee: "lnprob returned NaN."
         if (start) {
             if (lp == __builtin_huge_val()) atomicOr(st.d_err, 2);   // "The initial lnprob was +inf."
