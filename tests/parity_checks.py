@@ -181,6 +181,21 @@ def check_device_chain(ctx, cases=(("matern52", 150, 3, 10, 14), ("rbf", 40, 2, 
         h0.run_mcmc(q0, 5)
         np.testing.assert_allclose(d0.chain, h0.chain, rtol=1e-9, atol=1e-9)
         np.testing.assert_array_equal(d0.naccepted, h0.naccepted)
+        # zero steps: only the start positions are evaluated; emcee's error for a +inf start (the horseshoe term at
+        # log-noise == 0 is +inf, priors.py) comes back as the ValueError the host sampler raises
+        e0 = np.empty((0, 2, k // 2))
+        pos_z, lnp_z, ch_z, _, acc_z = g.mcmc_run(mean, par, q0, None, 0, e0, e0.astype(np.int32), e0)
+        np.testing.assert_array_equal(pos_z, q0)
+        assert ch_z.shape == (k, 0, P) and not acc_z.any()
+        fin = np.isfinite(lnp_z)
+        np.testing.assert_allclose(lnp_z[fin], lnprob_host(q0)[fin], rtol=0, atol=1e-7 * np.abs(lnp_z[fin]).max())
+        q_inf = q0.copy()
+        q_inf[0, -1] = 0.0
+        try:
+            g.mcmc_run(mean, par, q_inf, None, 0, e0, e0.astype(np.int32), e0)
+            raise AssertionError("a +inf start must be refused")
+        except ValueError as e:
+            assert "+inf" in str(e), str(e)
         g.close()
     # the model class: device chain (default) == host sampler (ROBO_MCMC_HOST=1)
     from robo_amd.kernels import Matern52Kernel
