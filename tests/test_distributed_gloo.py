@@ -1,4 +1,4 @@
-"""The N > 1 exchange steps of the sharded hot path on CPU, world_size 2: the library's own collective entry points
+"""The N > 1 exchange steps of the sharded hot path on CPU, world_size 2 (and 3, uneven shards): the library's own collective entry points
 (robo_amd/csrc/comm.hip) through the interpreter build, with tests/hipemu/fake_rccl.cpp standing in for librccl.so
 (ROBO_RCCL_LIB) and torch.distributed (gloo) doing what it does in a real job -- the rendezvous of the 128-byte id."""
 import os
@@ -78,7 +78,8 @@ def _worker(rank, world, port, out_dir):
     mine = _lib.Candidates(ctx, Xc[b:e])
     v, mx, am, owner, fl = c.acq_sharded(gps[0], "ei", 0.0, eta, mine, b, want_values=True)
     np.testing.assert_array_equal(v, v_ref[b:e])
-    assert (mx, am, fl) == (mx_ref, am_ref, fl_ref) and owner == (0 if am_ref < sharding.shard_range(Mc, 0, world)[1] else 1)
+    owner_ref = [r for r in range(world) if sharding.shard_range(Mc, r, world)[0] <= am_ref < sharding.shard_range(Mc, r, world)[1]][0]
+    assert (mx, am, fl) == (mx_ref, am_ref, fl_ref) and owner == owner_ref
     vm_ref, mxm_ref, amm_ref, _ = _lib.acq_marginal(gps, "log_ei", 0.0, np.full(5, eta), full)
     sb, se = sharding.shard_range(5, rank, world)
     vm, mxm, amm, _ = c.acq_marginal_sharded(gps[sb:se], 5, "log_ei", 0.0, np.full(se - sb, eta), full)
@@ -112,6 +113,16 @@ def test_sharded_exchange_world2(tmp_path):
         a = np.load(tmp_path / ("%s_0.npy" % name))
         b = np.load(tmp_path / ("%s_1.npy" % name))
         np.testing.assert_array_equal(a, b)        # bit-identical on both ranks
+
+
+def test_sharded_exchange_world3(tmp_path):
+    """uneven shards (701 candidates 234/234/233, 5 samples 2/2/1, 1 sample on rank 0 only): same checks, three ranks"""
+    port = _free_port()
+    mp.spawn(_worker, args=(3, port, str(tmp_path)), nprocs=3, join=True)
+    for name in ("total", "marg"):
+        a = np.load(tmp_path / ("%s_0.npy" % name))
+        for r in (1, 2):
+            np.testing.assert_array_equal(a, np.load(tmp_path / ("%s_%d.npy" % (name, r))))
 
 
 def _class_worker(rank, world, port, out_dir):
