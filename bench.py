@@ -354,19 +354,34 @@ def roofline_trsm(ctx, N, M_rows, trsm_ms_per_step, passes=1, kernel="trsm_step_
             "avg_launch_ms": avg_launch_ms}
 
 
-def clock_under_step(ctx, roof, step, ms_per_step):
-    """shader clock while one more `step` runs (include/robo_hip_diag.h: sampler waves on a second stream), and the fp64
-    peak at THAT clock next to the nominal 2.4 GHz figure `frac` is quoted against.  Information only."""
+def clock_during_step(D_, ctx, step, ms_per_step):
+    """shader clock while one more `step` runs (include/robo_hip_diag.h: sampler waves on a second stream) -> the block
+    for `roofline.shader_clock_under_kernel`.  EVERY rank calls it (a step of a sharded run contains a collective); the
+    peak at that clock is attached on rank 0 by with_clock().  Information only, and only in single-process runs: on the
+    HIP runtime a torch.distributed process brings along the sampler's stream did not run beside the
+    library's (r03zo: it reported the idle clock), so process-group runs skip it."""
+    if D_.dist is not None:
+        return {"skipped": "process-group run; see the single-process line"}
+    err = None
     try:
         ctx.clock_sample_begin(max(200, int(0.75 * ms_per_step * 1e3)))
-        step()
-        ck = ctx.clock_sample_end()
-        pk = FP64_MFMA_PEAK_TFLOPS * ck["mean"] / 2400.0
-        roof["shader_clock_under_kernel"] = {
-            "mhz": ck, "peak_at_that_clock_tflops": pk, "frac_of_peak_at_that_clock": roof["achieved"] / pk,
-            "note": "`frac` is against the nominal 2.4 GHz peak; this block: the clock the part held during one step"}
     except Exception as e:
-        roof["shader_clock_under_kernel"] = {"error": str(e)[:200]}
+        err = str(e)[:200]
+    step()                                   # always, on every rank: the collectives of all ranks must match
+    if err is None:
+        try:
+            return {"mhz": ctx.clock_sample_end()}
+        except Exception as e:
+            err = str(e)[:200]
+    return {"error": err}
+
+
+def with_clock(roof, clock):
+    if "mhz" in clock:
+        pk = FP64_MFMA_PEAK_TFLOPS * clock["mhz"]["mean"] / 2400.0
+        clock = dict(clock, peak_at_that_clock_tflops=pk, frac_of_peak_at_that_clock=roof["achieved"] / pk,
+                     note="`frac` is against the nominal 2.4 GHz peak; this block: the clock the part held during one step")
+    roof["shader_clock_under_kernel"] = clock
     return roof
 
 
@@ -435,6 +450,7 @@ def run_headline(args, D_, _lib, sharding):
         return evaluate()
 
     elapsed, best, trsm_ms = timed_steps(D_, ctx, step, args.steps, args.warmup)
+    clock = clock_during_step(D_, ctx, step, elapsed / args.steps * 1e3)  # every rank: the step holds a collective
 
     # SURVEY 8(d)'s full definition of an "EI eval" (PCIe-inclusive: H2D of the candidate batch into an existing
     # handle, D2H of the result) -- reported next to `value`, which is the resident-input rate
@@ -504,7 +520,7 @@ def run_headline(args, D_, _lib, sharding):
             roof["gemm_f64_microbench"] = {"lds_core_tflops": g_tf, "shader_mhz_under_load": g_mhz,
                                            "peak_at_that_clock_tflops": clock_peak,
                                            "frac_of_peak_at_that_clock": roof["achieved"] / clock_peak}
-        clock_under_step(ctx, roof, step, ms_per_step)
+        with_clock(roof, clock)
         k1_bytes = 8.0 * N * (N + 1) / 2 + 8.0 * N * D
         name = "BASELINE headline" if (N, D) == (4096, 16) else "BASELINE config 2" if (N, D) == (1024, 8) else "custom"
         out = {
@@ -585,12 +601,13 @@ def run_c3(args, D_, _lib, sharding):
         return float(mx), int(am)
 
     elapsed, best, trsm_ms = timed_steps(D_, ctx, step, args.steps, args.warmup)
+    clock = clock_during_step(D_, ctx, step, elapsed / args.steps * 1e3)  # every rank: the step holds a collective
     if rank != 0:
         return None
     ms = elapsed / args.steps * 1e3
     # elapsed_ms(25, 26) brackets the LAST sample's solve of a step
     roof = roofline_trsm(ctx, N, M, trsm_ms, kernel=cand.solve_kernel(), traffic=config_traffic("c3", cand.solve_kernel()))
-    clock_under_step(ctx, roof, step, ms)
+    with_clock(roof, clock)
     return {"metric": METRIC, "value": S * M * args.steps / elapsed, "unit": "LogEI sample-evals/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": True,
             "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
@@ -658,6 +675,7 @@ def run_c4(args, D_, _lib, sharding):
         return sharding.reduce_argmax((float(r[0]), int(r[1])) for r in rows)
 
     elapsed, best, trsm_ms = timed_steps(D_, ctx, step, args.steps, args.warmup)
+    clock = clock_during_step(D_, ctx, step, elapsed / args.steps * 1e3)  # every rank: the step holds a collective
     if rank != 0:
         return None
     ms = elapsed / args.steps * 1e3
@@ -669,9 +687,8 @@ def run_c4(args, D_, _lib, sharding):
                        "n_train": N, "dim": D, "candidates_per_gpu": M, "acquisition": "information_gain_per_unit_cost",
                        "parallelism": "candidate-shard x%d, replicated fits" % world},
             "argmax": list(best),
-            "roofline": clock_under_step(ctx, roofline_trsm(ctx, N, M, trsm_ms, kernel=cand_cost.solve_kernel(),
-                                                            traffic=config_traffic("c4", cand_cost.solve_kernel())),
-                                         step, ms),
+            "roofline": with_clock(roofline_trsm(ctx, N, M, trsm_ms, kernel=cand_cost.solve_kernel(),
+                                                 traffic=config_traffic("c4", cand_cost.solve_kernel())), clock),
             "device": ctx.name,
             "note": "roofline: the block-row solve of the LAST posterior of a step (the cost model's); at this batch "
                     "size the step is latency-bound, not MFMA-bound (see small_batch_latency_ms of the headline line)"}
@@ -714,6 +731,7 @@ def run_c5(args, D_, _lib, sharding):
         return mx, am
 
     elapsed, best, trsm_ms = timed_steps(D_, ctx, step, args.steps, args.warmup)
+    clock = clock_during_step(D_, ctx, step, elapsed / args.steps * 1e3)  # every rank: the step holds a collective
     if rank != 0:
         return None
     ms = elapsed / args.steps * 1e3
@@ -726,9 +744,9 @@ def run_c5(args, D_, _lib, sharding):
                        "parallelism": "candidate-shard x%d, replicated fit" % world},
             "gp_fit_ms": fit_ms, "algorithmic_tflops_whole_step": world * M * flops_ei(N, D) / (ms * 1e-3) / 1e12,
             "argmax": list(best),
-            "roofline": clock_under_step(ctx, roofline_trsm(ctx, N, M, trsm_ms, passes=-(-M // cand.chunk()),
-                                                            kernel=cand.solve_kernel(),
-                                                            traffic=config_traffic("c5", cand.solve_kernel())), step, ms),
+            "roofline": with_clock(roofline_trsm(ctx, N, M, trsm_ms, passes=-(-M // cand.chunk()),
+                                                 kernel=cand.solve_kernel(),
+                                                 traffic=config_traffic("c5", cand.solve_kernel())), clock),
             "device": ctx.name}
 
 
