@@ -87,7 +87,7 @@ int32_t robo_ctx_set_phase_events(robo_ctx* ctx, int32_t on);
  * winv_max / winv_min_blocks (batches of at most winv_max candidates on a factor of at least winv_min_blocks 128-row
  * blocks are evaluated through the explicit inverse factor, winv.hip; default 32768 / 6, measured r03b; 0 = never),
  * trsm_pair (1: two block rows of the solve per launch on one read of V; default 0: one), trsm_small_max, trsm_small_narrow,
- * trsm_small_deep, trsm_rows, predict_stepwise, gram_persistent, potrf_fused, potrf_tm4_min,
+ * trsm_small_deep, trsm_rows, predict_stepwise, gram_persistent, mcmc_block_step, potrf_fused, potrf_tm4_min,
  * potrf_max_wg, potrf_group (kernel-variant selection; A/B runs and tests).                                     */
 int32_t robo_ctx_set_tuning(robo_ctx* ctx, const char* key, int64_t value);
 const char* robo_last_error_string(void);

@@ -89,6 +89,7 @@ struct Tuning {
     int winv_min_blocks;
     int potrf_fused;             // 0: never fuse the next diagonal block into the trailing update
     int potrf_tm4_min, potrf_max_wg, potrf_group;
+    int mcmc_block_step;         // 1 (default): N <= 63 runs an ensemble half-step in ONE launch (0: the four-launch form)
     int gram_persistent;         // K1: persistent workgroups per CU; 0 (default, faster: r03d) = one workgroup per tile
 };
 void tuning_from_env(Tuning* t);
@@ -239,6 +240,7 @@ struct McmcState {
 int launch_mcmc_propose_scale(robo_ctx* ctx, const McmcState& st, int start, int first, int h, int it, const double* d_X,
                               double* d_Xs, int64_t rows_real, int64_t rows_pad, size_t xs_stride);
 int launch_mcmc_accept(robo_ctx* ctx, const McmcState& st, int start, int first, int h, int it);
+int launch_mcmc_block_step(robo_gp* gp, const McmcState& st, int start, int first, int h, int it);
 int launch_potrf(robo_gp* gp, const FitBuffers& fb);
 int launch_diag_timeline(robo_gp* gp, long long* d_stamps);
 int launch_cross_gram(robo_gp* gp, robo_cand* cand, int64_t c0, int64_t cn, double* d_out = nullptr);

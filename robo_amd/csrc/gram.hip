@@ -12,13 +12,10 @@
 // HBM traffic per launch: gram   8 * n_pad*(n_pad+64)/2 bytes written, 8*n*D read
 //                         cross  8 * rows*n_pad written, 8*(rows+n)*D read
 #include "common.h"
+#include "gram_tile.h"      // GT, GD, GLD, pair_cov_dot
 #include "kern_math.h"
 
 namespace robo {
-
-constexpr int GT = 64;      // tile edge
-constexpr int GD = 16;      // dims per LDS pass
-constexpr int GLD = GT + 2; // LDS leading dimension (doubles)
 
 __global__ __launch_bounds__(256) void scale_inputs_kernel(const double* __restrict__ in, double* __restrict__ out,
                                                            const double* __restrict__ inv_sqrt_m, long long rows_real,
@@ -132,73 +129,6 @@ __device__ __forceinline__ void pair_cov(const CovParams& cp, const double* __re
         for (int b = 0; b < 4; ++b) {
             if (fab) acc[a][b] *= exp_np(-ss[fab ? a : 0][fab ? b : 0]);
             cov[a][b] = cov_finish<T, KIND>(cp, acc[a][b], uu[a][b]);
-        }
-}
-
-// fp64 stationary kernels in K1: squared distances through  r2 = |x_i|^2 + |x_j|^2 - 2 x_i . x_j  with the row norms
-// reduced once per tile from the staged coordinates -- one FMA per pair and dimension instead of a subtraction and an
-// FMA.  K1 is bound by fp64 VALU issue (r02i PMC), and at D = 16 the 32 distance instructions were the largest
-// block left after the sqrt/exp trimming.  The expansion's cancellation error is ~|x|^2 eps <= 1e-15 ABSOLUTE in r2
-// (scaled coordinates, |x|^2 = O(1)), i.e. below one ulp of the O(1) covariance it feeds; r2 is clamped at 0 and the
-// diagonal entries are exact by construction (gram_kernel sets r2 = 0 there).  The cross-gram kernels (posterior)
-// and the fp32 K-build keep direct differences.
-template <int KIND>
-__device__ __forceinline__ void pair_cov_dot(const CovParams& cp, const double* __restrict__ X, long long i0,
-                                             long long j0, double* sI, double* sJ, double* sN, double (&cov)[4][4]) {
-    const int t = threadIdx.x, tx = t & 15, ty = t >> 4, dim = cp.dim;
-    double dot[4][4];
-#pragma unroll
-    for (int a = 0; a < 4; ++a)
-#pragma unroll
-        for (int b = 0; b < 4; ++b) dot[a][b] = 0.0;
-    double nrm = 0.0;                       // threads 0..63: |x_i|^2 of row i0 + t; 64..127: |x_j|^2 of row j0 + t - 64
-    const double* sMine = t < GT ? sI : sJ;
-    for (int d0 = 0; d0 < dim; d0 += GD) {
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const int idx = t + e * 256;
-            const int row = idx >> 4, d = idx & 15;
-            const bool ok = d0 + d < dim;
-            sI[d * GLD + row] = ok ? X[(i0 + row) * dim + d0 + d] : 0.0;
-            sJ[d * GLD + row] = ok ? X[(j0 + row) * dim + d0 + d] : 0.0;
-        }
-        __syncthreads();
-        const int dn = dim - d0 < GD ? dim - d0 : GD;
-        if (t < 2 * GT)
-            for (int d = 0; d < dn; ++d) {
-                const double x = sMine[d * GLD + (t & (GT - 1))];
-                nrm = fma(x, x, nrm);
-            }
-        for (int d = 0; d < dn; ++d) {
-            double xi[4], xj[4];
-#pragma unroll
-            for (int a = 0; a < 4; ++a) {
-                xi[a] = sI[d * GLD + ty * 4 + a];
-                xj[a] = sJ[d * GLD + tx * 4 + a];
-            }
-#pragma unroll
-            for (int a = 0; a < 4; ++a)
-#pragma unroll
-                for (int b = 0; b < 4; ++b) dot[a][b] = fma(xi[a], xj[b], dot[a][b]);
-        }
-        __syncthreads();
-    }
-    if (t < 2 * GT) sN[t] = nrm;
-    __syncthreads();
-    double ni[4], nj[4];
-#pragma unroll
-    for (int a = 0; a < 4; ++a) {
-        ni[a] = sN[ty * 4 + a];
-        nj[a] = sN[GT + tx * 4 + a];
-    }
-#pragma unroll
-    for (int a = 0; a < 4; ++a)
-#pragma unroll
-        for (int b = 0; b < 4; ++b) {
-            double r2 = fma(-2.0, dot[a][b], ni[a] + nj[b]);
-            r2 = r2 > 0.0 ? r2 : 0.0;
-            if (i0 + ty * 4 + a == j0 + tx * 4 + b) r2 = 0.0;     // the diagonal is exact
-            cov[a][b] = cov_finish<double, KIND>(cp, r2, 0.0);
         }
 }
 

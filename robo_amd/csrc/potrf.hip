@@ -16,6 +16,8 @@
 // is the MFMA-bound part, the 128-wide diagonal kernel the latency-bound part.
 #include "common.h"
 #include "gemm_f64.h"
+#include "gram_tile.h"
+#include "mcmc_dev.h"
 
 namespace robo {
 
@@ -633,6 +635,137 @@ __global__ __launch_bounds__(256) void potrf_diag_kernel(double* __restrict__ K,
     }
     diag_writeback(m, Kd, ld, Linv + (size_t)k * NB * NB);
     if (dbg && tid == 0) dbg[12] = clock64();
+}
+
+// ---- SMALL problems (N <= 63: one 64 x 64 gram tile, the first sixty iterations of a Bayesian optimisation): a whole
+// ensemble half-step per launch -------------------------------------------------------------------------------------
+// The device-resident chain of mcmc.hip is, per half-step, proposal + scaling | gram | this file's one-block
+// factorisation-with-likelihood | accept: four launches of ~5 us each around ~8 us of work at N = 40 (r03z: 34 us per
+// half-step).  Here one workgroup per walker does all of it: the proposal and its metrics in LDS (mcmc_dev.h), the gram
+// tile straight into the block-packed LDS image of the diagonal block (gram_tile.h: scaling while staging, the entries
+// of scale_inputs_kernel + gram_kernel bit for bit), diag128_factor_invert, potrf_diag_kernel's likelihood reductions,
+// the accept test and the walker's own chain record (a walker's entry for step `it` is final after ITS half-step).
+// For 64 <= N < 128 the three tiles of a walker would run one after the other on one CU (measured r03zf: 42.6 us
+// against 41.6 for the four launches, whose gram kernel spreads the tiles over the chip): those sizes keep four launches.
+template <int KIND>
+__global__ __launch_bounds__(256) void mcmc_block_step_kernel(McmcState st, int start, int first, int h, int it,
+                                                              const double* __restrict__ X,
+                                                              const double* __restrict__ y) {
+    __shared__ double smem[DIAG_SMEM_DOUBLES];
+    __shared__ int sfail;
+    const DiagSmem m = diag_carve(smem);
+    const int tid = threadIdx.x, w = blockIdx.x, P = st.P, n = st.n;
+    // the W image is unused until the first 16 x 16 factorisation writes its inverse: proposal and tile staging live there
+    double* sq = m.sW;
+    double* sism = sq + MAX_DIM + 8;
+    double* sI = sism + MAX_DIM;
+    double* sJ = sI + GD * GLD;
+    double* sN = sJ + GD * GLD;
+    double* sz = sN + 2 * GT;
+    int* sflag = reinterpret_cast<int*>(sz + 1);
+    const bool ok = mcmc_block_proposal(st, start, first, h, it, w, sq, sism, sz, sflag);
+    const FitSample sp = mcmc_fit_sample(st, sq, ok);            // uniform, in every thread's registers
+    const double z = *sz;
+    double prior = 0.0;
+    if (tid == 0) {
+        if (ok && st.prior_kind == 1) prior = default_prior_lnprob(sq, P, st.prior_par);
+        if (!ok) prior = -__builtin_huge_val();
+        sfail = 0;
+    }
+    const double q0 = tid < P ? sq[tid] : 0.0, q1 = tid + 256 < P ? sq[tid + 256] : 0.0;   // thread p keeps q[p]
+    // ---- K (rows / columns 0..63; the rest of the 128 x 128 block is identity padding) into the LDS image, with the
+    // rules of gram_kernel for rows / columns >= n
+    {
+        const int tx = tid & 15, ty = tid >> 4;
+        double cov[4][4];
+        pair_cov_dot<KIND>(sp.cov, X, 0, 0, sI, sJ, sN, cov, sism, (long long)n);
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+            const int gi = ty * 4 + a;
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {
+                const int gj = tx * 4 + b;
+                double val;
+                if (gi < n && gj < n) {
+                    val = cov[a][b];
+                    if (gi == gj) val += sp.noise;
+                } else if (gi == gj) {
+                    val = 1.0;
+                } else if (gi == n && gj < n) {
+                    val = y[gj] - sp.mean_c;
+                } else if (gj == n && gi < n) {
+                    val = y[gi] - sp.mean_c;
+                } else {
+                    val = 0.0;
+                }
+                if ((gj >> 4) <= (gi >> 4)) m.sL[blk_off(gi >> 4, gj >> 4) + bidx(gi & 15, gj & 15)] = val;
+            }
+        }
+    }
+    __syncthreads();
+    // (diag128_factor_invert stops after the sub-blocks that hold rows <= n: the blocks behind them are never read)
+    diag128_factor_invert(m.sL, m.sW, m.sT, m.sRd, m.sCol, 0, n, &sfail, nullptr);
+    // ---- (z.z, 2 sum log L_ii): the operations of potrf_diag_kernel's one-block branch, in its order
+    __syncthreads();
+    double qq = 0.0, lg = 0.0;
+    if (tid < NB && tid < n) {
+        const double zi = m.sL[blk_off(n >> 4, tid >> 4) + bidx(n & 15, tid & 15)];
+        qq = zi * zi;
+        lg = log(m.sL[blk_off(tid >> 4, tid >> 4) + bidx(tid & 15, tid & 15)]);
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+        qq += __shfl_xor(qq, o);
+        lg += __shfl_xor(lg, o);
+    }
+    __syncthreads();
+    double* red = m.sW;
+    if ((tid & 63) == 0 && tid < NB) {
+        red[tid >> 6] = qq;
+        red[2 + (tid >> 6)] = lg;
+    }
+    __syncthreads();
+    // ---- accept test (mcmc_accept_kernel's, for this walker)
+    const int half = st.k / 2, sw = start ? first + w : h * half + w;
+    if (tid == 0) {
+        const double lp = mcmc_lnprob(prior, sfail, red[0] + red[1], 2.0 * (red[2] + red[3]), n);
+        if (lp != lp) atomicOr(st.d_err, 1);
+        int acc = 0;
+        if (start) {
+            if (lp == __builtin_huge_val()) atomicOr(st.d_err, 2);
+            st.d_lnp[sw] = lp;
+        } else {
+            const size_t r = ((size_t)it * 2 + h) * half + w;
+            const double lnpdiff = ((double)P - 1.0) * log(z) + lp - st.d_lnp[sw];
+            if (lnpdiff > log(st.d_ua[r])) {
+                acc = 1;
+                st.d_lnp[sw] = lp;
+                st.d_nacc[sw] += 1;
+            }
+            if (st.d_lnprob) st.d_lnprob[(size_t)sw * st.n_steps + it] = st.d_lnp[sw];
+        }
+        *sflag = acc;
+    }
+    __syncthreads();
+    if (start) return;
+    const bool acc = *sflag != 0;
+    for (int p = tid, e = 0; p < P; p += 256, ++e) {
+        double* pp = st.d_pos + (size_t)sw * P + p;
+        const double v = acc ? (e == 0 ? q0 : q1) : *pp;
+        if (acc) *pp = v;
+        if (st.d_chain) st.d_chain[((size_t)sw * st.n_steps + it) * P + p] = v;
+    }
+}
+
+int launch_mcmc_block_step(robo_gp* gp, const McmcState& st, int start, int first, int h, int it) {
+    const int ns = start ? st.ns_eval : st.k / 2;
+    if (gp->kind == ROBO_KERNEL_MATERN52_ARD)
+        hipLaunchKernelGGL(mcmc_block_step_kernel<ROBO_KERNEL_MATERN52_ARD>, dim3(ns), dim3(256), 0, gp->ctx->stream, st,
+                           start, first, h, it, (const double*)gp->d_X, (const double*)gp->d_y);
+    else
+        hipLaunchKernelGGL(mcmc_block_step_kernel<ROBO_KERNEL_RBF_ARD>, dim3(ns), dim3(256), 0, gp->ctx->stream, st, start,
+                           first, h, it, (const double*)gp->d_X, (const double*)gp->d_y);
+    ROBO_LAUNCH_CHECK();
+    return ROBO_OK;
 }
 
 // Panel solve  X L_kk^T = A_ik  for the rows below the diagonal block of panel k, by block forward substitution

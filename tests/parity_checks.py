@@ -153,6 +153,24 @@ def check_device_chain(ctx, cases=(("matern52", 150, 3, 10, 14), ("rbf", 40, 2, 
             return smp.chain, smp.lnprobability, smp.naccepted.copy(), pos2, lnp2, state
 
         dev = run(lnprob_batch=lnprob_host, device_chain=lambda p, lnp, n, uz, pa, ua, a: g.mcmc_run(mean, par, p, lnp, n, uz, pa, ua, a))
+        if N + 1 <= 64:
+            # small problems: the half-step fused into ONE launch (default) against the four-launch form -- same accept
+            # decisions; likelihoods bit-identical on the emulator, within an ulp on the MI355X (fused-multiply-add
+            # contraction is decided per kernel)
+            ctx.set_tuning("mcmc_block_step", 0)
+            try:
+                dev4 = run(lnprob_batch=lnprob_host,
+                           device_chain=lambda p, lnp, n, uz, pa, ua, a: g.mcmc_run(mean, par, p, lnp, n, uz, pa, ua, a))
+            finally:
+                ctx.set_tuning("mcmc_block_step", None)
+            np.testing.assert_array_equal(dev[2], dev4[2])
+            for a_, b_ in ((dev[0], dev4[0]), (dev[3], dev4[3])):
+                np.testing.assert_allclose(a_, b_, rtol=1e-12, atol=1e-12)
+            fin4 = np.isfinite(dev4[1])
+            assert np.array_equal(fin4, np.isfinite(dev[1]))
+            np.testing.assert_allclose(dev[1][fin4], dev4[1][fin4], rtol=1e-13, atol=0)
+            if "hipemu" in ctx.name:
+                np.testing.assert_array_equal(dev[1][fin4], dev4[1][fin4])
         host = run(lnprob_batch=lnprob_host)
         orc = run(lnprob_batch=lnprob_oracle)
         assert dev[0].shape == (k, steps + 3, P) and np.all(np.isfinite(dev[0]))
