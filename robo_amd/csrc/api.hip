@@ -43,7 +43,7 @@ static const TuneKey TUNE_KEYS[] = {
     {"potrf_max_wg", nullptr, &Tuning::potrf_max_wg, 0},
     {"potrf_group", nullptr, &Tuning::potrf_group, 4},
     {"gram_persistent", nullptr, &Tuning::gram_persistent, 0},
-    {"mcmc_block_step", nullptr, &Tuning::mcmc_block_step, 1},
+    {"mcmc_block_step", nullptr, &Tuning::mcmc_block_step, 2},
 };
 
 static void tune_set(Tuning* t, const TuneKey& k, long long v) {
@@ -598,10 +598,13 @@ int32_t robo_gp_mcmc_run(robo_gp* g, double mean_c, int32_t prior_kind, const do
     fb.host_out = nullptr;             // the likelihood terms are consumed on the device
     fb.want_inverse = false;
     fb.S = half;
-    // small problems (one 64 x 64 gram tile): the whole half-step in one launch (potrf.hip mcmc_block_step_kernel)
-    const bool one_tile = g->n + 1 <= 64 && !g->fp32_gram && g->kind != ROBO_KERNEL_FABOLAS && c->tune.mcmc_block_step != 0;
+    // one-block problems: the whole half-step in one launch (potrf.hip mcmc_block_step_kernel; tuning: 0 never,
+    // 1 only below 64 points, 2 = default: every one-block problem)
+    const int bs = c->tune.mcmc_block_step;
+    const bool one_block = (bs >= 2 ? g->n_pad == NB : (bs == 1 && g->n + 1 <= 64)) && !g->fp32_gram &&
+                           g->kind != ROBO_KERNEL_FABOLAS;
     auto half_step = [&](int start, int first, int h, int it) -> int {
-        if (one_tile) return launch_mcmc_block_step(g, st, start, first, h, it);
+        if (one_block) return launch_mcmc_block_step(g, st, start, first, h, it);
         ROBO_TRY(launch_mcmc_propose_scale(c, st, start, first, h, it, g->d_X, g->d_bXs, g->n, g->n_pad, np * D));
         ROBO_TRY(launch_gram(g, fb));
         ROBO_TRY(launch_potrf(g, fb));

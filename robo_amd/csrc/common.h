@@ -89,7 +89,7 @@ struct Tuning {
     int winv_min_blocks;
     int potrf_fused;             // 0: never fuse the next diagonal block into the trailing update
     int potrf_tm4_min, potrf_max_wg, potrf_group;
-    int mcmc_block_step;         // 1 (default): N <= 63 runs an ensemble half-step in ONE launch (0: the four-launch form)
+    int mcmc_block_step;         // ensemble half-step in ONE launch: 2 (default) every one-block problem, 1 only N <= 63, 0 never
     int gram_persistent;         // K1: persistent workgroups per CU; 0 (default, faster: r03d) = one workgroup per tile
 };
 void tuning_from_env(Tuning* t);

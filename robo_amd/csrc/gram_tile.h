@@ -22,8 +22,10 @@ constexpr int GLD = GT + 2; // LDS leading dimension (doubles)
 template <int KIND>
 __device__ __forceinline__ void pair_cov_dot(const CovParams& cp, const double* __restrict__ X, long long i0,
                                              long long j0, double* sI, double* sJ, double* sN, double (&cov)[4][4],
-                                             const double* scale = nullptr, long long rows_real = 0) {
-    const int t = threadIdx.x, tx = t & 15, ty = t >> 4, dim = cp.dim;
+                                             const double* scale = nullptr, long long rows_real = 0, int tg = -1) {
+    // tg >= 0: index of this thread within the 256-thread group that owns the tile (several groups per workgroup, each
+    // with its own staging buffers; the barriers below are workgroup-wide, so all groups make the same calls)
+    const int t = tg >= 0 ? tg : (int)threadIdx.x, tx = t & 15, ty = t >> 4, dim = cp.dim;
     double dot[4][4];
 #pragma unroll
     for (int a = 0; a < 4; ++a)

@@ -637,54 +637,55 @@ __global__ __launch_bounds__(256) void potrf_diag_kernel(double* __restrict__ K,
     if (dbg && tid == 0) dbg[12] = clock64();
 }
 
-// ---- SMALL problems (N <= 63: one 64 x 64 gram tile, the first sixty iterations of a Bayesian optimisation): a whole
-// ensemble half-step per launch -------------------------------------------------------------------------------------
+// ---- one-block problems (N <= 126, the size of a Bayesian-optimisation run): a whole ensemble half-step per launch ---
 // The device-resident chain of mcmc.hip is, per half-step, proposal + scaling | gram | this file's one-block
 // factorisation-with-likelihood | accept: four launches of ~5 us each around ~8 us of work at N = 40 (r03z: 34 us per
 // half-step).  Here one workgroup per walker does all of it: the proposal and its metrics in LDS (mcmc_dev.h), the gram
-// tile straight into the block-packed LDS image of the diagonal block (gram_tile.h: scaling while staging, the entries
+// tiles straight into the block-packed LDS image of the diagonal block (gram_tile.h: scaling while staging, the entries
 // of scale_inputs_kernel + gram_kernel bit for bit), diag128_factor_invert, potrf_diag_kernel's likelihood reductions,
 // the accept test and the walker's own chain record (a walker's entry for step `it` is final after ITS half-step).
-// For 64 <= N < 128 the three tiles of a walker would run one after the other on one CU (measured r03zf: 42.6 us
-// against 41.6 for the four launches, whose gram kernel spreads the tiles over the chip): those sizes keep four launches.
-template <int KIND>
-__global__ __launch_bounds__(256) void mcmc_block_step_kernel(McmcState st, int start, int first, int h, int it,
-                                                              const double* __restrict__ X,
-                                                              const double* __restrict__ y) {
+// NG = 1: N <= 63, one 64 x 64 tile, 256 threads.  NG = 3: 64 <= N <= 126, 768 threads -- three groups of four waves
+// compute the tiles (0,0), (1,0), (1,1) side by side (one after the other on four waves they took as long as the four
+// launches, r03zf), then the upper two groups leave and the first one factors (a hardware barrier counts live waves).
+template <int KIND, int NG>
+__global__ __launch_bounds__(256 * NG) void mcmc_block_step_kernel(McmcState st, int start, int first, int h, int it,
+                                                                   const double* __restrict__ X,
+                                                                   const double* __restrict__ y) {
     __shared__ double smem[DIAG_SMEM_DOUBLES];
     __shared__ int sfail;
     const DiagSmem m = diag_carve(smem);
-    const int tid = threadIdx.x, w = blockIdx.x, P = st.P, n = st.n;
+    const int grp = threadIdx.x >> 8, tid = threadIdx.x & 255, w = blockIdx.x, P = st.P, n = st.n;
     // the W image is unused until the first 16 x 16 factorisation writes its inverse: proposal and tile staging live there
     double* sq = m.sW;
     double* sism = sq + MAX_DIM + 8;
-    double* sI = sism + MAX_DIM;
+    double* sz = sism + MAX_DIM;
+    int* sflag = reinterpret_cast<int*>(sz + 1);
+    double* sI = sz + 2 + grp * (2 * GD * GLD + 2 * GT);     // per group: sI, sJ, sN
     double* sJ = sI + GD * GLD;
     double* sN = sJ + GD * GLD;
-    double* sz = sN + 2 * GT;
-    int* sflag = reinterpret_cast<int*>(sz + 1);
+    static_assert(MAX_DIM + 8 + MAX_DIM + 2 + 3 * (2 * GD * GLD + 2 * GT) <= NBLK * BLK, "staging fits the W image");
     const bool ok = mcmc_block_proposal(st, start, first, h, it, w, sq, sism, sz, sflag);
     const FitSample sp = mcmc_fit_sample(st, sq, ok);            // uniform, in every thread's registers
     const double z = *sz;
     double prior = 0.0;
-    if (tid == 0) {
+    if (threadIdx.x == 0) {
         if (ok && st.prior_kind == 1) prior = default_prior_lnprob(sq, P, st.prior_par);
         if (!ok) prior = -__builtin_huge_val();
         sfail = 0;
     }
-    const double q0 = tid < P ? sq[tid] : 0.0, q1 = tid + 256 < P ? sq[tid + 256] : 0.0;   // thread p keeps q[p]
-    // ---- K (rows / columns 0..63; the rest of the 128 x 128 block is identity padding) into the LDS image, with the
-    // rules of gram_kernel for rows / columns >= n
+    const double q0 = tid < P ? sq[tid] : 0.0, q1 = tid + 256 < P ? sq[tid + 256] : 0.0;   // (group 0) thread p keeps q[p]
+    // ---- K into the LDS image: group g owns tile (0,0) / (1,0) / (1,1); rows / columns >= n as gram_kernel writes them
     {
+        const int bi = grp == 0 ? 0 : 1, bj = grp == 2 ? 1 : 0;
         const int tx = tid & 15, ty = tid >> 4;
         double cov[4][4];
-        pair_cov_dot<KIND>(sp.cov, X, 0, 0, sI, sJ, sN, cov, sism, (long long)n);
+        pair_cov_dot<KIND>(sp.cov, X, (long long)bi * GT, (long long)bj * GT, sI, sJ, sN, cov, sism, (long long)n, tid);
 #pragma unroll
         for (int a = 0; a < 4; ++a) {
-            const int gi = ty * 4 + a;
+            const int gi = bi * GT + ty * 4 + a;
 #pragma unroll
             for (int b = 0; b < 4; ++b) {
-                const int gj = tx * 4 + b;
+                const int gj = bj * GT + tx * 4 + b;
                 double val;
                 if (gi < n && gj < n) {
                     val = cov[a][b];
@@ -703,6 +704,7 @@ __global__ __launch_bounds__(256) void mcmc_block_step_kernel(McmcState st, int 
         }
     }
     __syncthreads();
+    if (grp != 0) return;
     // (diag128_factor_invert stops after the sub-blocks that hold rows <= n: the blocks behind them are never read)
     diag128_factor_invert(m.sL, m.sW, m.sT, m.sRd, m.sCol, 0, n, &sfail, nullptr);
     // ---- (z.z, 2 sum log L_ii): the operations of potrf_diag_kernel's one-block branch, in its order
@@ -758,12 +760,18 @@ __global__ __launch_bounds__(256) void mcmc_block_step_kernel(McmcState st, int 
 
 int launch_mcmc_block_step(robo_gp* gp, const McmcState& st, int start, int first, int h, int it) {
     const int ns = start ? st.ns_eval : st.k / 2;
-    if (gp->kind == ROBO_KERNEL_MATERN52_ARD)
-        hipLaunchKernelGGL(mcmc_block_step_kernel<ROBO_KERNEL_MATERN52_ARD>, dim3(ns), dim3(256), 0, gp->ctx->stream, st,
-                           start, first, h, it, (const double*)gp->d_X, (const double*)gp->d_y);
-    else
-        hipLaunchKernelGGL(mcmc_block_step_kernel<ROBO_KERNEL_RBF_ARD>, dim3(ns), dim3(256), 0, gp->ctx->stream, st, start,
-                           first, h, it, (const double*)gp->d_X, (const double*)gp->d_y);
+    const bool one_tile = gp->n + 1 <= GT;
+#define ROBO_BLOCK_STEP(KIND, NG)                                                                                     \
+    hipLaunchKernelGGL((mcmc_block_step_kernel<KIND, NG>), dim3(ns), dim3(256 * NG), 0, gp->ctx->stream, st, start, first, \
+                       h, it, (const double*)gp->d_X, (const double*)gp->d_y)
+    if (gp->kind == ROBO_KERNEL_MATERN52_ARD) {
+        if (one_tile) ROBO_BLOCK_STEP(ROBO_KERNEL_MATERN52_ARD, 1);
+        else ROBO_BLOCK_STEP(ROBO_KERNEL_MATERN52_ARD, 3);
+    } else {
+        if (one_tile) ROBO_BLOCK_STEP(ROBO_KERNEL_RBF_ARD, 1);
+        else ROBO_BLOCK_STEP(ROBO_KERNEL_RBF_ARD, 3);
+    }
+#undef ROBO_BLOCK_STEP
     ROBO_LAUNCH_CHECK();
     return ROBO_OK;
 }

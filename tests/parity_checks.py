@@ -102,7 +102,7 @@ def check_case(ctx, name, full=True):
     g.close()
 
 
-def check_device_chain(ctx, cases=(("matern52", 150, 3, 10, 14), ("rbf", 40, 2, 8, 10))):
+def check_device_chain(ctx, cases=(("matern52", 150, 3, 10, 14), ("rbf", 40, 2, 8, 10), ("matern52", 100, 4, 12, 9))):
     """robo_gp_mcmc_run (the whole stretch-move chain on the device) against the host sampler around the batched
     likelihood with the same RandomState: same accept decisions, positions and log-probabilities to rounding, the random
     stream ends in the same state; against the CPU oracle's log-probability through the same sampler; walkers outside
@@ -153,8 +153,9 @@ def check_device_chain(ctx, cases=(("matern52", 150, 3, 10, 14), ("rbf", 40, 2, 
             return smp.chain, smp.lnprobability, smp.naccepted.copy(), pos2, lnp2, state
 
         dev = run(lnprob_batch=lnprob_host, device_chain=lambda p, lnp, n, uz, pa, ua, a: g.mcmc_run(mean, par, p, lnp, n, uz, pa, ua, a))
-        if N + 1 <= 64:
-            # small problems: the half-step fused into ONE launch (default) against the four-launch form -- same accept
+        if N <= 126:
+            # one-block problems: the half-step fused into ONE launch (default; one tile group below 64 points, three
+            # above) against the four-launch form -- same accept
             # decisions; likelihoods bit-identical on the emulator, within an ulp on the MI355X (fused-multiply-add
             # contraction is decided per kernel)
             ctx.set_tuning("mcmc_block_step", 0)

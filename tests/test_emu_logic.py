@@ -42,7 +42,7 @@ def test_mcmc_marginal(emu_ctx):
 
 
 def test_device_resident_chain(emu_ctx):
-    P.check_device_chain(emu_ctx, cases=(("matern52", 150, 3, 10, 6), ("rbf", 40, 2, 8, 5)))
+    P.check_device_chain(emu_ctx, cases=(("matern52", 150, 3, 10, 6), ("rbf", 40, 2, 8, 5), ("matern52", 90, 2, 8, 3)))
 
 
 def test_elementwise_and_degenerate_branches(emu_ctx):
