@@ -13,6 +13,9 @@
 //   gram / potrf          the batched fit of gram.hip / potrf.hip, unchanged (likelihood terms stay on the device)
 //   mcmc_accept_kernel    lnp(q) = log-likelihood + log prior, emcee's accept test  (ndim - 1) log z + lnp(q) - lnp(s) >
 //                         log u, walker / log-probability / acceptance-count update, chain record after the second half
+// One-block problems (N <= 126, a Bayesian-optimisation run's own sizes) take all of that in ONE launch per half-step,
+// one workgroup per walker with the gram tiles written straight into the factorisation's LDS image
+// (potrf.hip: mcmc_block_step_kernel; same decisions, likelihoods within an ulp of this file's form).
 // The random numbers do not depend on the chain, so the caller draws them up front in emcee 2's order (per half-step:
 // rand for z, randint for the partners, rand for the accept test) -- same stream, same chain as the reference's sampler
 // up to the rounding of exp / log on the device.  q is formed without fused multiply-adds (numpy has none).
