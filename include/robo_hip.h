@@ -148,6 +148,12 @@ int32_t robo_gp_mcmc_run(robo_gp* gp, double mean_c, int32_t prior_kind, const d
                          int32_t n_steps, double a, const double* u_stretch, const int32_t* partner,
                          const double* u_accept, int32_t eval_start, double* pos, double* lnp, double* out_chain,
                          double* out_lnprob, int64_t* out_accepted);
+/* Host helper of robo_gp_mcmc_run: the random numbers of n_steps ensemble steps exactly as a legacy
+ * numpy.random.RandomState produces them in emcee 2's order -- per half-step rand(half), randint(half, size=half),
+ * rand(half) -- from the MT19937 state (key[624], pos) of RandomState.get_state(), which is advanced in place (hand it back
+ * with set_state).  Outputs [n_steps][2][half].  Pure host code; replaces 6 n_steps NumPy calls.                     */
+int32_t robo_mcmc_draws(uint32_t* mt_key, int32_t* mt_pos, int32_t n_steps, int32_t half, double* u_stretch,
+                        int32_t* partner, double* u_accept);
 /* The per-sample model fits of GaussianProcessMCMC.train (gaussian_process_mcmc.py:149-164: one
  * GaussianProcess per hyper-parameter sample, each a gp.compute on the SAME X, y) as one batched pass
  * that KEEPS the factors: gps[0] holds the training data (robo_gp_set_data); afterwards every gps[s]

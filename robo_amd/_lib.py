@@ -30,7 +30,7 @@ SYMBOLS = [
     "robo_last_error_string", "robo_version_string",
     "robo_gp_create", "robo_gp_destroy", "robo_gp_set_data", "robo_gp_set_output_transform",
     "robo_gp_set_precision", "robo_theta_size",
-    "robo_gp_fit", "robo_gp_loglik_batch", "robo_gp_mcmc_run", "robo_gp_fit_batch", "robo_gp_grad_loglik", "robo_gp_get_factor", "robo_gp_get_gram",
+    "robo_gp_fit", "robo_gp_loglik_batch", "robo_gp_mcmc_run", "robo_mcmc_draws", "robo_gp_fit_batch", "robo_gp_grad_loglik", "robo_gp_get_factor", "robo_gp_get_gram",
     "robo_cand_create", "robo_cand_destroy", "robo_cand_set_points", "robo_cand_create_uniform", "robo_cand_get_points",
     "robo_cand_create_random", "robo_cand_create_sobol", "robo_cand_get_point", "robo_cand_workspace_chunk", "robo_cand_last_solve_kernel",
     "robo_gp_predict_cand", "robo_gp_predict", "robo_gp_predict_cov", "robo_gp_predict_grad", "robo_gp_predict_mixture_cand",
@@ -119,6 +119,7 @@ def lib():
         "robo_gp_fit": [vp, _dp, dbl, _dp, C.POINTER(i32)],
         "robo_gp_loglik_batch": [vp, _dp, i32, dbl, _dp, C.POINTER(i32)],
         "robo_gp_fit_batch": [pp, i32, _dp, dbl, _dp, C.POINTER(i32)],
+        "robo_mcmc_draws": [C.POINTER(C.c_uint32), C.POINTER(i32), i32, i32, _dp, C.POINTER(i32), _dp],
         "robo_gp_mcmc_run": [vp, dbl, i32, _dp, i32, i32, dbl, _dp, C.POINTER(i32), _dp, i32, _dp, _dp, _dp, _dp,
                              C.POINTER(i64)],
         "robo_gp_grad_loglik": [vp, _dp, dbl, _dp, _dp, C.POINTER(i32)],
@@ -221,6 +222,24 @@ def device_count():
     n = C.c_int32(0)
     lib().robo_device_count(C.byref(n))
     return n.value
+
+
+def mcmc_draws(random_state, n_steps, half):
+    """(u_stretch, partner, u_accept), each (n_steps, 2, half): the numbers `random_state` (a legacy numpy RandomState)
+    would produce for n_steps emcee-2 ensemble steps -- rand(half), randint(half, size=half), rand(half) per half-step --
+    drawn by the library (robo_mcmc_draws) and with the stream advanced exactly as those calls would have advanced it."""
+    name, key, pos, has_gauss, cached = random_state.get_state()
+    if name != "MT19937":
+        raise ValueError("legacy MT19937 RandomState expected")
+    key = np.ascontiguousarray(key, dtype=np.uint32).copy()
+    p = C.c_int32(int(pos))
+    uz = np.empty((n_steps, 2, half))
+    ua = np.empty((n_steps, 2, half))
+    pa = np.empty((n_steps, 2, half), dtype=np.int32)
+    check(lib().robo_mcmc_draws(key.ctypes.data_as(C.POINTER(C.c_uint32)), C.byref(p), int(n_steps), int(half), _arr(uz),
+                                pa.ctypes.data_as(C.POINTER(C.c_int32)), _arr(ua)))
+    random_state.set_state((name, key, int(p.value), has_gauss, cached))
+    return uz, pa, ua
 
 
 class Context(object):

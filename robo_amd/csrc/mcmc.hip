@@ -115,3 +115,55 @@ int launch_mcmc_accept(robo_ctx* ctx, const McmcState& st, int start, int first,
 }
 
 }  // namespace robo
+
+// ---- the random numbers of n_steps ensemble steps, drawn like numpy.random.RandomState does (host code) --------------
+// emcee 2 draws per half-step  rand(k/2) -> randint(k/2, size=k/2) -> rand(k/2)  from a legacy RandomState
+// (gaussian_process_mcmc.py:117 hands it the model's stream).  The chain above needs them all up front; 1200 NumPy calls
+// for a 200-step chain were ~2 ms of a 17 ms Bayesian-optimisation iteration.  Legacy RandomState is frozen by NumPy's
+// compatibility policy: MT19937; random_sample = (a >> 5) * 2^26 + (b >> 6) over 2^53 from two 32-bit outputs; randint
+// below 2^32 = masked rejection on 32-bit outputs (no output consumed when the range is a single value).
+static inline uint32_t mt_next(uint32_t* key, int32_t* pos) {
+    constexpr int N = 624, M = 397;
+    if (*pos >= N) {
+        for (int kk = 0; kk < N; ++kk) {
+            const uint32_t y = (key[kk] & 0x80000000u) | (key[(kk + 1) % N] & 0x7fffffffu);
+            key[kk] = key[(kk + M) % N] ^ (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
+        }
+        *pos = 0;
+    }
+    uint32_t y = key[(*pos)++];
+    y ^= y >> 11;
+    y ^= (y << 7) & 0x9d2c5680u;
+    y ^= (y << 15) & 0xefc60000u;
+    y ^= y >> 18;
+    return y;
+}
+
+extern "C" int32_t robo_mcmc_draws(uint32_t* mt_key, int32_t* mt_pos, int32_t n_steps, int32_t half, double* u_stretch,
+                                   int32_t* partner, double* u_accept) {
+    if (!mt_key || !mt_pos || n_steps < 0 || half < 1 || *mt_pos < 0 || *mt_pos > 624) return ROBO_BAD_ARGUMENT;
+    if (n_steps > 0 && (!u_stretch || !partner || !u_accept)) return ROBO_BAD_ARGUMENT;
+    const uint32_t rng = (uint32_t)half - 1u;
+    uint32_t mask = rng;
+    mask |= mask >> 1; mask |= mask >> 2; mask |= mask >> 4; mask |= mask >> 8; mask |= mask >> 16;
+    auto uniform = [&]() {
+        const uint32_t a = mt_next(mt_key, mt_pos) >> 5, b = mt_next(mt_key, mt_pos) >> 6;
+        return ((double)a * 67108864.0 + (double)b) / 9007199254740992.0;
+    };
+    for (size_t hs = 0; hs < (size_t)n_steps * 2; ++hs) {
+        double* uz = u_stretch + hs * half;
+        double* ua = u_accept + hs * half;
+        int32_t* pa = partner + hs * half;
+        for (int w = 0; w < half; ++w) uz[w] = uniform();
+        for (int w = 0; w < half; ++w) {
+            uint32_t v = 0;
+            if (rng != 0u) {
+                do v = mt_next(mt_key, mt_pos) & mask;
+                while (v > rng);
+            }
+            pa[w] = (int32_t)v;
+        }
+        for (int w = 0; w < half; ++w) ua[w] = uniform();
+    }
+    return ROBO_OK;
+}

@@ -41,6 +41,29 @@ def test_mcmc_marginal(emu_ctx):
     P.check_mcmc_marginal(emu_ctx)
 
 
+def test_mcmc_draws_equal_numpy_legacy_stream(emu_ctx):
+    """robo_mcmc_draws == the RandomState calls of emcee 2's loop (rand, randint, rand per half-step): numbers AND the
+    state the stream is left in, across the MT19937 block boundary, with a cached Gaussian kept, for odd sizes"""
+    for seed, n_steps, half, burn in ((0, 7, 5, 0), (3, 40, 26, 11), (9, 3, 1, 617), (11, 25, 64, 1000), (2, 0, 4, 3)):
+        a, b = np.random.RandomState(seed), np.random.RandomState(seed)
+        for r in (a, b):
+            r.rand(burn)
+            r.randn(1)                      # leaves a cached Gaussian in the state: must survive
+        uz = np.empty((n_steps, 2, half)); ua = np.empty((n_steps, 2, half)); pa = np.empty((n_steps, 2, half), dtype=np.int64)
+        for it in range(n_steps):
+            for h in range(2):
+                uz[it, h] = a.rand(half)
+                pa[it, h] = a.randint(half, size=(half,))
+                ua[it, h] = a.rand(half)
+        uz2, pa2, ua2 = _lib.mcmc_draws(b, n_steps, half)
+        np.testing.assert_array_equal(uz2, uz)
+        np.testing.assert_array_equal(pa2, pa)
+        np.testing.assert_array_equal(ua2, ua)
+        sa, sb = a.get_state(), b.get_state()
+        assert sa[0] == sb[0] and np.array_equal(sa[1], sb[1]) and sa[2:] == sb[2:]
+        assert a.rand() == b.rand() and a.randn() == b.randn()
+
+
 def test_device_resident_chain(emu_ctx):
     P.check_device_chain(emu_ctx, cases=(("matern52", 150, 3, 10, 6), ("rbf", 40, 2, 8, 5), ("matern52", 90, 2, 8, 3)))
 
