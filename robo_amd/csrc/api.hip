@@ -234,6 +234,7 @@ int32_t robo_gp_destroy(robo_gp* g) {
     hipFree(g->d_LinvP);
     hipFree(g->d_llpart);
     hipFree(g->d_bllpart);
+    hipFree(g->d_bkeep);
     hipFree(g->d_theta);
     hipFree(g->d_Winv);
     hipFree(g->d_mcmc);
@@ -414,10 +415,10 @@ int32_t robo_gp_grad_loglik(robo_gp* g, const double* theta, double mean_c, doub
 static int batch_ensure(robo_gp* g, int S) {
     if (g->b_cap >= S && g->b_npad == g->n_pad) return ROBO_OK;
     hipFree(g->d_bK); hipFree(g->d_bLinv); hipFree(g->d_bXs); hipFree(g->d_bout);
-    hipFree(g->d_bsp); hipFree(g->d_bfail); hipFree(g->d_bllpart);   // d_bism lives in d_bsp's block
+    hipFree(g->d_bsp); hipFree(g->d_bfail); hipFree(g->d_bllpart); hipFree(g->d_bkeep);   // d_bism lives in d_bsp's block
     if (g->h_bstage) hipHostFree(g->h_bstage);
     g->d_bK = g->d_bLinv = g->d_bXs = g->d_bism = g->d_bout = g->h_bstage = nullptr;
-    g->d_bsp = nullptr; g->d_bfail = nullptr; g->d_bllpart = nullptr;
+    g->d_bsp = nullptr; g->d_bfail = nullptr; g->d_bllpart = nullptr; g->d_bkeep = nullptr;
     g->b_cap = 0;
     const size_t np = (size_t)g->n_pad, D = (size_t)g->dim;
     ROBO_TRY(dev_alloc(&g->d_bK, (size_t)S * np * np));
@@ -433,6 +434,7 @@ static int batch_ensure(robo_gp* g, int S) {
     }
     ROBO_TRY(dev_alloc(&g->d_bfail, (size_t)S));
     ROBO_TRY(dev_alloc(&g->d_bllpart, (size_t)S * (np / NB) * 4));
+    ROBO_TRY(dev_alloc(&g->d_bkeep, (size_t)S * sizeof(KeepDst)));
     // pinned staging: [S x FitSample | S x D ism] up, [S x 5 doubles] down (written by the device)
     const size_t bytes = (size_t)S * (sizeof(FitSample) + D * sizeof(double) + 5 * sizeof(double)) + 64;
     ROBO_HIP_CHECK(hipHostMalloc((void**)&g->h_bstage, bytes, 0));
@@ -672,29 +674,33 @@ int32_t robo_gp_fit_batch(robo_gp* const* gps, int32_t S, const double* thetas, 
     auto keep = [&](int s0, int ns, const int* status) -> int {
         const double* hout = reinterpret_cast<const double*>(reinterpret_cast<const FitSample*>(g0->h_bstage) + g0->b_cap) +
                              (size_t)g0->b_cap * D;      // the batch's [ns][5] result block (fit_batch_core)
+        // every kept factor goes to its handle in ONE launch (potrf.hip batch_keep_kernel)
+        std::vector<KeepDst> dst((size_t)ns);
+        for (int s = 0; s < ns; ++s) {
+            KeepDst& d = dst[(size_t)s];
+            memset(&d, 0, sizeof(d));
+            if (status[s] != ROBO_OK) continue;
+            robo_gp* g = gps[s0 + s];
+            d.ok = 1;
+            d.K = g->d_K; d.Linv = g->d_Linv; d.LinvP = g->d_LinvP; d.Xs = g->d_Xs; d.theta = g->d_theta; d.sp = g->d_sp;
+            if (g != g0) {   // every handle ends up self-contained: same training data as gps[0]
+                d.X = g->d_X;
+                d.y = g->d_y;
+            }
+        }
+        ROBO_HIP_CHECK(hipMemcpyAsync(g0->d_bkeep, dst.data(), (size_t)ns * sizeof(KeepDst), hipMemcpyHostToDevice, c->stream));
+        ROBO_TRY(launch_batch_keep(g0, reinterpret_cast<const KeepDst*>(g0->d_bkeep), ns));
         for (int s = 0; s < ns; ++s) {
             if (status[s] != ROBO_OK) continue;
             robo_gp* g = gps[s0 + s];
             g->diag_min = hout[5 * s + 3];
             g->diag_max = hout[5 * s + 4];
-            if (g != g0) {   // every handle ends up self-contained: same training data as gps[0]
-                ROBO_HIP_CHECK(hipMemcpyAsync(g->d_X, g0->d_X, (size_t)n * D * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
-                ROBO_HIP_CHECK(hipMemcpyAsync(g->d_y, g0->d_y, (size_t)n * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+            if (g != g0) {
                 g->n = n;
                 g->n_pad = g0->n_pad;
                 g->has_data = true;
                 g->fp32_gram = g0->fp32_gram;
             }
-            ROBO_HIP_CHECK(hipMemcpyAsync(g->d_K, g0->d_bK + (size_t)s * np * np, np * np * sizeof(double),
-                                          hipMemcpyDeviceToDevice, c->stream));
-            ROBO_HIP_CHECK(hipMemcpyAsync(g->d_Linv, g0->d_bLinv + (size_t)s * np * NB, np * NB * sizeof(double),
-                                          hipMemcpyDeviceToDevice, c->stream));
-            ROBO_TRY(launch_pack_linv(g));
-            ROBO_HIP_CHECK(hipMemcpyAsync(g->d_Xs, g0->d_bXs + (size_t)s * np * D, np * D * sizeof(double),
-                                          hipMemcpyDeviceToDevice, c->stream));
-            ROBO_HIP_CHECK(hipMemcpyAsync(g->d_theta, g0->d_bism + (size_t)s * D, (size_t)D * sizeof(double),
-                                          hipMemcpyDeviceToDevice, c->stream));
-            ROBO_HIP_CHECK(hipMemcpyAsync(g->d_sp, g0->d_bsp + s, sizeof(FitSample), hipMemcpyDeviceToDevice, c->stream));
             FitSample sp;
             double ism[MAX_DIM];
             ROBO_TRY(theta_to_sample(g, thetas + (size_t)(s0 + s) * P, mean_c, &sp, ism));

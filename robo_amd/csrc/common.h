@@ -147,6 +147,7 @@ struct robo_gp {
     robo::FitSample* d_bsp;
     int* d_bfail;
     double *d_llpart, *d_bllpart;   // log-likelihood partials of the tail kernel (own factor / batch workspace)
+    char* d_bkeep;                  // [b_cap] KeepDst records of robo_gp_fit_batch
     // workspace of robo_gp_grad_loglik (lazy, sized for n_pad_max): W^T, A = alpha alpha^T - K^-1, ...
     double *d_gV, *d_gA, *d_galpha, *d_gpart, *d_gout;
     // explicit inverse factor W = L^-1 for small candidate batches (winv.hip): lazy, rebuilt when the factor changes
@@ -220,6 +221,14 @@ struct FitBuffers {
 };
 int launch_scale_inputs_theta(robo_ctx* ctx, const double* d_in, double* d_out, const ThetaArgs& ta, int64_t rows_real,
                               int64_t rows_pad, int dim, double* d_ism_out, FitSample* d_sp_out);
+// destination of one sample of a batched fit that keeps its factors (potrf.hip batch_keep_kernel)
+struct KeepDst {
+    double *K, *Linv, *LinvP, *Xs, *theta;
+    double *X, *y;            // nullptr for gps[0] (owns the training data already)
+    FitSample* sp;
+    int ok;
+};
+int launch_batch_keep(robo_gp* g0, const KeepDst* d_dst, int ns);
 int launch_gram(robo_gp* gp, const FitBuffers& fb);
 // the device-resident hyper-parameter chain (mcmc.hip): everything the two kernels around the batched fit need
 struct McmcState {

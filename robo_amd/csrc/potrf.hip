@@ -1328,16 +1328,64 @@ __global__ __launch_bounds__(256) void potrf_step_kernel(double* __restrict__ K,
 //     Linv_b[16 cb + pi16(l & 15)][16 jb + 4 kk + (l >> 4)]
 // (pi16 on the row slot: register r of lane group g of the product is then row 16 cb + 4 g + r of the result --
 // four consecutive rows per lane, stored as two 16-byte pieces).
+__device__ __forceinline__ double linv_pack_entry(const double* __restrict__ W, int idx) {
+    const int f = idx >> 6, l = idx & 63;
+    int cb = 7;
+    while (f >= wp_offset(cb) + 4 * (cb + 1)) --cb;
+    const int rel = f - wp_offset(cb), jb = rel >> 2, kk = rel & 3;
+    return W[(size_t)(16 * cb + pi16(l & 15)) * NB + 16 * jb + 4 * kk + (l >> 4)];
+}
+
 __global__ __launch_bounds__(256) void linv_pack_kernel(const double* __restrict__ Linv, double* __restrict__ Wp) {
     const double* W = Linv + (size_t)blockIdx.x * NB * NB;
     double* out = Wp + (size_t)blockIdx.x * WP_BLOCK;
-    for (int idx = threadIdx.x; idx < WP_BLOCK; idx += 256) {
-        const int f = idx >> 6, l = idx & 63;
-        int cb = 7;
-        while (f >= wp_offset(cb) + 4 * (cb + 1)) --cb;
-        const int rel = f - wp_offset(cb), jb = rel >> 2, kk = rel & 3;
-        out[idx] = W[(size_t)(16 * cb + pi16(l & 15)) * NB + 16 * jb + 4 * kk + (l >> 4)];
+    for (int idx = threadIdx.x; idx < WP_BLOCK; idx += 256) out[idx] = linv_pack_entry(W, idx);
+}
+
+// robo_gp_fit_batch: the factors of a batched pass into the S handles they belong to, in ONE launch (grid.y = sample).
+// Per handle this was eight stream operations -- copies of K, the inverse blocks, the scaled inputs, the metrics, the
+// sample record, X and y, plus the fragment-packing launch: 416 operations for the 52 hyper-parameter samples of a
+// Bayesian-optimisation iteration, 1.8 ms where the batched fit itself takes 0.1 (r03zy).
+__global__ __launch_bounds__(256) void batch_keep_kernel(const KeepDst* __restrict__ dst, const double* __restrict__ bK,
+                                                         size_t k_stride, const double* __restrict__ bLinv,
+                                                         size_t linv_stride, const double* __restrict__ bXs,
+                                                         size_t xs_stride, const double* __restrict__ bism,
+                                                         const FitSample* __restrict__ bsp,
+                                                         const double* __restrict__ X0, const double* __restrict__ y0,
+                                                         int n, int np, int D) {
+    const int s = blockIdx.y;
+    const KeepDst d = dst[s];
+    if (!d.ok) return;
+    const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x, nt = (size_t)gridDim.x * blockDim.x;
+    const double2* srcK = reinterpret_cast<const double2*>(bK + (size_t)s * k_stride);
+    double2* dstK = reinterpret_cast<double2*>(d.K);
+    for (size_t i = t; i < (size_t)np * np / 2; i += nt) dstK[i] = srcK[i];
+    const double* srcL = bLinv + (size_t)s * linv_stride;
+    for (size_t i = t; i < (size_t)np * NB; i += nt) d.Linv[i] = srcL[i];
+    for (size_t i = t; i < (size_t)(np / NB) * WP_BLOCK; i += nt) {
+        const size_t b = i / WP_BLOCK;
+        d.LinvP[i] = linv_pack_entry(srcL + b * NB * NB, (int)(i - b * WP_BLOCK));
     }
+    const double* srcX = bXs + (size_t)s * xs_stride;
+    for (size_t i = t; i < (size_t)np * D; i += nt) d.Xs[i] = srcX[i];
+    for (size_t i = t; i < (size_t)D; i += nt) d.theta[i] = bism[(size_t)s * D + i];
+    if (t == 0) *d.sp = bsp[s];
+    if (d.X) {          // handles other than gps[0]: the training data itself
+        for (size_t i = t; i < (size_t)n * D; i += nt) d.X[i] = X0[i];
+        for (size_t i = t; i < (size_t)n; i += nt) d.y[i] = y0[i];
+    }
+}
+
+int launch_batch_keep(robo_gp* g0, const KeepDst* d_dst, int ns) {
+    const size_t np = (size_t)g0->n_pad;
+    size_t bx = (np * np / 2 + 255) / 256;
+    if (bx > 2048) bx = 2048;
+    hipLaunchKernelGGL(batch_keep_kernel, dim3((unsigned)bx, (unsigned)ns), dim3(256), 0, g0->ctx->stream, d_dst,
+                       (const double*)g0->d_bK, np * np, (const double*)g0->d_bLinv, np * NB, (const double*)g0->d_bXs,
+                       np * g0->dim, (const double*)g0->d_bism, (const FitSample*)g0->d_bsp, (const double*)g0->d_X,
+                       (const double*)g0->d_y, g0->n, g0->n_pad, g0->dim);
+    ROBO_LAUNCH_CHECK();
+    return ROBO_OK;
 }
 
 int launch_pack_linv(robo_gp* gp) {
