@@ -102,7 +102,8 @@ def check_case(ctx, name, full=True):
     g.close()
 
 
-def check_device_chain(ctx, cases=(("matern52", 150, 3, 10, 14), ("rbf", 40, 2, 8, 10), ("matern52", 100, 4, 12, 9))):
+def check_device_chain(ctx, cases=(("matern52", 150, 3, 10, 14), ("rbf", 40, 2, 8, 10), ("matern52", 100, 4, 12, 9),
+                                   ("fabolas", 50, 3, 12, 8))):
     """robo_gp_mcmc_run (the whole stretch-move chain on the device) against the host sampler around the batched
     likelihood with the same RandomState: same accept decisions, positions and log-probabilities to rounding, the random
     stream ends in the same state; against the CPU oracle's log-probability through the same sampler; walkers outside
@@ -113,7 +114,7 @@ def check_device_chain(ctx, cases=(("matern52", 150, 3, 10, 14), ("rbf", 40, 2, 
         rs = np.random.RandomState(61)
         X = rs.rand(N, D)
         y = np.sin(3 * X.sum(axis=1)) + 0.05 * rs.randn(N)
-        P = D + 2
+        P = O.n_kernel_params(kind, D) + 1          # fabolas: the two parameters of the linear fidelity kernel as well
         mean = float(np.mean(y))
         g = _lib.DeviceGP(ctx, kind, N, D)
         g.set_data(X, y)
