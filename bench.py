@@ -142,7 +142,15 @@ class TorchExchange(object):
 
 
 class Dist(object):
-    """process group plumbing (one process per GPU; backend nccl = RCCL over xGMI)"""
+    """One process per GPU.  Three ways into a multi-rank run, all ending in the library's own communicator
+    (robo_amd/csrc/comm.hip, RCCL all-gathers on the library's stream):
+
+    * ``spawn``  -- ``python bench.py --gpus N`` without WORLD_SIZE: the parent started this process as one of N ranks
+      (launch_ranks) and the 128-byte communicator id travels through a file in a private temporary directory.  No torch.
+    * ``torch``  -- under ``python -m torch.distributed.run``: RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* from the
+      environment; torch.distributed (backend nccl = RCCL) carries the id, nothing else.
+    * ``single`` -- one process, no communicator (ROBO_BENCH_FORCE_DIST=1: a one-rank communicator, the RCCL path alone).
+    """
 
     def __init__(self):
         self.rank = int(os.environ.get("RANK", "0"))
@@ -150,14 +158,25 @@ class Dist(object):
         self.world = int(os.environ.get("WORLD_SIZE", "1"))
         self.dist = None
         self.out_fd = None
-        if self.world > 1 or os.environ.get("ROBO_BENCH_FORCE_DIST") == "1":   # the latter: the RCCL path on one rank
-            import torch
-            import torch.distributed as dist
+        self.comm = None
+        self.exchange = None
+        self.rdv_dir = os.environ.get("ROBO_BENCH_RENDEZVOUS") or None
+        force = os.environ.get("ROBO_BENCH_FORCE_DIST") == "1"     # the RCCL path on one rank
+        if self.rdv_dir:
+            self.mode = "spawn"
+        elif self.world > 1 or force:
+            self.mode = "torch"
+        else:
+            self.mode = "single"
+        if self.mode != "single":
             # RCCL prints a version banner on the C-level stdout; the contract is ONE JSON line there.  Keep the
             # real stdout aside for that line and send everything else libraries write to fd 1 to stderr.
             sys.stdout.flush()
             self.out_fd = os.dup(1)
             os.dup2(2, 1)
+        if self.mode == "torch":
+            import torch
+            import torch.distributed as dist
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
             os.environ.setdefault("MASTER_PORT", "29533")
             torch.cuda.set_device(self.local_rank)
@@ -165,25 +184,52 @@ class Dist(object):
                                     device_id=torch.device("cuda", self.local_rank))
             self.dist = dist
 
+    @property
+    def multi(self):
+        """a communicator takes part in every step (also the forced one-rank form)"""
+        return self.mode != "single"
+
+    def device_ordinal(self):
+        return self.local_rank if self.multi and self.world > 1 else int(os.environ.get("ROBO_DEVICE", "0"))
+
+    def _comm_id(self, _lib):
+        """the 128-byte id: created on rank 0, to every rank out of band"""
+        if self.mode == "spawn":
+            path = os.path.join(self.rdv_dir, "comm_id.bin")
+            if self.rank == 0:
+                blob = _lib.Comm.create_id()
+                with open(path + ".tmp", "wb") as f:
+                    f.write(blob)
+                os.rename(path + ".tmp", path)           # atomic: a reader never sees a partial id
+                return blob
+            deadline = time.time() + float(os.environ.get("ROBO_BENCH_COMM_TIMEOUT", "240"))
+            while not os.path.exists(path):
+                if time.time() > deadline:
+                    raise RuntimeError("rank %d: no communicator id from rank 0 within the deadline" % self.rank)
+                time.sleep(0.01)
+            with open(path, "rb") as f:
+                return f.read()
+        box = [_lib.Comm.create_id() if self.rank == 0 else None]
+        if self.world > 1:
+            self.dist.broadcast_object_list(box, src=0)
+        return box[0]
+
     def make_comm(self, _lib, ctx):
         """the library's own communicator (robo_amd/csrc/comm.hip: RCCL all-gathers on the library's stream) for the
-        exchanges of the data path; torch.distributed only carries its 128-byte id (and the timing barrier)"""
-        if self.dist is None:
+        exchanges of the data path; the launcher (file / torch.distributed) only carries its 128-byte id"""
+        if not self.multi:
             return None
-        import torch
         err = ""
         try:
-            box = [_lib.Comm.create_id() if self.rank == 0 else None]
-            if self.world > 1:
-                self.dist.broadcast_object_list(box, src=0)
+            blob = self._comm_id(_lib)
             # ncclCommInitRank blocks until every rank has joined: run it on a helper thread with a deadline, so that a
-            # rank that cannot join turns into the fallback below instead of a hung scaling run (bench-only)
+            # rank that cannot join turns into an error (spawn) / the fallback below (torch) instead of a hung run
             import threading
             res = {}
 
             def _init():
                 try:
-                    res["comm"] = _lib.Comm(ctx, self.rank, self.world, box[0])
+                    res["comm"] = _lib.Comm(ctx, self.rank, self.world, blob)
                 except Exception as e:   # noqa: BLE001
                     res["err"] = "%s: %s" % (type(e).__name__, e)
 
@@ -195,33 +241,55 @@ class Dist(object):
                 err = res.get("err", "communicator setup timed out")
         except Exception as e:           # noqa: BLE001 -- measured anyway, and said so in the JSON line
             comm, err = None, "%s: %s" % (type(e).__name__, e)
-        ok = torch.tensor([1.0 if comm is not None else 0.0], device="cuda")
-        self.dist.all_reduce(ok, op=self.dist.ReduceOp.MIN)
-        if float(ok.item()) < 1.0:
-            # bench-only safety net (NOT part of the product): if the in-library communicator cannot be set up on this
-            # node, the same exchanges go through torch.distributed so that the scaling run still yields a measurement
-            if comm is not None:
-                comm.close()
-            sys.stderr.write("bench: library communicator unavailable (%s); torch.distributed exchange\n" % err)
-            self.exchange = "torch.distributed fallback (%s)" % (err or "another rank failed")
-            self.comm = TorchExchange(self.dist, self.rank, self.world)
-            return self.comm
-        self.exchange = "librobo_hip (RCCL all-gather on the library's stream, device pointers)"
+        if self.mode == "spawn":
+            if comm is None:
+                raise RuntimeError("rank %d: library communicator unavailable (%s)" % (self.rank, err))
+        else:
+            import torch
+            ok = torch.tensor([1.0 if comm is not None else 0.0], device="cuda")
+            self.dist.all_reduce(ok, op=self.dist.ReduceOp.MIN)
+            if float(ok.item()) < 1.0:
+                # bench-only safety net (NOT part of the product): if the in-library communicator cannot be set up on
+                # this node, the same exchanges go through torch.distributed so that the scaling run still yields a
+                # measurement
+                if comm is not None:
+                    comm.close()
+                sys.stderr.write("bench: library communicator unavailable (%s); torch.distributed exchange\n" % err)
+                self.exchange = "torch.distributed fallback (%s)" % (err or "another rank failed")
+                self.comm = TorchExchange(self.dist, self.rank, self.world)
+                return self.comm
+        self.exchange = "librobo_hip (RCCL all-gather on the library's stream, device pointers); id via %s" % (
+            "a file of the self-launcher" if self.mode == "spawn" else "torch.distributed")
         self.comm = comm
         from robo_amd import sharding
         sharding._comm = self.comm        # the module-level helpers (allgather_argmax ...) use this communicator too
         return self.comm
 
     def _lib_comm(self):
-        c = getattr(self, "comm", None)
+        c = self.comm
         return c if c is not None and not isinstance(c, TorchExchange) else None
+
+    def ranks_block(self, ctx):
+        """who took part, as the COMMUNICATOR saw it: world from robo_comm_info, every rank's (rank, device ordinal)
+        all-gathered through it.  COLLECTIVE in a multi-rank run (call it on every rank, outside the timed region)."""
+        c = self._lib_comm()
+        if c is None:
+            if isinstance(self.comm, TorchExchange):
+                rows = self.comm.allgather([float(self.rank), float(ctx.device)])
+                return {"ranks": [int(r[0]) for r in rows], "devices": [int(r[1]) for r in rows],
+                        "comm_world": self.world, "launcher": self.mode}
+            return {"ranks": [0], "devices": [int(ctx.device)], "comm_world": 1, "launcher": self.mode}
+        rk, wd = c.info()
+        rows = c.allgather([float(rk), float(ctx.device)])
+        return {"ranks": [int(r[0]) for r in rows], "devices": [int(r[1]) for r in rows], "comm_world": int(wd),
+                "launcher": self.mode}
 
     def barrier(self, ctx):
         """all ranks' device work finished: stream synchronisation + a collective on every rank.  With the library's
         communicator that collective is its own 8-byte all-gather on the library's stream (~30 us); torch's NCCL barrier
         (measured at several hundred us inside a 5-step timed region, r03zk) only when that communicator is absent."""
         ctx.synchronize()
-        if self.dist is None:
+        if not self.multi:
             return
         c = self._lib_comm()
         if c is not None:
@@ -233,7 +301,7 @@ class Dist(object):
         torch.cuda.synchronize()
 
     def max_over_ranks(self, seconds):
-        if self.dist is None:
+        if not self.multi:
             return seconds
         c = self._lib_comm()
         if c is not None:
@@ -252,12 +320,58 @@ class Dist(object):
             os.write(self.out_fd, line)
 
     def close(self):
-        if getattr(self, "comm", None) is not None and not isinstance(self.comm, TorchExchange):
+        if self._lib_comm() is not None:
             from robo_amd import sharding
             sharding.close_comm()
         if self.dist is not None:
             self.dist.barrier()
             self.dist.destroy_process_group()
+
+
+def launch_ranks(n, argv):
+    """``python bench.py --gpus N`` without a launcher around it: start N rank processes of this script (one per GPU,
+    RANK / LOCAL_RANK / WORLD_SIZE in their environment, a private directory for the communicator id), wait for all of
+    them, pass rank 0's JSON line through.  Returns the exit status (non-zero if any rank failed)."""
+    import shutil
+    import subprocess
+    import tempfile
+    rdv = tempfile.mkdtemp(prefix="robo_bench_")
+    procs = []
+    try:
+        for r in range(n):
+            env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), ROBO_BENCH_RENDEZVOUS=rdv)
+            env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC only on this host driver (RCCL needs it)
+            # rank 0 inherits stdout (the ONE JSON line); the other ranks' stdout goes to stderr
+            procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env,
+                                          stdout=None if r == 0 else sys.stderr))
+        deadline = time.time() + float(os.environ.get("ROBO_BENCH_LAUNCH_TIMEOUT", "3000"))
+        status = 0
+        pending = list(procs)
+        while pending:
+            for p in list(pending):
+                rc = p.poll()
+                if rc is not None:
+                    pending.remove(p)
+                    if rc != 0:
+                        status = status or rc
+            if status != 0 or time.time() > deadline:
+                # a rank died (or the run hung): the others would wait in a collective for ever -- stop exactly the
+                # processes started here
+                time.sleep(2.0)
+                for p in pending:
+                    if p.poll() is None:
+                        p.terminate()
+                for p in pending:
+                    try:
+                        p.wait(timeout=10)
+                    except Exception:      # noqa: BLE001
+                        p.kill()
+                status = status or 124
+                break
+            time.sleep(0.05)
+        return status
+    finally:
+        shutil.rmtree(rdv, ignore_errors=True)
 
 
 def timed_steps(D_, ctx, step, steps, warmup):
@@ -346,6 +460,10 @@ def roofline_trsm(ctx, N, M_rows, trsm_ms_per_step, passes=1, kernel="trsm_step_
         # chunk reduction, priced against the product's algorithmic flops (rows N^2)
         nb = 1
     avg_launch_ms = trsm_ms_per_step / (nb * passes)
+    if not avg_launch_ms > 0.0:          # no event pair (the interpreter build's clock, or a path that records none)
+        return {"bound": "mfma", "kernel": kernel, "achieved": None, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                "frac": None, "traffic": traffic, "algorithmic_flops_per_launch": float(M_rows) * N * N / nb,
+                "launches_per_step": nb * passes, "avg_launch_ms": None}
     achieved = (float(M_rows) * N * N / nb) / (avg_launch_ms * 1e-3) / 1e12
     return {"bound": "mfma", "kernel": kernel, "achieved": achieved, "peak": FP64_MFMA_PEAK_TFLOPS,
             "unit": "TFLOP/s", "frac": achieved / FP64_MFMA_PEAK_TFLOPS, "traffic": traffic,
@@ -360,7 +478,7 @@ def clock_during_step(D_, ctx, step, ms_per_step):
     peak at that clock is attached on rank 0 by with_clock().  Information only, and only in single-process runs: on the
     HIP runtime a torch.distributed process brings along the sampler's stream did not run beside the
     library's (r03zo: it reported the idle clock), so process-group runs skip it."""
-    if D_.dist is not None:
+    if D_.mode == "torch":
         return {"skipped": "process-group run; see the single-process line"}
     err = None
     try:
@@ -377,7 +495,7 @@ def clock_during_step(D_, ctx, step, ms_per_step):
 
 
 def with_clock(roof, clock):
-    if "mhz" in clock:
+    if "mhz" in clock and roof.get("achieved"):
         pk = FP64_MFMA_PEAK_TFLOPS * clock["mhz"]["mean"] / 2400.0
         clock = dict(clock, peak_at_that_clock_tflops=pk, frac_of_peak_at_that_clock=roof["achieved"] / pk,
                      note="`frac` is against the nominal 2.4 GHz peak; this block: the clock the part held during one step")
@@ -388,25 +506,51 @@ def with_clock(roof, clock):
 # ----------------------------------------------------------------------------------------------------
 # headline and config 2: one fitted GP, candidate shard
 # ----------------------------------------------------------------------------------------------------
+def candidate_shard(args, D_, sharding, scaling=None):
+    """this rank's part of the candidate axis -> (candidates here, global index of the first, candidates in the job).
+    weak: --m candidates on EVERY rank (the job grows with the ranks); strong: --m candidates in TOTAL, split into
+    contiguous shards (SURVEY 8(d)'s headline: one RandomSampling batch, robo/maximizers/random_sampling.py:42-50, G ways)"""
+    if (scaling or args.scaling) == "strong":
+        b, e = sharding.shard_range(args.m, D_.rank, D_.world)
+        return e - b, b, args.m
+    return args.m, D_.rank * args.m, args.m * D_.world
+
+
+def synthetic_candidates(args, D_, sharding, scaling=None):
+    """candidates = RandomState(1).rand(M, D).  strong: every rank's shard is a slice of THAT matrix (the
+    global argmax is the single-GPU argmax); weak: rank r draws its own batch from RandomState(1 + r)."""
+    m_loc, off, m_tot = candidate_shard(args, D_, sharding, scaling)
+    if (scaling or args.scaling) == "strong":
+        Xc = np.random.RandomState(1).rand(m_tot, args.d)[off:off + m_loc]
+    else:
+        Xc = np.random.RandomState(1 + D_.rank).rand(m_loc, args.d)
+    return np.ascontiguousarray(Xc), m_loc, off, m_tot
+
+
 def run_headline(args, D_, _lib, sharding):
     rank, world = D_.rank, D_.world
-    ctx = _lib.Context(D_.local_rank if world > 1 else int(os.environ.get("ROBO_DEVICE", "0")))
-    N, D, M = args.n, args.d, args.m
-    X, y, theta, Xc = synthetic(N, D, M, rank)
+    ctx = _lib.Context(D_.device_ordinal())
+    N, D = args.n, args.d
+    X, y, theta, _ = synthetic(N, D, 1, rank)
+    Xc, M, offset, M_total = synthetic_candidates(args, D_, sharding)
     mean_c, eta = float(np.mean(y)), float(y.min())
     gp = _lib.DeviceGP(ctx, "matern52", N, D)
     gp.set_data(X, y)
     cand = _lib.Candidates(ctx, Xc)          # candidates resident in HBM before the timed region
     comm = D_.make_comm(_lib, ctx)
+    ranks = D_.ranks_block(ctx)
 
-    def evaluate():
+    def evaluate_on(cand_, offset_):
         """one pass over this rank's candidates -> the global (max, argmax): with a communicator posterior, EI, local
         argmax, the all-gather of the per-rank incumbents and the cross-rank tie-break are ONE library call"""
         if comm is not None:
-            _, mx, am, _, _ = comm.acq_sharded(gp, args.acq, 0.0, eta, cand, rank * M)
+            _, mx, am, _, _ = comm.acq_sharded(gp, args.acq, 0.0, eta, cand_, offset_)
             return mx, am
-        _, mx, am, _ = gp.acq(args.acq, 0.0, eta, cand, want_values=False)
+        _, mx, am, _ = gp.acq(args.acq, 0.0, eta, cand_, want_values=False)
         return mx, am
+
+    def evaluate():
+        return evaluate_on(cand, offset)
 
     # ---- GP fit (replicated on every rank) ------------------------------------------------
     fit_ms, fit_phase, fit_ev_ms = [], [], []
@@ -414,16 +558,6 @@ def run_headline(args, D_, _lib, sharding):
         t0 = time.perf_counter()
         gp.fit(theta, mean_c)
         fit_ms.append((time.perf_counter() - t0) * 1e3)
-    # phase breakdown: separate fits with the library's internal phase events switched on (they are off by
-    # default -- the event packets themselves cost a fit ~30 us)
-    ctx.set_phase_events(True)
-    for _ in range(3):
-        t0 = time.perf_counter()
-        gp.fit(theta, mean_c)
-        fit_ev_ms.append((time.perf_counter() - t0) * 1e3)
-        fit_phase.append((ctx.elapsed_ms(20, 21), ctx.elapsed_ms(21, 22), ctx.elapsed_ms(22, 23), ctx.elapsed_ms(19, 21)))
-    ctx.set_phase_events(False)
-    gram_ms, chol_ms, ll_ms, k1_ms = fit_phase[int(np.argmin(fit_ev_ms))]
     # SURVEY 8(d)'s definition of GP-fit: incl. H2D of X, y, theta and D2H of the log-likelihood
     fit_h2d = []
     for _ in range(3):
@@ -431,26 +565,69 @@ def run_headline(args, D_, _lib, sharding):
         gp.set_data(X, y)
         gp.fit(theta, mean_c)
         fit_h2d.append((time.perf_counter() - t0) * 1e3)
-    # the MCMC inner loop evaluates half an ensemble of thetas at once (n_hypers = 3 (D + 2) made even = 54 at
-    # D = 16 -> 27 per half-step; robo/fmin/bayesian_optimization.py:85-87): one batched pass
-    S_half = max(1, (3 * (D + 2) + (3 * (D + 2)) % 2) // 2)
-    thetas = theta[None, :] + 0.1 * np.random.RandomState(7).randn(S_half, theta.size)
-    gp.loglik_batch(thetas, mean_c)
-    t0 = time.perf_counter()
-    gp.loglik_batch(thetas, mean_c)
-    batch_ms = (time.perf_counter() - t0) * 1e3
-    gp.grad_loglik(theta, mean_c)
-    t0 = time.perf_counter()
-    gp.grad_loglik(theta, mean_c)
-    grad_ms = (time.perf_counter() - t0) * 1e3
-    grad_dev_ms = ctx.elapsed_ms(28, 29)
-    gp.fit(theta, mean_c)          # the batch call leaves the GP unfitted
+    side = {}
+    if not args.lean:
+        # phase breakdown: separate fits with the library's internal phase events switched on (they are off by
+        # default -- the event packets themselves cost a fit ~30 us)
+        ctx.set_phase_events(True)
+        for _ in range(3):
+            t0 = time.perf_counter()
+            gp.fit(theta, mean_c)
+            fit_ev_ms.append((time.perf_counter() - t0) * 1e3)
+            fit_phase.append((ctx.elapsed_ms(20, 21), ctx.elapsed_ms(21, 22), ctx.elapsed_ms(22, 23), ctx.elapsed_ms(19, 21)))
+        ctx.set_phase_events(False)
+        gram_ms, chol_ms, ll_ms, k1_ms = fit_phase[int(np.argmin(fit_ev_ms))]
+        # the MCMC inner loop evaluates half an ensemble of thetas at once (n_hypers = 3 (D + 2) made even = 54 at
+        # D = 16 -> 27 per half-step; robo/fmin/bayesian_optimization.py:85-87): one batched pass
+        S_half = max(1, (3 * (D + 2) + (3 * (D + 2)) % 2) // 2)
+        thetas = theta[None, :] + 0.1 * np.random.RandomState(7).randn(S_half, theta.size)
+        gp.loglik_batch(thetas, mean_c)
+        t0 = time.perf_counter()
+        gp.loglik_batch(thetas, mean_c)
+        batch_ms = (time.perf_counter() - t0) * 1e3
+        gp.grad_loglik(theta, mean_c)
+        t0 = time.perf_counter()
+        gp.grad_loglik(theta, mean_c)
+        grad_ms = (time.perf_counter() - t0) * 1e3
+        grad_dev_ms = ctx.elapsed_ms(28, 29)
+        gp.fit(theta, mean_c)          # the batch call leaves the GP unfitted
+        k1_bytes = 8.0 * N * (N + 1) / 2 + 8.0 * N * D
+        side = {
+            "gp_fit_phases_ms": {"gram": gram_ms, "cholesky": chol_ms, "loglik": ll_ms},
+            # K1 against the HBM roofline: the gram kernel alone (event slots 19 -> 21); "gram" above also holds the
+            # staging of theta and the input scaling
+            "k_assembly": {"bytes": k1_bytes, "ms": k1_ms, "GB_per_s": k1_bytes / (k1_ms * 1e-3) / 1e9,
+                           "frac_of_8TBps": k1_bytes / (k1_ms * 1e-3) / 8.0e12},
+            "cholesky": {"flops": N ** 3 / 3.0, "ms": chol_ms, "TFLOP_per_s": N ** 3 / 3.0 / (chol_ms * 1e-3) / 1e12,
+                         "frac_of_mfma_peak": N ** 3 / 3.0 / (chol_ms * 1e-3) / 1e12 / FP64_MFMA_PEAK_TFLOPS},
+            "gp_fit_batched": {"thetas": S_half, "ms_total": batch_ms, "ms_per_theta": batch_ms / S_half},
+            "gp_grad_loglik_ms": {"total_incl_fit": grad_ms, "after_factorisation": grad_dev_ms},
+        }
 
     def step():
         return evaluate()
 
+    # batches of <= 16 384 candidates record the solve's event pair (slots 25 -> 26, the roofline's duration) only on
+    # request: two event packets, ~2 us of a >= 0.2 ms step
+    ctx.set_phase_events(M <= 16384)
     elapsed, best, trsm_ms = timed_steps(D_, ctx, step, args.steps, args.warmup)
+    ctx.set_phase_events(False)
+    solve_kernel = cand.solve_kernel()
     clock = clock_during_step(D_, ctx, step, elapsed / args.steps * 1e3)  # every rank: the step holds a collective
+
+    # the OTHER scaling of the same job, in the same run (multi-rank runs only; every rank takes part): the driver's
+    # `--gpus N` line then carries both the weak figure (--m candidates per GPU) and SURVEY 8(d)'s strong headline
+    # (--m candidates in total, split N ways)
+    other = None
+    if world > 1:
+        o_scaling = "weak" if args.scaling == "strong" else "strong"
+        Xo, Mo, off_o, Mo_total = synthetic_candidates(args, D_, sharding, o_scaling)
+        cand_o = _lib.Candidates(ctx, Xo)
+        el_o, best_o, _ = timed_steps(D_, ctx, lambda: evaluate_on(cand_o, off_o), args.steps, max(1, args.warmup))
+        other = {"scaling": o_scaling, "value": Mo_total * args.steps / el_o, "unit": "EI evals/s",
+                 "ms_per_step": el_o / args.steps * 1e3, "candidates_total": Mo_total,
+                 "candidates_rank0": Mo, "solve_kernel_rank0": cand_o.solve_kernel(), "argmax": list(best_o)}
+        cand_o.close()
 
     # SURVEY 8(d)'s full definition of an "EI eval" (PCIe-inclusive: H2D of the candidate batch into an existing
     # handle, D2H of the result) -- reported next to `value`, which is the resident-input rate
@@ -458,11 +635,14 @@ def run_headline(args, D_, _lib, sharding):
         cand.set_points(Xc)
         return evaluate()
 
-    elapsed_pcie, _, _ = timed_steps(D_, ctx, step_pcie, max(2, args.steps // 2), 1)
+    pcie_steps = max(2, args.steps // 2)
+    elapsed_pcie = None
+    if not args.lean:
+        elapsed_pcie, _, _ = timed_steps(D_, ctx, step_pcie, pcie_steps, 1)
     # small candidate batches on the same fitted GP (the reference's default RandomSampling draws 500 candidates): latency,
     # not throughput -- the 16/32-candidate block-row step
     small_ms = {}
-    if rank == 0:
+    if rank == 0 and not args.lean:
         # the explicit-inverse path (winv.hip): W = L^-1 is built lazily by the first small batch after a fit
         gp.fit(theta, mean_c)
         for m_small in (500, 8192):
@@ -489,78 +669,78 @@ def run_headline(args, D_, _lib, sharding):
             small_ms["%d_block_row_substitution" % m_small] = float(np.min(ts))
             ctx.set_tuning("winv_max", None)
             cs.close()
-    pcie_steps = max(2, args.steps // 2)
 
     out = None
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
-        value = world * M * args.steps / elapsed
-        try:
-            mb = ctx.microbench_mfma_f64_detail(4000)
-        except Exception:
-            mb = None
-        try:
-            g_tf, g_mhz = ctx.microbench_gemm_f64(0, 512, 2048, 3)
-            clock_peak = FP64_MFMA_PEAK_TFLOPS * g_mhz / 2400.0
-        except Exception:
-            g_tf = g_mhz = clock_peak = None
+        value = M_total * args.steps / elapsed
+        mb = g_tf = g_mhz = clock_peak = None
+        if not args.lean:
+            try:
+                mb = ctx.microbench_mfma_f64_detail(4000)
+            except Exception:
+                mb = None
+            try:
+                g_tf, g_mhz = ctx.microbench_gemm_f64(0, 512, 2048, 3)
+                clock_peak = FP64_MFMA_PEAK_TFLOPS * g_mhz / 2400.0
+            except Exception:
+                g_tf = g_mhz = clock_peak = None
         traffic = traffic_src = None
         try:   # PMC-measured HBM bytes per launch for this exact workload (tools/gpu_pmc.sh writes it, with the commit)
             tj = json.load(open(os.path.join(ROOT, "profiles", "trsm_traffic.json")))
-            if tj["workload"] == {"n_train": N, "dim": D, "candidates_per_gpu": M}:
+            if tj["workload"] == {"n_train": N, "dim": D, "candidates_per_gpu": M} and tj["kernel"] in solve_kernel:
                 traffic, traffic_src = tj["bytes_per_launch"], tj.get("commit")
         except Exception:
             pass
         if traffic is None and (N, D) == (1024, 8):
             traffic = config_traffic("c2", "trsm_step_gen_kernel")
-        roof = roofline_trsm(ctx, N, M, trsm_ms, kernel=cand.solve_kernel(), traffic=traffic)
+        roof = roofline_trsm(ctx, N, M, trsm_ms, kernel=solve_kernel, traffic=traffic)
         roof["traffic_measured_at_commit"] = traffic_src
-        roof["mfma_f64_microbench"] = mb
+        if mb is not None:
+            roof["mfma_f64_microbench"] = mb
         if clock_peak:
             roof["gemm_f64_microbench"] = {"lds_core_tflops": g_tf, "shader_mhz_under_load": g_mhz,
                                            "peak_at_that_clock_tflops": clock_peak,
-                                           "frac_of_peak_at_that_clock": roof["achieved"] / clock_peak}
+                                           "frac_of_peak_at_that_clock": (roof["achieved"] or 0.0) / clock_peak}
         with_clock(roof, clock)
-        k1_bytes = 8.0 * N * (N + 1) / 2 + 8.0 * N * D
         name = "BASELINE headline" if (N, D) == (4096, 16) else "BASELINE config 2" if (N, D) == (1024, 8) else "custom"
+        shard_txt = ("%d uniform candidates per GPU" % M) if args.scaling == "weak" else \
+            ("%d uniform candidates in total, contiguous shards of %d..%d per GPU" % (
+                M_total, M_total // world, -(-M_total // world)))
         out = {
             "metric": METRIC, "value": value, "unit": "EI evals/s", "n_gpus": world, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak",
+            "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": args.scaling,
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": "GP Matern-5/2 ARD N=%d D=%d, %d uniform candidates per GPU, %s xi=0, fp64, "
-                                   "candidate shard per GPU (%s)" % (N, D, M, args.acq.upper(), name),
-                       "n_train": N, "dim": D, "candidates_per_gpu": M, "acquisition": args.acq,
+            "config": {"workload": "GP Matern-5/2 ARD N=%d D=%d, %s, %s xi=0, fp64, "
+                                   "candidate shard per GPU (%s)" % (N, D, shard_txt, args.acq.upper(), name),
+                       "n_train": N, "dim": D, "candidates_per_gpu": M, "candidates_total": M_total,
+                       "acquisition": args.acq,
                        "parallelism": "candidate-shard x%d, replicated fit" % world},
             "algorithmic_tflops_whole_step": value * flops_ei(N, D) / 1e12,
-            # `value` is the resident-input rate (the bench contract: inputs in HBM when the timed region starts); SURVEY
-            # 8(d)'s host-buffer definition of an "EI eval" is this block
-            "pcie_inclusive": {"value": world * M * pcie_steps / elapsed_pcie, "unit": "EI evals/s",
-                               "ms_per_step": elapsed_pcie / pcie_steps * 1e3,
-                               "what": "SURVEY 8(d) definition: H2D of the %d x %d candidate batch (pageable host memory, "
-                                       "into an existing handle) + evaluation + D2H of (max, argmax)" % (M, D)},
             # GP-fit = robo_gp_fit wall time for one theta INCLUDING the H2D of X, y, theta and the D2H of
             # the log-likelihood; the data-resident refit (what an MCMC / L-BFGS loop pays per theta) next to it
             "gp_fit_ms": float(np.min(fit_h2d)),
             "gp_fit_data_resident_ms": float(np.min(fit_ms)),
-            "gp_fit_phases_ms": {"gram": gram_ms, "cholesky": chol_ms, "loglik": ll_ms},
             "gp_fit_frac_of_mfma_peak": (N ** 3 / 3.0 + N * (N + 1) / 2.0 * (3 * D + 16) + 2.0 * N * N)
             / (float(np.min(fit_ms)) * 1e-3) / 1e12 / FP64_MFMA_PEAK_TFLOPS,
-            # K1 against the HBM roofline: the gram kernel alone (event slots 19 -> 21); "gram" above also holds the
-            # staging of theta and the input scaling
-            "k_assembly": {"bytes": k1_bytes, "ms": k1_ms, "GB_per_s": k1_bytes / (k1_ms * 1e-3) / 1e9,
-                           "frac_of_8TBps": k1_bytes / (k1_ms * 1e-3) / 8.0e12},
-            "cholesky": {"flops": N ** 3 / 3.0, "ms": chol_ms, "TFLOP_per_s": N ** 3 / 3.0 / (chol_ms * 1e-3) / 1e12,
-                         "frac_of_mfma_peak": N ** 3 / 3.0 / (chol_ms * 1e-3) / 1e12 / FP64_MFMA_PEAK_TFLOPS},
-            "gp_fit_batched": {"thetas": S_half, "ms_total": batch_ms, "ms_per_theta": batch_ms / S_half},
-            "gp_grad_loglik_ms": {"total_incl_fit": grad_ms, "after_factorisation": grad_dev_ms},
-            "small_batch_latency_ms": small_ms,
             "argmax": list(best), "roofline": roof, "device": ctx.name,
         }
-        if getattr(D_, "exchange", None):
-            out["exchange"] = D_.exchange
+        out.update(ranks)
+        out.update(side)
+        if elapsed_pcie is not None:
+            # `value` is the resident-input rate (the bench contract: inputs in HBM when the timed region starts); SURVEY
+            # 8(d)'s host-buffer definition of an "EI eval" is this block
+            out["pcie_inclusive"] = {"value": M_total * pcie_steps / elapsed_pcie, "unit": "EI evals/s",
+                                     "ms_per_step": elapsed_pcie / pcie_steps * 1e3,
+                                     "what": "SURVEY 8(d) definition: H2D of the %d x %d candidate batch (pageable host "
+                                             "memory, into an existing handle) + evaluation + D2H of (max, argmax)" % (M, D)}
+        if small_ms:
+            out["small_batch_latency_ms"] = small_ms
+        if other is not None:
+            out["other_scaling"] = other
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(N, D, theta, X, y)
-        if world == 1 and (N, D) == (4096, 16):
+        if world == 1 and (N, D) == (4096, 16) and not args.lean:
             try:
                 out["hyper_inference"] = hyper_inference(not args.no_cpu_baseline)
                 small = hyper_inference(False, N=100)
@@ -575,7 +755,7 @@ def run_headline(args, D_, _lib, sharding):
 # ----------------------------------------------------------------------------------------------------
 def run_c3(args, D_, _lib, sharding):
     rank, world = D_.rank, D_.world
-    ctx = _lib.Context(D_.local_rank if world > 1 else int(os.environ.get("ROBO_DEVICE", "0")))
+    ctx = _lib.Context(D_.device_ordinal())
     N, D, M, S = args.n, args.d, args.m, 50
     X, y, theta, Xc = synthetic(N, D, M, 0)       # every rank sees ALL candidates; the samples are sharded
     thetas = theta[None, :] + 0.3 * np.random.RandomState(2).randn(S, theta.size)
@@ -587,6 +767,7 @@ def run_c3(args, D_, _lib, sharding):
     etas = np.full(e - b, eta)
     fit_s = []
     comm = D_.make_comm(_lib, ctx)
+    ranks = D_.ranks_block(ctx)
 
     def step():
         t0 = time.perf_counter()
@@ -608,7 +789,7 @@ def run_c3(args, D_, _lib, sharding):
     # elapsed_ms(25, 26) brackets the LAST sample's solve of a step
     roof = roofline_trsm(ctx, N, M, trsm_ms, kernel=cand.solve_kernel(), traffic=config_traffic("c3", cand.solve_kernel()))
     with_clock(roof, clock)
-    return {"metric": METRIC, "value": S * M * args.steps / elapsed, "unit": "LogEI sample-evals/s", "n_gpus": world,
+    return dict(ranks, **{"metric": METRIC, "value": S * M * args.steps / elapsed, "unit": "LogEI sample-evals/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": True,
             "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": "BASELINE config 3: 50 hyper-parameter samples (theta + 0.3 randn), N=2048 D=16, "
@@ -621,7 +802,7 @@ def run_c3(args, D_, _lib, sharding):
             "end_to_end_ms": ms, "fit_batch_ms_rank0": float(np.median(fit_s)) * 1e3,
             "fit_ms_per_sample": float(np.median(fit_s)) * 1e3 / (e - b),
             "algorithmic_tflops_whole_step": S * M * flops_ei(N, D) / (ms * 1e-3) / 1e12,
-            "argmax": list(best), "roofline": roof, "device": ctx.name}
+            "argmax": list(best), "roofline": roof, "device": ctx.name})
 
 
 # ----------------------------------------------------------------------------------------------------
@@ -631,8 +812,8 @@ def run_c4(args, D_, _lib, sharding):
     from robo_amd.util import epmgp
     from scipy.stats import norm
     rank, world = D_.rank, D_.world
-    ctx = _lib.Context(D_.local_rank if world > 1 else int(os.environ.get("ROBO_DEVICE", "0")))
-    N, D, M, Nb, Np = args.n, args.d, args.m, 50, 400
+    ctx = _lib.Context(D_.device_ordinal())
+    N, D, Nb, Np = args.n, args.d, 50, 400
     rs = np.random.RandomState(3)
     X = np.random.RandomState(0).rand(N, D)
     s = rs.rand(N)
@@ -649,7 +830,7 @@ def run_c4(args, D_, _lib, sharding):
     Xcost[:, -1] = s                                               # linear basis for the cost model
     gc.set_data(Xcost, cost)
     gc.fit(theta, float(np.mean(cost)))
-    Xc = np.random.RandomState(1 + rank).rand(M, D)
+    Xc, M, offset, M_total = synthetic_candidates(args, D_, sharding)
     Xc_cost = Xc.copy()
     Xc[:, -1] = (1.0 - Xc[:, -1]) ** 2
     zb = np.random.RandomState(4).rand(Nb, D)
@@ -662,6 +843,7 @@ def run_c4(args, D_, _lib, sharding):
     cand, cand_cost, rep = _lib.Candidates(ctx, Xc), _lib.Candidates(ctx, Xc_cost), _lib.Candidates(ctx, zb)
     sn2 = float(np.exp(theta[-1]))
     comm = D_.make_comm(_lib, ctx)
+    ranks = D_.ranks_block(ctx)
     ctx.set_phase_events(True)          # batches <= 16384 record the solve's event pair only on request
 
     def step():
@@ -671,7 +853,7 @@ def run_c4(args, D_, _lib, sharding):
         j = int(np.argmax(val))
         if comm is None:
             return float(val[j]), j
-        rows = comm.allgather([float(val[j]), float(j + rank * M)])     # 16 bytes per rank
+        rows = comm.allgather([float(val[j]), float(j + offset)])       # 16 bytes per rank
         return sharding.reduce_argmax((float(r[0]), int(r[1])) for r in rows)
 
     elapsed, best, trsm_ms = timed_steps(D_, ctx, step, args.steps, args.warmup)
@@ -679,19 +861,20 @@ def run_c4(args, D_, _lib, sharding):
     if rank != 0:
         return None
     ms = elapsed / args.steps * 1e3
-    return {"metric": METRIC, "value": world * M * args.steps / elapsed, "unit": "information gains/s", "n_gpus": world,
-            "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": True, "scaling": "weak",
+    return dict(ranks, **{"metric": METRIC, "value": M_total * args.steps / elapsed, "unit": "information gains/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": True, "scaling": args.scaling,
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": "BASELINE config 4: Fabolas product kernel N=4096 D=10+1, information gain per unit "
                                    "cost (Nb=50, Np=400, objective + cost GP), %d candidates per GPU" % M,
-                       "n_train": N, "dim": D, "candidates_per_gpu": M, "acquisition": "information_gain_per_unit_cost",
+                       "n_train": N, "dim": D, "candidates_per_gpu": M, "candidates_total": M_total,
+                       "acquisition": "information_gain_per_unit_cost",
                        "parallelism": "candidate-shard x%d, replicated fits" % world},
             "argmax": list(best),
             "roofline": with_clock(roofline_trsm(ctx, N, M, trsm_ms, kernel=cand_cost.solve_kernel(),
                                                  traffic=config_traffic("c4", cand_cost.solve_kernel())), clock),
             "device": ctx.name,
             "note": "roofline: the block-row solve of the LAST posterior of a step (the cost model's); at this batch "
-                    "size the step is latency-bound, not MFMA-bound (see small_batch_latency_ms of the headline line)"}
+                    "size the step is latency-bound, not MFMA-bound (see small_batch_latency_ms of the headline line)"})
 
 
 # ----------------------------------------------------------------------------------------------------
@@ -700,8 +883,9 @@ def run_c4(args, D_, _lib, sharding):
 def run_c5(args, D_, _lib, sharding):
     from scipy.stats import qmc
     rank, world = D_.rank, D_.world
-    ctx = _lib.Context(D_.local_rank if world > 1 else int(os.environ.get("ROBO_DEVICE", "0")))
-    N, D, M = args.n, args.d, args.m
+    ctx = _lib.Context(D_.device_ordinal())
+    N, D = args.n, args.d
+    M, offset, M_total = candidate_shard(args, D_, sharding)
     # one workspace pass for the whole shard (131 072 x 8320 doubles = 8.7 GB of the 288 GB): the HIP-event slots
     # bracket the solve of ONE pass, and the roofline below prices all M rows against it
     n_pad = (N + 1 + 127) // 128 * 128
@@ -719,13 +903,14 @@ def run_c5(args, D_, _lib, sharding):
     fit_ms = min(fit_ms, (time.perf_counter() - t0) * 1e3)
     # this rank's slice of the 2^20-point scrambled Sobol sequence, generated in HBM from SciPy's direction numbers
     # (bit-identical to qmc.Sobol(d, scramble=True, seed=0).random_base2(20)[rank * M : (rank + 1) * M])
-    cand = _lib.Candidates(ctx, m=M, sobol=qmc.Sobol(d=D, scramble=True, seed=0), first=rank * M)
+    cand = _lib.Candidates(ctx, m=M, sobol=qmc.Sobol(d=D, scramble=True, seed=0), first=offset)
 
     comm = D_.make_comm(_lib, ctx)
+    ranks = D_.ranks_block(ctx)
 
     def step():
         if comm is not None:
-            _, mx, am, _, _ = comm.acq_sharded(gp, "lcb", 1.0, 0.0, cand, rank * M)
+            _, mx, am, _, _ = comm.acq_sharded(gp, "lcb", 1.0, 0.0, cand, offset)
             return mx, am
         _, mx, am, _ = gp.acq("lcb", 1.0, 0.0, cand, want_values=False)
         return mx, am
@@ -735,19 +920,19 @@ def run_c5(args, D_, _lib, sharding):
     if rank != 0:
         return None
     ms = elapsed / args.steps * 1e3
-    return {"metric": METRIC, "value": world * M * args.steps / elapsed, "unit": "LCB evals/s", "n_gpus": world,
-            "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": True, "scaling": "weak",
+    return dict(ranks, **{"metric": METRIC, "value": M_total * args.steps / elapsed, "unit": "LCB evals/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": True, "scaling": args.scaling,
             "vs_baseline": None, "dtype": "f64 (covariance entries f32)", "data": "synthetic",
             "config": {"workload": "BASELINE config 5: N=8192 D=64, LCB kappa=1, %d scrambled-Sobol candidates per GPU "
                                    "(slice of 2^20), fp32 K-build + fp64 Cholesky/solve" % M,
-                       "n_train": N, "dim": D, "candidates_per_gpu": M, "acquisition": "lcb",
+                       "n_train": N, "dim": D, "candidates_per_gpu": M, "candidates_total": M_total, "acquisition": "lcb",
                        "parallelism": "candidate-shard x%d, replicated fit" % world},
-            "gp_fit_ms": fit_ms, "algorithmic_tflops_whole_step": world * M * flops_ei(N, D) / (ms * 1e-3) / 1e12,
+            "gp_fit_ms": fit_ms, "algorithmic_tflops_whole_step": M_total * flops_ei(N, D) / (ms * 1e-3) / 1e12,
             "argmax": list(best),
             "roofline": with_clock(roofline_trsm(ctx, N, M, trsm_ms, passes=-(-M // cand.chunk()),
                                                  kernel=cand.solve_kernel(),
                                                  traffic=config_traffic("c5", cand.solve_kernel())), clock),
-            "device": ctx.name}
+            "device": ctx.name})
 
 
 def main():
@@ -762,9 +947,29 @@ def main():
     ap.add_argument("--acq", default="ei")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--lib", default=None, help="alternative build of librobo_hip.so (A/B runs of kernel variants)")
+    ap.add_argument("--scaling", default=None, choices=["weak", "strong"],
+                    help="weak (default): --m candidates per GPU; strong: --m candidates in TOTAL, split over the ranks "
+                         "(SURVEY 8(d)'s headline; config 3 shards its 50 samples and is always strong)")
+    ap.add_argument("--lean", action="store_true",
+                    help="the timed region and the fit only: no side measurements (phases, micro-benchmarks, small batches)")
     args = ap.parse_args()
+    if args.gpus < 1:
+        ap.error("--gpus must be >= 1")
+    env_world = os.environ.get("WORLD_SIZE")
+    if env_world is not None and int(env_world) != args.gpus:
+        sys.stderr.write("bench.py: --gpus %d but the launcher started WORLD_SIZE=%s ranks; refusing to report a line "
+                         "for a job that is not the one asked for\n" % (args.gpus, env_world))
+        sys.exit(2)
+    if env_world is None and args.gpus > 1:
+        # no launcher around this process: be the launcher (one rank process per GPU), pass rank 0's line through
+        sys.exit(launch_ranks(args.gpus, sys.argv[1:]))
+    if args.config == "c3":
+        args.scaling = "strong"
+    args.scaling = args.scaling or "weak"
     defaults = {"headline": (4096, 16, 65536), "c2": (1024, 8, 65536), "c3": (2048, 16, 65536),
                 "c4": (4096, 11, 8192), "c5": (8192, 64, 131072)}[args.config]
+    if args.scaling == "strong" and args.config in ("c4", "c5"):      # BASELINE's totals: 8 x 8192, 8 x 2^17
+        defaults = defaults[:2] + (defaults[2] * 8,)
     args.n = args.n or defaults[0]
     args.d = args.d or defaults[1]
     args.m = args.m or defaults[2]
@@ -783,8 +988,7 @@ def main():
     runner = {"headline": run_headline, "c2": run_headline, "c3": run_c3, "c4": run_c4, "c5": run_c5}[args.config]
     out = runner(args, D_, _lib, sharding)
     if D_.rank == 0:
-        if getattr(D_, "exchange", None):
-            out.setdefault("exchange", D_.exchange)
+        out.setdefault("exchange", D_.exchange or "none (single process, no communicator)")
         D_.emit(out)
     D_.close()
 

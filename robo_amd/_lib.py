@@ -580,6 +580,12 @@ class Comm(object):
             lib().robo_comm_destroy(self._h)
             self._h = None
 
+    def info(self):
+        """(rank, world) as the communicator holds them (robo_comm_info)"""
+        r, w = C.c_int32(-1), C.c_int32(-1)
+        check(lib().robo_comm_info(self._h, C.byref(r), C.byref(w)))
+        return int(r.value), int(w.value)
+
     def allgather(self, values):
         """values: (count,) host doubles -> (world, count), identical on every rank"""
         v = _f64(np.asarray(values, dtype=np.float64).reshape(-1))
