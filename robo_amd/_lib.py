@@ -55,6 +55,11 @@ class RoboHipError(RuntimeError):
     pass
 
 
+class RoboBadShape(AssertionError):
+    """ROBO_BAD_SHAPE from the library (the reference uses ``assert`` for shapes, base_model.py:68-70,76) -- its own type
+    so that callers can tell the library's verdict from a Python-side assert"""
+
+
 _lib = None
 _lib_path = None
 _diag = None
@@ -212,7 +217,7 @@ def check(status):
     if status == NOT_FITTED:
         raise Exception('Model has to be trained first!')    # gaussian_process.py:241,273,322
     if status == BAD_SHAPE:
-        raise AssertionError(msg)                             # base_model.py:68-70,76 use assert
+        raise RoboBadShape(msg)                               # base_model.py:68-70,76 use assert
     if status == BAD_ARGUMENT:
         raise ValueError(msg)
     raise RoboHipError(msg)

@@ -99,8 +99,11 @@ class ClosedFormAcquisition(BaseAcquisitionFunction):
         library call (robo_acq_eval_cand_sharded); the reference's EI guards act on the flags OR-ed over all ranks,
         i.e. exactly as they would on the unsharded batch."""
         eta = self._eta(None)
+        n_here = int(np.asarray(X_slice).shape[0])
         if not self._is_native():
             from robo_amd import sharding
+            if n_here == 0:                           # more ranks than candidates: an empty shard still joins the exchange
+                return sharding.allgather_argmax(-np.inf, -1)[1]
             vals = np.asarray(self.compute(X_slice), dtype=np.float64).reshape(-1)
             if vals.shape[0] != X_slice.shape[0]:
                 vals = np.zeros(X_slice.shape[0])
@@ -109,13 +112,27 @@ class ClosedFormAcquisition(BaseAcquisitionFunction):
         model = self.model
         if not model.is_trained:
             raise Exception('Model has to be trained first!')
-        model._materialise()
-        norm = model.normalize if hasattr(model, "normalize") else model._normalised
-        cand = _lib.Candidates(model.gp.ctx, norm(X_slice))
-        try:
-            _, mx, am, _, flags = comm.acq_sharded(model.gp, self.kind, self.par, eta, cand, global_offset)
-        finally:
-            cand.close()
+        if n_here == 0:
+            # an empty shard takes part in the SAME collective the other ranks issue inside
+            # robo_acq_eval_cand_sharded (an all-gather of four doubles: max, global index or -1, flag word, status)
+            # and applies the same tie-break to what comes back
+            from robo_amd import sharding
+            rows = comm.allgather([0.0, -1.0, 0.0, 0.0])
+            best = sharding.reduce_argmax((float(r[0]), int(r[1])) for r in rows)
+            flags = 0
+            for r in rows:
+                flags |= int(r[2])
+                if int(r[3]) != _lib.OK:
+                    _lib.check(int(r[3]))             # another rank's local half failed: every rank raises
+            mx, am = best if best is not None else (0.0, -1)
+        else:
+            model._materialise()
+            norm = model.normalize if hasattr(model, "normalize") else model._normalised
+            cand = _lib.Candidates(model.gp.ctx, norm(X_slice))
+            try:
+                _, mx, am, _, flags = comm.acq_sharded(model.gp, self.kind, self.par, eta, cand, global_offset)
+            finally:
+                cand.close()
         self.last_max, self.last_argmax = mx, am
         if self.kind == "ei":
             if flags & _lib.FLAG_ZERO_SIGMA:

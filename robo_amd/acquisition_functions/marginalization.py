@@ -74,9 +74,13 @@ class MarginalizationGPMCMC(BaseAcquisitionFunction):
             and all(getattr(e.model, "is_trained", False) for e in self.estimators)
 
     def _shard(self):
+        # the opt-in flag FIRST: dist_info() is collective on first use (the communicator id is broadcast, every rank
+        # joins ncclCommInitRank) and must not run because a torch process group merely exists
+        if not self.sample_shard:
+            return None
         from robo_amd import sharding
         _, rank, world = sharding.dist_info()
-        if not self.sample_shard or world == 1:
+        if world == 1:
             return None
         return sharding.shard_range(len(self.estimators), rank, world)
 

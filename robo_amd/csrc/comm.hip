@@ -13,6 +13,7 @@
 #include <dlfcn.h>
 
 #include <cstdlib>
+#include <mutex>
 
 #include "common.h"
 
@@ -43,6 +44,8 @@ struct Rccl {
 
 static Rccl* rccl() {
     static Rccl api = {};
+    static std::mutex mu;                             // two contexts on two threads may create their communicators at once
+    std::lock_guard<std::mutex> lock(mu);
     if (api.handle) return &api;
     const char* name = getenv("ROBO_RCCL_LIB");       // (not a hot path: once per process)
     if (!name || !*name) name = "librccl.so";
@@ -85,7 +88,9 @@ static Rccl* rccl() {
     } while (0)
 
 // ---- device side of the exchanges ------------------------------------------------------------------------------------
-// this rank's message of the candidate shard: (best value, GLOBAL index as an exact fp64 < 2^53, flag word)
+// this rank's message of the candidate shard: (best value, GLOBAL index as an exact fp64 < 2^53, flag word, status of
+// this rank's local half -- ROBO_OK here; a rank whose half failed sends {0, -1, 0, its status} from the host)
+constexpr int BEST_MSG = 4;
 __global__ void comm_pack_best_kernel(const double* __restrict__ best_val, const long long* __restrict__ best_idx,
                                       const unsigned* __restrict__ flags, long long offset, double* __restrict__ send) {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
@@ -93,10 +98,12 @@ __global__ void comm_pack_best_kernel(const double* __restrict__ best_val, const
     send[0] = *best_val;
     send[1] = i < 0 ? -1.0 : (double)(i + offset);
     send[2] = (double)*flags;
+    send[3] = 0.0;
 }
 
 // np.argmax over the ranks' incumbents (NaN maximal, then the larger value, then the lower global index), flags OR-ed;
-// result straight into pinned host memory: [max, argmax (long long), flags (unsigned), owner rank (int)]
+// result straight into pinned host memory: [max, argmax (long long), flags (unsigned), owner rank (int), status of the
+// first rank whose local half failed (int, ROBO_OK if none), that rank (int)]
 __global__ void comm_best_kernel(const double* __restrict__ recv, int world, unsigned* __restrict__ flags,
                                  double* __restrict__ host) {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
@@ -104,10 +111,15 @@ __global__ void comm_best_kernel(const double* __restrict__ recv, int world, uns
     long long bi = -1;
     int owner = -1;
     unsigned f = 0u;
+    int bad_status = 0, bad_rank = -1;
     for (int r = 0; r < world; ++r) {
-        const double v = recv[3 * r];
-        const long long i = (long long)recv[3 * r + 1];
-        f |= (unsigned)recv[3 * r + 2];
+        const double v = recv[BEST_MSG * r];
+        const long long i = (long long)recv[BEST_MSG * r + 1];
+        f |= (unsigned)recv[BEST_MSG * r + 2];
+        if (bad_rank < 0 && recv[BEST_MSG * r + 3] != 0.0) {
+            bad_status = (int)recv[BEST_MSG * r + 3];
+            bad_rank = r;
+        }
         if (i < 0) continue;
         bool take;
         if (bi < 0) take = true;
@@ -127,22 +139,28 @@ __global__ void comm_best_kernel(const double* __restrict__ recv, int world, uns
     reinterpret_cast<long long*>(host)[1] = bi;
     reinterpret_cast<unsigned*>(host + 2)[0] = f;
     reinterpret_cast<int*>(host + 2)[1] = owner;
+    reinterpret_cast<int*>(host + 3)[0] = bad_status;
+    reinterpret_cast<int*>(host + 3)[1] = bad_rank;
     *flags = 0u;
 }
 
-// sample shard: this rank's partial sums + its flag word behind them
+// sample shard: this rank's partial sums + its flag word and the status of its local half behind them
 __global__ __launch_bounds__(256) void comm_pack_sum_kernel(const double* __restrict__ part, long long m, int have,
-                                                            const unsigned* __restrict__ flags,
+                                                            const unsigned* __restrict__ flags, int status,
                                                             double* __restrict__ send) {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < m) send[i] = have ? part[i] : 0.0;
-    if (i == m) send[m] = (double)*flags;
+    if (i == m) {
+        send[m] = (double)*flags;
+        send[m + 1] = (double)status;
+    }
 }
 
-// total[i] = sum over ranks IN RANK ORDER of their partial sums; flags OR-ed into the handle's flag word
+// total[i] = sum over ranks IN RANK ORDER of their partial sums; flags OR-ed into the handle's flag word; the status of
+// the first rank whose local half failed (and that rank) into pinned host memory
 __global__ __launch_bounds__(256) void comm_ordered_sum_kernel(const double* __restrict__ recv, long long stride,
                                                                int world, long long m, double* __restrict__ total,
-                                                               unsigned* __restrict__ flags) {
+                                                               unsigned* __restrict__ flags, int* __restrict__ host_status) {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < m) {
         double s = recv[i];
@@ -151,8 +169,17 @@ __global__ __launch_bounds__(256) void comm_ordered_sum_kernel(const double* __r
     }
     if (i == 0) {
         unsigned f = 0u;
-        for (int r = 0; r < world; ++r) f |= (unsigned)recv[(size_t)r * stride + m];
+        int bad_status = 0, bad_rank = -1;
+        for (int r = 0; r < world; ++r) {
+            f |= (unsigned)recv[(size_t)r * stride + m];
+            if (bad_rank < 0 && recv[(size_t)r * stride + m + 1] != 0.0) {
+                bad_status = (int)recv[(size_t)r * stride + m + 1];
+                bad_rank = r;
+            }
+        }
         *flags = f;
+        host_status[0] = bad_status;
+        host_status[1] = bad_rank;
     }
 }
 
@@ -164,7 +191,7 @@ struct robo_comm {
     void* nccl;
     double *d_send, *d_recv;
     size_t cap;          // doubles per rank the two buffers hold
-    double* h_pinned;    // [4]
+    double* h_pinned;    // [8]: results of comm_best_kernel [0..3], status pair of the ordered sum [4]
 };
 
 using namespace robo;
@@ -271,18 +298,28 @@ int32_t robo_acq_eval_cand_sharded(robo_comm* c, robo_gp* g, int32_t acq_kind, d
                            (const long long*)(k->d_part_idx + k->n_part), (const unsigned*)k->d_flags,
                            (long long)global_offset, c->d_send);
     } else {
-        const double none[3] = {0.0, -1.0, 0.0};     // an empty shard for the others; this rank reports its error
+        // an empty shard for the others, and this rank's status: EVERY rank returns the failure (a job whose ranks
+        // disagree about whether the call succeeded hangs in its next collective)
+        const double none[BEST_MSG] = {0.0, -1.0, 0.0, (double)status};
         hipMemcpyAsync(c->d_send, none, sizeof(none), hipMemcpyHostToDevice, st);
         hipStreamSynchronize(st);
     }
-    ROBO_NCCL_CHECK(rccl()->all_gather(c->d_send, c->d_recv, 3, NCCL_FLOAT64, c->nccl, st));
+    ROBO_NCCL_CHECK(rccl()->all_gather(c->d_send, c->d_recv, BEST_MSG, NCCL_FLOAT64, c->nccl, st));
     hipLaunchKernelGGL(comm_best_kernel, dim3(1), dim3(64), 0, st, (const double*)c->d_recv, c->world, k->d_flags,
                        c->h_pinned);
     if (ok && out_acq)
         ROBO_HIP_CHECK(hipMemcpyAsync(out_acq, k->d_acq, (size_t)k->m * sizeof(double), hipMemcpyDeviceToHost, st));
     ROBO_HIP_CHECK(hipStreamSynchronize(st));
-    if (!ok) return status;
+    if (!ok) return status;                          // (its own message stands in the error string)
     const double* hp = c->h_pinned;
+    {
+        int bad[2];
+        memcpy(bad, hp + 3, sizeof(bad));
+        if (bad[0] != ROBO_OK) {
+            set_error("robo_acq_eval_cand_sharded: the local half of rank %d failed with status %d", bad[1], bad[0]);
+            return bad[0];
+        }
+    }
     if (out_max) *out_max = hp[0];
     if (out_argmax) {
         long long i;
@@ -311,19 +348,30 @@ int32_t robo_acq_eval_marginal_cand_sharded(robo_comm* c, robo_gp* const* gps, i
     ROBO_HIP_CHECK(hipSetDevice(c->ctx->device));
     const long long m = (long long)k->m;
     // (out of device memory for the exchange buffers: nothing to send from -- the one error that leaves before the collective)
-    ROBO_TRY_COMM(comm_reserve(c, (size_t)m + 1));
+    ROBO_TRY_COMM(comm_reserve(c, (size_t)m + 2));
     int status = ROBO_OK;
     if (S_local > 0) status = api_acq_accumulate(gps, S_local, acq_kind, par, etas, k);
     const bool ok = status == ROBO_OK;
     // a failed rank still takes part in the collective (zeros): the others must not hang
     hipLaunchKernelGGL(comm_pack_sum_kernel, dim3((unsigned)((m + 1 + 255) / 256)), dim3(256), 0, st,
-                       (const double*)k->d_acq_sum, m, (ok && S_local > 0) ? 1 : 0, (const unsigned*)k->d_flags, c->d_send);
-    ROBO_NCCL_CHECK(rccl()->all_gather(c->d_send, c->d_recv, (size_t)m + 1, NCCL_FLOAT64, c->nccl, st));
+                       (const double*)k->d_acq_sum, m, (ok && S_local > 0) ? 1 : 0, (const unsigned*)k->d_flags, status,
+                       c->d_send);
+    ROBO_NCCL_CHECK(rccl()->all_gather(c->d_send, c->d_recv, (size_t)m + 2, NCCL_FLOAT64, c->nccl, st));
     hipLaunchKernelGGL(comm_ordered_sum_kernel, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, st,
-                       (const double*)c->d_recv, m + 1, c->world, m, k->d_acq_sum, k->d_flags);
-    if (!ok) {
-        hipStreamSynchronize(st);
-        return api_clear_flags(k, status);
+                       (const double*)c->d_recv, m + 2, c->world, m, k->d_acq_sum, k->d_flags,
+                       reinterpret_cast<int*>(c->h_pinned + 4));
+    // EVERY rank learns whether any rank's local half failed (a sum with a rank's samples missing must not be returned
+    // as ROBO_OK anywhere): one stream synchronisation before the argmax
+    hipStreamSynchronize(st);
+    if (!ok) return api_clear_flags(k, status);
+    {
+        int bad[2];
+        memcpy(bad, c->h_pinned + 4, sizeof(bad));
+        if (bad[0] != ROBO_OK) {
+            set_error("robo_acq_eval_marginal_cand_sharded: the local half of rank %d failed with status %d", bad[1],
+                      bad[0]);
+            return api_clear_flags(k, bad[0]);
+        }
     }
     ROBO_TRY_COMM(api_clear_flags(k, launch_argmax(k, k->d_acq_sum, (double)S_total)));
     return api_clear_flags(k, api_acq_read_back(k, k->d_acq, out_acq, out_max, out_argmax, out_flags));

@@ -201,7 +201,10 @@ class GaussianProcessMCMC(BaseModel):
         def run(p, lnp, n_steps, u_stretch, partner, u_accept, a):
             try:
                 return self.gp.mcmc_run(self.mean, prior, p, lnp, n_steps, u_stretch, partner, u_accept, a)
-            except AssertionError:      # ROBO_BAD_SHAPE: half an ensemble exceeds the batch workspace -> host sampler
+            except _lib.RoboBadShape:   # the LIBRARY declined (half an ensemble exceeds the batch workspace) -> host sampler;
+                # Python-side shape asserts of DeviceGP.mcmc_run are bugs and propagate.  (A NaN / inf proposal is
+                # out of bounds on the device, i.e. -inf and rejected; emcee 2 on the host raises "lnprob returned NaN"
+                # for it -- neither can be produced from finite walkers by a stretch move)
                 logger.info("device chain declined (%s); host sampler", _lib.last_error())
                 return None
         return run

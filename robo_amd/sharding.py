@@ -157,7 +157,9 @@ def sharded_argmax(acq, X):
     if world == 1:
         return int(acq.argmax(X)) if hasattr(acq, "argmax") else int(np.argmax(acq(X)))
     b, e = shard_range(X.shape[0], rank, world)
-    if hasattr(acq, "argmax_sharded") and e > b:
+    # which exchange runs is decided by the acquisition's CLASS, never by this rank's shard: a rank whose slice is empty
+    # (fewer candidates than ranks) must issue the same collective as the others
+    if hasattr(acq, "argmax_sharded"):
         return acq.argmax_sharded(c, X[b:e], b)
     if e > b:
         vals = np.asarray(acq(X[b:e]), dtype=np.float64).reshape(-1)

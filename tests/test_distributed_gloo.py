@@ -91,14 +91,17 @@ def _worker(rank, world, port, out_dir):
     v1, _, am1, _ = gps[0].acq("log_ei", 0.0, eta, full)
     np.testing.assert_array_equal(vm1, v1)
     assert amm1 == am1
-    # a rank whose local half fails still joins the exchange, then reports its error
+    # a rank whose local half fails still joins the exchange, and EVERY rank reports the failure (ranks that
+    # disagree about the outcome of a collective call hang in the next one)
     unfitted = _lib.DeviceGP(ctx, "matern52", N, D)
-    raised = False
-    try:
-        c.acq_sharded(unfitted if rank == 1 else gps[0], "ei", 0.0, eta, mine, b)
-    except Exception:
-        raised = True
-    assert raised == (rank == 1)
+    for bad in range(world):
+        with pytest.raises(Exception, match="trained first"):
+            c.acq_sharded(unfitted if rank == bad else gps[0], "ei", 0.0, eta, mine, b)
+        with pytest.raises(Exception, match="trained first"):
+            c.acq_marginal_sharded([unfitted] if rank == bad else gps[:1], world, "log_ei", 0.0, [eta], full)
+    # ... and the communicator is still usable afterwards
+    v2, mx2, am2, _, _ = c.acq_sharded(gps[0], "ei", 0.0, eta, mine, b, want_values=True)
+    assert (mx2, am2) == (mx_ref, am_ref)
     for h in gps + [full, mine, unfitted]:
         h.close()
     dist.barrier()
@@ -182,6 +185,9 @@ def _class_worker(rank, world, port, out_dir):
     cands = RandomSampling(acq, lo, hi, n_samples=203, rng=np.random.RandomState(8)).candidates()
     np.testing.assert_array_equal(x_sharded, cands[int(np.argmax(acq.compute(cands)))])
     assert sharding.sharded_argmax(acq, Xc) == int(np.argmax(acq.compute(Xc)))
+    # fewer candidates than ranks: the rank with an empty slice issues the same collective as the others
+    assert sharding.sharded_argmax(acq, Xc[:1]) == 0
+    assert sharding.sharded_argmax(lambda Z: -np.abs(Z).sum(axis=1), Xc[:1]) == 0     # generic (host-vector) form
     # device-generated candidates: per-rank Philox shards, the winner's point travels to every rank
     x_dev = DeviceRandomSampling(acq, lo, hi, n_samples=1001, rng=np.random.RandomState(9), shard=True).maximize()
     assert np.all(x_dev >= lo) and np.all(x_dev <= hi)

@@ -166,3 +166,18 @@ def test_reduce_argmax_matches_numpy():
             pairs.append((y[b + j], b + j))
         v, i = sharding.reduce_argmax(reversed(pairs))     # arrival order must not matter
         assert i == int(np.argmax(y))
+
+
+def test_marginalization_without_opt_in_never_touches_the_communicator(monkeypatch):
+    """an initialised process group alone must not make MarginalizationGPMCMC create a communicator (a
+    collective): the opt-in flag is looked at before sharding.dist_info()"""
+    from robo_amd.acquisition_functions.marginalization import MarginalizationGPMCMC
+
+    def boom():
+        raise AssertionError("dist_info() called although sample_shard is off")
+
+    monkeypatch.setattr(sharding, "dist_info", boom)
+    acq = MarginalizationGPMCMC.__new__(MarginalizationGPMCMC)
+    acq.sample_shard = False
+    acq.estimators = []
+    assert acq._shard() is None
