@@ -167,6 +167,13 @@ int32_t robo_gp_fit_batch(robo_gp* const* gps, int32_t S, const double* thetas, 
 /* copy the lower Cholesky factor (n x n, row-major, upper zeroed) back -- diagnostics/tests */
 int32_t robo_gp_get_factor(robo_gp* gp, double* out_L);
 int32_t robo_gp_get_gram(robo_gp* gp, const double* theta, double* out_K); /* K incl. noise, n x n  */
+/* cond_inf(L) = |L|_inf |L^-1|_inf of the current factor, EXACT (row sums of L and of the explicit inverse W, which is
+ * built for this factor if it has not been yet: ~1 ms at N = 4096, then cached until the next fit).  It is the number
+ * that decides whether small candidate batches of robo_gp_predict* / robo_acq_eval* (the reference's
+ * gp.predict, robo/models/gaussian_process.py:280-294) may go through W (forward error ~eps cond) or stay on the
+ * block-row substitution: the explicit inverse is used while it is <= the context's `winv_cond_max` (default 1e5).
+ * out[0] = cond_inf(L), out[1] = min L_ii, out[2] = max L_ii.  Diagnostics / tests.                         */
+int32_t robo_gp_factor_cond(robo_gp* gp, double* out);
 
 /* ---- candidates --------------------------------------------------------------------- */
 /* Xc: (m, dim) candidates in the GP's (normalised) input space; copied H2D here, once.    */

@@ -87,6 +87,7 @@ struct Tuning {
     int predict_stepwise;        // 1: cross-gram in memory + trsm_step_kernel (A/B)
     long long winv_max;          // batches <= this (and >= winv_min_blocks block rows) go through W = L^-1 (0: never)
     int winv_min_blocks;
+    long long winv_cond_max;     // ... while cond_inf(L) = |L|_inf |W|_inf stays below this (default 1e5)
     int potrf_fused;             // 0: never fuse the next diagonal block into the trailing update
     int potrf_tm4_min, potrf_max_wg, potrf_group;
     int mcmc_block_step;         // ensemble half-step in ONE launch: 2 (default) every one-block problem, 1 only N <= 63, 0 never
@@ -159,6 +160,8 @@ struct robo_gp {
     int* d_wprefix;                 // first canonical unit of every block row (winv_nbk + 1 entries)
     int winv_nbk, winv_units, winv_kc;
     double diag_min, diag_max;      // extreme diagonal entries of L over the training rows (0, 0: unknown)
+    double winv_cond;               // cond_inf(L) = |L|_inf |W|_inf of the factor W was built for (winv_gen); 0: unknown
+    double* d_wnorm;                // [2]: |L|_inf, |W|_inf (bit patterns, atomicMax)
 };
 
 struct robo_cand {

@@ -22,7 +22,8 @@
 // rounding, ~1e-13 relative -- same tolerances against the oracle).
 //
 // Numerics: W carries a forward error of ~eps cond(L) (the block-row solve: eps cond of a 128-block), so the caller
-// (api.hip) takes this path only while max L_ii / min L_ii stays below a bound and keeps the substitution otherwise.
+// (api.hip) takes this path only while cond_inf(L) = |L|_inf |W|_inf -- measured here when W is built
+// (winv_norm_kernel) -- stays below a bound and keeps the substitution otherwise.
 #include <algorithm>
 #include <vector>
 
@@ -102,6 +103,33 @@ __global__ __launch_bounds__(256) void winv_finish_kernel(const double* __restri
     mu[c] = b;
 }
 
+// |L|_inf and |W|_inf over the n training rows: one wave per row, max over rows through atomicMax on the bit pattern
+// (non-negative doubles order like their bits)
+__global__ __launch_bounds__(256) void winv_norm_kernel(const double* __restrict__ L, const double* __restrict__ W,
+                                                        int ld, int n, unsigned long long* __restrict__ out) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= n) return;
+    const double* l = L + (size_t)row * ld;
+    const double* w = W + (size_t)row * ld;
+    double sl = 0.0, sw = 0.0;
+    for (int j = lane; j <= row; j += 64) {
+        sl += fabs(l[j]);
+        sw += fabs(w[j]);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        sl += __shfl_xor(sl, o);
+        sw += __shfl_xor(sw, o);
+    }
+    if (lane == 0) {
+        // (a NaN anywhere in W makes its row sum NaN: the bit pattern of a NaN exceeds every finite one, the condition
+        // number comes out NaN and the caller keeps the substitution)
+        atomicMax(out, (unsigned long long)__double_as_longlong(sl));
+        atomicMax(out + 1, (unsigned long long)__double_as_longlong(sw));
+    }
+}
+
 // contraction blocks per unit: fixed by the number of block rows of the factor (and by nothing else)
 static int winv_kc(int nbk) { return nbk >= 16 ? 8 : (nbk >= 8 ? 4 : 2); }
 
@@ -142,6 +170,17 @@ int winv_ensure(robo_gp* gp) {
     if (gp->winv_gen != gp->fit_gen) {
         const int s = launch_triinv(gp, gp->d_Winv, gp->d_gV);
         if (s != ROBO_OK) return s;
+        // cond_inf(L) = |L|_inf |W|_inf, exact for the W just built: decides whether this factor may use W at all
+        if (!gp->d_wnorm) ROBO_HIP_CHECK(hipMalloc((void**)&gp->d_wnorm, 2 * sizeof(double)));
+        ROBO_HIP_CHECK(hipMemsetAsync(gp->d_wnorm, 0, 2 * sizeof(double), st));
+        hipLaunchKernelGGL(winv_norm_kernel, dim3((unsigned)((gp->n + 3) / 4)), dim3(256), 0, st, (const double*)gp->d_K,
+                           (const double*)gp->d_Winv, gp->n_pad, gp->n,
+                           reinterpret_cast<unsigned long long*>(gp->d_wnorm));
+        ROBO_LAUNCH_CHECK();
+        double norms[2] = {0.0, 0.0};
+        ROBO_HIP_CHECK(hipMemcpyAsync(norms, gp->d_wnorm, sizeof(norms), hipMemcpyDeviceToHost, st));
+        ROBO_HIP_CHECK(hipStreamSynchronize(st));
+        gp->winv_cond = norms[0] * norms[1];         // NaN (a broken W) compares false against every bound
         gp->winv_gen = gp->fit_gen;
     }
     return ROBO_OK;

@@ -6,6 +6,13 @@ MU_RTOL, MU_ATOL = 1e-9, 1e-10        # mean: relative to |mu|, floor relative t
 VAR_ATOL_REL_AMP = 1e-8               # variance: absolute, in units of k(x,x)
 LOGLIK_RTOL = 1e-10
 ACQ_RTOL = 1e-7                       # acquisition values computed from GPU (mu, var)
+# Mixed precision (BASELINE config 5: fp32 covariance ENTRIES, fp64 Cholesky / solve) against the ALL-fp64 oracle at
+# N=8192, D=64, sigma^2 = 1e-3.  An fp32 entry perturbs K by <= 6e-8 |k|; through K^-1 (cond ~ 1e3 N) that moves the mean
+# by ~1e-4..1e-3 of the O(1) targets and the variance by ~1e-7 k(x,x).  Measured on the MI355X (every round since r02):
+# max|dmu| 3.82e-4, max|dvar| 1.74e-7, log-likelihood 2.5e-6 relative.  The contract, with head-room for other inputs:
+MIXED_MU_ATOL = 2e-3
+MIXED_VAR_ATOL = 1e-6
+MIXED_LOGLIK_RTOL = 1e-5
 
 
 def assert_logei_close(actual, desired, z, rtol=1e-12, tail_rtol=1e-8):

@@ -199,6 +199,8 @@ static inline double __ddiv_rn(double a, double b) { volatile double r = a / b; 
 static inline int __ffsll(long long x) { return __builtin_ffsll(x); }
 static inline int __builtin_amdgcn_readlane(int v, int lane) { return hipemu::shfl_any(v, lane); }
 static inline int __double2loint(double x) { uint64_t u; std::memcpy(&u, &x, 8); return (int)(uint32_t)u; }
+static inline long long __double_as_longlong(double x) { long long u; std::memcpy(&u, &x, 8); return u; }
+static inline double __longlong_as_double(long long u) { double x; std::memcpy(&x, &u, 8); return x; }
 static inline int __double2hiint(double x) { uint64_t u; std::memcpy(&u, &x, 8); return (int)(uint32_t)(u >> 32); }
 static inline double __hiloint2double(int hi, int lo) {
     uint64_t u = ((uint64_t)(uint32_t)hi << 32) | (uint32_t)lo; double x; std::memcpy(&x, &u, 8); return x;

@@ -1101,21 +1101,108 @@ def check_winv_path(ctx, cases=(("matern52", 300, 5, 700), ("fabolas", 280, 4, 1
             np.testing.assert_allclose(var2, v2o, rtol=0, atol=VAR_ATOL_REL_AMP * amp)
             cand.close()
             g.close()
-        # conditioning guard: noise 1e-10 on a dense 1-d design -> diagonal ratio beyond the bound -> substitution
+        # conditioning guard: noise 1e-11 on a dense 1-d design -> cond_inf(L) beyond the bound -> substitution
         X = rs.rand(300, 1)
         y = np.sin(4 * X.sum(axis=1))
-        theta = np.array([0.0, np.log(0.3 ** 2), np.log(1e-10)])
+        theta = np.array([0.0, np.log(0.3 ** 2), np.log(1e-11)])
         g = _lib.DeviceGP(ctx, "matern52", 300, 1)
         g.set_data(X, y)
         g.fit(theta, float(y.mean()))
         cand = _lib.Candidates(ctx, rs.rand(100, 1))
         g.predict(cand)
-        assert cand.solve_kernel() != "winv_gemm_kernel", cand.solve_kernel()
+        assert cand.solve_kernel() != "winv_gemm_kernel", (cand.solve_kernel(), g.factor_cond())
         cand.close()
         g.close()
     finally:
         for key in ("winv_min_blocks", "winv_max", "ws_bytes"):
             ctx.set_tuning(key, None)
+
+
+def check_winv_guard_sweep(ctx, n=768, min_blocks=None, m=400, verbose=True,
+                           sweep=((2, (1e-3, 1e-5, 1e-7, 1e-9)), (1, (1e-7, 1e-9, 1e-10, 1e-11, 1e-12)))):
+    """The guard of the explicit-inverse posterior (api.hip decide_winv): cond_inf(L) = |L|_inf |W|_inf, exact, measured when
+    W = L^-1 is built.  Sweep noise x {uniform, clustered-near-incumbent} designs (2-d: the review's noise range; dense
+    1-d designs reach the bound):
+      * robo_gp_factor_cond equals NumPy's |L|_inf |L^-1|_inf of the factor read back;
+      * whichever path the guard picks meets tests/_tol.py against the oracle (mean 1e-10 + 1e-9 |mu|, variance
+        1e-8 k(x,x));
+      * the substitution is chosen BEFORE the explicit inverse would miss that tolerance: wherever the forced explicit
+        inverse misses it, the guard had picked the substitution;
+      * beyond the bound the chosen path is the substitution and its result is the forced substitution's, bit for bit.
+    Returns the table (design, noise, cond, chosen kernel, errors of the forced paths)."""
+    rs = np.random.RandomState(20)
+    if min_blocks is not None:
+        ctx.set_tuning("winv_min_blocks", min_blocks)
+    table = []
+    try:
+        for D, noises in sweep:
+            inc = rs.rand(D)
+            designs = {"uniform": rs.rand(n, D),
+                       # a quarter space-filling, the rest a cloud around the incumbent (what a BO run's data look like
+                       # after RandomSampling's N(incumbent, 0.1) candidates converged: random_sampling.py:43-47)
+                       "clustered": np.vstack([rs.rand(n // 4, D), np.clip(inc + 0.02 * rs.randn(n - n // 4, D), 0, 1)])}
+            for name, X in designs.items():
+                y = np.sin(3 * X.sum(axis=1))
+                c = float(y.mean())
+                Xs = np.vstack([rs.rand(m // 2, D), np.clip(X[-(m // 2):] + 0.01 * rs.randn(m // 2, D), 0, 1)])
+                for noise in noises:
+                    theta = np.concatenate([[0.0], np.full(D, np.log(0.25 * D)), [np.log(noise)]])
+                    g = _lib.DeviceGP(ctx, "matern52", n, D)
+                    g.set_data(X, y)
+                    g.fit(theta, c)
+                    L = O.gp_compute("matern52", theta, X)
+                    mu_o, var_o = O.gp_predict_diag("matern52", theta, L, X, y, c, Xs)
+                    cond, dmin, dmax = g.factor_cond()
+                    Ld = g.factor()
+                    cond_np = np.abs(Ld).sum(axis=1).max() * np.abs(np.linalg.inv(Ld)).sum(axis=1).max()
+                    np.testing.assert_allclose(cond, cond_np, rtol=1e-6)
+                    assert dmax / dmin <= cond                       # the diagonal ratio only bounds it from below
+                    tol_mu = MU_ATOL + MU_RTOL * np.abs(mu_o)
+                    tol_var = VAR_ATOL_REL_AMP * np.exp(theta[0])
+                    res = {}
+                    for path, (key, val) in (("chosen", (None, None)), ("inverse", ("winv_cond_max", 9 * 10 ** 18)),
+                                             ("substitution", ("winv_max", 0))):
+                        if key:
+                            ctx.set_tuning(key, val)
+                        try:
+                            cand = _lib.Candidates(ctx, Xs)
+                            mu, var = g.predict(cand)
+                            res[path] = (cand.solve_kernel(), mu, var, bool(np.all(np.abs(mu - mu_o) <= tol_mu) and
+                                                                             np.all(np.abs(var - var_o) <= tol_var)))
+                            cand.close()
+                        finally:
+                            if key:
+                                ctx.set_tuning(key, None)
+                    assert res["inverse"][0] == "winv_gemm_kernel" and res["substitution"][0] != "winv_gemm_kernel"
+                    kern, mu, var, ok = res["chosen"]
+                    row = (name, D, noise, cond, kern, float(np.abs(res["inverse"][1] - mu_o).max()),
+                           float(np.abs(res["substitution"][1] - mu_o).max()),
+                           float(np.abs(res["inverse"][2] - var_o).max()),
+                           float(np.abs(res["substitution"][2] - var_o).max()))
+                    table.append(row)
+                    if verbose:
+                        print("guard sweep %-9s D=%d noise %.0e cond_inf %.3g -> %-22s |dmu| inverse %.1e substitution %.1e"
+                              "  |dvar| %.1e / %.1e" % row)
+                    if kern == "winv_gemm_kernel":
+                        assert cond <= 1.0e5 and ok, row             # inside the bound AND inside the tolerance
+                        np.testing.assert_array_equal(mu, res["inverse"][1])
+                    else:
+                        assert cond > 1.0e5, row
+                        np.testing.assert_array_equal(mu, res["substitution"][1])
+                        np.testing.assert_array_equal(var, res["substitution"][2])
+                        # beyond the bound the problem's own conditioning is what is left (the factorisation's error,
+                        # shared by every path): the substitution stays within 10x the stated tolerance at cond 1e7
+                        assert np.all(np.abs(mu - mu_o) <= 10 * tol_mu) and np.all(np.abs(var - var_o) <= tol_var), row
+                    if not res["inverse"][3]:
+                        # the explicit inverse would have missed the stated tolerance here: the guard must not pick it
+                        assert kern != "winv_gemm_kernel", row
+                    g.close()
+    finally:
+        if min_blocks is not None:
+            ctx.set_tuning("winv_min_blocks", None)
+    # the sweep must actually exercise both sides of the bound
+    assert any(r[4] == "winv_gemm_kernel" for r in table) and any(r[4] != "winv_gemm_kernel" for r in table)
+    return table
 
 
 def check_gram_variants(ctx, cases=(("matern52", 300, 5), ("rbf", 200, 3))):

@@ -8,7 +8,8 @@ import numpy as np
 import pytest
 
 import parity_checks as P
-from _tol import LOGLIK_RTOL, MU_ATOL, MU_RTOL, VAR_ATOL_REL_AMP
+from _tol import (LOGLIK_RTOL, MIXED_LOGLIK_RTOL, MIXED_MU_ATOL, MIXED_VAR_ATOL, MU_ATOL, MU_RTOL,
+                  VAR_ATOL_REL_AMP)
 from oracle import gp_oracle as O
 from robo_amd import _lib
 
@@ -163,8 +164,8 @@ def _headline_inputs(N, D, M):
 
 
 def test_headline_size_against_oracle(ctx):
-    """N=4096, D=16 (BASELINE headline): fit + 65 536-candidate EI on the GPU; the oracle
-    evaluates a 4096-candidate slice in full and re-scores the GPU's top candidates."""
+    """N=4096, D=16 (BASELINE headline): fit + 65 536-candidate EI on the GPU against the oracle on ALL 65 536
+    candidates (mean, variance, EI, argmax) -- ~20 s of host BLAS at the box's diag-only rate."""
     N, D, M = 4096, 16, 65536
     X, y, theta, Xc = _headline_inputs(N, D, M)
     g = _lib.DeviceGP(ctx, "matern52", N, D)
@@ -177,17 +178,18 @@ def test_headline_size_against_oracle(ctx):
     cand = _lib.Candidates(ctx, Xc)
     vals, mx, am, flags = g.acq("ei", 0.0, eta, cand)
     mu, var = g.predict(cand)
-    sl = slice(0, 4096)
-    mo, vo = ogp.predict(Xc[sl], diag_only=True)
-    np.testing.assert_allclose(mu[sl], mo, rtol=MU_RTOL, atol=MU_ATOL)
-    np.testing.assert_allclose(var[sl], vo, rtol=0, atol=VAR_ATOL_REL_AMP)
-    np.testing.assert_allclose(vals[sl], O.ei(mo, vo, eta), rtol=1e-6, atol=1e-12)
-    # argmax: the oracle re-scores the GPU's 64 best candidates; its winner must be the GPU's
-    top = np.argsort(-vals)[:64]
-    mo, vo = ogp.predict(Xc[top], diag_only=True)
+    mo, vo = np.empty(M), np.empty(M)
+    for c0 in range(0, M, 4096):
+        mo[c0:c0 + 4096], vo[c0:c0 + 4096] = ogp.predict(Xc[c0:c0 + 4096], diag_only=True)
+    np.testing.assert_allclose(mu, mo, rtol=MU_RTOL, atol=MU_ATOL)
+    np.testing.assert_allclose(var, vo, rtol=0, atol=VAR_ATOL_REL_AMP)
     eo = O.ei(mo, vo, eta)
-    assert am == int(np.argmax(vals))
-    assert top[int(np.argmax(eo))] == am or abs(eo.max() - eo[list(top).index(am)]) <= 1e-7 * eo.max()
+    np.testing.assert_allclose(vals, eo, rtol=1e-6, atol=1e-12)
+    # argmax index identical to the oracle's over the whole batch (and to np.argmax of the device's own values)
+    assert am == int(np.argmax(vals)) == int(np.argmax(eo))
+    assert mx == vals[am]
+    print("headline parity over all %d candidates: max|dmu|=%.2e max|dvar|=%.2e max rel dEI=%.2e" % (
+        M, np.abs(mu - mo).max(), np.abs(var - vo).max(), np.max(np.abs(vals - eo) / np.maximum(np.abs(eo), 1e-300))))
     cand.close()
     g.close()
 
@@ -339,11 +341,20 @@ def test_config5_mixed_precision_lcb(ctx):
     assert best_o == am or abs(lo.max() - lo[list(sl).index(am)]) < 1e-2
     o64 = O.OracleGP("matern52", theta, lower=np.zeros(D), upper=np.ones(D))
     o64.train(X, y)
-    m64, v64 = o64.predict(Xc[:256], diag_only=True)
+    # the mixed-precision posterior against the ALL-fp64 oracle: a stated contract (tests/_tol.py), asserted on the
+    # first / last 256 candidates and the device's 64 best
+    m64, v64 = o64.predict(Xc[sl], diag_only=True)
+    ll64 = o64.loglikelihood(theta)
     print("config5: fit %.1f ms, %d-candidate LCB %.1f ms in passes of %d; mixed-precision error vs fp64 oracle: "
           "max|dmu|=%.2e max|dvar|=%.2e (loglik %.6g vs fp64 %.6g)" %
-          (t_fit * 1e3, M, t_acq * 1e3, cand.chunk(), np.abs(mu[:256] - m64).max(), np.abs(var[:256] - v64).max(), ll,
-           o64.loglikelihood(theta)))
+          (t_fit * 1e3, M, t_acq * 1e3, cand.chunk(), np.abs(mu[sl] - m64).max(), np.abs(var[sl] - v64).max(), ll, ll64))
+    np.testing.assert_allclose(mu[sl], m64, rtol=0, atol=MIXED_MU_ATOL)
+    np.testing.assert_allclose(var[sl], v64, rtol=0, atol=MIXED_VAR_ATOL)
+    np.testing.assert_allclose(ll, ll64, rtol=MIXED_LOGLIK_RTOL)
+    # the all-fp64 oracle's LCB winner among these candidates is the device's, or ties with it inside the mixed-
+    # precision bound on the mean
+    l64 = O.lcb(m64, v64)
+    assert sl[int(np.argmax(l64))] == am or l64.max() - l64[list(sl).index(am)] <= 2 * MIXED_MU_ATOL
     cand.close()
     g.close()
 
@@ -423,6 +434,12 @@ def test_winv_small_batch_path(ctx):
     substitution, chunk invariance, V consumers, refit, conditioning guard -- incl. the headline factor"""
     P.check_winv_path(ctx)
     P.check_winv_path(ctx, cases=(("matern52", 4096, 16, 500), ("matern52", 2000, 8, 8192)))
+
+
+def test_winv_condition_guard_sweep(ctx):
+    """noise 1e-3 .. 1e-12 x {uniform, clustered-near-incumbent} designs: the exact cond_inf(L) guard picks the
+    substitution before the explicit inverse would miss tests/_tol.py"""
+    P.check_winv_guard_sweep(ctx)
 
 
 def test_gram_kernel_variants(ctx):
