@@ -847,14 +847,18 @@ def run_c4(args, D_, _lib, sharding):
     ctx.set_phase_events(True)          # batches <= 16384 record the solve's event pair only on request
 
     def step():
-        ig, _, _ = _lib.ig_eval(gp, cand, rep, ep, sn2)            # posterior + cross-covariances + entropy change
-        log_cost, _ = gc.predict(cand_cost)
-        val = ig / np.exp(log_cost)                                # information gain per unit cost
-        j = int(np.argmax(val))
+        # posterior + cross-covariances + entropy change, the cost model's posterior, dH / (exp(log cost) + overhead) and
+        # the argmax in ONE library call (robo_ig_eval_per_cost_cand); sharded: + the 32-byte all-gather of the per-rank
+        # incumbents and the cross-rank tie-break on the device
         if comm is None:
-            return float(val[j]), j
-        rows = comm.allgather([float(val[j]), float(j + offset)])       # 16 bytes per rank
-        return sharding.reduce_argmax((float(r[0]), int(r[1])) for r in rows)
+            _, mx, am = _lib.ig_eval_per_cost(gp, cand, rep, ep, sn2, gc, cand_cost, 0.0, want_values=False)
+        elif isinstance(comm, TorchExchange):
+            _, mx, am = _lib.ig_eval_per_cost(gp, cand, rep, ep, sn2, gc, cand_cost, 0.0, want_values=False)
+            rows = comm.allgather([float(mx), float(am + offset)])
+            mx, am = sharding.reduce_argmax((float(r[0]), int(r[1])) for r in rows)
+        else:
+            _, mx, am, _ = comm.ig_per_cost_sharded(gp, cand, rep, ep, sn2, gc, cand_cost, 0.0, offset)
+        return float(mx), int(am)
 
     elapsed, best, trsm_ms = timed_steps(D_, ctx, step, args.steps, args.warmup)
     clock = clock_during_step(D_, ctx, step, elapsed / args.steps * 1e3)  # every rank: the step holds a collective

@@ -138,7 +138,10 @@ int32_t robo_gp_loglik_batch(robo_gp* gp, const double* thetas, int32_t S, doubl
  * sequence of launches, no host round trip between half-steps.  lnprob(theta) = log p(y | X, theta) + log prior(theta)
  * with the reference's protocol (:185-202: any |theta_p| > 20, or a factorisation that fails -> -inf).
  * prior_kind 0 = none, 1 = robo.priors.default_priors.DefaultPrior with prior_par = {lognormal loc, lognormal sigma,
- * tophat min, tophat max, horseshoe scale}.  The random numbers of a stretch-move chain do not depend on its state: the
+ * tophat min, tophat max, horseshoe scale}, 2 = robo.priors.env_priors.EnvPrior (robo/priors/env_priors.py:8-54, the prior
+ * robo/fmin/fabolas.py:120-127 gives FabolasGPMCMC, robo/models/fabolas_gp.py:49-77) with prior_par = {those five, n_ls,
+ * n_lr, normal mean, normal sigma}: tophat on theta[1 .. n_ls] only, plus NormalPrior.lnprob -- a pdf, as in the
+ * reference (robo/priors/base_prior.py:357) -- of each of the n_lr regression parameters behind them.  The random numbers of a stretch-move chain do not depend on its state: the
  * caller draws them in emcee 2's order -- per step and half-ensemble rand(k/2) for z, randint(k/2) for the partners,
  * rand(k/2) for the accept test -- into u_stretch / partner / u_accept, each [n_steps][2][k/2].
  * pos (k x P) and lnp (k): in = start positions (lnp evaluated here when eval_start != 0), out = final state;
@@ -269,6 +272,18 @@ int32_t robo_ig_eval_cand(robo_gp* gp, robo_cand* cand, robo_cand* rep, int32_t 
                           const double* logP, const double* lmb, const double* W, const double* dlogPdMu,
                           const double* dlogPdSigma, const double* dlogPdMudMu, double* out_dh, double* out_max,
                           int64_t* out_argmax);
+/* Information gain PER UNIT COST with its argmax on the device: replaces InformationGainPerUnitCost.compute
+ * (robo/acquisition_functions/information_gain_per_unit_cost.py:91-104)
+ *     log_cost = self.cost_model.predict(X)[0];  dh = InformationGain.compute(X);  dh / (np.exp(log_cost) + overhead)
+ * and the maximiser's argmax over it (robo/maximizers/random_sampling.py:48-50).  cost_gp: the fitted cost model;
+ * cost_cand: the SAME m candidates in the cost model's input space (Fabolas: linear basis on the fidelity column where
+ * the objective model has (1 - s)^2, robo/fmin/fabolas.py:130-131), a second handle on the same context.
+ * out_values (m,) nullable; out_max / out_argmax as robo_acq_eval.                                               */
+int32_t robo_ig_eval_per_cost_cand(robo_gp* gp, robo_cand* cand, robo_cand* rep, int32_t n_outcomes, double sn2,
+                                   const double* logP, const double* lmb, const double* W, const double* dlogPdMu,
+                                   const double* dlogPdSigma, const double* dlogPdMudMu, robo_gp* cost_gp,
+                                   robo_cand* cost_cand, double overhead, double* out_values, double* out_max,
+                                   int64_t* out_argmax);
 /* the same from innovations inputs supplied by any other model: s (m, nb) covariances between each
  * candidate and the representer points, v (m,) predictive variances                              */
 int32_t robo_ig_eval_moments(robo_ctx* ctx, int64_t m, int32_t nb, int32_t n_outcomes, double sn2, const double* s,
@@ -299,12 +314,20 @@ int32_t robo_comm_info(robo_comm* comm, int32_t* out_rank, int32_t* out_world);
  * device-generated shard, consistency checks, timings -- the few-hundred-byte side channel                         */
 int32_t robo_comm_allgather(robo_comm* comm, const double* send, int64_t count, double* recv);
 /* candidate shard: robo_acq_eval_cand on this rank's candidates (global index of candidate c = global_offset + c),
- * then the all-gather of the per-rank incumbents (24 B per rank) and np.argmax's tie-break across them on the device.
+ * then the all-gather of the per-rank incumbents (32 B per rank: max, index, flags, status) and np.argmax's tie-break across them on the device.
  * out_max / out_argmax: the GLOBAL maximum and its global index, identical on every rank; out_owner_rank: the rank
  * whose shard holds it; out_flags: OR over all ranks; out_acq (nullable): this rank's m values.                    */
 int32_t robo_acq_eval_cand_sharded(robo_comm* comm, robo_gp* gp, int32_t acq_kind, double par, double eta,
                                    robo_cand* cand, int64_t global_offset, double* out_acq, double* out_max,
                                    int64_t* out_argmax, int32_t* out_owner_rank, uint32_t* out_flags);
+/* candidate shard of the information gain per unit cost (BASELINE config 4: 65 536 candidates over 8 GPUs):
+ * robo_ig_eval_per_cost_cand on this rank's candidates, then the same exchange as robo_acq_eval_cand_sharded.     */
+int32_t robo_ig_eval_per_cost_cand_sharded(robo_comm* comm, robo_gp* gp, robo_cand* cand, robo_cand* rep,
+                                           int32_t n_outcomes, double sn2, const double* logP, const double* lmb,
+                                           const double* W, const double* dlogPdMu, const double* dlogPdSigma,
+                                           const double* dlogPdMudMu, robo_gp* cost_gp, robo_cand* cost_cand,
+                                           double overhead, int64_t global_offset, double* out_values, double* out_max,
+                                           int64_t* out_argmax, int32_t* out_owner_rank);
 /* sample shard: this rank's S_local fitted GPs (S_total over all ranks; S_local may be 0) on ALL candidates; the
  * per-rank partial sums are all-gathered (m doubles per rank) and added in rank order on the device, divided by
  * S_total, argmax.  Outputs as robo_acq_eval_marginal_cand, identical on every rank; equal to the single-process

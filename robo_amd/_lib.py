@@ -35,9 +35,9 @@ SYMBOLS = [
     "robo_cand_create_random", "robo_cand_create_sobol", "robo_cand_get_point", "robo_cand_workspace_chunk", "robo_cand_last_solve_kernel",
     "robo_gp_predict_cand", "robo_gp_predict", "robo_gp_predict_cov", "robo_gp_predict_grad", "robo_gp_predict_mixture_cand",
     "robo_acq_eval_cand", "robo_acq_eval", "robo_acq_eval_moments", "robo_acq_eval_marginal_cand", "robo_acq_eval_sum_cand",
-    "robo_ig_eval_cand", "robo_ig_eval_moments", "robo_gp_cross_cov",
+    "robo_ig_eval_cand", "robo_ig_eval_per_cost_cand", "robo_ig_eval_moments", "robo_gp_cross_cov",
     "robo_comm_create_id", "robo_comm_init", "robo_comm_destroy", "robo_comm_info", "robo_comm_allgather",
-    "robo_acq_eval_cand_sharded", "robo_acq_eval_marginal_cand_sharded",
+    "robo_acq_eval_cand_sharded", "robo_acq_eval_marginal_cand_sharded", "robo_ig_eval_per_cost_cand_sharded",
 ]
 COMM_ID_BYTES = 128
 # include/robo_hip_diag.h (librobo_hip_diag.so: tests, bench.py's roofline block, tools/)
@@ -153,6 +153,10 @@ def lib():
                                         C.POINTER(C.c_uint32)],
         "robo_acq_eval_sum_cand": [pp, i32, i32, dbl, _dp, vp, _dp, C.POINTER(C.c_uint32)],
         "robo_ig_eval_cand": [vp, vp, vp, i32, dbl, _dp, _dp, _dp, _dp, _dp, _dp, _dp, _dp, C.POINTER(i64)],
+        "robo_ig_eval_per_cost_cand": [vp, vp, vp, i32, dbl, _dp, _dp, _dp, _dp, _dp, _dp, vp, vp, dbl, _dp, _dp,
+                                       C.POINTER(i64)],
+        "robo_ig_eval_per_cost_cand_sharded": [vp, vp, vp, vp, i32, dbl, _dp, _dp, _dp, _dp, _dp, _dp, vp, vp, dbl, i64,
+                                               _dp, _dp, C.POINTER(i64), C.POINTER(i32)],
         "robo_ig_eval_moments": [vp, i64, i32, i32, dbl, _dp, _dp, _dp, _dp, _dp, _dp, _dp, _dp, _dp],
         "robo_gp_cross_cov": [vp, vp, vp, _dp],
         "robo_comm_create_id": [C.c_char_p],
@@ -479,7 +483,8 @@ class DeviceGP(object):
         return ll, st
 
     def mcmc_run(self, mean_c, prior, pos, lnp, n_steps, u_stretch, partner, u_accept, a=2.0):
-        """emcee 2's EnsembleSampler.run_mcmc on the device (robo_gp_mcmc_run): prior = None or (kind, 5 parameters);
+        """emcee 2's EnsembleSampler.run_mcmc on the device (robo_gp_mcmc_run): prior = None, (1, 5 parameters) DefaultPrior or
+        (2, 9 parameters) EnvPrior;
         lnp None = evaluate the start positions.  -> (pos, lnp, chain (k, n_steps, P), lnprob (k, n_steps), accepted (k))"""
         pos = np.array(pos, dtype=np.float64, order="C")
         k = pos.shape[0]
@@ -494,7 +499,14 @@ class DeviceGP(object):
         chain = np.empty((k, n_steps, self.n_theta))
         lnps = np.empty((k, n_steps))
         acc = np.zeros(k, dtype=np.int64)
-        kind, par = (0, np.zeros(5)) if prior is None else (int(prior[0]), _f64(prior[1], (5,)))
+        if prior is None:
+            kind, par = 0, np.zeros(9)
+        else:                                    # (kind, 5 parameters) DefaultPrior / (kind, 9 parameters) EnvPrior
+            kind = int(prior[0])
+            par = np.zeros(9)
+            given = _f64(prior[1]).reshape(-1)
+            assert given.size == (9 if kind == 2 else 5)
+            par[:given.size] = given
         check(lib().robo_gp_mcmc_run(self._h, float(mean_c), kind, _arr(par), k, n_steps, float(a), _arr(uz),
                                      pa.ctypes.data_as(C.POINTER(C.c_int32)), _arr(ua), int(eval_start), _arr(pos),
                                      _arr(lnp), _arr(chain), _arr(lnps), acc.ctypes.data_as(C.POINTER(C.c_int64))))
@@ -614,6 +626,19 @@ class Comm(object):
                                                C.byref(am), C.byref(own), C.byref(fl)))
         return out, mx.value, am.value, own.value, fl.value
 
+    def ig_per_cost_sharded(self, gp, cand, rep, ep, sn2, cost_gp, cost_cand, overhead, global_offset,
+                            want_values=False):
+        """candidate shard of the information gain per unit cost -> (this rank's values or None, GLOBAL max, GLOBAL
+        argmax, owner rank)"""
+        assert rep.m == ep.nb and cost_cand.m == cand.m
+        out = np.empty(cand.m) if want_values else None
+        mx, am, own = C.c_double(0), C.c_int64(0), C.c_int32(0)
+        check(lib().robo_ig_eval_per_cost_cand_sharded(self._h, gp._h, cand._h, rep._h, ep.W.size, float(sn2),
+                                                       *ep.args(), cost_gp._h, cost_cand._h, float(overhead),
+                                                       int(global_offset), _arr(out) if want_values else None,
+                                                       C.byref(mx), C.byref(am), C.byref(own)))
+        return out, mx.value, am.value, own.value
+
     def acq_marginal_sharded(self, gps, s_total, kind, par, etas, cand, want_values=True):
         """sample shard: this rank's fitted GPs (possibly none) -> (mean over ALL s_total samples or None, max,
         argmax, flags), identical on every rank"""
@@ -687,6 +712,18 @@ def ig_eval(gp, cand, rep, ep, sn2, want_values=True):
     mx, am = C.c_double(0), C.c_int64(0)
     check(lib().robo_ig_eval_cand(gp._h, cand._h, rep._h, ep.W.size, float(sn2), *ep.args(),
                                   _arr(out) if want_values else None, C.byref(mx), C.byref(am)))
+    return out, mx.value, am.value
+
+
+def ig_eval_per_cost(gp, cand, rep, ep, sn2, cost_gp, cost_cand, overhead=0.0, want_values=True):
+    """information gain per unit cost of every candidate, dH / (exp(cost mean) + overhead), and its argmax, in one
+    library call -> (values or None, max, argmax)"""
+    assert rep.m == ep.nb and cost_cand.m == cand.m
+    out = np.empty(cand.m) if want_values else None
+    mx, am = C.c_double(0), C.c_int64(0)
+    check(lib().robo_ig_eval_per_cost_cand(gp._h, cand._h, rep._h, ep.W.size, float(sn2), *ep.args(), cost_gp._h,
+                                           cost_cand._h, float(overhead), _arr(out) if want_values else None,
+                                           C.byref(mx), C.byref(am)))
     return out, mx.value, am.value
 
 

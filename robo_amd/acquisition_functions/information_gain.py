@@ -55,6 +55,11 @@ class InformationGain(BaseAcquisitionFunction):
         self.Np = Np
         self.rng = np.random.RandomState(np.random.randint(0, 10000)) if rng is None else rng
         self._ep = None
+        # candidate shard over GPUs (explicit opt-in, like RandomSampling.shard): the representer points come from an
+        # ensemble sampler whose stream -- as in the reference, where emcee ignores the RandomState object handed to it
+        # (information_gain.py:139-142) -- is seeded from OS entropy, i.e. differs from rank to rank; with shard = True
+        # update() adopts rank 0's points on every rank, so that all shards are scored against ONE p_min
+        self.shard = False
 
     # ---- representer points ------------------------------------------------------------------
     def sampling_acquisition_wrapper(self, x):
@@ -90,6 +95,12 @@ class InformationGain(BaseAcquisitionFunction):
         self.model = model
         self.sn2 = self.model.get_noise()
         self.sample_representer_points()
+        if self.shard:
+            from robo_amd import sharding
+            if sharding.dist_info()[2] > 1:
+                zb, lmb = np.asarray(self.zb, dtype=np.float64), np.asarray(self.lmb, dtype=np.float64)
+                row0 = sharding.allgather_rows(np.concatenate([zb.ravel(), lmb.ravel()]))[0]
+                self.zb, self.lmb = row0[:zb.size].reshape(zb.shape), row0[zb.size:].reshape(lmb.shape)
         mu, var = self.model.predict(np.array(self.zb), full_cov=True)
         self.logP, self.dlogPdMu, self.dlogPdSigma, self.dlogPdMudMu = epmgp.joint_min(mu, var,
                                                                                        with_derivatives=True)

@@ -527,9 +527,19 @@ int32_t robo_gp_mcmc_run(robo_gp* g, double mean_c, int32_t prior_kind, const do
                          double* out_lnprob, int64_t* out_accepted) {
     if (!g || !pos || !lnp || n_walkers < 2 || (n_walkers & 1) || n_steps < 0 || !(a > 1.0)) return ROBO_BAD_ARGUMENT;
     if (n_steps > 0 && (!u_stretch || !partner || !u_accept)) return ROBO_BAD_ARGUMENT;
-    if (prior_kind != 0 && (prior_kind != 1 || !prior_par)) {
-        set_error("robo_gp_mcmc_run: prior kind %d (0 = none, 1 = DefaultPrior)", prior_kind);
+    if (prior_kind != 0 && ((prior_kind != 1 && prior_kind != 2) || !prior_par)) {
+        set_error("robo_gp_mcmc_run: prior kind %d (0 = none, 1 = DefaultPrior, 2 = EnvPrior)", prior_kind);
         return ROBO_BAD_ARGUMENT;
+    }
+    if (prior_kind == 2) {
+        const int P_ = robo_theta_size(g ? g->kind : 0, g ? g->dim : 1);
+        const double n_ls = prior_par[5], n_lr = prior_par[6];
+        if (!(n_ls >= 0 && n_lr >= 0 && n_ls == (double)(int)n_ls && n_lr == (double)(int)n_lr &&
+              1 + (int)n_ls + (int)n_lr <= P_ - 1) || !(prior_par[8] > 0.0)) {
+            set_error("robo_gp_mcmc_run: EnvPrior with n_ls=%g n_lr=%g sigma=%g does not fit %d hyper-parameters", n_ls,
+                      n_lr, prior_par[8], P_);
+            return ROBO_BAD_ARGUMENT;
+        }
     }
     if (!g->has_data) {
         set_error("robo_gp_mcmc_run before robo_gp_set_data");
@@ -579,7 +589,7 @@ int32_t robo_gp_mcmc_run(robo_gp* g, double mean_c, int32_t prior_kind, const do
     st.d_uz = d_uz; st.d_ua = d_ua; st.d_partner = d_partner;
     st.k = k; st.P = P; st.D = D; st.kind = g->kind; st.n = g->n; st.n_steps = n_steps; st.ns_eval = half;
     st.prior_kind = prior_kind; st.a = a; st.mean_c = mean_c;
-    if (prior_kind == 1) for (int i = 0; i < 5; ++i) st.prior_par[i] = prior_par[i];
+    if (prior_kind != 0) for (int i = 0; i < (prior_kind == 2 ? 9 : 5); ++i) st.prior_par[i] = prior_par[i];
     st.d_sp = g->d_bsp; st.d_ism = g->d_bism; st.d_out = g->d_bout; st.d_fail = g->d_bfail;
     hipStream_t s = c->stream;
     ROBO_HIP_CHECK(hipMemcpyAsync(st.d_pos, pos, (size_t)k * P * sizeof(double), hipMemcpyHostToDevice, s));
@@ -1433,9 +1443,10 @@ int32_t robo_gp_cross_cov(robo_gp* g, robo_cand* k, robo_cand* rep, double* out_
     return ROBO_OK;
 }
 
-int32_t robo_ig_eval_cand(robo_gp* g, robo_cand* k, robo_cand* rep, int32_t npts, double sn2, const double* logP,
-                          const double* lmb, const double* W, const double* dlogPdMu, const double* dlogPdSigma,
-                          const double* dlogPdMudMu, double* out_dh, double* out_max, int64_t* out_argmax) {
+// dH of every candidate of k into k->d_acq_sum (asynchronous)
+static int ig_core(robo_gp* g, robo_cand* k, robo_cand* rep, int32_t npts, double sn2, const double* logP,
+                   const double* lmb, const double* W, const double* dlogPdMu, const double* dlogPdSigma,
+                   const double* dlogPdMudMu) {
     if (!g || !k || !rep || !logP || !lmb || !W || !dlogPdMu || !dlogPdSigma || !dlogPdMudMu) return ROBO_BAD_ARGUMENT;
     const int nb = (int)rep->m;
     ROBO_TRY(ig_check(nb, npts));
@@ -1457,8 +1468,41 @@ int32_t robo_ig_eval_cand(robo_gp* g, robo_cand* k, robo_cand* rep, int32_t npts
         ROBO_TRY(launch_ig_dh(g->ctx, k->d_S, k->d_var, k->d_F, k->d_Q, k->d_G, k->d_igc, c0, cn, k->m, nb, npts, kf,
                               sn2, H, k->d_acq_sum));
     }
+    return ROBO_OK;
+}
+
+// dH / (exp(log-cost mean) + overhead) of every candidate into k->d_acq (and the best of them into the argmax slots):
+// the local half of robo_ig_eval_per_cost_cand and of its sharded form (comm.hip)
+static int ig_per_cost_core(robo_gp* g, robo_cand* k, robo_cand* rep, int32_t npts, double sn2, const double* logP,
+                            const double* lmb, const double* W, const double* dlogPdMu, const double* dlogPdSigma,
+                            const double* dlogPdMudMu, robo_gp* cost_gp, robo_cand* cost_k, double overhead) {
+    if (!cost_gp || !cost_k || !k) return ROBO_BAD_ARGUMENT;
+    if (cost_k->m != k->m || cost_k->ctx != k->ctx || cost_gp->ctx != k->ctx || cost_k == k) {
+        set_error("information gain per unit cost: the cost model's candidate handle must hold the same %lld candidates "
+                  "(in the cost model's input space) on the same context", (long long)k->m);
+        return ROBO_BAD_SHAPE;
+    }
+    ROBO_TRY(ig_core(g, k, rep, npts, sn2, logP, lmb, W, dlogPdMu, dlogPdSigma, dlogPdMudMu));
+    ROBO_TRY(predict_core(cost_gp, cost_k, false));           // cost_k->d_mean: the cost model's (log-cost) mean
+    ROBO_TRY(launch_per_cost(k->ctx, k->d_acq_sum, cost_k->d_mean, overhead, k->m));
+    return launch_argmax(k, k->d_acq_sum, 1.0);
+}
+
+int32_t robo_ig_eval_cand(robo_gp* g, robo_cand* k, robo_cand* rep, int32_t npts, double sn2, const double* logP,
+                          const double* lmb, const double* W, const double* dlogPdMu, const double* dlogPdSigma,
+                          const double* dlogPdMudMu, double* out_dh, double* out_max, int64_t* out_argmax) {
+    ROBO_TRY(ig_core(g, k, rep, npts, sn2, logP, lmb, W, dlogPdMu, dlogPdSigma, dlogPdMudMu));
     ROBO_TRY(launch_argmax(k, k->d_acq_sum, 1.0));
     return acq_read_back(k, k->d_acq, out_dh, out_max, out_argmax, nullptr);
+}
+
+int32_t robo_ig_eval_per_cost_cand(robo_gp* g, robo_cand* k, robo_cand* rep, int32_t npts, double sn2, const double* logP,
+                                   const double* lmb, const double* W, const double* dlogPdMu, const double* dlogPdSigma,
+                                   const double* dlogPdMudMu, robo_gp* cost_gp, robo_cand* cost_k, double overhead,
+                                   double* out_values, double* out_max, int64_t* out_argmax) {
+    ROBO_TRY(ig_per_cost_core(g, k, rep, npts, sn2, logP, lmb, W, dlogPdMu, dlogPdSigma, dlogPdMudMu, cost_gp, cost_k,
+                              overhead));
+    return acq_read_back(k, k->d_acq, out_values, out_max, out_argmax, nullptr);
 }
 
 int32_t robo_ig_eval_moments(robo_ctx* ctx, int64_t m, int32_t nb, int32_t npts, double sn2, const double* s,
@@ -1506,6 +1550,11 @@ int api_acq_local(robo_gp* g, int kind, double par, double eta, robo_cand* k) {
     ROBO_TRY(check_acq_kind(kind));
     ROBO_TRY(predict_core(g, k, false));
     return clear_flags_on_error(k, launch_acq(g->ctx, k, kind, par, eta, false, false));
+}
+int api_ig_per_cost_local(robo_gp* g, robo_cand* k, robo_cand* rep, int npts, double sn2, const double* const* ep,
+                          robo_gp* cost_gp, robo_cand* cost_k, double overhead) {
+    return clear_flags_on_error(k, ig_per_cost_core(g, k, rep, npts, sn2, ep[0], ep[1], ep[2], ep[3], ep[4], ep[5], cost_gp,
+                                                     cost_k, overhead));
 }
 int api_acq_accumulate(robo_gp* const* gps, int S, int kind, double par, const double* etas, robo_cand* k) {
     return acq_accumulate(gps, S, kind, par, etas, k);

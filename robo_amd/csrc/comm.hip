@@ -23,6 +23,8 @@ int api_acq_accumulate(robo_gp* const* gps, int S, int kind, double par, const d
 int api_acq_read_back(robo_cand* k, const double* d_vec, double* out_vec, double* out_max, int64_t* out_argmax,
                       uint32_t* out_flags);
 int api_clear_flags(robo_cand* k, int status);
+int api_ig_per_cost_local(robo_gp* g, robo_cand* k, robo_cand* rep, int npts, double sn2, const double* const* ep,
+                          robo_gp* cost_gp, robo_cand* cost_k, double overhead);
 
 // rccl.h, the five entry points used (signatures as in /opt/rocm/include/rccl/rccl.h:187,220,260,339,678)
 struct NcclId { char internal[ROBO_COMM_ID_BYTES]; };
@@ -280,18 +282,11 @@ int32_t robo_comm_allgather(robo_comm* c, const double* send, int64_t count, dou
     return ROBO_OK;
 }
 
-int32_t robo_acq_eval_cand_sharded(robo_comm* c, robo_gp* g, int32_t acq_kind, double par, double eta, robo_cand* k,
-                                   int64_t global_offset, double* out_acq, double* out_max, int64_t* out_argmax,
-                                   int32_t* out_owner_rank, uint32_t* out_flags) {
-    if (!c || !g || !k) return ROBO_BAD_ARGUMENT;
-    if (g->ctx != c->ctx || k->ctx != c->ctx) {
-        set_error("robo_acq_eval_cand_sharded: the GP, the candidates and the communicator must share one context");
-        return ROBO_BAD_ARGUMENT;
-    }
+// The exchange of a candidate shard: this rank's incumbent (left in the handle's argmax slots by the local half, whose
+// status is `status`) -> the global (max, argmax, owner, flags) on every rank.  No early return before the collective.
+static int exchange_best(robo_comm* c, robo_cand* k, int status, int64_t global_offset, const char* who, double* out_acq,
+                         double* out_max, int64_t* out_argmax, int32_t* out_owner_rank, uint32_t* out_flags) {
     hipStream_t st = c->ctx->stream;
-    ROBO_HIP_CHECK(hipSetDevice(c->ctx->device));
-    // no early return between here and the collective: a rank that left would leave the others waiting in it
-    int status = api_acq_local(g, acq_kind, par, eta, k);
     const bool ok = status == ROBO_OK;
     if (ok) {
         hipLaunchKernelGGL(comm_pack_best_kernel, dim3(1), dim3(64), 0, st, (const double*)(k->d_part_val + k->n_part),
@@ -316,7 +311,7 @@ int32_t robo_acq_eval_cand_sharded(robo_comm* c, robo_gp* g, int32_t acq_kind, d
         int bad[2];
         memcpy(bad, hp + 3, sizeof(bad));
         if (bad[0] != ROBO_OK) {
-            set_error("robo_acq_eval_cand_sharded: the local half of rank %d failed with status %d", bad[1], bad[0]);
+            set_error("%s: the local half of rank %d failed with status %d", who, bad[1], bad[0]);
             return bad[0];
         }
     }
@@ -333,6 +328,37 @@ int32_t robo_acq_eval_cand_sharded(robo_comm* c, robo_gp* g, int32_t acq_kind, d
     if (out_flags) *out_flags = f;
     if (out_owner_rank) *out_owner_rank = owner;
     return ROBO_OK;
+}
+
+int32_t robo_acq_eval_cand_sharded(robo_comm* c, robo_gp* g, int32_t acq_kind, double par, double eta, robo_cand* k,
+                                   int64_t global_offset, double* out_acq, double* out_max, int64_t* out_argmax,
+                                   int32_t* out_owner_rank, uint32_t* out_flags) {
+    if (!c || !g || !k) return ROBO_BAD_ARGUMENT;
+    if (g->ctx != c->ctx || k->ctx != c->ctx) {
+        set_error("robo_acq_eval_cand_sharded: the GP, the candidates and the communicator must share one context");
+        return ROBO_BAD_ARGUMENT;
+    }
+    ROBO_HIP_CHECK(hipSetDevice(c->ctx->device));
+    const int status = api_acq_local(g, acq_kind, par, eta, k);
+    return exchange_best(c, k, status, global_offset, "robo_acq_eval_cand_sharded", out_acq, out_max, out_argmax,
+                         out_owner_rank, out_flags);
+}
+
+int32_t robo_ig_eval_per_cost_cand_sharded(robo_comm* c, robo_gp* g, robo_cand* k, robo_cand* rep, int32_t npts, double sn2,
+                                           const double* logP, const double* lmb, const double* W, const double* dlogPdMu,
+                                           const double* dlogPdSigma, const double* dlogPdMudMu, robo_gp* cost_gp,
+                                           robo_cand* cost_k, double overhead, int64_t global_offset, double* out_values,
+                                           double* out_max, int64_t* out_argmax, int32_t* out_owner_rank) {
+    if (!c || !g || !k || !rep || !cost_gp || !cost_k) return ROBO_BAD_ARGUMENT;
+    if (g->ctx != c->ctx || k->ctx != c->ctx || rep->ctx != c->ctx) {
+        set_error("robo_ig_eval_per_cost_cand_sharded: the GPs, the candidates and the communicator must share one context");
+        return ROBO_BAD_ARGUMENT;
+    }
+    ROBO_HIP_CHECK(hipSetDevice(c->ctx->device));
+    const double* ep[6] = {logP, lmb, W, dlogPdMu, dlogPdSigma, dlogPdMudMu};
+    const int status = api_ig_per_cost_local(g, k, rep, npts, sn2, ep, cost_gp, cost_k, overhead);
+    return exchange_best(c, k, status, global_offset, "robo_ig_eval_per_cost_cand_sharded", out_values, out_max,
+                         out_argmax, out_owner_rank, nullptr);
 }
 
 int32_t robo_acq_eval_marginal_cand_sharded(robo_comm* c, robo_gp* const* gps, int32_t S_local, int32_t S_total,

@@ -237,7 +237,7 @@ int launch_gram(robo_gp* gp, const FitBuffers& fb);
 struct McmcState {
     int k, P, D, kind, n, n_steps, ns_eval, prior_kind;
     double a, mean_c;
-    double prior_par[5];
+    double prior_par[9];            // mcmc_dev.h PRIOR_PAR
     double *d_pos, *d_lnp, *d_q, *d_z, *d_prior;      // (k x P), (k), (k/2 x P), (k/2), (k/2)
     long long* d_nacc;                                // (k)
     int *d_it, *d_err;
@@ -258,6 +258,7 @@ int launch_diag_timeline(robo_gp* gp, long long* d_stamps);
 int launch_cross_gram(robo_gp* gp, robo_cand* cand, int64_t c0, int64_t cn, double* d_out = nullptr);
 // posterior of a chunk through W = L^-1 (winv.hip): fills cand->d_q / d_mu (and d_V when store_v)
 int winv_ensure(robo_gp* gp);
+int launch_per_cost(robo_ctx* ctx, double* d_dh, const double* d_log_cost, double overhead, int64_t m);
 int launch_predict_winv(robo_gp* gp, robo_cand* cand, int64_t c0, int64_t cn, bool store_v);
 int launch_trsm(robo_gp* gp, robo_cand* cand, int64_t c0, int64_t cn);
 int launch_predict_fused(robo_gp* gp, robo_cand* cand, int64_t c0, int64_t cn);

@@ -214,4 +214,20 @@ int launch_ig_dh(robo_ctx* ctx, const double* d_S, const double* d_var, double* 
     return ROBO_OK;
 }
 
+// information gain per unit cost (robo/acquisition_functions/information_gain_per_unit_cost.py:91-104):
+//     acquisition_value = dh / (exp(log_cost) + overhead)
+// with log_cost the cost model's predictive mean; in place on the gains
+__global__ __launch_bounds__(256) void per_cost_kernel(double* __restrict__ dh, const double* __restrict__ log_cost,
+                                                       double overhead, long long m) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < m) dh[i] = dh[i] / (exp(log_cost[i]) + overhead);
+}
+
+int launch_per_cost(robo_ctx* ctx, double* d_dh, const double* d_log_cost, double overhead, int64_t m) {
+    hipLaunchKernelGGL(per_cost_kernel, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, ctx->stream, d_dh, d_log_cost,
+                       overhead, (long long)m);
+    ROBO_LAUNCH_CHECK();
+    return ROBO_OK;
+}
+
 }  // namespace robo

@@ -47,7 +47,7 @@ __global__ __launch_bounds__(256) void mcmc_propose_scale_kernel(McmcState st, i
         if (threadIdx.x == 0) {
             st.d_z[w] = sz;
             double prior = 0.0;
-            if (ok && st.prior_kind == 1) prior = default_prior_lnprob(sq, P, st.prior_par);
+            if (ok && st.prior_kind != 0) prior = prior_lnprob(st.prior_kind, sq, P, st.prior_par);
             st.d_prior[w] = ok ? prior : -__builtin_huge_val();
             st.d_sp[w] = mcmc_fit_sample(st, sq, ok);
         }

@@ -4,9 +4,16 @@
 
 namespace robo {
 
-// robo/priors/default_priors.py:7-37 through robo_amd/priors/priors.py: lognormal on theta[0], tophat on the length
-// scales, horseshoe on the noise; par = {lognormal loc, sigma, tophat min, max, horseshoe scale}
-__device__ __forceinline__ double default_prior_lnprob(const double* th, int P, const double* par) {
+// The priors the library evaluates itself (robo_gp_mcmc_run's prior_kind):
+//   1  robo/priors/default_priors.py:7-37 (DefaultPrior): lognormal on theta[0], tophat on theta[1 .. P-2], horseshoe on
+//      the noise; par = {lognormal loc, sigma, tophat min, max, horseshoe scale}
+//   2  robo/priors/env_priors.py:8-54 (EnvPrior, the Fabolas kernels' prior, wired at robo/fmin/fabolas.py:120-127): the
+//      tophat covers only the n_ls length scales theta[1 .. n_ls]; the n_lr parameters of the Bayesian-linear-regression
+//      kernel behind them each ADD NormalPrior.lnprob -- which is a pdf, not a log-pdf (robo/priors/base_prior.py:357,
+//      mirrored: SURVEY A.3 #10) -- in the reference's order of summation; par = {.. the five above .., n_ls, n_lr,
+//      normal mean, normal sigma}
+constexpr int PRIOR_PAR = 9;
+__device__ __forceinline__ double prior_lnprob(int kind, const double* th, int P, const double* par) {
     const double ninf = -__builtin_huge_val();
     const double yv = th[0] - par[0];
     double lp;
@@ -16,8 +23,16 @@ __device__ __forceinline__ double default_prior_lnprob(const double* th, int P, 
     } else {
         lp = ninf;
     }
-    for (int p = 1; p < P - 1; ++p)
+    const int ls_end = kind == 2 ? 1 + (int)par[5] : P - 1;
+    for (int p = 1; p < ls_end; ++p)
         if (th[p] < par[2] || th[p] > par[3]) lp = ninf;
+    if (kind == 2) {
+        const int lr_end = ls_end + (int)par[6];
+        for (int p = ls_end; p < lr_end && p < P - 1; ++p) {
+            const double u = (th[p] - par[7]) / par[8];
+            lp += exp(-0.5 * (u * u)) / (par[8] * sqrt(2.0 * M_PI));
+        }
+    }
     const double noise = th[P - 1];
     const double r = par[4] / exp(noise);
     double hs = log(log(1.0 + 3.0 * (r * r)));

@@ -669,7 +669,7 @@ __global__ __launch_bounds__(256 * NG) void mcmc_block_step_kernel(McmcState st,
     const double z = *sz;
     double prior = 0.0;
     if (threadIdx.x == 0) {
-        if (ok && st.prior_kind == 1) prior = default_prior_lnprob(sq, P, st.prior_par);
+        if (ok && st.prior_kind != 0) prior = prior_lnprob(st.prior_kind, sq, P, st.prior_par);
         if (!ok) prior = -__builtin_huge_val();
         sfail = 0;
     }

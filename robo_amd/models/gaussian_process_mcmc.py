@@ -185,16 +185,21 @@ class GaussianProcessMCMC(BaseModel):
     # ---- likelihood ------------------------------------------------------------------------------
     def _device_chain(self):
         """The whole ensemble chain on the device (robo_gp_mcmc_run) when the prior is one the library evaluates itself:
-        none, or exactly DefaultPrior (robo/priors/default_priors.py).  Other priors (Fabolas' EnvPrior ...) keep the
-        host sampler around the batched likelihood.  ROBO_MCMC_HOST=1 forces the host sampler (A/B, tests)."""
+        none, exactly DefaultPrior (robo/priors/default_priors.py) or exactly EnvPrior (robo/priors/env_priors.py:8-54,
+        FabolasGPMCMC's prior in robo.fmin.fabolas).  Other priors keep the host sampler around the batched likelihood.
+        ROBO_MCMC_HOST=1 forces the host sampler (A/B, tests)."""
         if os.environ.get("ROBO_MCMC_HOST") == "1":
             return None
-        from robo_amd.priors import DefaultPrior
+        from robo_amd.priors import DefaultPrior, EnvPrior
         if self.prior is None:
             prior = None
         elif type(self.prior) is DefaultPrior:
             pr = self.prior
             prior = (1, [pr.ln_prior.mean, pr.ln_prior.sigma, pr.tophat.min, pr.tophat.max, pr.horseshoe.scale])
+        elif type(self.prior) is EnvPrior and 1 + self.prior.n_ls + self.prior.n_lr <= len(self.kernel):
+            pr = self.prior
+            prior = (2, [pr.ln_prior.mean, pr.ln_prior.sigma, pr.tophat.min, pr.tophat.max, pr.horseshoe.scale,
+                         pr.n_ls, pr.n_lr, pr.bayes_lin_prior.mean, pr.bayes_lin_prior.sigma])
         else:
             return None
 

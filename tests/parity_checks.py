@@ -103,14 +103,17 @@ def check_case(ctx, name, full=True):
 
 
 def check_device_chain(ctx, cases=(("matern52", 150, 3, 10, 14), ("rbf", 40, 2, 8, 10), ("matern52", 100, 4, 12, 9),
-                                   ("fabolas", 50, 3, 12, 8))):
+                                   ("fabolas", 50, 3, 12, 8), ("fabolas", 60, 3, 12, 8, "env"),
+                                   ("fabolas", 170, 4, 10, 6, "env"))):
     """robo_gp_mcmc_run (the whole stretch-move chain on the device) against the host sampler around the batched
     likelihood with the same RandomState: same accept decisions, positions and log-probabilities to rounding, the random
     stream ends in the same state; against the CPU oracle's log-probability through the same sampler; walkers outside
     the reference's |theta| <= 20 bounds and outside the prior's support (-inf); the model class end to end."""
     from robo_amd.util.ensemble_sampler import EnsembleSampler
-    from robo_amd.priors import DefaultPrior
-    for kind, N, D, k, steps in cases:
+    from robo_amd.priors import DefaultPrior, EnvPrior
+    for case in cases:
+        kind, N, D, k, steps = case[:5]
+        prior_name = case[5] if len(case) > 5 else "default"
         rs = np.random.RandomState(61)
         X = rs.rand(N, D)
         y = np.sin(3 * X.sum(axis=1)) + 0.05 * rs.randn(N)
@@ -118,9 +121,21 @@ def check_device_chain(ctx, cases=(("matern52", 150, 3, 10, 14), ("rbf", 40, 2, 
         mean = float(np.mean(y))
         g = _lib.DeviceGP(ctx, kind, N, D)
         g.set_data(X, y)
-        prior = DefaultPrior(P, rng=np.random.RandomState(62))
-        par = (1, [prior.ln_prior.mean, prior.ln_prior.sigma, prior.tophat.min, prior.tophat.max, prior.horseshoe.scale])
+        if prior_name == "env":
+            # FabolasGPMCMC's prior (robo/fmin/fabolas.py:120-127): tophat on the D - 1 length scales only, a normal PDF
+            # term per regression parameter, lognormal(-2, 1) amplitude, horseshoe(0.001) noise
+            prior = EnvPrior(P, n_ls=D - 1, n_lr=2, rng=np.random.RandomState(62))
+            par = (2, [prior.ln_prior.mean, prior.ln_prior.sigma, prior.tophat.min, prior.tophat.max,
+                       prior.horseshoe.scale, prior.n_ls, prior.n_lr, prior.bayes_lin_prior.mean,
+                       prior.bayes_lin_prior.sigma])
+            prior.lnprob_batch = lambda T: np.array([prior.lnprob(t) for t in np.atleast_2d(T)])
+        else:
+            prior = DefaultPrior(P, rng=np.random.RandomState(62))
+            par = (1, [prior.ln_prior.mean, prior.ln_prior.sigma, prior.tophat.min, prior.tophat.max,
+                       prior.horseshoe.scale])
         p0 = prior.sample_from_prior(k)
+        if prior_name == "env":
+            p0[:, -1] = np.clip(p0[:, -1], -14.0, None)      # horseshoe(0.001) samples reach exp(-30): keep K factorable
         p0[1, 2] = 23.0          # outside |theta| <= 20: -inf at the start, moves in through a partner
         p0[2, 1] = 5.0           # outside the tophat: -inf prior
 
@@ -242,6 +257,32 @@ def check_device_chain(ctx, cases=(("matern52", 150, 3, 10, 14), ("rbf", 40, 2, 
             os.environ.pop("ROBO_MCMC_HOST", None)
             _lib.default_context().set_tuning("ws_bytes", None)
     np.testing.assert_array_equal(hyp["declined"][0], hyp["1"][0])
+    np.testing.assert_allclose(hyp["0"][0], hyp["1"][0], rtol=1e-9, atol=1e-9)
+    np.testing.assert_allclose(hyp["0"][1][0], hyp["1"][1][0], rtol=1e-7, atol=1e-9)
+    np.testing.assert_allclose(hyp["0"][1][1], hyp["1"][1][1], rtol=1e-6, atol=1e-10)
+    # FabolasGPMCMC with EnvPrior (config 4's model, robo/fmin/fabolas.py:104-135): device chain == host sampler
+    from robo_amd.kernels import FabolasKernel
+    from robo_amd.models.fabolas_gp import FabolasGPMCMC
+    rs = np.random.RandomState(68)
+    Xf = np.concatenate([rs.rand(70, 2) * 3 - 1, rs.rand(70, 1) * 0.9 + 0.1], axis=1)
+    yf = np.sin(Xf[:, 0]) * np.cos(2 * Xf[:, 1]) + 0.3 * (1 - Xf[:, 2]) ** 2
+    hyp = {}
+    for mode in ("0", "1"):
+        os.environ["ROBO_MCMC_HOST"] = mode
+        try:
+            kernel = FabolasKernel(3, metric=0.01)
+            m = FabolasGPMCMC(kernel, basis_func=lambda s_: (1 - s_) ** 2,
+                              prior=EnvPrior(len(kernel) + 1, n_ls=2, n_lr=2, rng=np.random.RandomState(69)),
+                              n_hypers=12, chain_length=10, burnin_steps=8, rng=np.random.RandomState(70),
+                              lower=-np.ones(2), upper=2 * np.ones(2), device=None)
+            chain = m._device_chain()
+            assert (chain is None) == (mode == "1")          # EnvPrior is a prior the library evaluates itself
+            m.train(Xf, yf)
+            m.train(Xf, yf)
+            Xt = np.concatenate([Xf[:7, :2] + 0.1, np.ones((7, 1))], axis=1)
+            hyp[mode] = (np.array(m.hypers), m.predict(Xt))
+        finally:
+            os.environ.pop("ROBO_MCMC_HOST", None)
     np.testing.assert_allclose(hyp["0"][0], hyp["1"][0], rtol=1e-9, atol=1e-9)
     np.testing.assert_allclose(hyp["0"][1][0], hyp["1"][1][0], rtol=1e-7, atol=1e-9)
     np.testing.assert_allclose(hyp["0"][1][1], hyp["1"][1][1], rtol=1e-6, atol=1e-10)

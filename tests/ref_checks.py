@@ -307,7 +307,16 @@ def check_ref_infogain_cost(device=None):
         _check_ep(e, gold, "_%d" % i)
         np.testing.assert_allclose(mc_cost.models[i].predict(inp["Xc"])[0], gold["log_cost_%d" % i], rtol=1e-8,
                                    atol=1e-9)
+        assert e._native_cost()             # gains, cost posterior, division and argmax: ONE library call
         _ig_close(e.compute(inp["Xc"]), gold["ig_%d" % i])
+        assert e.argmax(inp["Xc"]) == int(np.argmax(gold["ig_%d" % i]))
+        # a candidate outside the box takes the reference's np.spacing(1) / cost branch (host) -- same values elsewhere
+        Xo = inp["Xc"].copy()
+        Xo[3, 0] = upper[0] + 1.0
+        vo = e.compute(Xo)
+        keep = np.arange(Xo.shape[0]) != 3
+        _ig_close(vo[keep], gold["ig_%d" % i][keep])
+        assert 0.0 < vo[3] < 1e-10
     _ig_close(marg.compute(inp["Xc"]), gold["marg"])
 
 

@@ -63,6 +63,14 @@ def test_self_launch_weak():
     assert out["other_scaling"]["scaling"] == "strong" and out["other_scaling"]["candidates_total"] == 601
 
 
+def test_config4_sharded_information_gain_per_unit_cost():
+    """bench.py --config c4: robo_ig_eval_per_cost_cand on one rank == its sharded form on two (same 300 candidates)"""
+    shape = ["--config", "c4", "--n", "200", "--d", "4", "--m", "300"]
+    one = _line(_run(["--gpus", "1"] + shape))
+    two = _line(_run(["--gpus", "2", "--scaling", "strong"] + shape))
+    assert two["ranks"] == [0, 1] and two["argmax"] == one["argmax"] and two["config"]["candidates_total"] == 300
+
+
 def test_world_size_mismatch_is_an_error():
     """a launcher that started another number of ranks than --gpus asks for must not yield a line"""
     res = _run(["--gpus", "2"], env_extra={"WORLD_SIZE": "3", "RANK": "0", "LOCAL_RANK": "0"})

@@ -237,6 +237,34 @@ def _class_worker(rank, world, port, out_dir):
     m_sh, v_sh = big.predict(Xc)
     np.testing.assert_allclose(m_sh, m_ref, rtol=1e-13)
     np.testing.assert_allclose(v_sh, v_ref, rtol=1e-9)
+    # candidate shard of the information gain per unit cost (BASELINE config 4: Fabolas objective + cost models): the
+    # global argmax of robo_ig_eval_per_cost_cand_sharded == the single-rank np.argmax of the same candidates
+    from robo_amd.kernels import FabolasKernel
+    from robo_amd.models.fabolas_gp import FabolasGP
+    rs = np.random.RandomState(31)
+    Xf = np.concatenate([lo[:2] + (hi[:2] - lo[:2]) * rs.rand(40, 2), rs.rand(40, 1) * 0.9 + 0.1], axis=1)
+    yf = np.sin(Xf[:, 0]) + 0.2 * (1 - Xf[:, 2]) ** 2
+    cf = np.log(0.2 + 3.0 * Xf[:, 2])
+    obj = FabolasGP(FabolasKernel(3, metric=0.5), basis_function=lambda s_: (1 - s_) ** 2, noise=1e-3, lower=lo[:2],
+                    upper=hi[:2], rng=np.random.RandomState(32))
+    cost = FabolasGP(FabolasKernel(3, metric=0.5), basis_function=lambda s_: s_, noise=1e-3, lower=lo[:2], upper=hi[:2],
+                     rng=np.random.RandomState(33))
+    obj.train(Xf, yf, do_optimize=False)
+    cost.train(Xf, cf, do_optimize=False)
+    is_env = np.array([0, 0, 1])
+    np.random.seed(34)
+    igc = A.InformationGainPerUnitCost(obj, cost, np.append(lo[:2], 0), np.append(hi[:2], 1), is_env,
+                                       sampling_acquisition=A.EI, n_representer=10, Np=50,
+                                       rng=np.random.RandomState(35))
+    igc.shard = True                    # rank 0's representer points on every rank (the sampler's stream is OS-seeded)
+    igc.update(obj, cost, overhead=0.3)
+    np.testing.assert_array_equal(sharding.allgather_rows(np.asarray(igc.zb).ravel())[0], np.asarray(igc.zb).ravel())
+    Xq = np.concatenate([lo[:2] + (hi[:2] - lo[:2]) * np.random.RandomState(36).rand(77, 2),
+                         np.random.RandomState(37).rand(77, 1)], axis=1)
+    want = igc.compute(Xq)
+    assert igc._native_cost() and igc.argmax(Xq) == int(np.argmax(want))
+    assert sharding.sharded_argmax(igc, Xq) == int(np.argmax(want))
+    assert sharding.sharded_argmax(igc, Xq[:1]) == 0                 # one candidate, two ranks: an empty shard joins
     dist.barrier()
     sharding.close_comm()
     dist.destroy_process_group()

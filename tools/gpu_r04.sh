@@ -1,0 +1,71 @@
+#!/bin/bash
+# One GPU-box session of round 3.  usage: tools/gpu_r04.sh <tag> [tests] [bench] [configs] [prof] [pmc] [fit] [small]
+TAG=${1:-r04}; shift
+OUT=gpurun_out/$TAG; mkdir -p $OUT; export TMPDIR=/tmp
+cd "$(dirname "$0")/.."
+for what in "$@"; do case $what in
+tests)
+  timeout 1500 python -m pytest tests -m gpu -q -x --durations=15 > $OUT/pytest_gpu.log 2>&1; echo "pytest rc=$?" >> $OUT/summary.txt
+  tail -30 $OUT/pytest_gpu.log >> $OUT/summary.txt ;;
+smoke)
+  timeout 300 python __graft_entry__.py smoke > $OUT/smoke.txt 2>&1; echo "smoke rc=$?" >> $OUT/summary.txt ;;
+bench)
+  timeout 600 python bench.py --gpus 1 > $OUT/bench.json 2> $OUT/bench.err; echo "bench rc=$?" >> $OUT/summary.txt
+  python - <<PY >> $OUT/summary.txt 2>&1
+import json; d=json.load(open('$OUT/bench.json'))
+print('value', d['value'], 'ms', d['ms_per_step'], 'frac', d['roofline']['frac'], 'fit', d['gp_fit_ms'], d.get('gp_fit_data_resident_ms'), d['gp_fit_phases_ms'], 'k1', d['k_assembly'], 'small', d['small_batch_latency_ms'], 'batched', d['gp_fit_batched'])
+PY
+  ;;
+configs)
+  : > $OUT/configs.jsonl
+  for c in c2 c3 c4 c5; do
+    timeout 600 python bench.py --gpus 1 --config $c --no-cpu-baseline >> $OUT/configs.jsonl 2>> $OUT/configs.err; echo "$c rc=$?" >> $OUT/summary.txt
+  done
+  timeout 900 python bench.py --gpus 1 --config c5 --m 1048576 --steps 2 --warmup 1 --no-cpu-baseline >> $OUT/configs.jsonl 2>> $OUT/configs.err; echo "c5 full rc=$?" >> $OUT/summary.txt
+  cut -c1-300 $OUT/configs.jsonl >> $OUT/summary.txt ;;
+dist)
+  # the RCCL path on ONE rank, both scalings (torchrun-style process group) + the self-launcher's one-rank form (no torch)
+  for sc in weak strong; do
+    ROBO_BENCH_FORCE_DIST=1 timeout 600 python bench.py --gpus 1 --scaling $sc --no-cpu-baseline --lean > $OUT/forcedist_$sc.json 2> $OUT/forcedist_$sc.err; echo "forcedist $sc rc=$?" >> $OUT/summary.txt
+  done
+  RDV=$(mktemp -d); RANK=0 LOCAL_RANK=0 WORLD_SIZE=1 ROBO_BENCH_RENDEZVOUS=$RDV timeout 600 python bench.py --gpus 1 --scaling strong --no-cpu-baseline --lean > $OUT/spawn1_strong.json 2> $OUT/spawn1.err; echo "spawn1 rc=$?" >> $OUT/summary.txt
+  ROBO_BENCH_FORCE_DIST=1 timeout 600 python bench.py --gpus 1 --config c3 --no-cpu-baseline > $OUT/forcedist_c3.json 2>> $OUT/forcedist.err; echo "forcedist c3 rc=$?" >> $OUT/summary.txt
+  # what --gpus 2 does on a one-GPU box: both ranks fail or run on device 0/1 -- must end non-zero, not hang
+  timeout 300 python bench.py --gpus 2 --lean --no-cpu-baseline > $OUT/gpus2_on_one_gpu.json 2> $OUT/gpus2_on_one_gpu.err; echo "gpus2-on-1-gpu rc=$? (expected non-zero)" >> $OUT/summary.txt
+  cut -c1-260 $OUT/forcedist_weak.json $OUT/forcedist_strong.json $OUT/spawn1_strong.json $OUT/forcedist_c3.json >> $OUT/summary.txt; tail -3 $OUT/forcedist_strong.err >> $OUT/summary.txt ;;
+prof)
+  timeout 900 rocprofv3 --kernel-trace --stats -d $OUT/prof -o bench -- python bench.py --gpus 1 --no-cpu-baseline > $OUT/prof_bench.json 2> $OUT/prof.err; echo "rocprof rc=$?" >> $OUT/summary.txt
+  python tools/rocpd_stats.py $OUT/prof/bench_results.db > $OUT/bench_kernel_stats.csv 2>> $OUT/prof.err
+  find $OUT/prof -size +20M -delete
+  head -16 $OUT/bench_kernel_stats.csv >> $OUT/summary.txt ;;
+pmc)
+  for C in FETCH_SIZE WRITE_SIZE "SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE"; do
+    name=$(echo $C | tr ' ' '_')
+    timeout 600 rocprofv3 --kernel-trace --pmc $C -d $OUT/pmc/$name -o pmc -- python bench.py --gpus 1 --steps 1 --warmup 0 --no-cpu-baseline > $OUT/pmc_$name.json 2> $OUT/pmc_$name.err
+    echo "pmc $C rc=$?" >> $OUT/summary.txt
+  done
+  python tools/rocpd_pmc.py $OUT/pmc > $OUT/pmc_summary.txt 2>&1
+  find $OUT/pmc -size +30M -delete
+  grep -i "trsm_step\|potrf_step\|gram_kernel\|potrf_panel" $OUT/pmc_summary.txt | head -24 >> $OUT/summary.txt ;;
+pmcconf)
+  # HBM traffic of the dominant kernel of the other configurations: FETCH_SIZE and WRITE_SIZE passes, one step each
+  for cfg in "c2 trsm_step_gen_kernel 1024 8 65536" "c3 trsm_step_gen_kernel 2048 16 65536" "c4 winv_gemm_kernel 4096 11 8192" "c5 trsm_step_kernel 8192 64 131072"; do
+    set -- $cfg
+    for C in FETCH_SIZE WRITE_SIZE; do
+      timeout 600 rocprofv3 --kernel-trace --pmc $C -d $OUT/pmc_$1/$C -o pmc -- python bench.py --gpus 1 --config $1 --steps 1 --warmup 0 --no-cpu-baseline > /dev/null 2> $OUT/pmc_$1_$C.err
+      echo "pmc $1 $C rc=$?" >> $OUT/summary.txt
+    done
+    python tools/rocpd_pmc.py $OUT/pmc_$1 > $OUT/pmc_summary_$1.txt 2>&1
+    python tools/make_traffic_json.py $OUT/pmc_summary_$1.txt $(cat .git_head 2>/dev/null || echo unknown) $2 $1 $3 $4 $5 > $OUT/trsm_traffic_$1.json 2>> $OUT/summary.txt
+    find $OUT/pmc_$1 -size +30M -delete
+    grep bytes_per_launch $OUT/trsm_traffic_$1.json >> $OUT/summary.txt
+  done ;;
+fit)
+  python tools/diag_timeline.py > $OUT/diag_timeline.txt 2>&1
+  timeout 600 bash tools/gpu_fit_trace.sh $TAG 4096 > $OUT/fit_trace.log 2>&1
+  cat $OUT/diag_timeline.txt >> $OUT/summary.txt; tail -3 $OUT/trace_4096.txt >> $OUT/summary.txt 2>/dev/null ;;
+small)
+  timeout 300 python tools/small_m_timing.py > $OUT/small_m.txt 2>&1; cat $OUT/small_m.txt >> $OUT/summary.txt ;;
+*) echo "unknown step $what" >> $OUT/summary.txt ;;
+esac; done
+cat $OUT/summary.txt
