@@ -102,6 +102,113 @@ def cpu_baseline(N, D, theta, X, y, budget_s=12.0):
             "gp_fit_ms": fit_s * 1e3}
 
 
+def _blas_threads():
+    try:
+        from threadpoolctl import threadpool_info
+        return int(max([p.get("num_threads", 1) for p in threadpool_info()] + [1]))
+    except Exception:
+        return os.cpu_count() or 1
+
+
+def cpu_baseline_c3(N, D, M, thetas, X, y, budget_s=14.0):
+    """config 3 on the host cores, the reference's call sequence restated (george is not installable): per hyper-
+    parameter sample one gp.compute (gaussian_process_mcmc.py:149-164 -> gaussian_process.py:119) and, per 500-candidate
+    RandomSampling batch, gp.predict with the full covariance + LogEI's per-point Python loop (log_ei.py:79-120);
+    MarginalizationGPMCMC averages the S vectors (marginalization.py:115-121).  Bounded sample: a few samples' fits and a
+    few batches each; the rate for the config's shape (one fit per sample per 65 536 candidates) follows from the two."""
+    from oracle import gp_oracle as O
+    eta = float(y.min())
+    rs = np.random.RandomState(98)
+    t_fit, t_eval, n_eval, n_fit = 0.0, 0.0, 0, 0
+    while t_fit + t_eval < budget_s and n_fit < len(thetas):
+        t0 = time.perf_counter()
+        gp = O.OracleGP("matern52", thetas[n_fit], lower=np.zeros(D), upper=np.ones(D))
+        gp.train(X, y)
+        t_fit += time.perf_counter() - t0
+        n_fit += 1
+        for _ in range(2):
+            Xb = rs.rand(500, D)
+            t0 = time.perf_counter()
+            mu, var = gp.predict(Xb)                     # full covariance, then np.diag, like the reference
+            O.log_ei(mu, var, eta)                       # the reference's per-point loop
+            t_eval += time.perf_counter() - t0
+            n_eval += 500
+    per_fit, per_eval = t_fit / n_fit, t_eval / n_eval
+    return {"value": M / (per_fit + M * per_eval), "unit": "LogEI sample-evals/s", "cores": _blas_threads(),
+            "kind": "port", "os_cpu_count": os.cpu_count(),
+            "sample": "%d samples' fits (%.0f ms each, N=%d) and %d candidates in batches of 500 (full MxM covariance + "
+                      "LogEI's Python loop, %.1f us per candidate); value = the rate of one sample's %d candidates "
+                      "incl. its fit" % (n_fit, per_fit * 1e3, N, n_eval, per_eval * 1e6, M),
+            "note": "restatement of the george call sequence on NumPy/SciPy (BASELINE.md 3.5)"}
+
+
+def cpu_baseline_c4(N, D, theta, X, y, Xcost, cost, Xc, Xc_cost, zb, ep_arrays, W, sn2, budget_s=14.0):
+    """config 4 on the host cores: the reference's per-candidate loop (information_gain.py:112 over
+    information_gain_per_unit_cost.py:91-104) restated -- per candidate x one model.predict(x) and one
+    predict_variance(rep, x) = a full (Nb+1) x (Nb+1) posterior covariance through K^-1 (gaussian_process.py:243-248),
+    the innovation algebra (_dh_fun) and the cost model's predict."""
+    from oracle import gp_oracle as O
+    from oracle import ig_oracle as IG
+    t0 = time.perf_counter()
+    gp = O.OracleGP("fabolas", theta, normalize_input=False)
+    gp.train(X, y)
+    gc = O.OracleGP("fabolas", theta, normalize_input=False)
+    gc.train(Xcost, cost)
+    fit_s = time.perf_counter() - t0
+    logP, lmb, dMu, dSig, dMM = ep_arrays
+    done, t = 0, 0.0
+    vals = []
+    while t < budget_s and done < Xc.shape[0]:
+        x, xc = Xc[done:done + 1], Xc_cost[done:done + 1]
+        t0 = time.perf_counter()
+        v = gp.predict(x)[1][0]
+        cov = gp.predict(np.concatenate((zb, x)), full_cov=True)[1]
+        dh = IG.dh_fun(v, cov[-1, :-1][:, None], sn2, logP, lmb, dMu, dSig, dMM, W)
+        vals.append(dh / np.exp(gc.predict(xc)[0][0]))
+        t += time.perf_counter() - t0
+        done += 1
+    return {"value": done / t, "unit": "information gains/s", "cores": _blas_threads(), "kind": "port",
+            "os_cpu_count": os.cpu_count(), "gp_fit_ms": fit_s * 1e3 / 2,
+            "sample": "%d candidates, one at a time like the reference (predict + predict_variance over Nb=%d "
+                      "representers + dH + cost predict), N=%d" % (done, zb.shape[0], N),
+            "note": "restatement of the george call sequence on NumPy/SciPy (BASELINE.md 3.5)",
+            "_values": vals}
+
+
+def cpu_baseline_c5(N, D, theta, X, y, budget_s=12.0):
+    """config 5 on the host cores: fp64 throughout (the reference has no mixed precision): gp.compute at N=8192, then
+    gp.predict (full covariance) + LCB on 500-candidate batches; diag-only variant next to it."""
+    from oracle import gp_oracle as O
+    t0 = time.perf_counter()
+    gp = O.OracleGP("matern52", theta, lower=np.zeros(D), upper=np.ones(D))
+    gp.train(X, y)
+    fit_s = time.perf_counter() - t0
+    rs = np.random.RandomState(97)
+    done, t = 0, 0.0
+    while t < budget_s and done < 5000:
+        Xb = rs.rand(500, D)
+        t0 = time.perf_counter()
+        mu, var = gp.predict(Xb)
+        O.lcb(mu, var)
+        t += time.perf_counter() - t0
+        done += 500
+    fd, tf = 0, 0.0
+    while tf < budget_s / 2 and fd < 16384:
+        Xb = rs.rand(2048, D)
+        t0 = time.perf_counter()
+        mu, var = gp.predict(Xb, diag_only=True)
+        O.lcb(mu, var)
+        tf += time.perf_counter() - t0
+        fd += 2048
+    return {"value": done / t, "unit": "LCB evals/s", "cores": _blas_threads(), "kind": "port",
+            "os_cpu_count": os.cpu_count(), "gp_fit_ms": fit_s * 1e3,
+            "sample": "%d candidates in batches of 500 (reference call sequence: full MxM covariance, np.diag), N=%d "
+                      "D=%d, all fp64; oracle fit %.0f ms" % (done, N, D, fit_s * 1e3),
+            "fair_diag_only": {"value": fd / tf, "unit": "LCB evals/s",
+                               "sample": "%d candidates in batches of 2048, diagonal variance only" % fd},
+            "note": "restatement of the george call sequence on NumPy/SciPy (BASELINE.md 3.5)"}
+
+
 class TorchExchange(object):
     """bench.py's safety net only (see Dist.make_comm): the two exchanges over torch.distributed, host-mediated"""
 
@@ -455,7 +562,7 @@ def roofline_trsm(ctx, N, M_rows, trsm_ms_per_step, passes=1, kernel="trsm_step_
     rows N^2 / nb (SURVEY.md 8d's triangular-solve term), duration from HIP events on the library's stream
     (slots 25 -> 26) averaged over the nb launches of a pass"""
     nb = (N + 127) // 128
-    if kernel == "winv_gemm_kernel":
+    if kernel.startswith("winv_"):
         # the explicit-inverse path is ONE triangular product per pass; the event pair brackets cross-gram + product +
         # chunk reduction, priced against the product's algorithmic flops (rows N^2)
         nb = 1
@@ -802,7 +909,8 @@ def run_c3(args, D_, _lib, sharding):
             "end_to_end_ms": ms, "fit_batch_ms_rank0": float(np.median(fit_s)) * 1e3,
             "fit_ms_per_sample": float(np.median(fit_s)) * 1e3 / (e - b),
             "algorithmic_tflops_whole_step": S * M * flops_ei(N, D) / (ms * 1e-3) / 1e12,
-            "argmax": list(best), "roofline": roof, "device": ctx.name})
+            "argmax": list(best), "roofline": roof, "device": ctx.name},
+                **({} if (world > 1 or args.no_cpu_baseline) else {"cpu_baseline": cpu_baseline_c3(N, D, M, thetas, X, y)}))
 
 
 # ----------------------------------------------------------------------------------------------------
@@ -865,7 +973,7 @@ def run_c4(args, D_, _lib, sharding):
     if rank != 0:
         return None
     ms = elapsed / args.steps * 1e3
-    return dict(ranks, **{"metric": METRIC, "value": M_total * args.steps / elapsed, "unit": "information gains/s", "n_gpus": world,
+    out = dict(ranks, **{"metric": METRIC, "value": M_total * args.steps / elapsed, "unit": "information gains/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": True, "scaling": args.scaling,
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": "BASELINE config 4: Fabolas product kernel N=4096 D=10+1, information gain per unit "
@@ -879,6 +987,15 @@ def run_c4(args, D_, _lib, sharding):
             "device": ctx.name,
             "note": "roofline: the block-row solve of the LAST posterior of a step (the cost model's); at this batch "
                     "size the step is latency-bound, not MFMA-bound (see small_batch_latency_ms of the headline line)"})
+    if world == 1 and not args.no_cpu_baseline:
+        cb = cpu_baseline_c4(N, D, theta, X, y, Xcost, cost, Xc, Xc_cost, zb, (logP, lmb, dMu, dSig, dMM), W, sn2)
+        # the sampled candidates double as a live check of the device's values against the restated reference loop
+        cpu_vals = np.array(cb.pop("_values"))
+        dev_vals, _, _ = _lib.ig_eval_per_cost(gp, cand, rep, ep, sn2, gc, cand_cost, 0.0, want_values=True)
+        cb["max_rel_diff_vs_device_on_the_sample"] = float(np.max(
+            np.abs(dev_vals[:cpu_vals.size] - cpu_vals) / np.maximum(np.abs(cpu_vals), 1e-300)))
+        out["cpu_baseline"] = cb
+    return out
 
 
 # ----------------------------------------------------------------------------------------------------
@@ -924,7 +1041,7 @@ def run_c5(args, D_, _lib, sharding):
     if rank != 0:
         return None
     ms = elapsed / args.steps * 1e3
-    return dict(ranks, **{"metric": METRIC, "value": M_total * args.steps / elapsed, "unit": "LCB evals/s", "n_gpus": world,
+    out = dict(ranks, **{"metric": METRIC, "value": M_total * args.steps / elapsed, "unit": "LCB evals/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": True, "scaling": args.scaling,
             "vs_baseline": None, "dtype": "f64 (covariance entries f32)", "data": "synthetic",
             "config": {"workload": "BASELINE config 5: N=8192 D=64, LCB kappa=1, %d scrambled-Sobol candidates per GPU "
@@ -937,6 +1054,9 @@ def run_c5(args, D_, _lib, sharding):
                                                  kernel=cand.solve_kernel(),
                                                  traffic=config_traffic("c5", cand.solve_kernel())), clock),
             "device": ctx.name})
+    if world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline_c5(N, D, theta, X, y)
+    return out
 
 
 def main():

@@ -86,6 +86,8 @@ int32_t robo_ctx_set_phase_events(robo_ctx* ctx, int32_t on);
  * "env" re-reads all variables.  Keys: ws_bytes (solve workspace per candidate handle, default 6 GiB),
  * winv_max / winv_min_blocks (batches of at most winv_max candidates on a factor of at least winv_min_blocks 128-row
  * blocks are evaluated through the explicit inverse factor, winv.hip; default 32768 / 6, measured r03b; 0 = never),
+ * winv_cond_max (... while cond_inf(L) <= this, default 1e5: robo_gp_factor_cond), winv_rows (form of that product: -1 auto,
+ * 0 chunked units + reduction pass, 1 one workgroup per (candidate tile, block row) over the whole contraction range),
  * trsm_pair (1: two block rows of the solve per launch on one read of V; default 0: one), trsm_small_max, trsm_small_narrow,
  * trsm_small_deep, trsm_rows, predict_stepwise, gram_persistent, mcmc_block_step, potrf_fused, potrf_tm4_min,
  * potrf_max_wg, potrf_group (kernel-variant selection; A/B runs and tests).                                     */

@@ -87,6 +87,8 @@ struct Tuning {
     int predict_stepwise;        // 1: cross-gram in memory + trsm_step_kernel (A/B)
     long long winv_max;          // batches <= this (and >= winv_min_blocks block rows) go through W = L^-1 (0: never)
     int winv_min_blocks;
+    int winv_rows;               // explicit-inverse product per (tile, block row) over the whole contraction range: -1 auto
+                                 // (batches that fill the chip that way), 0 never (chunked units + reduction), 1 always
     long long winv_cond_max;     // ... while cond_inf(L) = |L|_inf |W|_inf stays below this (default 1e5)
     int potrf_fused;             // 0: never fuse the next diagonal block into the trailing update
     int potrf_tm4_min, potrf_max_wg, potrf_group;

@@ -89,6 +89,68 @@ __global__ __launch_bounds__(256) void winv_reduce_kernel(const double* __restri
     }
 }
 
+// LARGE batches (enough (candidate tile, block row) pairs to fill the chip on their own): one workgroup per pair over the
+// WHOLE contraction range, heaviest block rows first (the dispatcher hands the next workgroup to the first free slot:
+// longest-processing-time scheduling, 0.97-0.99 balance from 4096 candidates up at N = 4096), and the block row's
+// |v|^2 and v.z partial sums straight from the accumulators: no unit tiles in memory (0.33 ms of HBM traffic per 8192
+// candidates at N = 4096), no chunk-reduction pass.  Every V entry is ONE accumulator chain in k order -- the association is
+// fixed by n_pad alone; which of the two forms runs depends on the batch size (launch_predict_winv), as the switch to the
+// block-row substitution does, so values agree across batch sizes to rounding (~1e-13 relative), not bit for bit.
+template <bool STORE_V>
+__global__ __launch_bounds__(256, 2) void winv_row_kernel(const double* __restrict__ Ks, int ldk,
+                                                          const double* __restrict__ W, int ldw, int nbk,
+                                                          const double* __restrict__ z, int n, double* __restrict__ V,
+                                                          int ldv, double* __restrict__ qpart,
+                                                          double* __restrict__ mupart, long long rows) {
+    __shared__ double smem[GEMM_SMEM_DOUBLES];
+    const int ct = blockIdx.x;
+    const int j = nbk - 1 - (int)blockIdx.y;
+    Acc acc;
+    acc_zero(acc);
+    gemm_nt_128<false>(Ks + (size_t)ct * NB * ldk, ldk, W + (size_t)j * NB * ldw, ldw, 0, (j + 1) * NB, acc, smem);
+    const int lane = threadIdx.x & 63, wx = (threadIdx.x >> 6) & 1;
+    double zc[4];
+    bool okc[4];
+#pragma unroll
+    for (int tn = 0; tn < 4; ++tn) {
+        const int col = j * NB + acc_col(tn);
+        okc[tn] = col < n;
+        zc[tn] = okc[tn] ? z[col] : 0.0;
+    }
+    // this lane: 16 rows x 4 columns; a row's 128 columns live in 16 lanes (lane & 15) x 4 tn x 2 waves (wx)
+#pragma unroll
+    for (int tm = 0; tm < 4; ++tm)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            double q = 0.0, m = 0.0;
+#pragma unroll
+            for (int tn = 0; tn < 4; ++tn) {
+                const double v = okc[tn] ? acc.t[tm][tn][r] : 0.0;
+                if (STORE_V)
+                    V[((size_t)ct * NB + acc_row(tm, r)) * ldv + (size_t)j * NB + acc_col(tn)] = v;
+                q = fma(v, v, q);
+                m = fma(v, zc[tn], m);
+            }
+#pragma unroll
+            for (int o = 8; o > 0; o >>= 1) {
+                q += __shfl_xor(q, o);
+                m += __shfl_xor(m, o);
+            }
+            if ((lane & 15) == 0) {
+                // [row][wx] pairs: the two column halves of a row are added below, wx = 0 first
+                smem[(acc_row(tm, r) * 2 + wx) * 2] = q;
+                smem[(acc_row(tm, r) * 2 + wx) * 2 + 1] = m;
+            }
+        }
+    __syncthreads();
+    if (threadIdx.x < NB) {
+        const int row = threadIdx.x;
+        const long long c = (long long)ct * NB + row;
+        qpart[(size_t)j * rows + c] = smem[(row * 2) * 2] + smem[(row * 2 + 1) * 2];
+        mupart[(size_t)j * rows + c] = smem[(row * 2) * 2 + 1] + smem[(row * 2 + 1) * 2 + 1];
+    }
+}
+
 __global__ __launch_bounds__(256) void winv_finish_kernel(const double* __restrict__ qpart,
                                                           const double* __restrict__ mupart, int nbk, long long rows,
                                                           double* __restrict__ q, double* __restrict__ mu) {
@@ -200,24 +262,43 @@ int launch_predict_winv(robo_gp* gp, robo_cand* cand, int64_t c0, int64_t cn, bo
     hipStream_t st = gp->ctx->stream;
     const int n_pad = gp->n_pad, nbk = gp->winv_nbk, nu = gp->winv_units;
     const unsigned cts = (unsigned)(cn / NB);
+    // whole contraction range per (candidate tile, block row) when those pairs fill the chip by themselves: decided from
+    // the handle's TOTAL batch (not this workspace pass), so a chunked workspace yields the values of a single pass
+    const long long slots = 2LL * gp->ctx->num_cu;
+    const int rows_mode = gp->ctx->tune.winv_rows;                 // -1 auto, 0 never, 1 always (A/B, tests)
+    const bool whole = rows_mode >= 0 ? rows_mode != 0 : (cand->m_pad / NB) * (long long)(nbk + 1) >= 2 * slots;
     int s = grow(&cand->d_Ks, &cand->ks_bytes, (size_t)cn * n_pad * sizeof(double));
-    if (s == ROBO_OK) s = grow(&cand->d_P, &cand->p_bytes, (size_t)cts * nu * NB * NB * sizeof(double));
+    if (s == ROBO_OK && !whole) s = grow(&cand->d_P, &cand->p_bytes, (size_t)cts * nu * NB * NB * sizeof(double));
     if (s == ROBO_OK) s = grow(&cand->d_qpart, &cand->qpart_bytes, (size_t)2 * nbk * cn * sizeof(double));
     if (s != ROBO_OK) return s;
     double* qpart = cand->d_qpart;
     double* mupart = cand->d_qpart + (size_t)nbk * cn;
     s = launch_cross_gram(gp, cand, c0, cn, cand->d_Ks);
     if (s != ROBO_OK) return s;
-    cand->solve_kernel = "winv_gemm_kernel";
-    hipLaunchKernelGGL(winv_gemm_kernel, dim3(cts, (unsigned)nu), dim3(256), 0, st, (const double*)cand->d_Ks, n_pad,
-                       (const double*)gp->d_Winv, n_pad, (const int4*)gp->d_wunits, nu, cand->d_P);
     const double* z = gp->d_K + (size_t)gp->n * n_pad;
-    if (store_v)
-        hipLaunchKernelGGL(winv_reduce_kernel<true>, dim3((unsigned)nbk, cts), dim3(256), 0, st, (const double*)cand->d_P,
-                           (const int*)gp->d_wprefix, nu, z, gp->n, cand->d_V, n_pad, qpart, mupart, (long long)cn);
-    else
-        hipLaunchKernelGGL(winv_reduce_kernel<false>, dim3((unsigned)nbk, cts), dim3(256), 0, st, (const double*)cand->d_P,
-                           (const int*)gp->d_wprefix, nu, z, gp->n, cand->d_V, n_pad, qpart, mupart, (long long)cn);
+    if (whole) {
+        cand->solve_kernel = "winv_row_kernel";
+        if (store_v)
+            hipLaunchKernelGGL(winv_row_kernel<true>, dim3(cts, (unsigned)nbk), dim3(256), 0, st, (const double*)cand->d_Ks,
+                               n_pad, (const double*)gp->d_Winv, n_pad, nbk, z, gp->n, cand->d_V, n_pad, qpart, mupart,
+                               (long long)cn);
+        else
+            hipLaunchKernelGGL(winv_row_kernel<false>, dim3(cts, (unsigned)nbk), dim3(256), 0, st, (const double*)cand->d_Ks,
+                               n_pad, (const double*)gp->d_Winv, n_pad, nbk, z, gp->n, cand->d_V, n_pad, qpart, mupart,
+                               (long long)cn);
+    } else {
+        cand->solve_kernel = "winv_gemm_kernel";
+        hipLaunchKernelGGL(winv_gemm_kernel, dim3(cts, (unsigned)nu), dim3(256), 0, st, (const double*)cand->d_Ks, n_pad,
+                           (const double*)gp->d_Winv, n_pad, (const int4*)gp->d_wunits, nu, cand->d_P);
+        if (store_v)
+            hipLaunchKernelGGL(winv_reduce_kernel<true>, dim3((unsigned)nbk, cts), dim3(256), 0, st,
+                               (const double*)cand->d_P, (const int*)gp->d_wprefix, nu, z, gp->n, cand->d_V, n_pad, qpart,
+                               mupart, (long long)cn);
+        else
+            hipLaunchKernelGGL(winv_reduce_kernel<false>, dim3((unsigned)nbk, cts), dim3(256), 0, st,
+                               (const double*)cand->d_P, (const int*)gp->d_wprefix, nu, z, gp->n, cand->d_V, n_pad, qpart,
+                               mupart, (long long)cn);
+    }
     hipLaunchKernelGGL(winv_finish_kernel, dim3((unsigned)((cn + 255) / 256)), dim3(256), 0, st, (const double*)qpart,
                        (const double*)mupart, nbk, (long long)cn, cand->d_q + c0, cand->d_mu + c0);
     ROBO_LAUNCH_CHECK();

@@ -1077,7 +1077,12 @@ def check_winv_path(ctx, cases=(("matern52", 300, 5, 700), ("fabolas", 280, 4, 1
     rs = np.random.RandomState(43)
     try:
         ctx.set_tuning("winv_min_blocks", 2)
-        for kind, N, D, M in cases:
+        import itertools
+        # both forms of the product: chunked units + reduction (small batches) and one workgroup per (tile, block row) over
+        # the whole contraction range with the reductions in its epilogue (batches that fill the chip) -- forced in turn
+        for (kind, N, D, M), rows_mode in itertools.product(cases, (0, 1)):
+            ctx.set_tuning("winv_rows", rows_mode)
+            winv_name = "winv_row_kernel" if rows_mode else "winv_gemm_kernel"
             X = rs.rand(N, D)
             y = np.sin(3 * X.sum(axis=1))
             P = O.n_kernel_params(kind, D) + 1
@@ -1098,8 +1103,15 @@ def check_winv_path(ctx, cases=(("matern52", 300, 5, 700), ("fabolas", 280, 4, 1
             ctx.set_tuning("winv_max", None)
             cand = _lib.Candidates(ctx, Xc)
             mu_w, var_w = g.predict(cand)
-            assert cand.solve_kernel() == "winv_gemm_kernel"
+            assert cand.solve_kernel() == winv_name
             vals, mx, am_w, _ = g.acq("ei", 0.0, eta, cand)
+            # the other form of the product on the same batch: rounding-level agreement
+            ctx.set_tuning("winv_rows", 1 - rows_mode)
+            mu_x, var_x = g.predict(cand)
+            assert cand.solve_kernel() != winv_name and cand.solve_kernel().startswith("winv_")
+            np.testing.assert_allclose(mu_x, mu_w, rtol=0, atol=1e-12 * max(1.0, np.abs(mu_w).max()))
+            np.testing.assert_allclose(var_x, var_w, rtol=0, atol=1e-12 * amp)
+            ctx.set_tuning("winv_rows", rows_mode)
             mu_o, var_o = ogp.predict(Xc, diag_only=True)
             np.testing.assert_allclose(mu_w, mu_o, rtol=MU_RTOL, atol=MU_ATOL)
             np.testing.assert_allclose(var_w, var_o, rtol=0, atol=VAR_ATOL_REL_AMP * amp)
@@ -1114,7 +1126,7 @@ def check_winv_path(ctx, cases=(("matern52", 300, 5, 700), ("fabolas", 280, 4, 1
             ctx.set_tuning("ws_bytes", 2 * 128 * n_pad * 8)
             c2 = _lib.Candidates(ctx, Xc)
             mu_c, var_c = g.predict(c2)
-            assert c2.solve_kernel() == "winv_gemm_kernel" and (M <= 256 or c2.chunk() == 256)
+            assert c2.solve_kernel() == winv_name and (M <= 256 or c2.chunk() == 256)
             c2.close()
             ctx.set_tuning("ws_bytes", None)
             np.testing.assert_array_equal(mu_c, mu_w)
@@ -1151,11 +1163,11 @@ def check_winv_path(ctx, cases=(("matern52", 300, 5, 700), ("fabolas", 280, 4, 1
         g.fit(theta, float(y.mean()))
         cand = _lib.Candidates(ctx, rs.rand(100, 1))
         g.predict(cand)
-        assert cand.solve_kernel() != "winv_gemm_kernel", (cand.solve_kernel(), g.factor_cond())
+        assert not cand.solve_kernel().startswith("winv_"), (cand.solve_kernel(), g.factor_cond())
         cand.close()
         g.close()
     finally:
-        for key in ("winv_min_blocks", "winv_max", "ws_bytes"):
+        for key in ("winv_min_blocks", "winv_max", "ws_bytes", "winv_rows"):
             ctx.set_tuning(key, None)
 
 
@@ -1214,7 +1226,7 @@ def check_winv_guard_sweep(ctx, n=768, min_blocks=None, m=400, verbose=True,
                         finally:
                             if key:
                                 ctx.set_tuning(key, None)
-                    assert res["inverse"][0] == "winv_gemm_kernel" and res["substitution"][0] != "winv_gemm_kernel"
+                    assert res["inverse"][0].startswith("winv_") and not res["substitution"][0].startswith("winv_")
                     kern, mu, var, ok = res["chosen"]
                     row = (name, D, noise, cond, kern, float(np.abs(res["inverse"][1] - mu_o).max()),
                            float(np.abs(res["substitution"][1] - mu_o).max()),
@@ -1224,7 +1236,7 @@ def check_winv_guard_sweep(ctx, n=768, min_blocks=None, m=400, verbose=True,
                     if verbose:
                         print("guard sweep %-9s D=%d noise %.0e cond_inf %.3g -> %-22s |dmu| inverse %.1e substitution %.1e"
                               "  |dvar| %.1e / %.1e" % row)
-                    if kern == "winv_gemm_kernel":
+                    if kern.startswith("winv_"):
                         assert cond <= 1.0e5 and ok, row             # inside the bound AND inside the tolerance
                         np.testing.assert_array_equal(mu, res["inverse"][1])
                     else:
@@ -1236,13 +1248,13 @@ def check_winv_guard_sweep(ctx, n=768, min_blocks=None, m=400, verbose=True,
                         assert np.all(np.abs(mu - mu_o) <= 10 * tol_mu) and np.all(np.abs(var - var_o) <= tol_var), row
                     if not res["inverse"][3]:
                         # the explicit inverse would have missed the stated tolerance here: the guard must not pick it
-                        assert kern != "winv_gemm_kernel", row
+                        assert not kern.startswith("winv_"), row
                     g.close()
     finally:
         if min_blocks is not None:
             ctx.set_tuning("winv_min_blocks", None)
     # the sweep must actually exercise both sides of the bound
-    assert any(r[4] == "winv_gemm_kernel" for r in table) and any(r[4] != "winv_gemm_kernel" for r in table)
+    assert any(r[4].startswith("winv_") for r in table) and any(not r[4].startswith("winv_") for r in table)
     return table
 
 
