@@ -198,6 +198,101 @@ __global__ __launch_bounds__(256, KIND == ROBO_KERNEL_FABOLAS ? 3 : 6) void gram
 }
 
 
+// ---- K1 with the pair dot products on the matrix pipe (r04) --------------------------------------------------------------
+// gram_kernel spends 16 of its 69 fp64 VALU instructions per pair (D = 16) on x_i . x_j and stages both coordinate blocks
+// through LDS behind two barriers per tile.  Here r2 = |x_i|^2 + |x_j|^2 - 2 x_i . x_j takes the cross term from
+// v_mfma_f64_16x16x4_f64 -- ceil(D / 4) instructions per 16 x 16 pair tile on the otherwise idle matrix pipe -- with both
+// operands read straight from global memory in fragment order (X is L2 resident: 0.5 MB at N = 4096); no LDS, no barrier,
+// every wave runs on its own.  Wave w of a workgroup owns rows 16 w .. 16 w + 15 of the 64 x 64 tile and its four 16 x 16
+// sub-tiles.  Row norms come from the operand fragments themselves (two cross-lane adds), the diagonal is exact by
+// construction, r2 is clamped at 0: the same error model as pair_cov_dot (|x|^2 eps <= 1e-15 absolute in r2); entries
+// differ from gram_kernel's in the last bits only (the dot product's association), K and the oracle's agree to rtol 1e-13.
+// Fragment maps (gemm_f64.h): A/B operand lane l holds row l & 15, k = l >> 4; C reg r of lane l = (row (l >> 4) + 4 r,
+// col l & 15).
+template <int KIND>
+__global__ __launch_bounds__(256) void gram_mfma_kernel(const double* __restrict__ Xs, size_t xs_stride,
+                                                        const double* __restrict__ y, double* __restrict__ K,
+                                                        size_t k_stride, int n, int n_pad,
+                                                        const FitSample* __restrict__ sp, int* __restrict__ fail) {
+    if (blockIdx.x == 0 && threadIdx.x == 0) fail[blockIdx.y] = 0;
+    Xs += (size_t)blockIdx.y * xs_stride;
+    K += (size_t)blockIdx.y * k_stride;
+    const CovParams cp = sp[blockIdx.y].cov;
+    const double noise = sp[blockIdx.y].noise, mean_c = sp[blockIdx.y].mean_c;
+    int bi, bj;
+    tri_tile(blockIdx.x, bi, bj);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, dim = cp.dim;
+    const int i0 = bi * GT + wave * 16, j0 = bj * GT;      // first row of this wave's strip, first column of the tile
+    const int lr = lane & 15, lk = lane >> 4;
+    v4d acc[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) acc[c] = v4d{0.0, 0.0, 0.0, 0.0};
+    double na = 0.0, nb[4] = {0.0, 0.0, 0.0, 0.0};
+    const double* pa = Xs + (size_t)(i0 + lr) * dim + lk;
+    const double* pb = Xs + (size_t)(j0 + lr) * dim + lk;
+    for (int k0 = 0; k0 < dim; k0 += 4) {
+        const bool ok = k0 + lk < dim;
+        const double a = ok ? pa[k0] : 0.0;
+        double b[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) b[c] = ok ? pb[(size_t)c * 16 * dim + k0] : 0.0;
+        na = fma(a, a, na);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            nb[c] = fma(b[c], b[c], nb[c]);
+            acc[c] = mfma_f64(a, b[c], acc[c]);
+        }
+    }
+    // |x|^2 of row (lane & 15): the four k-slices of a row sit in lanes l, l + 16, l + 32, l + 48
+    na += __shfl_xor(na, 16);
+    na += __shfl_xor(na, 32);
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        nb[c] += __shfl_xor(nb[c], 16);
+        nb[c] += __shfl_xor(nb[c], 32);
+    }
+    double ni[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) ni[r] = __shfl(na, lk + 4 * r);      // norm of C-layout row (l >> 4) + 4 r
+    double val[4][4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            double r2 = fma(-2.0, acc[c][r], ni[r] + nb[c]);
+            val[c][r] = r2 > 0.0 ? r2 : 0.0;
+        }
+    if (bi != bj && bi * GT + GT <= n) {
+        // interior tile (all rows and columns are training points, no diagonal entry): a workgroup-uniform branch, the
+        // values as they are
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                K[(size_t)(i0 + lk + 4 * r) * n_pad + j0 + c * 16 + lr] = cov_finish<double, KIND>(cp, val[c][r], 0.0);
+        return;
+    }
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int gi = i0 + lk + 4 * r, gj = j0 + c * 16 + lr;
+            double v = cov_finish<double, KIND>(cp, gi == gj ? 0.0 : val[c][r], 0.0);     // the diagonal is exact
+            if (gi < n && gj < n) {
+                if (gi == gj) v += noise;
+            } else if (gi == gj) {
+                v = 1.0;
+            } else if (gi == n && gj < n) {
+                v = y[gj] - mean_c;
+            } else if (gj == n && gi < n) {
+                v = y[gi] - mean_c;
+            } else {
+                v = 0.0;
+            }
+            K[(size_t)gi * n_pad + gj] = v;
+        }
+}
+
 // ---- K1, single theta, fp64 stationary kernels: PERSISTENT workgroups -------------------------------------------------
 // gram_kernel above launches one short workgroup per 64 x 64 tile (2211 at N = 4096): every resident workgroup goes
 // through  load coordinates -> barrier -> 16 LDS-fed distance passes -> sqrt / exp -> store  in the same phase at the
@@ -443,6 +538,22 @@ int launch_gram(robo_gp* gp, const FitBuffers& fb) {
         else
             hipLaunchKernelGGL(gram_persistent_kernel<ROBO_KERNEL_RBF_ARD>, dim3(grid), dim3(256), 0, gp->ctx->stream,
                                fb.Xs, (const double*)gp->d_y, fb.K, gp->n, gp->n_pad, fb.sp, fb.fail, counter, tiles);
+        ROBO_LAUNCH_CHECK();
+        return ROBO_OK;
+    }
+    // fp64 stationary kernels on two or more 128-blocks: the pair dot products on the matrix pipe (gram_mfma_kernel);
+    // tuning gram_mfma: -1 auto, 0 never, 1 wherever it applies.  One-block problems keep gram_kernel: the fused ensemble
+    // step of the hyper-parameter chain (potrf.hip) builds the same entries with pair_cov_dot, bit for bit
+    if (!gp->fp32_gram && gp->kind != ROBO_KERNEL_FABOLAS &&
+        (tune.gram_mfma > 0 || (tune.gram_mfma < 0 && gp->n_pad >= 2 * NB))) {
+        if (gp->kind == ROBO_KERNEL_MATERN52_ARD)
+            hipLaunchKernelGGL(gram_mfma_kernel<ROBO_KERNEL_MATERN52_ARD>, dim3(tiles, fb.S), dim3(256), 0, gp->ctx->stream,
+                               fb.Xs, fb.xs_stride, (const double*)gp->d_y, fb.K, fb.k_stride, gp->n, gp->n_pad, fb.sp,
+                               fb.fail);
+        else
+            hipLaunchKernelGGL(gram_mfma_kernel<ROBO_KERNEL_RBF_ARD>, dim3(tiles, fb.S), dim3(256), 0, gp->ctx->stream,
+                               fb.Xs, fb.xs_stride, (const double*)gp->d_y, fb.K, fb.k_stride, gp->n, gp->n_pad, fb.sp,
+                               fb.fail);
         ROBO_LAUNCH_CHECK();
         return ROBO_OK;
     }

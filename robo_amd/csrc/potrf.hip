@@ -1401,6 +1401,11 @@ int launch_potrf(robo_gp* gp, const FitBuffers& fb) {
     // fb.fail[0 .. S) was zeroed by the gram kernel (launch_gram always precedes this)
     const Tuning& tune = ctx->tune;
     const bool fused = S <= 2 && tune.potrf_fused != 0;
+    // n a multiple of 128 (every BASELINE size): the last block holds the augmented row ALONE.  Its diagonal entry is never
+    // read -- z = L^-1 (y - mean) is complete once the last REAL panel has passed over row n, the likelihood needs z.z and the
+    // real pivots only -- so that block is neither updated nor factored nor inverted: one link less in the chain
+    // panel -> tile update -> 128 pivots -> next panel (r04: the 33rd link of the N = 4096 fit)
+    const int nbf = (gp->n % NB == 0 && nb > 1) ? nb - 1 : nb;       // diagonal blocks that are factored
 #define ROBO_DIAG(KK)                                                                                          \
     hipLaunchKernelGGL(potrf_diag_kernel, dim3(S), dim3(256), 0, ctx->stream, fb.K, fb.k_stride, ld, (KK), gp->n, \
                        fb.Linv, fb.linv_stride, fb.fail, (long long*)nullptr, (double*)nullptr, (double*)nullptr)
@@ -1433,6 +1438,7 @@ int launch_potrf(robo_gp* gp, const FitBuffers& fb) {
         for (int k = 0; k + 1 < nb; ++k) {
             const int rem = nb - k - 1, tiles = rem * (rem + 1) / 2;
             ROBO_PANEL(k);
+            if (k + 1 >= nbf) break;          // what is left is the augmented row's own block: nothing to factor
             // 128-row tiles: one diagonal workgroup + at most (CUs - 1) persistent tile workgroups (one per CU: the
             // diagonal block's LDS image sizes every workgroup of the launch)
             if (tiles * S >= tm4_min) ROBO_STEP(4, true, tiles < max_wg ? tiles : max_wg, k, k, NB, 0, tiles);
@@ -1450,6 +1456,7 @@ int launch_potrf(robo_gp* gp, const FitBuffers& fb) {
         for (int k0 = 0; k0 < nb; k0 += G) {
             const int g = nb - k0 < G ? nb - k0 : G;          // panels in this group
             for (int kk = k0; kk < k0 + g; ++kk) {
+                if (kk >= nbf) break;         // the augmented row's own block
                 // left-looking inside the group: block column kk <- panels k0 .. kk-1, all rows >= kk
                 if (kk > k0) ROBO_UPDATE(nb - kk, kk - 1, k0, (kk - k0) * NB, 1);
                 ROBO_DIAG(kk);
@@ -1464,9 +1471,9 @@ int launch_potrf(robo_gp* gp, const FitBuffers& fb) {
 #undef ROBO_PANEL
 #undef ROBO_DIAG
     // the explicit 128 x 128 inverses of all diagonal blocks, off the factorisation's critical path
-    hipLaunchKernelGGL(potrf_inverse_kernel, dim3(nb, S), dim3(256), 0, ctx->stream, (const double*)fb.K, fb.k_stride, ld,
+    hipLaunchKernelGGL(potrf_inverse_kernel, dim3(nbf, S), dim3(256), 0, ctx->stream, (const double*)fb.K, fb.k_stride, ld,
                        fb.Linv, fb.linv_stride, gp->n, fb.LinvP, fb.ll_part, fb.want_inverse ? 1 : 0);
-    hipLaunchKernelGGL(loglik_finish_kernel, dim3(S), dim3(64), 0, ctx->stream, (const double*)fb.ll_part, nb, fb.out,
+    hipLaunchKernelGGL(loglik_finish_kernel, dim3(S), dim3(64), 0, ctx->stream, (const double*)fb.ll_part, nbf, fb.out,
                        (const int*)fb.fail, fb.host_out);
     ROBO_LAUNCH_CHECK();
     return ROBO_OK;

@@ -64,6 +64,8 @@ fit)
   python tools/diag_timeline.py > $OUT/diag_timeline.txt 2>&1
   timeout 600 bash tools/gpu_fit_trace.sh $TAG 4096 > $OUT/fit_trace.log 2>&1
   cat $OUT/diag_timeline.txt >> $OUT/summary.txt; tail -3 $OUT/trace_4096.txt >> $OUT/summary.txt 2>/dev/null ;;
+gram)
+  timeout 300 python tools/gram_timing.py > $OUT/gram_timing.txt 2>&1; cat $OUT/gram_timing.txt >> $OUT/summary.txt ;;
 small)
   timeout 300 python tools/small_m_timing.py > $OUT/small_m.txt 2>&1; cat $OUT/small_m.txt >> $OUT/summary.txt ;;
 *) echo "unknown step $what" >> $OUT/summary.txt ;;

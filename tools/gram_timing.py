@@ -10,15 +10,17 @@ for N, D in ((4096, 16), (2048, 16), (8192, 64)):
     g = _lib.DeviceGP(ctx, "matern52", N, D); g.set_data(X, y)
     ctx.set_phase_events(True)
     nbytes = 8.0 * N * (N + 1) / 2 + 8.0 * N * D
-    for wpc in (0, 1, 2, 3, 4, 5, 6, 8):
+    for label, mfma, wpc in (("mfma dots (default)", 1, 0), ("valu dots", 0, 0), ("valu dots, persistent x4", 0, 4)):
+        ctx.set_tuning("gram_mfma", mfma)
         ctx.set_tuning("gram_persistent", wpc)
         ks, ps = [], []
         for _ in range(6):
             g.fit(theta, 0.0)
             ks.append(ctx.elapsed_ms(19, 21)); ps.append(ctx.elapsed_ms(20, 21))
         k = min(ks)
-        print("N=%d D=%d gram_persistent=%d: kernel %.1f us (%.2f TB/s, %.1f %% of 8 TB/s), phase %.1f us"
-              % (N, D, wpc, k * 1e3, nbytes / (k * 1e-3) / 1e12, 100 * nbytes / (k * 1e-3) / 8e12, min(ps) * 1e3))
+        print("N=%d D=%d %-26s kernel %.1f us (%.2f TB/s, %.1f %% of 8 TB/s), phase %.1f us"
+              % (N, D, label + ":", k * 1e3, nbytes / (k * 1e-3) / 1e12, 100 * nbytes / (k * 1e-3) / 8e12, min(ps) * 1e3))
     ctx.set_tuning("gram_persistent", None)
+    ctx.set_tuning("gram_mfma", None)
     ctx.set_phase_events(False)
     g.close()
