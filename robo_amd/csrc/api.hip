@@ -45,7 +45,8 @@ static const TuneKey TUNE_KEYS[] = {
     {"potrf_max_wg", nullptr, &Tuning::potrf_max_wg, 0},
     {"potrf_group", nullptr, &Tuning::potrf_group, 4},
     {"gram_persistent", nullptr, &Tuning::gram_persistent, 0},
-    {"gram_mfma", nullptr, &Tuning::gram_mfma, -1},
+    {"gram_mfma", nullptr, &Tuning::gram_mfma, 0},
+    {"gram_half", nullptr, &Tuning::gram_half, 0},
     {"mcmc_block_step", nullptr, &Tuning::mcmc_block_step, 2},
 };
 

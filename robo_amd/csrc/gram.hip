@@ -198,6 +198,143 @@ __global__ __launch_bounds__(256, KIND == ROBO_KERNEL_FABOLAS ? 3 : 6) void gram
 }
 
 
+// ---- K1 on 32 x 64 tiles (r04) ------------------------------------------------------------------------------------------
+// gram_kernel's 2211 tiles at N = 4096 meet 1536 workgroup slots (6 per CU): the launch runs as two rounds of workgroups
+// where 1.44 would do, and a workgroup's lifetime is a dependent chain (coordinates -> LDS -> distance passes -> rsq ->
+// 13-term Horner -> stores).  Half-height tiles -- 32 rows x 64 columns, a 2 x 4 micro-tile per thread, 4422 tiles, eight
+// workgroups per CU -- quantise the tail in units of half the work and halve every workgroup's chain.  Same arithmetic
+// per entry, in the same order, as gram_kernel<double, KIND> (pair_cov_dot): K is bit-identical.
+// MEASURED (r04d, MI355X, HIP events around the kernel): N = 4096 D = 16 36.9 us against gram_kernel's 33.8; N = 2048 17.9
+// against 19.8; N = 8192 D = 64 251 against 184 -- the column block is staged once per 2048 pairs instead of once per 4096,
+// and that costs more than the finer tail gains: the launch is not lost to round quantisation.  Tested option (tuning
+// gram_half = 1), default off.
+constexpr int HT = 32;          // tile rows
+constexpr int HLD = HT + 2;
+
+__device__ __forceinline__ void half_tile(int t, int& bi, int& bj) {
+    // row blocks 2 p and 2 p + 1 (32 rows each) both own column blocks 0 .. p (64 columns each): 2 (p + 1) tiles per pair
+    int p = (int)((sqrt(4.0 * (double)t + 1.0) - 1.0) * 0.5);
+    while ((p + 1) * (p + 2) <= t) ++p;
+    while (p * (p + 1) > t) --p;
+    const int rem = t - p * (p + 1);
+    bi = 2 * p + (rem > p ? 1 : 0);
+    bj = rem > p ? rem - (p + 1) : rem;
+}
+
+template <int KIND>
+__global__ __launch_bounds__(256, 8) void gram_half_kernel(const double* __restrict__ Xs, size_t xs_stride,
+                                                           const double* __restrict__ y, double* __restrict__ K,
+                                                           size_t k_stride, int n, int n_pad,
+                                                           const FitSample* __restrict__ sp, int* __restrict__ fail) {
+    if (blockIdx.x == 0 && threadIdx.x == 0) fail[blockIdx.y] = 0;
+    __shared__ double sI[GD * HLD];
+    __shared__ double sJ[GD * GLD];
+    __shared__ double sN[HT + GT];
+    Xs += (size_t)blockIdx.y * xs_stride;
+    K += (size_t)blockIdx.y * k_stride;
+    const CovParams cp = sp[blockIdx.y].cov;
+    const double noise = sp[blockIdx.y].noise, mean_c = sp[blockIdx.y].mean_c;
+    int bi, bj;
+    half_tile(blockIdx.x, bi, bj);
+    const long long i0 = (long long)bi * HT, j0 = (long long)bj * GT;
+    const int t = threadIdx.x, tx = t & 15, ty = t >> 4, dim = cp.dim;
+    double dot[2][4];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) dot[a][b] = 0.0;
+    double nrm = 0.0;                 // threads 0..31: |x_i|^2 of row i0 + t; 32..95: |x_j|^2 of row j0 + t - 32
+    for (int d0 = 0; d0 < dim; d0 += GD) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int idx = t + e * 256;
+            const int row = idx >> 4, d = idx & 15;
+            const bool ok = d0 + d < dim;
+            if (e < 2) sI[d * HLD + row] = ok ? Xs[(i0 + row) * dim + d0 + d] : 0.0;
+            sJ[d * GLD + row] = ok ? Xs[(j0 + row) * dim + d0 + d] : 0.0;
+        }
+        __syncthreads();
+        const int dn = dim - d0 < GD ? dim - d0 : GD;
+        if (t < HT) {
+            for (int d = 0; d < dn; ++d) {
+                const double x = sI[d * HLD + t];
+                nrm = fma(x, x, nrm);
+            }
+        } else if (t < HT + GT) {
+            for (int d = 0; d < dn; ++d) {
+                const double x = sJ[d * GLD + t - HT];
+                nrm = fma(x, x, nrm);
+            }
+        }
+#pragma unroll 4
+        for (int d = 0; d < dn; ++d) {
+            double xi[2], xj[4];
+#pragma unroll
+            for (int a = 0; a < 2; ++a) xi[a] = sI[d * HLD + ty * 2 + a];
+#pragma unroll
+            for (int b = 0; b < 4; ++b) xj[b] = sJ[d * GLD + tx * 4 + b];
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int b = 0; b < 4; ++b) dot[a][b] = fma(xi[a], xj[b], dot[a][b]);
+        }
+        __syncthreads();
+    }
+    if (t < HT + GT) sN[t] = nrm;
+    __syncthreads();
+    double ni[2], nj[4];
+#pragma unroll
+    for (int a = 0; a < 2; ++a) ni[a] = sN[ty * 2 + a];
+#pragma unroll
+    for (int b = 0; b < 4; ++b) nj[b] = sN[HT + tx * 4 + b];
+    double cov[2][4];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            double r2 = fma(-2.0, dot[a][b], ni[a] + nj[b]);
+            r2 = r2 > 0.0 ? r2 : 0.0;
+            if (i0 + ty * 2 + a == j0 + tx * 4 + b) r2 = 0.0;          // the diagonal is exact
+            cov[a][b] = cov_finish<double, KIND>(cp, r2, 0.0);
+        }
+    if (j0 + GT <= i0 && (int)i0 + HT <= n) {
+        // interior tile: no diagonal entry, every row and column a training point (workgroup-uniform branch)
+#pragma unroll
+        for (int a = 0; a < 2; ++a) {
+            double2* dst = reinterpret_cast<double2*>(K + (size_t)(i0 + ty * 2 + a) * n_pad + j0 + tx * 4);
+            dst[0] = make_double2(cov[a][0], cov[a][1]);
+            dst[1] = make_double2(cov[a][2], cov[a][3]);
+        }
+        return;
+    }
+#pragma unroll
+    for (int a = 0; a < 2; ++a) {
+        const int gi = (int)i0 + ty * 2 + a;
+        double v[4];
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            const int gj = (int)j0 + tx * 4 + b;
+            double val;
+            if (gi < n && gj < n) {
+                val = cov[a][b];
+                if (gi == gj) val += noise;
+            } else if (gi == gj) {
+                val = 1.0;
+            } else if (gi == n && gj < n) {
+                val = y[gj] - mean_c;
+            } else if (gj == n && gi < n) {
+                val = y[gi] - mean_c;
+            } else {
+                val = 0.0;
+            }
+            v[b] = val;
+        }
+        double2* dst = reinterpret_cast<double2*>(K + (size_t)gi * n_pad + j0 + tx * 4);
+        dst[0] = make_double2(v[0], v[1]);
+        dst[1] = make_double2(v[2], v[3]);
+    }
+}
+
 // ---- K1 with the pair dot products on the matrix pipe (r04) --------------------------------------------------------------
 // gram_kernel spends 16 of its 69 fp64 VALU instructions per pair (D = 16) on x_i . x_j and stages both coordinate blocks
 // through LDS behind two barriers per tile.  Here r2 = |x_i|^2 + |x_j|^2 - 2 x_i . x_j takes the cross term from
@@ -209,6 +346,8 @@ __global__ __launch_bounds__(256, KIND == ROBO_KERNEL_FABOLAS ? 3 : 6) void gram
 // differ from gram_kernel's in the last bits only (the dot product's association), K and the oracle's agree to rtol 1e-13.
 // Fragment maps (gemm_f64.h): A/B operand lane l holds row l & 15, k = l >> 4; C reg r of lane l = (row (l >> 4) + 4 r,
 // col l & 15).
+// MEASURED SLOWER than gram_kernel (r04c: 37.2 vs 33.8 us at N = 4096 D = 16; 311 vs 182 us at N = 8192 D = 64) although it
+// issues ~28 % fewer fp64 VALU instructions per pair (tools/isa_count.py): kept as a tested option, default off.
 template <int KIND>
 __global__ __launch_bounds__(256) void gram_mfma_kernel(const double* __restrict__ Xs, size_t xs_stride,
                                                         const double* __restrict__ y, double* __restrict__ K,
@@ -541,11 +680,10 @@ int launch_gram(robo_gp* gp, const FitBuffers& fb) {
         ROBO_LAUNCH_CHECK();
         return ROBO_OK;
     }
-    // fp64 stationary kernels on two or more 128-blocks: the pair dot products on the matrix pipe (gram_mfma_kernel);
-    // tuning gram_mfma: -1 auto, 0 never, 1 wherever it applies.  One-block problems keep gram_kernel: the fused ensemble
-    // step of the hyper-parameter chain (potrf.hip) builds the same entries with pair_cov_dot, bit for bit
-    if (!gp->fp32_gram && gp->kind != ROBO_KERNEL_FABOLAS &&
-        (tune.gram_mfma > 0 || (tune.gram_mfma < 0 && gp->n_pad >= 2 * NB))) {
+    // A/B option (tuning gram_mfma = 1): the pair dot products on the matrix pipe -- MEASURED SLOWER (r04c, MI355X: N = 4096
+    // D = 16 37.2 vs 33.8 us, N = 8192 D = 64 311 vs 182 us: its operands come from global memory in fragment order, 8-byte
+    // strided loads, and a 16 x 16 x 4 fp64 MFMA per 4 dimensions does not amortise them)
+    if (!gp->fp32_gram && gp->kind != ROBO_KERNEL_FABOLAS && tune.gram_mfma > 0) {
         if (gp->kind == ROBO_KERNEL_MATERN52_ARD)
             hipLaunchKernelGGL(gram_mfma_kernel<ROBO_KERNEL_MATERN52_ARD>, dim3(tiles, fb.S), dim3(256), 0, gp->ctx->stream,
                                fb.Xs, fb.xs_stride, (const double*)gp->d_y, fb.K, fb.k_stride, gp->n, gp->n_pad, fb.sp,
@@ -554,6 +692,21 @@ int launch_gram(robo_gp* gp, const FitBuffers& fb) {
             hipLaunchKernelGGL(gram_mfma_kernel<ROBO_KERNEL_RBF_ARD>, dim3(tiles, fb.S), dim3(256), 0, gp->ctx->stream,
                                fb.Xs, fb.xs_stride, (const double*)gp->d_y, fb.K, fb.k_stride, gp->n, gp->n_pad, fb.sp,
                                fb.fail);
+        ROBO_LAUNCH_CHECK();
+        return ROBO_OK;
+    }
+    if (!gp->fp32_gram && gp->kind != ROBO_KERNEL_FABOLAS && tune.gram_half > 0) {
+        // A/B option: 32 x 64 tiles, bit-identical entries (measured slower at N >= 4096, see gram_half_kernel)
+        const int P2 = gp->n_pad / GT;                       // pairs of 32-row blocks
+        const int half_tiles = P2 * (P2 + 1);
+        if (gp->kind == ROBO_KERNEL_MATERN52_ARD)
+            hipLaunchKernelGGL(gram_half_kernel<ROBO_KERNEL_MATERN52_ARD>, dim3(half_tiles, fb.S), dim3(256), 0,
+                               gp->ctx->stream, fb.Xs, fb.xs_stride, (const double*)gp->d_y, fb.K, fb.k_stride, gp->n,
+                               gp->n_pad, fb.sp, fb.fail);
+        else
+            hipLaunchKernelGGL(gram_half_kernel<ROBO_KERNEL_RBF_ARD>, dim3(half_tiles, fb.S), dim3(256), 0,
+                               gp->ctx->stream, fb.Xs, fb.xs_stride, (const double*)gp->d_y, fb.K, fb.k_stride, gp->n,
+                               gp->n_pad, fb.sp, fb.fail);
         ROBO_LAUNCH_CHECK();
         return ROBO_OK;
     }

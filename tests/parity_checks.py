@@ -1298,8 +1298,13 @@ def check_gram_variants(ctx, cases=(("matern52", 300, 5), ("rbf", 200, 3), ("mat
         try:
             ctx.set_tuning("gram_mfma", 0)
             ctx.set_tuning("gram_persistent", 0)
+            ctx.set_tuning("gram_half", 0)
             K0 = g.gram(theta)
             ll0 = g.fit(theta, float(y.mean()))
+            ctx.set_tuning("gram_half", 1)              # 32 x 64 tiles: the same entries, bit for bit
+            np.testing.assert_array_equal(g.gram(theta), K0)
+            assert g.fit(theta, float(y.mean())) == ll0
+            ctx.set_tuning("gram_half", 0)
             for wpc in (4, 1, 3):
                 ctx.set_tuning("gram_persistent", wpc)
                 np.testing.assert_array_equal(g.gram(theta), K0)
@@ -1309,10 +1314,12 @@ def check_gram_variants(ctx, cases=(("matern52", 300, 5), ("rbf", 200, 3), ("mat
             Km = g.gram(theta)
             llm = g.fit(theta, float(y.mean()))
             ctx.set_tuning("gram_mfma", None)
-            np.testing.assert_array_equal(g.gram(theta), Km if N + 1 > 128 else K0)     # the default form
+            ctx.set_tuning("gram_half", None)
+            np.testing.assert_array_equal(g.gram(theta), K0)     # the default form
         finally:
             ctx.set_tuning("gram_persistent", None)
             ctx.set_tuning("gram_mfma", None)
+            ctx.set_tuning("gram_half", None)
         Ko = O.kernel_matrix(kind, theta[:-1], X) + (np.exp(theta[-1]) + 1.25e-12) * np.eye(N)
         np.testing.assert_allclose(K0, Ko, rtol=1e-13, atol=1e-15)
         np.testing.assert_allclose(Km, Ko, rtol=1e-13, atol=1e-15)

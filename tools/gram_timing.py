@@ -10,8 +10,10 @@ for N, D in ((4096, 16), (2048, 16), (8192, 64)):
     g = _lib.DeviceGP(ctx, "matern52", N, D); g.set_data(X, y)
     ctx.set_phase_events(True)
     nbytes = 8.0 * N * (N + 1) / 2 + 8.0 * N * D
-    for label, mfma, wpc in (("mfma dots (default)", 1, 0), ("valu dots", 0, 0), ("valu dots, persistent x4", 0, 4)):
+    for label, mfma, wpc, half in (("32x64 tiles", 0, 0, 1), ("64x64 tiles", 0, 0, 0), ("64x64 tiles, mfma dots", 1, 0, 0),
+                                   ("64x64 tiles, persistent x4", 0, 4, 0)):
         ctx.set_tuning("gram_mfma", mfma)
+        ctx.set_tuning("gram_half", half)
         ctx.set_tuning("gram_persistent", wpc)
         ks, ps = [], []
         for _ in range(6):
@@ -22,5 +24,6 @@ for N, D in ((4096, 16), (2048, 16), (8192, 64)):
               % (N, D, label + ":", k * 1e3, nbytes / (k * 1e-3) / 1e12, 100 * nbytes / (k * 1e-3) / 8e12, min(ps) * 1e3))
     ctx.set_tuning("gram_persistent", None)
     ctx.set_tuning("gram_mfma", None)
+    ctx.set_tuning("gram_half", None)
     ctx.set_phase_events(False)
     g.close()
