@@ -19,7 +19,7 @@ PY
 configs)
   : > $OUT/configs.jsonl
   for c in c2 c3 c4 c5; do
-    timeout 600 python bench.py --gpus 1 --config $c --no-cpu-baseline >> $OUT/configs.jsonl 2>> $OUT/configs.err; echo "$c rc=$?" >> $OUT/summary.txt
+    timeout 900 python bench.py --gpus 1 --config $c >> $OUT/configs.jsonl 2>> $OUT/configs.err; echo "$c rc=$?" >> $OUT/summary.txt
   done
   timeout 900 python bench.py --gpus 1 --config c5 --m 1048576 --steps 2 --warmup 1 --no-cpu-baseline >> $OUT/configs.jsonl 2>> $OUT/configs.err; echo "c5 full rc=$?" >> $OUT/summary.txt
   cut -c1-300 $OUT/configs.jsonl >> $OUT/summary.txt ;;
@@ -64,6 +64,24 @@ fit)
   python tools/diag_timeline.py > $OUT/diag_timeline.txt 2>&1
   timeout 600 bash tools/gpu_fit_trace.sh $TAG 4096 > $OUT/fit_trace.log 2>&1
   cat $OUT/diag_timeline.txt >> $OUT/summary.txt; tail -3 $OUT/trace_4096.txt >> $OUT/summary.txt 2>/dev/null ;;
+sustained)
+  # the headline under steady power: 200 timed steps, the shader clock sampled during one more step at the end
+  timeout 600 python bench.py --gpus 1 --steps 200 --warmup 5 --lean --no-cpu-baseline > $OUT/bench_sustained.json 2> $OUT/bench_sustained.err; echo "sustained rc=$?" >> $OUT/summary.txt
+  python - <<PY >> $OUT/summary.txt 2>&1
+import json; d=json.load(open('$OUT/bench_sustained.json'))
+print('sustained: value', d['value'], 'ms/step', d['ms_per_step'], 'frac', d['roofline']['frac'], 'clock', d['roofline'].get('shader_clock_under_kernel'))
+PY
+  ;;
+k1pmc)
+  # K1 alone: VALU instruction counts and busy cycles of the gram kernel over 4 headline fits (separate passes per group)
+  for C in "SQ_INSTS_VALU SQ_ACTIVE_INST_VALU" "SQ_BUSY_CYCLES SQ_WAVE_CYCLES" "GRBM_GUI_ACTIVE SQ_WAVES" "FETCH_SIZE" "WRITE_SIZE"; do
+    name=$(echo $C | tr ' ' '_')
+    FIT_REPS=4 timeout 300 rocprofv3 --kernel-trace --pmc $C -d $OUT/k1pmc/$name -o pmc -- python tools/fit_only.py > $OUT/k1pmc_$name.txt 2> $OUT/k1pmc_$name.err
+    echo "k1pmc $C rc=$?" >> $OUT/summary.txt
+  done
+  python tools/rocpd_pmc.py $OUT/k1pmc > $OUT/k1pmc_summary.txt 2>&1
+  find $OUT/k1pmc -size +30M -delete
+  grep -i "gram_kernel" $OUT/k1pmc_summary.txt >> $OUT/summary.txt ;;
 gram)
   timeout 300 python tools/gram_timing.py > $OUT/gram_timing.txt 2>&1; cat $OUT/gram_timing.txt >> $OUT/summary.txt ;;
 small)
