@@ -992,8 +992,9 @@ def run_c4(args, D_, _lib, sharding):
         # the sampled candidates double as a live check of the device's values against the restated reference loop
         cpu_vals = np.array(cb.pop("_values"))
         dev_vals, _, _ = _lib.ig_eval_per_cost(gp, cand, rep, ep, sn2, gc, cand_cost, 0.0, want_values=True)
-        cb["max_rel_diff_vs_device_on_the_sample"] = float(np.max(
-            np.abs(dev_vals[:cpu_vals.size] - cpu_vals) / np.maximum(np.abs(cpu_vals), 1e-300)))
+        # (the parity tests' measure for information gains: absolute difference in units of the largest gain)
+        cb["max_abs_diff_vs_device_on_the_sample_over_max_gain"] = float(
+            np.max(np.abs(dev_vals[:cpu_vals.size] - cpu_vals)) / np.max(np.abs(cpu_vals)))
         out["cpu_baseline"] = cb
     return out
 

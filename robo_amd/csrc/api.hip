@@ -47,6 +47,7 @@ static const TuneKey TUNE_KEYS[] = {
     {"gram_persistent", nullptr, &Tuning::gram_persistent, 0},
     {"gram_mfma", nullptr, &Tuning::gram_mfma, 0},
     {"gram_half", nullptr, &Tuning::gram_half, 0},
+    {"gram_occ", nullptr, &Tuning::gram_occ, 0},
     {"mcmc_block_step", nullptr, &Tuning::mcmc_block_step, 2},
 };
 

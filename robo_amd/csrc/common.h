@@ -94,6 +94,7 @@ struct Tuning {
     int potrf_tm4_min, potrf_max_wg, potrf_group;
     int mcmc_block_step;         // ensemble half-step in ONE launch: 2 (default) every one-block problem, 1 only N <= 63, 0 never
     int gram_mfma;               // K1 with x.x' on the matrix pipe (gram_mfma_kernel; measured slower, r04c: default 0 = never)
+    int gram_occ;                // K1 (Matern, fp64): 7 / 8 = gram_kernel compiled for that many workgroups per CU (A/B); else 6
     int gram_half;               // K1 on 32 x 64 tiles (gram_half_kernel; measured slower at the headline, r04d: default 0 = never)
     int gram_persistent;         // K1: persistent workgroups per CU; 0 (default, faster: r03d) = one workgroup per tile
 };

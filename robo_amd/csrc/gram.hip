@@ -137,8 +137,9 @@ __device__ __forceinline__ void pair_cov(const CovParams& cp, const double* __re
 // as row n of the factor (DESIGN.md "augmented row").
 // (six workgroups per CU = 80 VGPRs; the Fabolas product kernel needs more live values -- one Matern factor per pair and
 // dimension -- and spilled 92 registers under that cap: three per CU for it)
-template <class T, int KIND>
-__global__ __launch_bounds__(256, KIND == ROBO_KERNEL_FABOLAS ? 3 : 6) void gram_kernel(const double* __restrict__ Xs, size_t xs_stride,
+// WPC: workgroups per CU the register allocation is asked to allow (0: the default, six -- three for the Fabolas kernel)
+template <class T, int KIND, int WPC = 0>
+__global__ __launch_bounds__(256, WPC > 0 ? WPC : (KIND == ROBO_KERNEL_FABOLAS ? 3 : 6)) void gram_kernel(const double* __restrict__ Xs, size_t xs_stride,
                                                    const double* __restrict__ y, double* __restrict__ K,
                                                    size_t k_stride, int n, int n_pad,
                                                    const FitSample* __restrict__ sp, int* __restrict__ fail) {
@@ -707,6 +708,24 @@ int launch_gram(robo_gp* gp, const FitBuffers& fb) {
             hipLaunchKernelGGL(gram_half_kernel<ROBO_KERNEL_RBF_ARD>, dim3(half_tiles, fb.S), dim3(256), 0,
                                gp->ctx->stream, fb.Xs, fb.xs_stride, (const double*)gp->d_y, fb.K, fb.k_stride, gp->n,
                                gp->n_pad, fb.sp, fb.fail);
+        ROBO_LAUNCH_CHECK();
+        return ROBO_OK;
+    }
+    if (!gp->fp32_gram && gp->kind == ROBO_KERNEL_MATERN52_ARD && tune.gram_occ >= 4 && tune.gram_occ <= 8 &&
+        tune.gram_occ != 6) {
+        // A/B option: the same kernel compiled for 4 / 5 / 7 / 8 workgroups per CU (default six = 80 VGPRs).  Measured
+        // (r04f, N = 4096 D = 16): seven 41.5 us, eight 45.2 us (64 VGPRs, 76 bytes of scratch) against 34.6 us
+#define ROBO_GRAM_OCC(W)                                                                                             \
+    hipLaunchKernelGGL((gram_kernel<double, ROBO_KERNEL_MATERN52_ARD, W>), dim3(tiles, fb.S), dim3(256), 0,          \
+                       gp->ctx->stream, fb.Xs, fb.xs_stride, (const double*)gp->d_y, fb.K, fb.k_stride, gp->n,       \
+                       gp->n_pad, fb.sp, fb.fail)
+        switch (tune.gram_occ) {
+            case 4: ROBO_GRAM_OCC(4); break;
+            case 5: ROBO_GRAM_OCC(5); break;
+            case 7: ROBO_GRAM_OCC(7); break;
+            default: ROBO_GRAM_OCC(8); break;
+        }
+#undef ROBO_GRAM_OCC
         ROBO_LAUNCH_CHECK();
         return ROBO_OK;
     }

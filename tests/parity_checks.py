@@ -104,7 +104,7 @@ def check_case(ctx, name, full=True):
 
 def check_device_chain(ctx, cases=(("matern52", 150, 3, 10, 14), ("rbf", 40, 2, 8, 10), ("matern52", 100, 4, 12, 9),
                                    ("fabolas", 50, 3, 12, 8), ("fabolas", 60, 3, 12, 8, "env"),
-                                   ("fabolas", 170, 4, 10, 6, "env"))):
+                                   ("fabolas", 170, 4, 14, 6, "env"))):
     """robo_gp_mcmc_run (the whole stretch-move chain on the device) against the host sampler around the batched
     likelihood with the same RandomState: same accept decisions, positions and log-probabilities to rounding, the random
     stream ends in the same state; against the CPU oracle's log-probability through the same sampler; walkers outside

@@ -66,7 +66,8 @@ def test_mcmc_draws_equal_numpy_legacy_stream(emu_ctx):
 
 def test_device_resident_chain(emu_ctx):
     P.check_device_chain(emu_ctx, cases=(("matern52", 150, 3, 10, 6), ("rbf", 40, 2, 8, 5), ("matern52", 90, 2, 8, 3),
-                                               ("fabolas", 50, 3, 12, 4)))
+                                               ("fabolas", 50, 3, 12, 4), ("fabolas", 60, 3, 12, 4, "env"),
+                                               ("fabolas", 150, 4, 14, 3, "env")))
 
 
 def test_elementwise_and_degenerate_branches(emu_ctx):

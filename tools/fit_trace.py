@@ -16,7 +16,7 @@ def main(path):
     ks = [t for t in tabs if "kernel_symbol" in t][0]
     rows = c.execute("select s.kernel_name, d.start, d.end from %s d join %s s on d.kernel_id=s.id order by d.start"
                      % (kd, ks)).fetchall()
-    last = max(i for i, r in enumerate(rows) if "::gram_" in r[0] and "cross" not in r[0])
+    last = max(i for i, r in enumerate(rows) if "gram_" in r[0] and "cross" not in r[0])
     rows = rows[last:]
     t0 = rows[0][1]
     prev = rows[0][1]

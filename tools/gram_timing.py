@@ -10,8 +10,10 @@ for N, D in ((4096, 16), (2048, 16), (8192, 64)):
     g = _lib.DeviceGP(ctx, "matern52", N, D); g.set_data(X, y)
     ctx.set_phase_events(True)
     nbytes = 8.0 * N * (N + 1) / 2 + 8.0 * N * D
-    for label, mfma, wpc, half in (("32x64 tiles", 0, 0, 1), ("64x64 tiles", 0, 0, 0), ("64x64 tiles, mfma dots", 1, 0, 0),
-                                   ("64x64 tiles, persistent x4", 0, 4, 0)):
+    for label, mfma, wpc, half, occ in (("64x64 tiles (default)", 0, 0, 0, 0), ("64x64 tiles, 4 WG/CU", 0, 0, 0, 4), ("64x64 tiles, 5 WG/CU", 0, 0, 0, 5), ("64x64 tiles, 7 WG/CU", 0, 0, 0, 7),
+                                        ("64x64 tiles, 8 WG/CU", 0, 0, 0, 8), ("32x64 tiles", 0, 0, 1, 0),
+                                        ("64x64 tiles, mfma dots", 1, 0, 0, 0), ("64x64 tiles, persistent x4", 0, 4, 0, 0)):
+        ctx.set_tuning("gram_occ", occ)
         ctx.set_tuning("gram_mfma", mfma)
         ctx.set_tuning("gram_half", half)
         ctx.set_tuning("gram_persistent", wpc)
@@ -25,5 +27,6 @@ for N, D in ((4096, 16), (2048, 16), (8192, 64)):
     ctx.set_tuning("gram_persistent", None)
     ctx.set_tuning("gram_mfma", None)
     ctx.set_tuning("gram_half", None)
+    ctx.set_tuning("gram_occ", None)
     ctx.set_phase_events(False)
     g.close()
