@@ -5,7 +5,8 @@ OUT=gpurun_out/$TAG; mkdir -p $OUT; export TMPDIR=/tmp
 cd "$(dirname "$0")/.."
 for what in "$@"; do case $what in
 tests)
-  timeout 1500 python -m pytest tests -m gpu -q -x --durations=15 > $OUT/pytest_gpu.log 2>&1; echo "pytest rc=$?" >> $OUT/summary.txt
+  timeout 1500 python -m pytest tests -m gpu -q -x -rP --durations=15 > $OUT/pytest_gpu.log 2>&1; echo "pytest rc=$?" >> $OUT/summary.txt
+  grep -h "headline parity\|config5:\|guard sweep" $OUT/pytest_gpu.log >> $OUT/summary.txt
   tail -30 $OUT/pytest_gpu.log >> $OUT/summary.txt ;;
 smoke)
   timeout 300 python __graft_entry__.py smoke > $OUT/smoke.txt 2>&1; echo "smoke rc=$?" >> $OUT/summary.txt ;;
@@ -88,4 +89,5 @@ small)
   timeout 300 python tools/small_m_timing.py > $OUT/small_m.txt 2>&1; cat $OUT/small_m.txt >> $OUT/summary.txt ;;
 *) echo "unknown step $what" >> $OUT/summary.txt ;;
 esac; done
+echo "commit $(cat .git_head 2>/dev/null || echo unknown)" >> $OUT/summary.txt
 cat $OUT/summary.txt
