@@ -35,7 +35,6 @@ static const TuneKey TUNE_KEYS[] = {
     {"trsm_small_deep", nullptr, &Tuning::trsm_small_deep, -1},
     {"trsm_rows", nullptr, &Tuning::trsm_rows, 1},
     {"trsm_pair", nullptr, &Tuning::trsm_pair, 0},
-    {"trsm_prio_bit", nullptr, &Tuning::trsm_prio_bit, -1},
     {"predict_stepwise", nullptr, &Tuning::predict_stepwise, 0},
     {"winv_max", &Tuning::winv_max, nullptr, 32768},
     {"winv_min_blocks", nullptr, &Tuning::winv_min_blocks, 6},

@@ -142,7 +142,6 @@ __device__ __forceinline__ void gen_cross_tile_t(const CovParams& cp, const doub
 }
 
 // acc(8 x 2 tiles per wave) -= A[0:128, k-tile] * B[0:128, k-tile]^T restricted to the wave's 32 B rows
-template <int PB = 0>
 __device__ __forceinline__ void tile_mfma_t(const double* sA, const double* sB, AccTt& acc, int wave) {
     const int lane = threadIdx.x & 63;
     const double* pa = sA + (lane & 15) * LDS_LD + (lane >> 4);
@@ -154,18 +153,17 @@ __device__ __forceinline__ void tile_mfma_t(const double* sA, const double* sB, 
         for (int rb = 0; rb < 8; ++rb) a[rb] = pa[rb * 16 * LDS_LD + kk * 4];
 #pragma unroll
         for (int mb = 0; mb < 2; ++mb) b[mb] = -pb[mb * 16 * LDS_LD + kk * 4];
-        if (ROBO_SETPRIO) __builtin_amdgcn_s_setprio(PB + 1);
+        if (ROBO_SETPRIO) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int rb = 0; rb < 8; ++rb)
 #pragma unroll
             for (int mb = 0; mb < 2; ++mb) acc.t[rb][mb] = mfma_f64(a[rb], b[mb], acc.t[rb][mb]);
-        if (ROBO_SETPRIO) __builtin_amdgcn_s_setprio(PB);
+        if (ROBO_SETPRIO) __builtin_amdgcn_s_setprio(0);
     }
 }
 
 // acc -= A[:, 0:kend] * B[:, 0:kend]^T  (A: 128 rows of L, B: the workgroup's 128 rows of V; both k-contiguous);
 // staging and pipeline of gemm_nt<4, .> (gemm_f64.h), wave tiling 1 x 4 instead of 2 x 2
-template <int PB = 0>
 __device__ __forceinline__ void gemm_t(const double* __restrict__ A, int lda, const double* __restrict__ B, int ldb,
                                        int kend, AccTt& acc, double* smem) {
     constexpr int SA = stage_a<4>(), ST = SA + STAGE_B;
@@ -184,7 +182,7 @@ __device__ __forceinline__ void gemm_t(const double* __restrict__ A, int lda, co
             ra = tile_load_regs<128>(A, lda, (kt + 1) * BK);
             rb = tile_load_regs<128>(B, ldb, (kt + 1) * BK);
         }
-        tile_mfma_t<PB>(cur, cur + SA, acc, threadIdx.x >> 6);
+        tile_mfma_t(cur, cur + SA, acc, threadIdx.x >> 6);
         if (more) {
             tile_store_lds<128>(nxt, ra);
             tile_store_lds<128>(nxt + SA, rb);
@@ -261,14 +259,14 @@ __device__ __forceinline__ void solve_store_reduce_t(const AccTt& T, const doubl
     }
 }
 
-// the block rows i0 .. i1-1 of one workgroup; PB: the wave priority outside MFMA bursts (inside: PB + 1)
-template <int KIND, int PB>
-__device__ __forceinline__ void step_gen_rows(const double* __restrict__ Xcs, const double* __restrict__ Xs,
-                                              double* __restrict__ V, int ldv, const double* __restrict__ L, int ld,
-                                              const double* __restrict__ LinvP, int i0, int i1, int n,
-                                              double* __restrict__ q, double* __restrict__ mu, long long c0,
-                                              const CovParams& cp, double* smem) {
-    if (PB) __builtin_amdgcn_s_setprio(PB);
+template <int KIND>
+__global__ __launch_bounds__(256, 2) void trsm_step_gen_kernel(const double* __restrict__ Xcs,
+                                                               const double* __restrict__ Xs, double* __restrict__ V,
+                                                               int ldv, const double* __restrict__ L, int ld,
+                                                               const double* __restrict__ LinvP, int i0, int i1, int n,
+                                                               double* __restrict__ q, double* __restrict__ mu,
+                                                               long long c0, CovParams cp) {
+    __shared__ double smem[GEMM_SMEM_DOUBLES];
     double* Vrow = V + (size_t)blockIdx.x * NB * ldv;
     const long long cw = c0 + (long long)blockIdx.x * NB;   // first candidate of this workgroup
     // block rows i0 .. i1-1 in one launch (ROBO_TRSM_ROWS, default 1): a block row only reads columns this same
@@ -278,29 +276,11 @@ __device__ __forceinline__ void step_gen_rows(const double* __restrict__ Xcs, co
     for (int i = i0; i < i1; ++i) {
         AccTt acc;
         gen_cross_tile_t<KIND>(cp, Xcs + (size_t)cw * cp.dim, Xs + (size_t)i * NB * cp.dim, n - i * NB, smem, acc);
-        if (i > 0) gemm_t<PB>(L + (size_t)i * NB * ld, ld, Vrow, ldv, i * NB, acc, smem);
+        if (i > 0) gemm_t(L + (size_t)i * NB * ld, ld, Vrow, ldv, i * NB, acc, smem);
         solve_store_reduce_t(acc, LinvP + (size_t)i * WP_BLOCK, L + (size_t)n * ld + (size_t)i * NB, n - i * NB,
                              Vrow + (size_t)i * NB, ldv, q + cw, mu + cw, i == 0, threadIdx.x >> 6);
         __syncthreads();   // V_i (global, workgroup scope) before the next block row stages it
     }
-}
-
-// prio_bit >= 0 (tuning trsm_prio_bit, A/B): workgroups with that bit of their index set run at wave priority 2 (3 inside
-// MFMA bursts), the others at 0 (1).  The two workgroups of a CU generate their K* tiles (fp64 VALU, ~20k cycles per wave)
-// at the same time and then compete for the matrix pipe; with unequal priorities one of them generates alone, starts
-// its products, and the other generates under those products -- if the bit separates co-resident workgroups.
-template <int KIND>
-__global__ __launch_bounds__(256, 2) void trsm_step_gen_kernel(const double* __restrict__ Xcs,
-                                                               const double* __restrict__ Xs, double* __restrict__ V,
-                                                               int ldv, const double* __restrict__ L, int ld,
-                                                               const double* __restrict__ LinvP, int i0, int i1, int n,
-                                                               double* __restrict__ q, double* __restrict__ mu,
-                                                               long long c0, CovParams cp, int prio_bit) {
-    __shared__ double smem[GEMM_SMEM_DOUBLES];
-    if (prio_bit >= 0 && ((blockIdx.x >> prio_bit) & 1))
-        step_gen_rows<KIND, 2>(Xcs, Xs, V, ldv, L, ld, LinvP, i0, i1, n, q, mu, c0, cp, smem);
-    else
-        step_gen_rows<KIND, 0>(Xcs, Xs, V, ldv, L, ld, LinvP, i0, i1, n, q, mu, c0, cp, smem);
 }
 
 
@@ -828,8 +808,7 @@ int launch_predict_fused(robo_gp* gp, robo_cand* cand, int64_t c0, int64_t cn) {
     hipLaunchKernelGGL(trsm_step_gen_kernel<KIND>, grid, dim3(256), 0, gp->ctx->stream,                        \
                        (const double*)cand->d_Xcs, (const double*)gp->d_Xs, cand->d_V, gp->n_pad,             \
                        (const double*)gp->d_K, gp->n_pad, (const double*)gp->d_LinvP, i,                      \
-                       (i + rows < nbk ? i + rows : nbk), gp->n, cand->d_q, cand->d_mu, (long long)c0, gp->cov,     \
-                       tune.trsm_prio_bit)
+                       (i + rows < nbk ? i + rows : nbk), gp->n, cand->d_q, cand->d_mu, (long long)c0, gp->cov)
     cand->solve_kernel = "trsm_step_gen_kernel";
     const int rows = tune.trsm_rows < 1 ? 1 : tune.trsm_rows;
     int i_first = 0;
