@@ -557,6 +557,43 @@ def hyper_inference(with_cpu, N=200):
     return out
 
 
+def bo_iteration(N=4096, D=16):
+    """One iteration of the reference's loop at the headline size with ITS defaults (robo/solver/bayesian_optimization.py:
+    236-245: model.train -> acquisition_func.update -> maximize_func.maximize with RandomSampling's 500 candidates,
+    robo/maximizers/random_sampling.py:9), through the product classes, wall clock: what a user of robo.fmin pays per
+    iteration beside the objective function.  do_optimize=False: hyper-parameter inference is timed separately
+    (hyper_inference)."""
+    from robo_amd.kernels import Matern52Kernel
+    from robo_amd.models import GaussianProcess
+    from robo_amd.acquisition_functions import EI
+    from robo_amd.maximizers import RandomSampling
+    rs = np.random.RandomState(0)
+    X = rs.rand(N, D)
+    y = np.sinc(X * 10 - 5).sum(axis=1)
+    y = (y - y.mean()) / y.std()
+    theta = default_theta(D)
+    kernel = Matern52Kernel(np.exp(theta[1:-1]), ndim=D, log_amp=theta[0])
+    model = GaussianProcess(kernel, noise=1e-3, lower=np.zeros(D), upper=np.ones(D), rng=np.random.RandomState(1))
+    acq = EI(model)
+    maxi = RandomSampling(acq, np.zeros(D), np.ones(D), rng=np.random.RandomState(2))
+    ts = {"train": [], "update": [], "maximize": [], "total": []}
+    for it in range(6):
+        np.random.seed(it)
+        t0 = time.perf_counter()
+        model.train(X, y, do_optimize=False)
+        t1 = time.perf_counter()
+        acq.update(model)
+        t2 = time.perf_counter()
+        maxi.maximize()
+        t3 = time.perf_counter()
+        if it:                                   # the first iteration allocates
+            for k_, v_ in (("train", t1 - t0), ("update", t2 - t1), ("maximize", t3 - t2), ("total", t3 - t0)):
+                ts[k_].append(v_ * 1e3)
+    return {"n_train": N, "dim": D, "candidates": 500, "what": "GaussianProcess.train(do_optimize=False) + EI.update + "
+            "RandomSampling.maximize (the reference's 500 candidates, drawn in its Python loop), median of 5",
+            "ms": {k_: float(np.median(v_)) for k_, v_ in ts.items()}}
+
+
 def roofline_trsm(ctx, N, M_rows, trsm_ms_per_step, passes=1, kernel="trsm_step_gen_kernel", traffic=None):
     """the dominant kernel of every configuration is the block-row solve: algorithmic flops per launch =
     rows N^2 / nb (SURVEY.md 8d's triangular-solve term), duration from HIP events on the library's stream
@@ -848,6 +885,10 @@ def run_headline(args, D_, _lib, sharding):
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(N, D, theta, X, y)
         if world == 1 and (N, D) == (4096, 16) and not args.lean:
+            try:
+                out["bo_iteration"] = bo_iteration()
+            except Exception as e:            # noqa: BLE001 -- an extra block; never costs the headline line
+                out["bo_iteration"] = {"error": "%s: %s" % (type(e).__name__, str(e)[:200])}
             try:
                 out["hyper_inference"] = hyper_inference(not args.no_cpu_baseline)
                 small = hyper_inference(False, N=100)

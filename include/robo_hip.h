@@ -179,6 +179,12 @@ int32_t robo_gp_get_gram(robo_gp* gp, const double* theta, double* out_K); /* K 
  * block-row substitution: the explicit inverse is used while it is <= the context's `winv_cond_max` (default 1e5).
  * out[0] = cond_inf(L), out[1] = min L_ii, out[2] = max L_ii.  Diagnostics / tests.                         */
 int32_t robo_gp_factor_cond(robo_gp* gp, double* out);
+/* Start building that explicit inverse NOW, asynchronously (returns without waiting for the device): called right after the
+ * final fit of GaussianProcess.train (robo/models/gaussian_process.py:119) so that the build (0.9 ms at N = 4096) runs while
+ * the host prepares the next acquisition maximisation (robo/maximizers/random_sampling.py:38-47 draws its 500 candidates in
+ * a Python loop) and the first robo_gp_predict* / robo_acq_eval* of a small batch finds W in place.  A no-op where a small
+ * batch would not use W (factor of fewer than winv_min_blocks blocks, fp32 K-build, diagonal ratio beyond the bound).  */
+int32_t robo_gp_prefetch_inverse(robo_gp* gp);
 
 /* ---- candidates --------------------------------------------------------------------- */
 /* Xc: (m, dim) candidates in the GP's (normalised) input space; copied H2D here, once.    */

@@ -30,7 +30,7 @@ SYMBOLS = [
     "robo_last_error_string", "robo_version_string",
     "robo_gp_create", "robo_gp_destroy", "robo_gp_set_data", "robo_gp_set_output_transform",
     "robo_gp_set_precision", "robo_theta_size",
-    "robo_gp_fit", "robo_gp_loglik_batch", "robo_gp_mcmc_run", "robo_mcmc_draws", "robo_gp_fit_batch", "robo_gp_grad_loglik", "robo_gp_get_factor", "robo_gp_get_gram", "robo_gp_factor_cond",
+    "robo_gp_fit", "robo_gp_loglik_batch", "robo_gp_mcmc_run", "robo_mcmc_draws", "robo_gp_fit_batch", "robo_gp_grad_loglik", "robo_gp_get_factor", "robo_gp_get_gram", "robo_gp_factor_cond", "robo_gp_prefetch_inverse",
     "robo_cand_create", "robo_cand_destroy", "robo_cand_set_points", "robo_cand_create_uniform", "robo_cand_get_points",
     "robo_cand_create_random", "robo_cand_create_sobol", "robo_cand_get_point", "robo_cand_workspace_chunk", "robo_cand_last_solve_kernel",
     "robo_gp_predict_cand", "robo_gp_predict", "robo_gp_predict_cov", "robo_gp_predict_grad", "robo_gp_predict_mixture_cand",
@@ -131,6 +131,7 @@ def lib():
         "robo_gp_get_factor": [vp, _dp],
         "robo_gp_get_gram": [vp, _dp, _dp],
         "robo_gp_factor_cond": [vp, _dp],
+        "robo_gp_prefetch_inverse": [vp],
         "robo_cand_create": [vp, _dp, i64, i32, pp],
         "robo_cand_destroy": [vp],
         "robo_cand_set_points": [vp, _dp, i64],
@@ -516,6 +517,10 @@ class DeviceGP(object):
         out = np.empty((self.n, self.n))
         check(lib().robo_gp_get_factor(self._h, _arr(out)))
         return out
+
+    def prefetch_inverse(self):
+        """start building W = L^-1 for small candidate batches now, asynchronously (robo_gp_prefetch_inverse)"""
+        check(lib().robo_gp_prefetch_inverse(self._h))
 
     def factor_cond(self):
         """(cond_inf(L) -- exact, from the explicit inverse --, min L_ii, max L_ii) of the current factor"""

@@ -243,6 +243,7 @@ int32_t robo_gp_destroy(robo_gp* g) {
     hipFree(g->d_theta);
     hipFree(g->d_Winv);
     hipFree(g->d_wnorm);
+    if (g->h_wnorm) hipHostFree(g->h_wnorm);
     hipFree(g->d_mcmc);
     hipFree(g->d_wunits);
     hipFree(g->d_wprefix);
@@ -759,6 +760,20 @@ int32_t robo_gp_get_gram(robo_gp* g, const double* theta, double* out_K) {
         for (int j = 0; j < g->n; ++j)
             out_K[(size_t)i * g->n + j] = j <= i ? h[(size_t)i * np + j] : h[(size_t)j * np + i];
     return ROBO_OK;
+}
+
+int32_t robo_gp_prefetch_inverse(robo_gp* g) {
+    if (!g) return ROBO_BAD_ARGUMENT;
+    if (!g->fitted) {
+        set_error("Model has to be trained first!");
+        return ROBO_NOT_FITTED;
+    }
+    const Tuning& t = g->ctx->tune;
+    // the same conditions under which a small batch would ask for W (decide_winv), minus the batch size
+    if (g->fp32_gram || t.predict_stepwise || t.winv_max <= 0 || (g->n + NB - 1) / NB < t.winv_min_blocks) return ROBO_OK;
+    if (!(g->diag_min > 0.0 && g->diag_max <= (double)t.winv_cond_max * g->diag_min)) return ROBO_OK;
+    ROBO_HIP_CHECK(hipSetDevice(g->ctx->device));
+    return winv_launch(g);
 }
 
 int32_t robo_gp_factor_cond(robo_gp* g, double* out) {

@@ -167,6 +167,8 @@ struct robo_gp {
     double diag_min, diag_max;      // extreme diagonal entries of L over the training rows (0, 0: unknown)
     double winv_cond;               // cond_inf(L) = |L|_inf |W|_inf of the factor W was built for (winv_gen); 0: unknown
     double* d_wnorm;                // [2]: |L|_inf, |W|_inf (bit patterns, atomicMax)
+    double* h_wnorm;                // pinned copy of the two norms (written by an asynchronous copy behind the build)
+    unsigned long long winv_launched;   // fit_gen whose W build has been LAUNCHED (robo_gp_prefetch_inverse) but not yet read
 };
 
 struct robo_cand {
@@ -263,6 +265,7 @@ int launch_diag_timeline(robo_gp* gp, long long* d_stamps);
 int launch_cross_gram(robo_gp* gp, robo_cand* cand, int64_t c0, int64_t cn, double* d_out = nullptr);
 // posterior of a chunk through W = L^-1 (winv.hip): fills cand->d_q / d_mu (and d_V when store_v)
 int winv_ensure(robo_gp* gp);
+int winv_launch(robo_gp* gp);
 int launch_per_cost(robo_ctx* ctx, double* d_dh, const double* d_log_cost, double overhead, int64_t m);
 int launch_predict_winv(robo_gp* gp, robo_cand* cand, int64_t c0, int64_t cn, bool store_v);
 int launch_trsm(robo_gp* gp, robo_cand* cand, int64_t c0, int64_t cn);

@@ -195,8 +195,11 @@ __global__ __launch_bounds__(256) void winv_norm_kernel(const double* __restrict
 // contraction blocks per unit: fixed by the number of block rows of the factor (and by nothing else)
 static int winv_kc(int nbk) { return nbk >= 16 ? 8 : (nbk >= 8 ? 4 : 2); }
 
-// W of the current factor + the unit table for its number of block rows
-int winv_ensure(robo_gp* gp) {
+// The asynchronous half of the W build: buffers and unit table for this factor's number of block rows, the triinv launches,
+// the two row-sum reductions and the copy of their results into pinned memory -- nothing waits for the device (apart from
+// the first-use staging of the unit table).  robo_gp_prefetch_inverse calls it right after a fit, so that the build runs
+// while the host prepares its candidates; winv_ensure finishes it.
+int winv_launch(robo_gp* gp) {
     hipStream_t st = gp->ctx->stream;
     const size_t np = (size_t)gp->n_pad_max;
     if (!gp->d_Winv) {
@@ -229,20 +232,29 @@ int winv_ensure(robo_gp* gp) {
         gp->winv_units = (int)units.size();
         gp->winv_kc = kc;
     }
+    if (gp->winv_gen == gp->fit_gen || gp->winv_launched == gp->fit_gen) return ROBO_OK;
+    const int s = launch_triinv(gp, gp->d_Winv, gp->d_gV);
+    if (s != ROBO_OK) return s;
+    // cond_inf(L) = |L|_inf |W|_inf, exact for the W just built: decides whether this factor may use W at all
+    if (!gp->d_wnorm) ROBO_HIP_CHECK(hipMalloc((void**)&gp->d_wnorm, 2 * sizeof(double)));
+    if (!gp->h_wnorm) ROBO_HIP_CHECK(hipHostMalloc((void**)&gp->h_wnorm, 2 * sizeof(double), 0));
+    ROBO_HIP_CHECK(hipMemsetAsync(gp->d_wnorm, 0, 2 * sizeof(double), st));
+    hipLaunchKernelGGL(winv_norm_kernel, dim3((unsigned)((gp->n + 3) / 4)), dim3(256), 0, st, (const double*)gp->d_K,
+                       (const double*)gp->d_Winv, gp->n_pad, gp->n, reinterpret_cast<unsigned long long*>(gp->d_wnorm));
+    ROBO_LAUNCH_CHECK();
+    ROBO_HIP_CHECK(hipMemcpyAsync(gp->h_wnorm, gp->d_wnorm, 2 * sizeof(double), hipMemcpyDeviceToHost, st));
+    gp->winv_launched = gp->fit_gen;
+    return ROBO_OK;
+}
+
+// W of the current factor (built here unless a prefetch already launched it) and its condition number
+int winv_ensure(robo_gp* gp) {
+    if (gp->winv_gen == gp->fit_gen && gp->winv_nbk == (gp->n + NB - 1) / NB) return ROBO_OK;
+    const int s = winv_launch(gp);
+    if (s != ROBO_OK) return s;
     if (gp->winv_gen != gp->fit_gen) {
-        const int s = launch_triinv(gp, gp->d_Winv, gp->d_gV);
-        if (s != ROBO_OK) return s;
-        // cond_inf(L) = |L|_inf |W|_inf, exact for the W just built: decides whether this factor may use W at all
-        if (!gp->d_wnorm) ROBO_HIP_CHECK(hipMalloc((void**)&gp->d_wnorm, 2 * sizeof(double)));
-        ROBO_HIP_CHECK(hipMemsetAsync(gp->d_wnorm, 0, 2 * sizeof(double), st));
-        hipLaunchKernelGGL(winv_norm_kernel, dim3((unsigned)((gp->n + 3) / 4)), dim3(256), 0, st, (const double*)gp->d_K,
-                           (const double*)gp->d_Winv, gp->n_pad, gp->n,
-                           reinterpret_cast<unsigned long long*>(gp->d_wnorm));
-        ROBO_LAUNCH_CHECK();
-        double norms[2] = {0.0, 0.0};
-        ROBO_HIP_CHECK(hipMemcpyAsync(norms, gp->d_wnorm, sizeof(norms), hipMemcpyDeviceToHost, st));
-        ROBO_HIP_CHECK(hipStreamSynchronize(st));
-        gp->winv_cond = norms[0] * norms[1];         // NaN (a broken W) compares false against every bound
+        ROBO_HIP_CHECK(hipStreamSynchronize(gp->ctx->stream));      // (returns at once when a prefetched build has finished)
+        gp->winv_cond = gp->h_wnorm[0] * gp->h_wnorm[1];             // NaN (a broken W) compares false against every bound
         gp->winv_gen = gp->fit_gen;
     }
     return ROBO_OK;

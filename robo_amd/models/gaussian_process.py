@@ -156,6 +156,10 @@ class GaussianProcess(BaseModel):
             gp.fit(theta, self.mean)
         self._fitted_theta = theta
         self.is_trained = True
+        # what follows a train() in the reference's loop is an acquisition maximisation over a small candidate batch
+        # (solver/bayesian_optimization.py:236-245, 500 candidates by default): the explicit inverse factor those batches
+        # use is built on the device while the host prepares them
+        gp.prefetch_inverse()
 
     def get_noise(self):
         return self.noise

@@ -1167,13 +1167,24 @@ def check_winv_path(ctx, cases=(("matern52", 300, 5, 700), ("fabolas", 280, 4, 1
             _, S_o = IG.innovation_inputs(ogp, Xc, Xc[40:52] if M > 52 else Xc[:12])
             np.testing.assert_allclose(S, S_o, rtol=0, atol=1e-9 * amp)
             rep.close()
-            # a refit at another theta rebuilds W
+            # a refit at another theta rebuilds W -- here through the asynchronous prefetch (robo_gp_prefetch_inverse:
+            # what GaussianProcess.train() issues after its final fit); a second prefetch and a prefetch followed by
+            # another fit are harmless
             theta2 = theta.copy()
             theta2[1] += 0.4
             o2 = O.OracleGP(kind, theta2, normalize_input=False)
             o2.train(X, y)
+            g.fit(theta, ogp.mean)
+            g.prefetch_inverse()
             g.fit(theta2, o2.mean)
+            g.prefetch_inverse()
+            g.prefetch_inverse()
             mu2, var2 = g.predict(cand)
+            assert cand.solve_kernel() == winv_name
+            g.fit(theta2, o2.mean)
+            mu2b, var2b = g.predict(cand)              # built on demand: the same bits
+            np.testing.assert_array_equal(mu2, mu2b)
+            np.testing.assert_array_equal(var2, var2b)
             m2o, v2o = o2.predict(Xc, diag_only=True)
             np.testing.assert_allclose(mu2, m2o, rtol=MU_RTOL, atol=MU_ATOL)
             np.testing.assert_allclose(var2, v2o, rtol=0, atol=VAR_ATOL_REL_AMP * amp)
