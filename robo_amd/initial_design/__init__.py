@@ -9,13 +9,12 @@ def _rng(rng):
 
 
 def init_random_uniform(lower, upper, n_points, rng=None):
-    """(n_points, D) uniform in the box, drawn ROW BY ROW like the reference (:29-30)."""
+    """(n_points, D) uniform in the box: the numbers the reference draws row by row (:29-30) -- a legacy RandomState
+    fills an array in C order from one sequential stream, so ONE (n_points, D) call yields the same values, bit for bit,
+    as n_points calls of size D (pinned by tests/test_host_logic.py against the reference's own loop); the Python loop
+    was 2.3 ms of the 500-candidate maximisation of a BO iteration."""
     rng = _rng(rng)
-    d = lower.shape[0]
-    out = np.empty((n_points, d))
-    for i in range(n_points):
-        out[i] = rng.uniform(lower, upper, d)
-    return out
+    return rng.uniform(lower, upper, (int(n_points), lower.shape[0]))
 
 
 def init_latin_hypercube_sampling(lower, upper, n_points, rng=None):

@@ -44,10 +44,10 @@ class RandomSampling(BaseMaximizer):
         rand = init_random_uniform(self.lower, self.upper, n_uniform)
         loc = self.objective_func.model.get_incumbent()[0]
         scale = np.ones([self.lower.shape[0]]) * 0.1
-        # one np.random.normal(loc, scale) call per point, like the reference's list comprehension (same stream, same
-        # values); the clip is applied once to the stacked draws instead of per point
-        local = np.clip(np.array([np.random.normal(loc, scale) for _ in range(n_local)]).reshape(n_local, self.lower.shape[0]),
-                        self.lower, self.upper)
+        # the reference draws np.random.normal(loc, scale) once per point in a list comprehension (:44) from the GLOBAL
+        # stream; one (n_local, D) call takes the same numbers from that stream in the same order (bit-identical, also
+        # across the cached second Gaussian of odd D: tests/test_host_logic.py); the clip is applied once to the block
+        local = np.clip(np.random.normal(loc, scale, (n_local, self.lower.shape[0])), self.lower, self.upper)
         return np.concatenate((rand, local), axis=0)
 
     def maximize(self):

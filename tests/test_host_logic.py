@@ -92,8 +92,11 @@ def test_initial_designs_properties():
 
 
 @needs_ref
-def test_random_sampling_candidates_match_reference():
-    """same candidate batch as robo/maximizers/random_sampling.py:38-47 under the same global seed"""
+@pytest.mark.parametrize("D", [2, 3])
+def test_random_sampling_candidates_match_reference(D):
+    """same candidate batch as robo/maximizers/random_sampling.py:38-47 under the same global seed (the reference draws
+    row by row in Python loops; here one block call per recipe part -- same stream, same values, also for odd D where a
+    Gaussian draw leaves a cached second value behind)"""
     _ref()
     from robo.maximizers.random_sampling import RandomSampling as RefRS
     from robo_amd.maximizers import RandomSampling
@@ -102,7 +105,7 @@ def test_random_sampling_candidates_match_reference():
         class model(object):
             @staticmethod
             def get_incumbent():
-                return np.array([0.3, 0.6]), 0.0
+                return np.array([0.3, 0.6, 0.95][:D]), 0.0
 
         def __init__(self):
             self.seen = None
@@ -111,12 +114,12 @@ def test_random_sampling_candidates_match_reference():
             self.seen = X
             return -np.sum((X - 0.4) ** 2, axis=1)
 
-    lo, hi = np.zeros(2), np.ones(2)
+    lo, hi = np.zeros(D), np.array([1.0, 2.0, 1.5][:D])
     a, b = Acq(), Acq()
     np.random.seed(11)
-    x_ref = RefRS(b, lo, hi, n_samples=200).maximize()
+    x_ref = RefRS(b, lo, hi, n_samples=201).maximize()
     np.random.seed(11)
-    x = RandomSampling(a, lo, hi, n_samples=200).maximize()
+    x = RandomSampling(a, lo, hi, n_samples=201).maximize()
     np.testing.assert_array_equal(a.seen, b.seen)
     np.testing.assert_array_equal(x, x_ref)
 
