@@ -183,7 +183,9 @@ int32_t robo_gp_factor_cond(robo_gp* gp, double* out);
  * final fit of GaussianProcess.train (robo/models/gaussian_process.py:119) so that the build (0.9 ms at N = 4096) runs while
  * the host prepares the next acquisition maximisation (robo/maximizers/random_sampling.py:38-47 draws its 500 candidates in
  * a Python loop) and the first robo_gp_predict* / robo_acq_eval* of a small batch finds W in place.  A no-op where a small
- * batch would not use W (factor of fewer than winv_min_blocks blocks, fp32 K-build, diagonal ratio beyond the bound).  */
+ * batch would not use W (factor of fewer than winv_min_blocks blocks, fp32 K-build, diagonal ratio beyond the bound) and
+ * on a handle that has never evaluated a small batch through W (nothing is allocated or built speculatively for models
+ * that only see large batches): from the second iteration of a loop on.                                            */
 int32_t robo_gp_prefetch_inverse(robo_gp* gp);
 
 /* ---- candidates --------------------------------------------------------------------- */

@@ -772,6 +772,9 @@ int32_t robo_gp_prefetch_inverse(robo_gp* g) {
     // the same conditions under which a small batch would ask for W (decide_winv), minus the batch size
     if (g->fp32_gram || t.predict_stepwise || t.winv_max <= 0 || (g->n + NB - 1) / NB < t.winv_min_blocks) return ROBO_OK;
     if (!(g->diag_min > 0.0 && g->diag_max <= (double)t.winv_cond_max * g->diag_min)) return ROBO_OK;
+    // only for handles that HAVE served a small batch through W before (its buffers exist): a model that is only ever asked
+    // for large batches never pays the two n_pad^2 buffers or the build
+    if (!g->d_Winv) return ROBO_OK;
     ROBO_HIP_CHECK(hipSetDevice(g->ctx->device));
     return winv_launch(g);
 }

@@ -1175,7 +1175,7 @@ def check_winv_path(ctx, cases=(("matern52", 300, 5, 700), ("fabolas", 280, 4, 1
             o2 = O.OracleGP(kind, theta2, normalize_input=False)
             o2.train(X, y)
             g.fit(theta, ogp.mean)
-            g.prefetch_inverse()
+            g.prefetch_inverse()                       # (this handle has used W above: the prefetch is live)
             g.fit(theta2, o2.mean)
             g.prefetch_inverse()
             g.prefetch_inverse()
