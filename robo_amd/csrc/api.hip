@@ -44,6 +44,7 @@ static const TuneKey TUNE_KEYS[] = {
     {"potrf_tm4_min", nullptr, &Tuning::potrf_tm4_min, 96},
     {"potrf_max_wg", nullptr, &Tuning::potrf_max_wg, 0},
     {"potrf_group", nullptr, &Tuning::potrf_group, 4},
+    {"potrf_tail_split", nullptr, &Tuning::potrf_tail_split, 1},
     {"gram_persistent", nullptr, &Tuning::gram_persistent, 0},
     {"gram_mfma", nullptr, &Tuning::gram_mfma, 0},
     {"gram_half", nullptr, &Tuning::gram_half, 0},

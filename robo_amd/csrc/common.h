@@ -92,6 +92,7 @@ struct Tuning {
     long long winv_cond_max;     // ... while cond_inf(L) = |L|_inf |W|_inf stays below this (default 1e5)
     int potrf_fused;             // 0: never fuse the next diagonal block into the trailing update
     int potrf_tm4_min, potrf_max_wg, potrf_group;
+    int potrf_tail_split;        // fused step: the ragged last round of 128-row tiles as half / quarter tiles on more workgroups
     int mcmc_block_step;         // ensemble half-step in ONE launch: 2 (default) every one-block problem, 1 only N <= 63, 0 never
     int gram_mfma;               // K1 with x.x' on the matrix pipe (gram_mfma_kernel; measured slower, r04c: default 0 = never)
     int gram_occ;                // K1 (Matern, fp64): 7 / 8 = gram_kernel compiled for that many workgroups per CU (A/B); else 6

@@ -1244,6 +1244,32 @@ __device__ __forceinline__ void update_tiles_persistent(double* __restrict__ K, 
     }
 }
 
+// 32 TM rows of tile t (row-major index in the lower triangle of the trailing matrix) by this workgroup: the plain NT GEMM on
+// top of the stored C, ascending k -- the same bits as the 128-row tile kernel leaves there
+template <int TM>
+__device__ __forceinline__ void update_subtile(double* __restrict__ K, int ld, int k, int t, int h, double* smem) {
+    int ii, jj;
+    tri_decode(t, ii, jj);
+    const size_t row0 = (size_t)(k + 1 + ii) * NB + (size_t)h * (32 * TM);
+    const double* A = K + row0 * ld + (size_t)k * NB;
+    const double* B = K + ((size_t)(k + 1 + jj) * NB) * ld + (size_t)k * NB;
+    double* C = K + row0 * ld + (size_t)(k + 1 + jj) * NB;
+    AccT<TM> acc;
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+        for (int tn = 0; tn < 4; ++tn)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc.t[tm][tn][r] = C[(size_t)acc_row<TM>(tm, r) * ld + acc_col(tn)];
+    gemm_nt<TM, true>(A, ld, B, ld, 0, NB, acc, smem);
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+        for (int tn = 0; tn < 4; ++tn)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) C[(size_t)acc_row<TM>(tm, r) * ld + acc_col(tn)] = acc.t[tm][tn][r];
+}
+
 // Trailing update of step k fused with the NEXT diagonal block:
 //   A_ij <- A_ij - A_ik * A_jk^T   for k < j <= i (right-looking, K = 128), and workgroup 0 -- which
 //   owns tile (k+1, k+1) -- goes on to factor and invert it (diag128_factor_invert) while the other
@@ -1282,7 +1308,27 @@ __global__ __launch_bounds__(256) void potrf_step_kernel(double* __restrict__ K,
     }
     if (FUSED && TM == 4) {
         // workgroups 1 .. gridDim.x-1 share tiles 1 .. ntiles-1 (tile 0 is workgroup 0's)
-        update_tiles_persistent(K, ld, k, (int)blockIdx.x, (int)gridDim.x - 1, ntiles, smem);
+        const int W = (int)gridDim.x - 1, Tp = ntiles - 1;
+        int full_end = ntiles, split = 0, left = 0;
+        if (first_col != 0 && Tp > W) {
+            // tail split (first_col doubles as its switch on this path): with R full rounds of tiles per workgroup, the
+            // `left` tiles of the ragged last round are cut into halves / quarters and spread over 2 / 4 times as many
+            // workgroups -- the launch ends a (half / quarter tile) after the last full round instead of a whole tile
+            // after it (k = 0: 527 tiles on 255 workgroups = 2 rounds + 17 tiles; k = 5..9: one round + 122 .. 20)
+            const int R = Tp / W;
+            left = Tp - R * W;
+            if (left > 0) split = 4 * left <= W ? 4 : (2 * left <= W ? 2 : 0);
+            if (split) full_end = 1 + R * W;
+        }
+        update_tiles_persistent(K, ld, k, (int)blockIdx.x, W, full_end, smem);
+        if (split) {
+            const int q = (int)blockIdx.x - 1;
+            if (q < split * left) {
+                __syncthreads();       // the last k-step's fragment reads before the sub-tile's staging stores
+                if (split == 4) update_subtile<1>(K, ld, k, full_end + q / 4, q % 4, smem);
+                else update_subtile<2>(K, ld, k, full_end + q / 2, q % 2, smem);
+            }
+        }
         return;
     }
     constexpr int SPLIT = 4 / TM;                    // row sub-tiles per 128-row block
@@ -1441,7 +1487,8 @@ int launch_potrf(robo_gp* gp, const FitBuffers& fb) {
             if (k + 1 >= nbf) break;          // what is left is the augmented row's own block: nothing to factor
             // 128-row tiles: one diagonal workgroup + at most (CUs - 1) persistent tile workgroups (one per CU: the
             // diagonal block's LDS image sizes every workgroup of the launch)
-            if (tiles * S >= tm4_min) ROBO_STEP(4, true, tiles < max_wg ? tiles : max_wg, k, k, NB, 0, tiles);
+            if (tiles * S >= tm4_min)
+                ROBO_STEP(4, true, tiles < max_wg ? tiles : max_wg, k, k, NB, tune.potrf_tail_split != 0 ? 1 : 0, tiles);
             else ROBO_STEP(1, true, 1 + (tiles - 1) * 4, k, k, NB, 0, tiles);
         }
     } else {

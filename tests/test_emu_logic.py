@@ -170,14 +170,20 @@ def test_persistent_tile_updates(emu_ctx, monkeypatch):
     L_ref = g.factor().copy()
     try:
         emu_ctx.set_tuning("potrf_tm4_min", 1)
-        for cap in (4, 3, 64):          # 3 / 2 tile workgroups sharing 9 tiles; one tile each
-            emu_ctx.set_tuning("potrf_max_wg", cap)
-            ll = g.fit(theta, ogp.mean)
-            np.testing.assert_allclose(ll, ogp.loglikelihood(theta), rtol=1e-10)
-            np.testing.assert_array_equal(g.factor(), L_ref)
+        # step 0 has 10 tiles (9 for the tile workgroups).  cap 4: 3 workgroups x 3 rounds; cap 3: 2 workgroups, 4 rounds +
+        # 1 tile -> as two 64-row halves; cap 5: 4 workgroups, 2 rounds + 1 tile -> as four 32-row quarters; cap 9: 8
+        # workgroups, 1 round + 1 tile -> quarters; cap 64: one tile each.  With the tail split off: whole tiles only.
+        for split in (1, 0):
+            emu_ctx.set_tuning("potrf_tail_split", split)
+            for cap in (4, 3, 5, 9, 64):
+                emu_ctx.set_tuning("potrf_max_wg", cap)
+                ll = g.fit(theta, ogp.mean)
+                np.testing.assert_allclose(ll, ogp.loglikelihood(theta), rtol=1e-10)
+                np.testing.assert_array_equal(g.factor(), L_ref)
     finally:
         emu_ctx.set_tuning("potrf_tm4_min", None)
         emu_ctx.set_tuning("potrf_max_wg", None)
+        emu_ctx.set_tuning("potrf_tail_split", None)
     np.testing.assert_allclose(L_ref, ogp.L, rtol=0, atol=1e-11)
     g.close()
 
