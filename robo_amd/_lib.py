@@ -213,11 +213,12 @@ def last_error():
     return lib().robo_last_error_string().decode("utf-8", "replace")
 
 
-def check(status):
-    """Map a robo_status to the exception the reference raises at the same point."""
+def check(status, msg=None):
+    """Map a robo_status to the exception the reference raises at the same point.  msg: the text to use instead of the
+    library's last error string (a status that arrived from ANOTHER rank has no local error string)."""
     if status == OK:
         return
-    msg = last_error()
+    msg = last_error() if msg is None else msg
     if status == NOT_POSITIVE_DEFINITE:
         raise np.linalg.LinAlgError(msg or "matrix is not positive definite")
     if status == NOT_FITTED:

@@ -123,7 +123,7 @@ class ClosedFormAcquisition(BaseAcquisitionFunction):
             for r in rows:
                 flags |= int(r[2])
                 if int(r[3]) != _lib.OK:
-                    _lib.check(int(r[3]))             # another rank's local half failed: every rank raises
+                    _lib.check(int(r[3]), "the local half of another rank's shard failed (status %d)" % int(r[3]))
             mx, am = best if best is not None else (0.0, -1)
         else:
             model._materialise()

@@ -73,7 +73,7 @@ class InformationGainPerUnitCost(InformationGain):
             rows = comm.allgather(msg)
             for r in rows:
                 if int(r[3]) != _lib.OK:
-                    _lib.check(int(r[3]))
+                    _lib.check(int(r[3]), "the local half of another rank's shard failed (status %d)" % int(r[3]))
             return sharding.reduce_argmax((float(r[0]), int(r[1])) for r in rows)[1]
         return int(self._per_cost(X_slice, False, comm, global_offset)[2])
 
