@@ -143,3 +143,63 @@ def test_generic_plugin_model_with_robo_amd_acquisitions(emu):
     np.testing.assert_allclose(A.PI(dm).compute(Xt), gold["pi"], rtol=1e-12)
     np.testing.assert_allclose(A.LCB(dm).compute(Xt), gold["lcb"], rtol=1e-12)
     assert A.EI(dm).compute(Xt).shape == (5,)
+
+
+def test_reference_single_point_maximizers_drive_robo_amd_acquisitions(emu):
+    """The reference's OTHER maximisers -- GridSearch, SciPyOptimizer, DifferentialEvolution (robo/maximizers/*.py,
+    imported unchanged) -- call the acquisition with ONE point at a time (scipy_optimizer.py:44,
+    differential_evolution.py:29, grid_search.py:60; SURVEY 8b "who calls it").  Driving robo_amd's EI on the device GP
+    they must land where they land with the reference's own EI on the oracle-backed reference model (same seeds): the
+    same grid point; the same optimum of the restarts / the evolution to optimiser tolerance."""
+    from oracle import gp_oracle as O
+    from robo_amd.kernels import Matern52Kernel
+    from robo_amd.models import GaussianProcess
+    from robo_amd import acquisition_functions as A
+    _, _, _, BaseModel, ref_acq = _reference()
+    from robo.maximizers.grid_search import GridSearch
+    from robo.maximizers.scipy_optimizer import SciPyOptimizer
+    from robo.maximizers.differential_evolution import DifferentialEvolution
+
+    def models(lo, hi, X, y, theta):
+        class OracleModel(BaseModel):
+            def train(self, X, y, do_optimize=False):
+                self.gp = O.OracleGP("matern52", theta, lower=lo, upper=hi)
+                self.gp.train(X, y)
+                self.X, self.y = self.gp.X, self.gp.y
+
+            def predict(self, X_test, **kw):
+                return self.gp.predict(X_test, diag_only=True)
+
+            def get_incumbent(self):
+                return self.gp.get_incumbent()
+
+        ref_model = OracleModel()
+        ref_model.train(X, y)
+        D = lo.shape[0]
+        mine = GaussianProcess(Matern52Kernel(np.exp(theta[1:-1]), ndim=D, log_amp=theta[0]), noise=np.exp(theta[-1]),
+                               lower=lo, upper=hi, rng=np.random.RandomState(0))
+        mine.train(X, y, do_optimize=False)
+        return ref_acq["ei"](ref_model), A.EI(mine)
+
+    # 1-d: the grid search picks the same grid point
+    lo, hi = np.zeros(1), np.ones(1) * 6
+    rs = np.random.RandomState(3)
+    X = rs.rand(9, 1) * 6
+    y = (X[:, 0] - 2.2) ** 2
+    ref_ei, my_ei = models(lo, hi, X, y, np.array([np.log(4.0), np.log(0.1), np.log(1e-3)]))
+    np.testing.assert_array_equal(GridSearch(my_ei, lo, hi, resolution=200).maximize(),
+                                  GridSearch(ref_ei, lo, hi, resolution=200).maximize())
+    # 2-d Branin: L-BFGS-B restarts and differential evolution, global NumPy stream seeded as the reference uses it
+    lo, hi = np.array([-5.0, 0.0]), np.array([10.0, 15.0])
+    X = lo + (hi - lo) * rs.rand(14, 2)
+    y = np.array([branin(x) for x in X])
+    ref_ei, my_ei = models(lo, hi, X, y, THETA)
+    for make in (lambda acq: SciPyOptimizer(acq, lo, hi, n_restarts=6, rng=np.random.RandomState(4)),
+                 lambda acq: DifferentialEvolution(acq, lo, hi, n_iters=8, rng=np.random.RandomState(4))):
+        np.random.seed(9)
+        x_ref = make(ref_ei).maximize()
+        np.random.seed(9)
+        x_mine = make(my_ei).maximize()
+        assert np.all(x_mine >= lo) and np.all(x_mine <= hi)
+        np.testing.assert_allclose(x_mine, x_ref, rtol=0, atol=1e-3 * (hi - lo).max())
+        np.testing.assert_allclose(my_ei(x_mine[None, :]), ref_ei(x_ref[None, :]), rtol=1e-5, atol=1e-12)
