@@ -203,3 +203,49 @@ def test_reference_single_point_maximizers_drive_robo_amd_acquisitions(emu):
         assert np.all(x_mine >= lo) and np.all(x_mine <= hi)
         np.testing.assert_allclose(x_mine, x_ref, rtol=0, atol=1e-3 * (hi - lo).max())
         np.testing.assert_allclose(my_ei(x_mine[None, :]), ref_ei(x_ref[None, :]), rtol=1e-5, atol=1e-12)
+
+
+def test_models_survive_deepcopy_and_pickle_and_the_reference_marginalisation(emu):
+    """the reference deep-copies acquisition functions together with their models
+    (robo/acquisition_functions/marginalization.py:36,67), so an object holding a ctypes handle must survive
+    copy.deepcopy / pickle.  A trained GaussianProcess and a trained GaussianProcessMCMC are copied both ways and predict
+    the same numbers; the REFERENCE's own MarginalizationGPMCMC (imported unchanged) wraps robo_amd's EI over robo_amd's
+    GaussianProcessMCMC and returns what robo_amd's fused marginalisation returns."""
+    import copy
+    import pickle
+    from robo_amd.kernels import Matern52Kernel
+    from robo_amd.models import GaussianProcess, GaussianProcessMCMC
+    from robo_amd.priors import DefaultPrior
+    from robo_amd import acquisition_functions as A
+    _reference()
+    from robo.acquisition_functions.marginalization import MarginalizationGPMCMC as RefMarginalization
+    lo, hi = np.array([-5.0, 0.0]), np.array([10.0, 15.0])
+    rs = np.random.RandomState(2)
+    X = lo + (hi - lo) * rs.rand(16, 2)
+    y = np.array([branin(x) for x in X])
+    Xt = lo + (hi - lo) * rs.rand(33, 2)
+    gp = GaussianProcess(Matern52Kernel(np.exp(THETA[1:-1]), ndim=2, log_amp=THETA[0]), noise=np.exp(THETA[-1]), lower=lo,
+                         upper=hi, rng=np.random.RandomState(0))
+    gp.train(X, y, do_optimize=False)
+    want = gp.predict(Xt)
+    for clone in (copy.deepcopy(gp), pickle.loads(pickle.dumps(gp))):
+        got = clone.predict(Xt)
+        np.testing.assert_array_equal(got[0], want[0])
+        np.testing.assert_array_equal(got[1], want[1])
+        np.testing.assert_array_equal(A.EI(clone).compute(Xt), A.EI(gp).compute(Xt))
+    kernel = 2 * Matern52Kernel(np.ones(2), ndim=2)
+    mc = GaussianProcessMCMC(kernel, prior=DefaultPrior(len(kernel) + 1, rng=np.random.RandomState(3)), n_hypers=8,
+                             chain_length=6, burnin_steps=6, lower=lo, upper=hi, rng=np.random.RandomState(4))
+    mc.train(X, y)
+    want = mc.predict(Xt)
+    for clone in (copy.deepcopy(mc), pickle.loads(pickle.dumps(mc))):
+        got = clone.predict(Xt)
+        np.testing.assert_allclose(got[0], want[0], rtol=1e-13)
+        np.testing.assert_allclose(got[1], want[1], rtol=1e-12)
+    # the reference's marginalisation: deep copies of robo_amd's EI, one per hyper-parameter sample (marginalization.py:34-46)
+    for cls in (A.EI, A.LogEI, A.LCB):
+        ref_marg = RefMarginalization(cls(mc))
+        ref_marg.update(mc)
+        mine = A.MarginalizationGPMCMC(cls(mc))
+        mine.update(mc)
+        np.testing.assert_allclose(ref_marg.compute(Xt), mine.compute(Xt), rtol=1e-12, atol=1e-15)
