@@ -40,6 +40,7 @@ static const TuneKey TUNE_KEYS[] = {
     {"winv_min_blocks", nullptr, &Tuning::winv_min_blocks, 6},
     {"winv_cond_max", &Tuning::winv_cond_max, nullptr, 100000},
     {"winv_rows", nullptr, &Tuning::winv_rows, -1},
+    {"winv_kc_shift", nullptr, &Tuning::winv_kc_shift, -1},
     {"potrf_fused", nullptr, &Tuning::potrf_fused, 1},
     {"potrf_tm4_min", nullptr, &Tuning::potrf_tm4_min, 96},
     {"potrf_max_wg", nullptr, &Tuning::potrf_max_wg, 0},
@@ -246,8 +247,10 @@ int32_t robo_gp_destroy(robo_gp* g) {
     hipFree(g->d_wnorm);
     if (g->h_wnorm) hipHostFree(g->h_wnorm);
     hipFree(g->d_mcmc);
-    hipFree(g->d_wunits);
-    hipFree(g->d_wprefix);
+    for (int v = 0; v < 3; ++v) {
+        hipFree(g->d_wunits[v]);
+        hipFree(g->d_wprefix[v]);
+    }
     hipFree(g->d_gV);
     hipFree(g->d_gA);
     hipFree(g->d_galpha);

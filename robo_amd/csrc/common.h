@@ -87,6 +87,7 @@ struct Tuning {
     int predict_stepwise;        // 1: cross-gram in memory + trsm_step_kernel (A/B)
     long long winv_max;          // batches <= this (and >= winv_min_blocks block rows) go through W = L^-1 (0: never)
     int winv_min_blocks;
+    int winv_kc_shift;           // chunked explicit-inverse product: -1 auto (by batch size), 0 / 1 / 2 = the batch chunk depth, half, quarter
     int winv_rows;               // explicit-inverse product per (tile, block row) over the whole contraction range: -1 auto
                                  // (batches that fill the chip that way), 0 never (chunked units + reduction), 1 always
     long long winv_cond_max;     // ... while cond_inf(L) = |L|_inf |W|_inf stays below this (default 1e5)
@@ -162,9 +163,12 @@ struct robo_gp {
     size_t mcmc_bytes;
     double* d_Winv;                 // (n_pad_max, n_pad_max) row-major, lower block triangle valid
     unsigned long long winv_gen;    // fit_gen the inverse was built for (0: none)
-    int* d_wunits;                  // unit table of the triangular product for winv_nbk block rows (int4 per unit)
-    int* d_wprefix;                 // first canonical unit of every block row (winv_nbk + 1 entries)
-    int winv_nbk, winv_units, winv_kc;
+    // unit tables of the triangular product for winv_nbk block rows, one per contraction-chunk depth (the batch depth, half
+    // and a quarter of it: small batches take shallower units -- more of them, shorter critical path)
+    int* d_wunits[3];               // int4 per unit
+    int* d_wprefix[3];              // first canonical unit of every block row (winv_nbk + 1 entries)
+    int winv_units[3], winv_kc[3];
+    int winv_nbk;
     double diag_min, diag_max;      // extreme diagonal entries of L over the training rows (0, 0: unknown)
     double winv_cond;               // cond_inf(L) = |L|_inf |W|_inf of the factor W was built for (winv_gen); 0: unknown
     double* d_wnorm;                // [2]: |L|_inf, |W|_inf (bit patterns, atomicMax)

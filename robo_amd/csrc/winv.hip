@@ -17,9 +17,11 @@
 //   winv_reduce_kernel   per (candidate tile, block row): the unit tiles added IN CHUNK ORDER -> V tile (stored only
 //                        for callers that consume V: entropy search, full covariance), |v|^2 and v.z of its 128 columns
 //   winv_finish_kernel   per candidate: the block rows' partial sums added in block-row order -> q, mu
-// The association of every V entry is therefore fixed by (n_pad, KC) alone: values do not depend on the batch size, the
-// workspace chunking or the launch order (bit-identical across them; they differ from the block-row solve's by
-// rounding, ~1e-13 relative -- same tolerances against the oracle).
+// The association of every V entry is therefore fixed by (n_pad, KC) alone: values do not depend on the workspace chunking or
+// the launch order (bit-identical across them; they differ from the block-row solve's by rounding, ~1e-13 relative -- same
+// tolerances against the oracle).  KC itself is picked from the handle's total batch (r04: the batch depth from eight
+// candidate tiles on, half of it for three to seven, a quarter for one or two -- the units of a small batch are its
+// critical path), so values agree ACROSS batch-size classes to rounding, like across the other paths.
 //
 // Numerics: W carries a forward error of ~eps cond(L) (the block-row solve: eps cond of a 128-block), so the caller
 // (api.hip) takes this path only while cond_inf(L) = |L|_inf |W|_inf -- measured here when W is built
@@ -192,8 +194,12 @@ __global__ __launch_bounds__(256) void winv_norm_kernel(const double* __restrict
     }
 }
 
-// contraction blocks per unit: fixed by the number of block rows of the factor (and by nothing else)
-static int winv_kc(int nbk) { return nbk >= 16 ? 8 : (nbk >= 8 ? 4 : 2); }
+// contraction blocks per unit: fixed by the number of block rows of the factor and the depth variant v (0: batches of eight
+// candidate tiles and more; 1, 2: half / a quarter of that for smaller batches, whose critical path is one unit)
+static int winv_kc(int nbk, int v) {
+    const int kc = (nbk >= 16 ? 8 : (nbk >= 8 ? 4 : 2)) >> v;
+    return kc < 1 ? 1 : kc;
+}
 
 // The asynchronous half of the W build: buffers and unit table for this factor's number of block rows, the triinv launches,
 // the two row-sum reductions and the copy of their results into pinned memory -- nothing waits for the device (apart from
@@ -209,28 +215,31 @@ int winv_launch(robo_gp* gp) {
     if (!gp->d_gV) ROBO_HIP_CHECK(hipMalloc((void**)&gp->d_gV, np * np * sizeof(double)));   // W^T, scratch of the build
     const int nbk = (gp->n + NB - 1) / NB;
     if (gp->winv_nbk != nbk) {
-        const int kc = winv_kc(nbk);
-        std::vector<int> prefix(nbk + 1, 0);
-        std::vector<int4> units;
-        for (int j = 0; j < nbk; ++j) {
-            prefix[j] = (int)units.size();
-            for (int k0 = 0; k0 <= j; k0 += kc) units.push_back(make_int4(j, k0, std::min(k0 + kc, j + 1), (int)units.size()));
-        }
-        prefix[nbk] = (int)units.size();
-        // launch order: heaviest first (stable: ties keep the canonical order)
-        std::stable_sort(units.begin(), units.end(), [](const int4& a, const int4& b) { return a.z - a.y > b.z - b.y; });
-        if (gp->d_wunits) ROBO_HIP_CHECK(hipFree(gp->d_wunits));
-        if (gp->d_wprefix) ROBO_HIP_CHECK(hipFree(gp->d_wprefix));
-        gp->d_wunits = gp->d_wprefix = nullptr;
         gp->winv_nbk = 0;
-        ROBO_HIP_CHECK(hipMalloc((void**)&gp->d_wunits, units.size() * sizeof(int4)));
-        ROBO_HIP_CHECK(hipMalloc((void**)&gp->d_wprefix, prefix.size() * sizeof(int)));
-        ROBO_HIP_CHECK(hipMemcpyAsync(gp->d_wunits, units.data(), units.size() * sizeof(int4), hipMemcpyHostToDevice, st));
-        ROBO_HIP_CHECK(hipMemcpyAsync(gp->d_wprefix, prefix.data(), prefix.size() * sizeof(int), hipMemcpyHostToDevice, st));
-        ROBO_HIP_CHECK(hipStreamSynchronize(st));   // the staging vectors die with this scope
+        for (int v = 0; v < 3; ++v) {
+            const int kc = winv_kc(nbk, v);
+            std::vector<int> prefix(nbk + 1, 0);
+            std::vector<int4> units;
+            for (int j = 0; j < nbk; ++j) {
+                prefix[j] = (int)units.size();
+                for (int k0 = 0; k0 <= j; k0 += kc)
+                    units.push_back(make_int4(j, k0, std::min(k0 + kc, j + 1), (int)units.size()));
+            }
+            prefix[nbk] = (int)units.size();
+            // launch order: heaviest first (stable: ties keep the canonical order)
+            std::stable_sort(units.begin(), units.end(), [](const int4& a, const int4& b) { return a.z - a.y > b.z - b.y; });
+            if (gp->d_wunits[v]) ROBO_HIP_CHECK(hipFree(gp->d_wunits[v]));
+            if (gp->d_wprefix[v]) ROBO_HIP_CHECK(hipFree(gp->d_wprefix[v]));
+            gp->d_wunits[v] = gp->d_wprefix[v] = nullptr;
+            ROBO_HIP_CHECK(hipMalloc((void**)&gp->d_wunits[v], units.size() * sizeof(int4)));
+            ROBO_HIP_CHECK(hipMalloc((void**)&gp->d_wprefix[v], prefix.size() * sizeof(int)));
+            ROBO_HIP_CHECK(hipMemcpyAsync(gp->d_wunits[v], units.data(), units.size() * sizeof(int4), hipMemcpyHostToDevice, st));
+            ROBO_HIP_CHECK(hipMemcpyAsync(gp->d_wprefix[v], prefix.data(), prefix.size() * sizeof(int), hipMemcpyHostToDevice, st));
+            ROBO_HIP_CHECK(hipStreamSynchronize(st));   // the staging vectors die with this scope
+            gp->winv_units[v] = (int)units.size();
+            gp->winv_kc[v] = kc;
+        }
         gp->winv_nbk = nbk;
-        gp->winv_units = (int)units.size();
-        gp->winv_kc = kc;
     }
     if (gp->winv_gen == gp->fit_gen || gp->winv_launched == gp->fit_gen) return ROBO_OK;
     const int s = launch_triinv(gp, gp->d_Winv, gp->d_gV);
@@ -272,8 +281,16 @@ static int grow(double** p, size_t* have, size_t need) {
 
 int launch_predict_winv(robo_gp* gp, robo_cand* cand, int64_t c0, int64_t cn, bool store_v) {
     hipStream_t st = gp->ctx->stream;
-    const int n_pad = gp->n_pad, nbk = gp->winv_nbk, nu = gp->winv_units;
+    const int n_pad = gp->n_pad, nbk = gp->winv_nbk;
     const unsigned cts = (unsigned)(cn / NB);
+    // chunk depth of the unit form by the handle's TOTAL batch (not this workspace pass: a chunked workspace yields the values
+    // of a single pass): eight candidate tiles and more take the batch depth, three to seven half of it, one or two a quarter
+    // -- a 500-candidate batch is work-bound at ~0.11 ms (4 x 528 block products) and a single tile at 0.03 ms, but a unit
+    // of eight products is 0.11-0.16 ms long on its own
+    const long long cts_total = cand->m_pad / NB;
+    const int shift = gp->ctx->tune.winv_kc_shift;
+    const int v = shift >= 0 ? (shift > 2 ? 2 : shift) : (cts_total >= 8 ? 0 : (cts_total >= 3 ? 1 : 2));
+    const int nu = gp->winv_units[v];
     // whole contraction range per (candidate tile, block row) when those pairs fill the chip by themselves: decided from
     // the handle's TOTAL batch (not this workspace pass), so a chunked workspace yields the values of a single pass
     const long long slots = 2LL * gp->ctx->num_cu;
@@ -301,14 +318,14 @@ int launch_predict_winv(robo_gp* gp, robo_cand* cand, int64_t c0, int64_t cn, bo
     } else {
         cand->solve_kernel = "winv_gemm_kernel";
         hipLaunchKernelGGL(winv_gemm_kernel, dim3(cts, (unsigned)nu), dim3(256), 0, st, (const double*)cand->d_Ks, n_pad,
-                           (const double*)gp->d_Winv, n_pad, (const int4*)gp->d_wunits, nu, cand->d_P);
+                           (const double*)gp->d_Winv, n_pad, (const int4*)gp->d_wunits[v], nu, cand->d_P);
         if (store_v)
             hipLaunchKernelGGL(winv_reduce_kernel<true>, dim3((unsigned)nbk, cts), dim3(256), 0, st,
-                               (const double*)cand->d_P, (const int*)gp->d_wprefix, nu, z, gp->n, cand->d_V, n_pad, qpart,
+                               (const double*)cand->d_P, (const int*)gp->d_wprefix[v], nu, z, gp->n, cand->d_V, n_pad, qpart,
                                mupart, (long long)cn);
         else
             hipLaunchKernelGGL(winv_reduce_kernel<false>, dim3((unsigned)nbk, cts), dim3(256), 0, st,
-                               (const double*)cand->d_P, (const int*)gp->d_wprefix, nu, z, gp->n, cand->d_V, n_pad, qpart,
+                               (const double*)cand->d_P, (const int*)gp->d_wprefix[v], nu, z, gp->n, cand->d_V, n_pad, qpart,
                                mupart, (long long)cn);
     }
     hipLaunchKernelGGL(winv_finish_kernel, dim3((unsigned)((cn + 255) / 256)), dim3(256), 0, st, (const double*)qpart,

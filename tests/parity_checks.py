@@ -1142,6 +1142,18 @@ def check_winv_path(ctx, cases=(("matern52", 300, 5, 700), ("fabolas", 280, 4, 1
             np.testing.assert_allclose(var_w, var_o, rtol=0, atol=VAR_ATOL_REL_AMP * amp)
             np.testing.assert_allclose(mu_w, mu_b, rtol=0, atol=1e-11 * max(1.0, np.abs(mu_b).max()))
             np.testing.assert_allclose(var_w, var_b, rtol=0, atol=1e-11 * amp)
+            if not rows_mode:
+                # the chunked form's three unit depths (by default picked from the batch size: whole batches, 3..7 candidate
+                # tiles, 1..2): each within the stated tolerances of the oracle, rounding-level agreement with each other
+                for shift in (0, 1, 2):
+                    ctx.set_tuning("winv_kc_shift", shift)
+                    mu_k, var_k = g.predict(cand)
+                    assert cand.solve_kernel() == "winv_gemm_kernel"
+                    np.testing.assert_allclose(mu_k, mu_o, rtol=MU_RTOL, atol=MU_ATOL)
+                    np.testing.assert_allclose(var_k, var_o, rtol=0, atol=VAR_ATOL_REL_AMP * amp)
+                    np.testing.assert_allclose(mu_k, mu_w, rtol=0, atol=3e-11 * max(1.0, np.abs(mu_w).max()))
+                    np.testing.assert_allclose(var_k, var_w, rtol=0, atol=3e-11 * amp)
+                ctx.set_tuning("winv_kc_shift", None)
             ei_o = O.ei(mu_o, var_o, eta)
             want, srt = int(np.argmax(ei_o)), np.sort(ei_o)
             assert am_w == int(np.argmax(vals)) and (am_w == want or srt[-1] - srt[-2] <= 1e-7 * abs(ei_o[want]))
@@ -1203,7 +1215,7 @@ def check_winv_path(ctx, cases=(("matern52", 300, 5, 700), ("fabolas", 280, 4, 1
         cand.close()
         g.close()
     finally:
-        for key in ("winv_min_blocks", "winv_max", "ws_bytes", "winv_rows"):
+        for key in ("winv_min_blocks", "winv_max", "ws_bytes", "winv_rows", "winv_kc_shift"):
             ctx.set_tuning(key, None)
 
 

@@ -38,6 +38,12 @@ for N, D in ((4096, 16), (2048, 16), (1000, 8), (500, 4)):
             ctx.set_tuning("winv_max", winv); ctx.set_tuning("winv_min_blocks", 1); ctx.set_tuning("trsm_small_max", small)
             out.append(best(lambda: g.acq("ei", 0.0, eta, cand, want_values=False)))
         kern = cand.solve_kernel()
+        depths = []
+        ctx.set_tuning("winv_rows", 0)
+        for shift in (0, 1, 2):                  # the chunked form at its three unit depths
+            ctx.set_tuning("winv_kc_shift", shift)
+            depths.append(best(lambda: g.acq("ei", 0.0, eta, cand, want_values=False)))
+        ctx.set_tuning("winv_kc_shift", None)
         forms = []
         for rows in (0, 1):                      # the two forms of the explicit-inverse product, forced
             ctx.set_tuning("winv_rows", rows)
@@ -45,8 +51,9 @@ for N, D in ((4096, 16), (2048, 16), (1000, 8), (500, 4)):
         for k in ("winv_max", "winv_min_blocks", "trsm_small_max", "winv_rows"):
             ctx.set_tuning(k, None)
         dflt = best(lambda: g.acq("ei", 0.0, eta, cand, want_values=False))
-        print("N=%5d M=%6d: 128-cand step %.3f ms, 32-cand step %.3f ms, explicit inverse %.3f ms (%s; chunked units %.3f, "
-              "whole-range rows %.3f); default policy %.3f ms (%s)"
-              % (N, M, out[0], out[1], out[2], kern, forms[0], forms[1], dflt, cand.solve_kernel()))
+        print("N=%5d M=%6d: 128-cand step %.3f ms, 32-cand step %.3f ms, explicit inverse %.3f ms (%s; chunked units %.3f "
+              "[depth full/half/quarter %.3f/%.3f/%.3f], whole-range rows %.3f); default policy %.3f ms (%s)"
+              % (N, M, out[0], out[1], out[2], kern, forms[0], depths[0], depths[1], depths[2], forms[1], dflt,
+                 cand.solve_kernel()))
         cand.close()
     g.close()
