@@ -20,8 +20,8 @@
 // The association of every V entry is therefore fixed by (n_pad, KC) alone: values do not depend on the workspace chunking or
 // the launch order (bit-identical across them; they differ from the block-row solve's by rounding, ~1e-13 relative -- same
 // tolerances against the oracle).  KC itself is picked from the handle's total batch (r04: the batch depth from eight
-// candidate tiles on, half of it for three to seven, a quarter for one or two -- the units of a small batch are its
-// critical path), so values agree ACROSS batch-size classes to rounding, like across the other paths.
+// candidate tiles on, half of it below -- the units of a small batch are its critical path), so values agree ACROSS
+// batch-size classes to rounding, like across the other paths.
 //
 // Numerics: W carries a forward error of ~eps cond(L) (the block-row solve: eps cond of a 128-block), so the caller
 // (api.hip) takes this path only while cond_inf(L) = |L|_inf |W|_inf -- measured here when W is built
@@ -284,12 +284,14 @@ int launch_predict_winv(robo_gp* gp, robo_cand* cand, int64_t c0, int64_t cn, bo
     const int n_pad = gp->n_pad, nbk = gp->winv_nbk;
     const unsigned cts = (unsigned)(cn / NB);
     // chunk depth of the unit form by the handle's TOTAL batch (not this workspace pass: a chunked workspace yields the values
-    // of a single pass): eight candidate tiles and more take the batch depth, three to seven half of it, one or two a quarter
-    // -- a 500-candidate batch is work-bound at ~0.11 ms (4 x 528 block products) and a single tile at 0.03 ms, but a unit
-    // of eight products is 0.11-0.16 ms long on its own
+    // of a single pass): eight candidate tiles and more take the batch depth, fewer take half of it -- a unit is the critical
+    // path of a small batch.  Measured (r04x, MI355X, ms for depth full / half / quarter): N = 4096: 1..128 candidates 0.221 /
+    // 0.182 / 0.222, 500 candidates 0.291 / 0.295 / 0.340; N = 2048, 500 candidates 0.214 / 0.159 / 0.169; N = 1000: 0.138 /
+    // 0.120 / 0.132; from 2048 candidates up the full depth wins (0.72 / 0.75 / 0.89).  A quarter never wins (its reduction
+    // pass reads twice the unit tiles): the third table is only reachable through the tuning key.
     const long long cts_total = cand->m_pad / NB;
     const int shift = gp->ctx->tune.winv_kc_shift;
-    const int v = shift >= 0 ? (shift > 2 ? 2 : shift) : (cts_total >= 8 ? 0 : (cts_total >= 3 ? 1 : 2));
+    const int v = shift >= 0 ? (shift > 2 ? 2 : shift) : (cts_total >= 8 ? 0 : 1);
     const int nu = gp->winv_units[v];
     // whole contraction range per (candidate tile, block row) when those pairs fill the chip by themselves: decided from
     // the handle's TOTAL batch (not this workspace pass), so a chunked workspace yields the values of a single pass
