@@ -87,6 +87,7 @@ struct Tuning {
     int predict_stepwise;        // 1: cross-gram in memory + trsm_step_kernel (A/B)
     long long winv_max;          // batches <= this (and >= winv_min_blocks block rows) go through W = L^-1 (0: never)
     int winv_min_blocks;
+    int winv_gemv;               // explicit-inverse posterior of <= 8 candidates as a matrix-vector product: -1 auto, 0 never
     int winv_kc_shift;           // chunked explicit-inverse product: -1 auto (by batch size), 0 / 1 / 2 = the batch chunk depth, half, quarter
     int winv_rows;               // explicit-inverse product per (tile, block row) over the whole contraction range: -1 auto
                                  // (batches that fill the chip that way), 0 never (chunked units + reduction), 1 always

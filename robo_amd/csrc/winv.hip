@@ -153,6 +153,67 @@ __global__ __launch_bounds__(256, 2) void winv_row_kernel(const double* __restri
     }
 }
 
+// A HANDFUL of candidates (the 1 x D calls of the reference's single-point maximisers, robo/maximizers/scipy_optimizer.py:44,
+// differential_evolution.py:29, grid_search.py:60): V = K_* W^T is a matrix-vector product, bound by reading W once (67 MB at
+// N = 4096) -- the 128-candidate tile of the GEMM forms spends 127/128 of its MFMAs on padding rows and still takes 0.18 ms.
+// One workgroup per slab of GV_ROWS rows of W: thread t walks k = t, t + 256, ... <= the slab's last column with the slab's
+// W entries (coalesced along k) and the MC candidates' K_* entries (L2-resident) in registers, GV_ROWS x MC partial sums per
+// thread, one block reduction at the end; |v|^2 and v.z per slab, added up by winv_finish_kernel in slab order.
+constexpr int GV_ROWS = 8;
+template <int MC, bool STORE_V>
+__global__ __launch_bounds__(256) void winv_gemv_kernel(const double* __restrict__ Ks, int ldk,
+                                                        const double* __restrict__ W, int ldw,
+                                                        const double* __restrict__ z, int n, double* __restrict__ V,
+                                                        int ldv, double* __restrict__ qpart,
+                                                        double* __restrict__ mupart, long long rows) {
+    __shared__ double red[4][GV_ROWS * MC];
+    const int j0 = (int)blockIdx.x * GV_ROWS, t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int kend = j0 >= n ? 0 : (j0 + GV_ROWS < n ? j0 + GV_ROWS : n);   // columns < kend (entries beyond a row's diagonal are 0)
+    double acc[GV_ROWS][MC];
+#pragma unroll
+    for (int r = 0; r < GV_ROWS; ++r)
+#pragma unroll
+        for (int c = 0; c < MC; ++c) acc[r][c] = 0.0;
+    for (int k = t; k < kend; k += 256) {
+        double ks[MC], w[GV_ROWS];
+#pragma unroll
+        for (int c = 0; c < MC; ++c) ks[c] = Ks[(size_t)c * ldk + k];
+#pragma unroll
+        for (int r = 0; r < GV_ROWS; ++r) w[r] = (j0 + r < n && k <= j0 + r) ? W[(size_t)(j0 + r) * ldw + k] : 0.0;
+#pragma unroll
+        for (int r = 0; r < GV_ROWS; ++r)
+#pragma unroll
+            for (int c = 0; c < MC; ++c) acc[r][c] = fma(w[r], ks[c], acc[r][c]);
+    }
+#pragma unroll
+    for (int r = 0; r < GV_ROWS; ++r)
+#pragma unroll
+        for (int c = 0; c < MC; ++c) {
+            double s = acc[r][c];
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+            if (lane == 0) red[wave][r * MC + c] = s;
+        }
+    __syncthreads();
+    // thread c < MC finishes candidate c: its GV_ROWS entries of V, their share of |v|^2 and v.z
+    if (t < MC) {
+        double q = 0.0, m = 0.0;
+#pragma unroll
+        for (int r = 0; r < GV_ROWS; ++r) {
+            const int j = j0 + r;
+            const double v = j < n ? (red[0][r * MC + t] + red[1][r * MC + t]) + (red[2][r * MC + t] + red[3][r * MC + t]) : 0.0;
+            if (STORE_V) V[(size_t)t * ldv + j] = v;      // (0 for columns >= n)
+            q = fma(v, v, q);
+            m = fma(v, j < n ? z[j] : 0.0, m);
+        }
+        qpart[(size_t)blockIdx.x * rows + t] = q;
+        mupart[(size_t)blockIdx.x * rows + t] = m;
+    } else if (t < rows) {
+        qpart[(size_t)blockIdx.x * rows + t] = 0.0;      // padding candidates of the tile: defined, never read by a caller
+        mupart[(size_t)blockIdx.x * rows + t] = 0.0;
+    }
+}
+
 __global__ __launch_bounds__(256) void winv_finish_kernel(const double* __restrict__ qpart,
                                                           const double* __restrict__ mupart, int nbk, long long rows,
                                                           double* __restrict__ q, double* __restrict__ mu) {
@@ -298,16 +359,35 @@ int launch_predict_winv(robo_gp* gp, robo_cand* cand, int64_t c0, int64_t cn, bo
     const long long slots = 2LL * gp->ctx->num_cu;
     const int rows_mode = gp->ctx->tune.winv_rows;                 // -1 auto, 0 never, 1 always (A/B, tests)
     const bool whole = rows_mode >= 0 ? rows_mode != 0 : (cand->m_pad / NB) * (long long)(nbk + 1) >= 2 * slots;
+    // a handful of candidates: matrix-vector form (tuning winv_gemv: -1 auto = at most 8 candidates unless another form is
+    // forced, 0 never, 1 whenever it applies)
+    const int gemv_mode = gp->ctx->tune.winv_gemv;
+    const bool gemv = (gemv_mode > 0 || (gemv_mode < 0 && rows_mode < 0 && shift < 0)) && cand->m <= 8 && cand->m_pad == NB;
+    const int nslab = nbk * NB / GV_ROWS;       // through the last block row: its columns >= n are stored as 0, like the other forms
+    const int nparts = gemv ? nslab : nbk;
     int s = grow(&cand->d_Ks, &cand->ks_bytes, (size_t)cn * n_pad * sizeof(double));
-    if (s == ROBO_OK && !whole) s = grow(&cand->d_P, &cand->p_bytes, (size_t)cts * nu * NB * NB * sizeof(double));
-    if (s == ROBO_OK) s = grow(&cand->d_qpart, &cand->qpart_bytes, (size_t)2 * nbk * cn * sizeof(double));
+    if (s == ROBO_OK && !whole && !gemv) s = grow(&cand->d_P, &cand->p_bytes, (size_t)cts * nu * NB * NB * sizeof(double));
+    if (s == ROBO_OK) s = grow(&cand->d_qpart, &cand->qpart_bytes, (size_t)2 * nparts * cn * sizeof(double));
     if (s != ROBO_OK) return s;
     double* qpart = cand->d_qpart;
-    double* mupart = cand->d_qpart + (size_t)nbk * cn;
+    double* mupart = cand->d_qpart + (size_t)nparts * cn;
     s = launch_cross_gram(gp, cand, c0, cn, cand->d_Ks);
     if (s != ROBO_OK) return s;
     const double* z = gp->d_K + (size_t)gp->n * n_pad;
-    if (whole) {
+    if (gemv) {
+        cand->solve_kernel = "winv_gemv_kernel";
+#define ROBO_GEMV(MC, SV)                                                                                            \
+    hipLaunchKernelGGL((winv_gemv_kernel<MC, SV>), dim3((unsigned)nslab), dim3(256), 0, st, (const double*)cand->d_Ks,  \
+                       n_pad, (const double*)gp->d_Winv, n_pad, z, gp->n, cand->d_V, n_pad, qpart, mupart, (long long)cn)
+        if (cand->m == 1) {
+            if (store_v) ROBO_GEMV(1, true);
+            else ROBO_GEMV(1, false);
+        } else {
+            if (store_v) ROBO_GEMV(8, true);
+            else ROBO_GEMV(8, false);
+        }
+#undef ROBO_GEMV
+    } else if (whole) {
         cand->solve_kernel = "winv_row_kernel";
         if (store_v)
             hipLaunchKernelGGL(winv_row_kernel<true>, dim3(cts, (unsigned)nbk), dim3(256), 0, st, (const double*)cand->d_Ks,
@@ -331,7 +411,7 @@ int launch_predict_winv(robo_gp* gp, robo_cand* cand, int64_t c0, int64_t cn, bo
                                mupart, (long long)cn);
     }
     hipLaunchKernelGGL(winv_finish_kernel, dim3((unsigned)((cn + 255) / 256)), dim3(256), 0, st, (const double*)qpart,
-                       (const double*)mupart, nbk, (long long)cn, cand->d_q + c0, cand->d_mu + c0);
+                       (const double*)mupart, nparts, (long long)cn, cand->d_q + c0, cand->d_mu + c0);
     ROBO_LAUNCH_CHECK();
     return ROBO_OK;
 }

@@ -1158,6 +1158,30 @@ def check_winv_path(ctx, cases=(("matern52", 300, 5, 700), ("fabolas", 280, 4, 1
             want, srt = int(np.argmax(ei_o)), np.sort(ei_o)
             assert am_w == int(np.argmax(vals)) and (am_w == want or srt[-1] - srt[-2] <= 1e-7 * abs(ei_o[want]))
             assert am_w == am_b or srt[-1] - srt[-2] <= 1e-7 * abs(ei_o[want])
+            if not rows_mode:
+                # a handful of candidates (the reference's 1 x D callers): the matrix-vector form, against the oracle and
+                # against the chunked form of the same points; full covariance through it (a consumer of V itself)
+                ctx.set_tuning("winv_rows", None)
+                for m_few in (1, 5, 8):
+                    few = _lib.Candidates(ctx, Xc[:m_few])
+                    mu_f, var_f = g.predict(few)
+                    assert few.solve_kernel() == "winv_gemv_kernel", few.solve_kernel()
+                    np.testing.assert_allclose(mu_f, mu_o[:m_few], rtol=MU_RTOL, atol=MU_ATOL)
+                    np.testing.assert_allclose(var_f, var_o[:m_few], rtol=0, atol=VAR_ATOL_REL_AMP * amp)
+                    ctx.set_tuning("winv_gemv", 0)
+                    mu_g, var_g = g.predict(few)
+                    assert few.solve_kernel() in ("winv_gemm_kernel", "winv_row_kernel")
+                    ctx.set_tuning("winv_gemv", None)
+                    np.testing.assert_allclose(mu_f, mu_g, rtol=0, atol=3e-11 * max(1.0, np.abs(mu_g).max()))
+                    np.testing.assert_allclose(var_f, var_g, rtol=0, atol=3e-11 * amp)
+                    _, _, am_f, _ = g.acq("ei", 0.0, eta, few)
+                    assert am_f == int(np.argmax(O.ei(mu_o[:m_few], var_o[:m_few], eta)))
+                    few.close()
+                mu5, cov5 = g.predict_cov(Xc[:5])
+                _, cov5_o = ogp.predict(Xc[:5], full_cov=True)
+                np.testing.assert_allclose(np.clip(cov5, np.finfo(float).eps, np.inf), cov5_o, rtol=0,
+                                           atol=VAR_ATOL_REL_AMP * amp)
+                ctx.set_tuning("winv_rows", rows_mode)
             # chunked passes: same bits
             n_pad = (N + 1 + 127) // 128 * 128
             ctx.set_tuning("ws_bytes", 2 * 128 * n_pad * 8)
@@ -1215,7 +1239,7 @@ def check_winv_path(ctx, cases=(("matern52", 300, 5, 700), ("fabolas", 280, 4, 1
         cand.close()
         g.close()
     finally:
-        for key in ("winv_min_blocks", "winv_max", "ws_bytes", "winv_rows", "winv_kc_shift"):
+        for key in ("winv_min_blocks", "winv_max", "ws_bytes", "winv_rows", "winv_kc_shift", "winv_gemv"):
             ctx.set_tuning(key, None)
 
 

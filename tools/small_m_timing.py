@@ -31,13 +31,16 @@ for N, D in ((4096, 16), (2048, 16), (1000, 8), (500, 4)):
     t0 = time.perf_counter(); g.acq("ei", 0.0, eta, np.random.rand(500, D), want_values=False); t2 = (time.perf_counter() - t0) * 1e3
     print("N=%d: W = L^-1 build + cond_inf(L) on a refitted factor: %.3f ms (cond_inf %.3g); 500-candidate call with W in place "
           "%.3f ms, right after a refit (build included) %.3f ms" % (N, min(wb), cond, t1, t2))
-    for M in ((1, 128, 500, 2048, 8192, 16384, 32768) if N == 4096 else (500, 8192)):
+    for M in ((1, 8, 128, 500, 2048, 8192, 16384, 32768) if N == 4096 else (1, 500, 8192)):
         cand = _lib.Candidates(ctx, np.random.RandomState(1).rand(M, D))
         out = []
         for winv, small in ((0, 0), (0, 1000000), (1 << 30, 1000000)):
             ctx.set_tuning("winv_max", winv); ctx.set_tuning("winv_min_blocks", 1); ctx.set_tuning("trsm_small_max", small)
             out.append(best(lambda: g.acq("ei", 0.0, eta, cand, want_values=False)))
         kern = cand.solve_kernel()
+        ctx.set_tuning("winv_gemv", 1)
+        gemv_ms = best(lambda: g.acq("ei", 0.0, eta, cand, want_values=False)) if M <= 8 else float("nan")
+        ctx.set_tuning("winv_gemv", 0)
         depths = []
         ctx.set_tuning("winv_rows", 0)
         for shift in (0, 1, 2):                  # the chunked form at its three unit depths
@@ -48,12 +51,12 @@ for N, D in ((4096, 16), (2048, 16), (1000, 8), (500, 4)):
         for rows in (0, 1):                      # the two forms of the explicit-inverse product, forced
             ctx.set_tuning("winv_rows", rows)
             forms.append(best(lambda: g.acq("ei", 0.0, eta, cand, want_values=False)))
-        for k in ("winv_max", "winv_min_blocks", "trsm_small_max", "winv_rows"):
+        for k in ("winv_max", "winv_min_blocks", "trsm_small_max", "winv_rows", "winv_gemv"):
             ctx.set_tuning(k, None)
         dflt = best(lambda: g.acq("ei", 0.0, eta, cand, want_values=False))
         print("N=%5d M=%6d: 128-cand step %.3f ms, 32-cand step %.3f ms, explicit inverse %.3f ms (%s; chunked units %.3f "
-              "[depth full/half/quarter %.3f/%.3f/%.3f], whole-range rows %.3f); default policy %.3f ms (%s)"
-              % (N, M, out[0], out[1], out[2], kern, forms[0], depths[0], depths[1], depths[2], forms[1], dflt,
+              "[depth full/half/quarter %.3f/%.3f/%.3f], whole-range rows %.3f, matrix-vector %.3f); default policy %.3f ms (%s)"
+              % (N, M, out[0], out[1], out[2], kern, forms[0], depths[0], depths[1], depths[2], forms[1], gemv_ms, dflt,
                  cand.solve_kernel()))
         cand.close()
     g.close()
