@@ -1007,7 +1007,10 @@ static int cand_ensure_workspace(robo_cand* k, int n_pad, bool single_chunk) {
 static bool winv_candidate(const robo_gp* g, const robo_cand* k) {
     const Tuning& t = g->ctx->tune;
     if (g->fp32_gram || t.predict_stepwise || t.winv_max <= 0) return false;
-    if (k->m_pad > t.winv_max || (g->n + NB - 1) / NB < t.winv_min_blocks) return false;
+    // a handful of candidates (the matrix-vector form, winv.hip) pays from three block rows on: N = 300 0.044 vs 0.065 ms,
+    // N = 500 0.053 vs 0.086 ms against the 32-candidate substitution (r04x); larger batches from winv_min_blocks on
+    const int min_blocks = (k->m <= 8 && t.winv_gemv != 0 && t.winv_min_blocks > 3) ? 3 : t.winv_min_blocks;
+    if (k->m_pad > t.winv_max || (g->n + NB - 1) / NB < min_blocks) return false;
     return g->diag_min > 0.0 && g->diag_max <= (double)t.winv_cond_max * g->diag_min;
 }
 

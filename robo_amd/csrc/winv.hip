@@ -167,13 +167,16 @@ __global__ __launch_bounds__(256) void winv_gemv_kernel(const double* __restrict
                                                         int ldv, double* __restrict__ qpart,
                                                         double* __restrict__ mupart, long long rows) {
     __shared__ double red[4][GV_ROWS * MC];
-    const int j0 = (int)blockIdx.x * GV_ROWS, t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    // heaviest slabs (the last rows of W: longest contraction) first
+    const int slab = (int)gridDim.x - 1 - (int)blockIdx.x;
+    const int j0 = slab * GV_ROWS, t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int kend = j0 >= n ? 0 : (j0 + GV_ROWS < n ? j0 + GV_ROWS : n);   // columns < kend (entries beyond a row's diagonal are 0)
     double acc[GV_ROWS][MC];
 #pragma unroll
     for (int r = 0; r < GV_ROWS; ++r)
 #pragma unroll
         for (int c = 0; c < MC; ++c) acc[r][c] = 0.0;
+#pragma unroll 4
     for (int k = t; k < kend; k += 256) {
         double ks[MC], w[GV_ROWS];
 #pragma unroll
@@ -206,11 +209,8 @@ __global__ __launch_bounds__(256) void winv_gemv_kernel(const double* __restrict
             q = fma(v, v, q);
             m = fma(v, j < n ? z[j] : 0.0, m);
         }
-        qpart[(size_t)blockIdx.x * rows + t] = q;
-        mupart[(size_t)blockIdx.x * rows + t] = m;
-    } else if (t < rows) {
-        qpart[(size_t)blockIdx.x * rows + t] = 0.0;      // padding candidates of the tile: defined, never read by a caller
-        mupart[(size_t)blockIdx.x * rows + t] = 0.0;
+        qpart[(size_t)slab * rows + t] = q;
+        mupart[(size_t)slab * rows + t] = m;
     }
 }
 
@@ -220,6 +220,7 @@ __global__ __launch_bounds__(256) void winv_finish_kernel(const double* __restri
     const long long c = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= rows) return;
     double a = 0.0, b = 0.0;
+#pragma unroll 8      // (the partials were just written by other CUs: eight loads in flight instead of a chain of L2 misses)
     for (int j = 0; j < nbk; ++j) {
         a += qpart[(size_t)j * rows + c];
         b += mupart[(size_t)j * rows + c];
@@ -252,6 +253,36 @@ __global__ __launch_bounds__(256) void winv_norm_kernel(const double* __restrict
         // number comes out NaN and the caller keeps the substitution)
         atomicMax(out, (unsigned long long)__double_as_longlong(sl));
         atomicMax(out + 1, (unsigned long long)__double_as_longlong(sw));
+    }
+}
+
+// the matrix-vector form leaves n / 8 slab partials per candidate (512 at N = 4096): one WAVE per candidate adds them -- lane l the
+// partials l, l + 64, ... in ascending order, then the butterfly -- instead of one thread walking all of them (a chain of
+// dependent L2 misses: it cost more than the product itself)
+__global__ __launch_bounds__(256) void winv_finish_few_kernel(const double* __restrict__ qpart,
+                                                              const double* __restrict__ mupart, int nparts,
+                                                              long long rows, int mc, double* __restrict__ q,
+                                                              double* __restrict__ mu) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int c = wave; c < mc; c += 4) {
+        double a = 0.0, b = 0.0;
+        for (int p = lane; p < nparts; p += 64) {
+            a += qpart[(size_t)p * rows + c];
+            b += mupart[(size_t)p * rows + c];
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            a += __shfl_xor(a, o);
+            b += __shfl_xor(b, o);
+        }
+        if (lane == 0) {
+            q[c] = a;
+            mu[c] = b;
+        }
+    }
+    for (long long c = mc + threadIdx.x; c < rows; c += 256) {       // padding candidates: defined values
+        q[c] = 0.0;
+        mu[c] = 0.0;
     }
 }
 
@@ -410,8 +441,12 @@ int launch_predict_winv(robo_gp* gp, robo_cand* cand, int64_t c0, int64_t cn, bo
                                (const double*)cand->d_P, (const int*)gp->d_wprefix[v], nu, z, gp->n, cand->d_V, n_pad, qpart,
                                mupart, (long long)cn);
     }
-    hipLaunchKernelGGL(winv_finish_kernel, dim3((unsigned)((cn + 255) / 256)), dim3(256), 0, st, (const double*)qpart,
-                       (const double*)mupart, nparts, (long long)cn, cand->d_q + c0, cand->d_mu + c0);
+    if (gemv)
+        hipLaunchKernelGGL(winv_finish_few_kernel, dim3(1), dim3(256), 0, st, (const double*)qpart, (const double*)mupart,
+                           nparts, (long long)cn, cand->m == 1 ? 1 : 8, cand->d_q + c0, cand->d_mu + c0);
+    else
+        hipLaunchKernelGGL(winv_finish_kernel, dim3((unsigned)((cn + 255) / 256)), dim3(256), 0, st, (const double*)qpart,
+                           (const double*)mupart, nparts, (long long)cn, cand->d_q + c0, cand->d_mu + c0);
     ROBO_LAUNCH_CHECK();
     return ROBO_OK;
 }
