@@ -53,7 +53,7 @@ pmc)
   grep -i "trsm_step\|potrf_step\|gram_kernel\|potrf_panel" $OUT/pmc_summary.txt | head -24 >> $OUT/summary.txt ;;
 pmcconf)
   # HBM traffic of the dominant kernel of the other configurations: FETCH_SIZE and WRITE_SIZE passes, one step each
-  for cfg in "c2 trsm_step_gen_kernel 1024 8 65536" "c3 trsm_step_gen_kernel 2048 16 65536" "c4 winv_gemm_kernel 4096 11 8192" "c5 trsm_step_kernel 8192 64 131072"; do
+  for cfg in "c2 trsm_step_gen_kernel 1024 8 65536" "c3 trsm_step_gen_kernel 2048 16 65536" "c4 winv_row_kernel 4096 11 8192" "c5 trsm_step_kernel 8192 64 131072"; do
     set -- $cfg
     for C in FETCH_SIZE WRITE_SIZE; do
       timeout 600 rocprofv3 --kernel-trace --pmc $C -d $OUT/pmc_$1/$C -o pmc -- python bench.py --gpus 1 --config $1 --steps 1 --warmup 0 --no-cpu-baseline > /dev/null 2> $OUT/pmc_$1_$C.err
