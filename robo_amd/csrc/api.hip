@@ -1,6 +1,7 @@
 // C ABI of librobo_hip.so (see include/robo_hip.h for the contract and the reference call
 // sites each entry point replaces).  Host-side orchestration only: every number is
 // produced by the kernels in gram.hip / potrf.hip / predict.hip / acq.hip.
+#include <atomic>
 #include <cctype>
 #include <cmath>
 #include <cstdarg>
@@ -47,6 +48,8 @@ static const TuneKey TUNE_KEYS[] = {
     {"potrf_max_wg", nullptr, &Tuning::potrf_max_wg, 0},
     {"potrf_group", nullptr, &Tuning::potrf_group, 4},
     {"potrf_tail_split", nullptr, &Tuning::potrf_tail_split, 1},
+    {"potrf_split", nullptr, &Tuning::potrf_split, 1},
+    {"potrf_lead", nullptr, &Tuning::potrf_lead, -1},
     {"gram_persistent", nullptr, &Tuning::gram_persistent, 0},
     {"gram_mfma", nullptr, &Tuning::gram_mfma, 0},
     {"gram_half", nullptr, &Tuning::gram_half, 0},
@@ -71,6 +74,18 @@ void tuning_from_env(Tuning* t) {
     if (t->ws_bytes < 1) t->ws_bytes = (long long)6 << 30;   // callers round down to whole 128-candidate blocks
 }
 
+int ctx_aux_streams(robo_ctx* c) {
+    if (c->aux_ready) return ROBO_OK;
+    ROBO_HIP_CHECK(hipSetDevice(c->device));
+    ROBO_HIP_CHECK(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
+    for (int i = 0; i < ROBO_AUX_STREAMS; ++i) {
+        ROBO_HIP_CHECK(hipStreamCreateWithFlags(&c->aux[i], hipStreamNonBlocking));
+        ROBO_HIP_CHECK(hipEventCreateWithFlags(&c->ev_join[i], hipEventDisableTiming));
+    }
+    c->aux_ready = true;
+    return ROBO_OK;
+}
+
 static size_t workspace_bytes(const robo_ctx* c) { return (size_t)c->tune.ws_bytes; }
 
 template <class T>
@@ -79,11 +94,7 @@ static int dev_alloc(T** p, size_t count) {
     return ROBO_OK;
 }
 
-#define ROBO_TRY(expr)                \
-    do {                              \
-        int _s = (expr);              \
-        if (_s != ROBO_OK) return _s; \
-    } while (0)
+
 
 }  // namespace robo
 
@@ -136,6 +147,14 @@ int32_t robo_ctx_destroy(robo_ctx* c) {
     hipSetDevice(c->device);
     hipStreamSynchronize(c->stream);
     for (int i = 0; i < 32; ++i) hipEventDestroy(c->events[i]);
+    if (c->aux_ready) {
+        hipEventDestroy(c->ev_fork);
+        for (int i = 0; i < ROBO_AUX_STREAMS; ++i) {
+            hipStreamSynchronize(c->aux[i]);
+            hipStreamDestroy(c->aux[i]);
+            hipEventDestroy(c->ev_join[i]);
+        }
+    }
     hipFree(c->d_scalars);
     hipFree(c->d_fail);
     hipHostFree(c->h_pinned);
@@ -325,7 +344,7 @@ static int theta_to_sample(const robo_gp* g, const double* theta, double mean_c,
 }
 
 static unsigned long long next_fit_gen() {
-    static unsigned long long gen = 0;
+    static std::atomic<unsigned long long> gen{0};   // contexts of several devices fit on their own threads (multi.hip)
     return ++gen;
 }
 

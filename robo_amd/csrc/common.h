@@ -68,6 +68,12 @@ void set_error(const char* fmt, ...);
         }                                                                                          \
     } while (0)
 
+#define ROBO_TRY(expr)                \
+    do {                              \
+        int _s = (expr);              \
+        if (_s != ROBO_OK) return _s; \
+    } while (0)
+
 static inline int round_up(int x, int m) { return (x + m - 1) / m * m; }
 static inline int64_t round_up64(int64_t x, int64_t m) { return (x + m - 1) / m * m; }
 
@@ -94,6 +100,8 @@ struct Tuning {
     long long winv_cond_max;     // ... while cond_inf(L) = |L|_inf |W|_inf stays below this (default 1e5)
     int potrf_fused;             // 0: never fuse the next diagonal block into the trailing update
     int potrf_tm4_min, potrf_max_wg, potrf_group;
+    int potrf_split;             // batched fit: sub-batches on their own streams with staggered group boundaries (1: one stream)
+    int potrf_lead;              // ... first-group size step between sub-batches (-1: G / splits)
     int potrf_tail_split;        // fused step: the ragged last round of 128-row tiles as half / quarter tiles on more workgroups
     int mcmc_block_step;         // ensemble half-step in ONE launch: 2 (default) every one-block problem, 1 only N <= 63, 0 never
     int gram_mfma;               // K1 with x.x' on the matrix pipe (gram_mfma_kernel; measured slower, r04c: default 0 = never)
@@ -103,11 +111,20 @@ struct Tuning {
 };
 void tuning_from_env(Tuning* t);
 }  // namespace robo
+struct robo_ctx;
+namespace robo {
+int ctx_aux_streams(robo_ctx* ctx);   // api.hip: create ctx->aux / ev_fork / ev_join once
+}
 
+constexpr int ROBO_AUX_STREAMS = 3;
 struct robo_ctx {
     int device;
     hipStream_t stream;
     bool own_stream;
+    // side streams of the batched factorisation's sub-batches (potrf.hip), created on first use; fork / join events
+    hipStream_t aux[ROBO_AUX_STREAMS];
+    hipEvent_t ev_fork, ev_join[ROBO_AUX_STREAMS];
+    bool aux_ready;
     hipEvent_t events[32];
     bool phase_events;   // record the internal phase events of robo_gp_fit (robo_ctx_set_phase_events, default off)
     char name[256];

@@ -1452,22 +1452,28 @@ int launch_potrf(robo_gp* gp, const FitBuffers& fb) {
     // real pivots only -- so that block is neither updated nor factored nor inverted: one link less in the chain
     // panel -> tile update -> 128 pivots -> next panel (r04: the 33rd link of the N = 4096 fit)
     const int nbf = (gp->n % NB == 0 && nb > 1) ? nb - 1 : nb;       // diagonal blocks that are factored
-#define ROBO_DIAG(KK)                                                                                          \
-    hipLaunchKernelGGL(potrf_diag_kernel, dim3(S), dim3(256), 0, ctx->stream, fb.K, fb.k_stride, ld, (KK), gp->n, \
-                       fb.Linv, fb.linv_stride, fb.fail, (long long*)nullptr, (double*)nullptr, (double*)nullptr)
-#define ROBO_PANEL(KK)                                                                                         \
-    hipLaunchKernelGGL(potrf_panel_kernel, dim3((nb - (KK)-1) * 2, S), dim3(256), 0, ctx->stream, fb.K,        \
-                       fb.k_stride, ld, (KK), (const double*)fb.Linv, fb.linv_stride, (long long*)nullptr)
-#define ROBO_STEP(TM, F, GRID, BASE, KOP, DEPTH, FIRST, NT)                                                       \
-    hipLaunchKernelGGL((potrf_step_kernel<TM, F>), dim3((GRID), S), dim3(256), 0, ctx->stream, fb.K, fb.k_stride, \
-                       ld, (BASE), gp->n, fb.Linv, fb.linv_stride, fb.fail, (KOP), (DEPTH), (FIRST), (NT))
+    // every launch of the factorisation as a function of (stream, first sample, samples): the batched path may run
+    // sub-batches on their own streams (below)
+    auto diag = [&](hipStream_t st, int s0, int ns, int kk) {
+        hipLaunchKernelGGL(potrf_diag_kernel, dim3(ns), dim3(256), 0, st, fb.K + (size_t)s0 * fb.k_stride, fb.k_stride, ld, kk,
+                           gp->n, fb.Linv + (size_t)s0 * fb.linv_stride, fb.linv_stride, fb.fail + s0, (long long*)nullptr,
+                           (double*)nullptr, (double*)nullptr);
+    };
+    auto panel = [&](hipStream_t st, int s0, int ns, int kk) {
+        hipLaunchKernelGGL(potrf_panel_kernel, dim3((nb - kk - 1) * 2, ns), dim3(256), 0, st,
+                           fb.K + (size_t)s0 * fb.k_stride, fb.k_stride, ld, kk,
+                           (const double*)(fb.Linv + (size_t)s0 * fb.linv_stride), fb.linv_stride, (long long*)nullptr);
+    };
+#define ROBO_STEP(TM, F, ST, S0, NS, GRID, BASE, KOP, DEPTH, FIRST, NT)                                              \
+    hipLaunchKernelGGL((potrf_step_kernel<TM, F>), dim3((GRID), (NS)), dim3(256), 0, (ST),                            \
+                       fb.K + (size_t)(S0)*fb.k_stride, fb.k_stride, ld, (BASE), gp->n,                               \
+                       fb.Linv + (size_t)(S0)*fb.linv_stride, fb.linv_stride, fb.fail + (S0), (KOP), (DEPTH), (FIRST), (NT))
     // tile height, measured (N = 4096, S = 1): 128-row tiles 43 us/step at 384..528 blocks, 64-row tiles
     // slower (55 us: B panel re-read twice), 32-row tiles 16 us vs 21 us once blocks < 96
-#define ROBO_UPDATE(TILES, BASE, KOP, DEPTH, FIRST)                                                            \
-    do {                                                                                                       \
-        if ((TILES) * S >= 96) ROBO_STEP(4, false, (TILES), BASE, KOP, DEPTH, FIRST, 0);                          \
-        else if ((TILES) > 0) ROBO_STEP(1, false, (TILES)*4, BASE, KOP, DEPTH, FIRST, 0);                         \
-    } while (0)
+    auto update = [&](hipStream_t st, int s0, int ns, int tiles, int base, int kop, int depth, int first) {
+        if (tiles * ns >= 96) ROBO_STEP(4, false, st, s0, ns, tiles, base, kop, depth, first, 0);
+        else if (tiles > 0) ROBO_STEP(1, false, st, s0, ns, tiles * 4, base, kop, depth, first, 0);
+    };
     if (nb == 1 && !fb.want_inverse) {
         // one block, likelihood only: factor and reduce in one launch
         hipLaunchKernelGGL(potrf_diag_kernel, dim3(S), dim3(256), 0, ctx->stream, fb.K, fb.k_stride, ld, 0, gp->n, fb.Linv,
@@ -1480,16 +1486,18 @@ int launch_potrf(robo_gp* gp, const FitBuffers& fb) {
     const int max_wg = wg_cap >= 2 ? wg_cap : ctx->num_cu;
     if (fused) {
         // single theta: trailing update of step k + diagonal block k+1 (workgroup 0) in one launch
-        ROBO_DIAG(0);
+        hipStream_t st = ctx->stream;
+        diag(st, 0, S, 0);
         for (int k = 0; k + 1 < nb; ++k) {
             const int rem = nb - k - 1, tiles = rem * (rem + 1) / 2;
-            ROBO_PANEL(k);
+            panel(st, 0, S, k);
             if (k + 1 >= nbf) break;          // what is left is the augmented row's own block: nothing to factor
             // 128-row tiles: one diagonal workgroup + at most (CUs - 1) persistent tile workgroups (one per CU: the
             // diagonal block's LDS image sizes every workgroup of the launch)
             if (tiles * S >= tm4_min)
-                ROBO_STEP(4, true, tiles < max_wg ? tiles : max_wg, k, k, NB, tune.potrf_tail_split != 0 ? 1 : 0, tiles);
-            else ROBO_STEP(1, true, 1 + (tiles - 1) * 4, k, k, NB, 0, tiles);
+                ROBO_STEP(4, true, st, 0, S, tiles < max_wg ? tiles : max_wg, k, k, NB, tune.potrf_tail_split != 0 ? 1 : 0,
+                          tiles);
+            else ROBO_STEP(1, true, st, 0, S, 1 + (tiles - 1) * 4, k, k, NB, 0, tiles);
         }
     } else {
         // batched thetas: the chip is full, and a 128-deep update is bound by reading and writing its C
@@ -1499,24 +1507,53 @@ int launch_potrf(robo_gp* gp, const FitBuffers& fb) {
         // receives all G panels in ONE (128 G)-deep update -- 1/G of the C traffic.  Bitwise the same
         // factor: every element still accumulates its products in ascending k on top of the stored value.
         // measured, 27 thetas at N = 4096 (ms per theta): G=1 0.668, 2 0.596, 4 0.574, 6 0.566
-        const int G = tune.potrf_group < 1 ? 1 : (tune.potrf_group > 8 ? 8 : tune.potrf_group);
-        for (int k0 = 0; k0 < nb; k0 += G) {
-            const int g = nb - k0 < G ? nb - k0 : G;          // panels in this group
-            for (int kk = k0; kk < k0 + g; ++kk) {
-                if (kk >= nbf) break;         // the augmented row's own block
-                // left-looking inside the group: block column kk <- panels k0 .. kk-1, all rows >= kk
-                if (kk > k0) ROBO_UPDATE(nb - kk, kk - 1, k0, (kk - k0) * NB, 1);
-                ROBO_DIAG(kk);
-                if (kk + 1 < nb) ROBO_PANEL(kk);
+        const int G = tune.potrf_group < 1 ? 1 : (tune.potrf_group > 16 ? 16 : tune.potrf_group);
+        // `lead` = size of the FIRST group (1..G); all later groups hold G panels.  Where the group boundaries fall
+        // changes which launches carry which products, never the order in which an element accumulates them.
+        auto chain = [&](hipStream_t st, int s0, int ns, int lead) {
+            int k0 = 0;
+            while (k0 < nb) {
+                const int want = k0 == 0 ? lead : G;
+                const int g = nb - k0 < want ? nb - k0 : want;        // panels in this group
+                for (int kk = k0; kk < k0 + g; ++kk) {
+                    if (kk >= nbf) break;         // the augmented row's own block
+                    // left-looking inside the group: block column kk <- panels k0 .. kk-1, all rows >= kk
+                    if (kk > k0) update(st, s0, ns, nb - kk, kk - 1, k0, (kk - k0) * NB, 1);
+                    diag(st, s0, ns, kk);
+                    if (kk + 1 < nb) panel(st, s0, ns, kk);
+                }
+                const int rem = nb - (k0 + g);                    // block rows/columns beyond the group
+                if (rem > 0) update(st, s0, ns, rem * (rem + 1) / 2, k0 + g - 1, k0, g * NB, 0);
+                k0 += g;
             }
-            const int rem = nb - (k0 + g);                    // block rows/columns beyond the group
-            if (rem > 0) ROBO_UPDATE(rem * (rem + 1) / 2, k0 + g - 1, k0, g * NB, 0);
+        };
+        // Sub-batches on their own streams (potrf_split, r05): the latency-bound phases of a group (diagonal blocks on
+        // S of 256 CUs, panels, the left-looking column updates) of one sub-batch can run beside the chip-wide trailing
+        // update of another IF their group boundaries do not coincide -- hence a different first-group size per
+        // sub-batch (sub-batch j leads with G - j G / splits panels).
+        int splits = tune.potrf_split < 1 ? 1 : (tune.potrf_split > ROBO_AUX_STREAMS + 1 ? ROBO_AUX_STREAMS + 1 : tune.potrf_split);
+        if (S < 2 * splits || nb < 2 * G) splits = 1;
+        if (splits == 1) {
+            chain(ctx->stream, 0, S, G);
+        } else {
+            ROBO_TRY(ctx_aux_streams(ctx));
+            ROBO_HIP_CHECK(hipEventRecord(ctx->ev_fork, ctx->stream));
+            for (int j = 0; j < splits; ++j) {
+                const int s0 = (int)((long long)S * j / splits), s1 = (int)((long long)S * (j + 1) / splits);
+                hipStream_t st = j == 0 ? ctx->stream : ctx->aux[j - 1];
+                if (j > 0) ROBO_HIP_CHECK(hipStreamWaitEvent(st, ctx->ev_fork, 0));
+                int lead = tune.potrf_lead > 0 && j > 0 ? tune.potrf_lead * j : G - (G * j) / splits;
+                if (lead < 1) lead = 1;
+                if (lead > G) lead = G;
+                chain(st, s0, s1 - s0, lead);
+                if (j > 0) {
+                    ROBO_HIP_CHECK(hipEventRecord(ctx->ev_join[j - 1], st));
+                    ROBO_HIP_CHECK(hipStreamWaitEvent(ctx->stream, ctx->ev_join[j - 1], 0));
+                }
+            }
         }
     }
-#undef ROBO_UPDATE
 #undef ROBO_STEP
-#undef ROBO_PANEL
-#undef ROBO_DIAG
     // the explicit 128 x 128 inverses of all diagonal blocks, off the factorisation's critical path
     hipLaunchKernelGGL(potrf_inverse_kernel, dim3(nbf, S), dim3(256), 0, ctx->stream, (const double*)fb.K, fb.k_stride, ld,
                        fb.Linv, fb.linv_stride, gp->n, fb.LinvP, fb.ll_part, fb.want_inverse ? 1 : 0);

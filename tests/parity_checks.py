@@ -582,6 +582,50 @@ def check_batched_likelihoods(ctx, sizes=((60, 3), (300, 4))):
         g.close()
 
 
+def check_batched_split(ctx, N=520, D=3, S=5, variants=((2, 2, -1), (2, 3, -1), (2, 2, 1), (3, 1, -1), (16, 1, -1))):
+    """The batched factorisation with its sub-batches on separate streams and staggered group boundaries
+    (potrf_split / potrf_group / potrf_lead, potrf.hip launch_potrf): likelihoods AND kept factors bit-identical to the
+    one-stream schedule -- every element accumulates the same products in the same order whatever launch carries them."""
+    rs = np.random.RandomState(41)
+    X = rs.rand(N, D)
+    y = np.sin(3 * X.sum(axis=1))
+    base = np.concatenate([[0.0], np.full(D, np.log(0.3 * D)), [np.log(1e-2)]])
+    thetas = base[None, :] + 0.3 * rs.randn(S, base.size)
+    mean_c = float(y.mean())
+    g = _lib.DeviceGP(ctx, "matern52", N, D)
+    g.set_data(X, y)
+    gps = [_lib.DeviceGP(ctx, "matern52", N, D) for _ in range(S)]
+    gps[0].set_data(X, y)
+    try:
+        ctx.set_tuning("potrf_split", 1)
+        ctx.set_tuning("potrf_group", 1)
+        ref, st = g.loglik_batch(thetas, mean_c)
+        assert np.all(st == _lib.OK)
+        ll, st = _lib.fit_batch(gps, thetas, mean_c)
+        np.testing.assert_array_equal(ll, ref)
+        L_ref = [gp.factor().copy() for gp in gps]
+        ogp = O.OracleGP("matern52", thetas[1], normalize_input=False)
+        ogp.train(X, y)
+        np.testing.assert_allclose(ref[1], ogp.loglikelihood(thetas[1]), rtol=LOGLIK_RTOL)
+        for group, split, lead in variants:
+            ctx.set_tuning("potrf_group", group)
+            ctx.set_tuning("potrf_split", split)
+            ctx.set_tuning("potrf_lead", lead)
+            ll, st = g.loglik_batch(thetas, mean_c)
+            assert np.all(st == _lib.OK)
+            np.testing.assert_array_equal(ll, ref, err_msg="group %d split %d lead %d" % (group, split, lead))
+            ll, st = _lib.fit_batch(gps, thetas, mean_c)
+            np.testing.assert_array_equal(ll, ref)
+            for gp, L in zip(gps, L_ref):
+                np.testing.assert_array_equal(gp.factor(), L)
+    finally:
+        for key in ("potrf_split", "potrf_group", "potrf_lead"):
+            ctx.set_tuning(key, None)
+        g.close()
+        for gp in gps:
+            gp.close()
+
+
 def check_fit_batch(ctx, sizes=((60, 3), (300, 4)), kind="matern52"):
     """robo_gp_fit_batch (the per-sample model fits of GaussianProcessMCMC.train in one batched pass that keeps
     the factors) == S sequential robo_gp_fit calls on S handles: log-likelihood, Cholesky factor and posterior bit

@@ -99,6 +99,11 @@ def test_batched_likelihoods(emu_ctx):
     P.check_batched_likelihoods(emu_ctx)
 
 
+def test_batched_split_streams(emu_ctx):
+    """sub-batches on side streams with staggered group boundaries: same bits (5 panels at N = 520)"""
+    P.check_batched_split(emu_ctx)
+
+
 def test_grad_loglik(emu_ctx):
     P.check_grad_loglik(emu_ctx)
 

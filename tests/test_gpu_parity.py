@@ -103,6 +103,13 @@ def test_batched_likelihoods(ctx):
     P.check_batched_likelihoods(ctx, sizes=((60, 3), (300, 4), (1500, 8)))
 
 
+def test_batched_split_streams(ctx):
+    """sub-batches of a batched factorisation on side streams with staggered group boundaries: likelihoods and kept
+    factors bit-identical to the one-stream schedule (17 panels, 9 thetas; 2 / 3 / 4 streams, groups of 2 .. 6)"""
+    P.check_batched_split(ctx, N=2100, D=6, S=9, variants=((4, 1, -1), (6, 2, -1), (6, 2, 1), (4, 3, -1), (2, 4, -1),
+                                                              (6, 3, 2), (3, 2, -1)))
+
+
 def test_grad_loglik(ctx):
     P.check_grad_loglik(ctx)
     P.check_grad_loglik(ctx, cases=(("matern52", 1500, 8), ("rbf", 1100, 40)))
