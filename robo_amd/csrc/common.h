@@ -100,6 +100,7 @@ struct Tuning {
     long long winv_cond_max;     // ... while cond_inf(L) = |L|_inf |W|_inf stays below this (default 1e5)
     int potrf_fused;             // 0: never fuse the next diagonal block into the trailing update
     int potrf_tm4_min, potrf_max_wg, potrf_group;
+    int potrf_thin_last;         // batched fit: 32-row tiles for the block row that holds only the augmented row (1; 0 = A/B)
     int potrf_split;             // batched fit: sub-batches on their own streams with staggered group boundaries (1: one stream)
     int potrf_lead;              // ... first-group size step between sub-batches (-1: G / splits)
     int potrf_tail_split;        // fused step: the ragged last round of 128-row tiles as half / quarter tiles on more workgroups

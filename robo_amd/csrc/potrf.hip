@@ -785,7 +785,8 @@ int launch_mcmc_block_step(robo_gp* gp, const McmcState& st, int start, int firs
 // and register r of an accumulator-layout Y_c IS the B fragment of its rows 4r..4r+3, so every product takes its
 // B operand straight from the previous results and its A operand (L_sc or W_ss, shared by the whole workgroup)
 // from the LDS image of the diagonal block: 36 products = 144 MFMAs per strip, no LDS round trip on the chain.
-constexpr int PANEL_SMEM_DOUBLES = (NBLK + NSB) * BLK;   // 36 blocks of L_kk + 8 W_ss: 88 KB
+constexpr int PANEL_SMEM_DOUBLES = NBLK * BLK;   // the 28 strictly lower blocks of L_kk + the 8 W_ss in the diagonal slots: 72 KB,
+                                                 // two workgroups per CU (r05; 88 KB with the unused diagonal blocks of L: one)
 
 // Within every 16-block the panel kernel indexes panel columns through the 4x4 index transpose pi(a) = (a >> 2) | ((a & 3) << 2)
 // (an involution): register r of lane (i = l & 15, g = l >> 4) of an accumulator-layout Y_s is then X[strip row i][16 s + 4 g + r],
@@ -804,7 +805,6 @@ __global__ __launch_bounds__(256) void potrf_panel_kernel(double* __restrict__ K
                                                           long long* __restrict__ dbg) {
     __shared__ double smem[PANEL_SMEM_DOUBLES];
     double* sL = smem;
-    double* sWd = smem + NBLK * BLK;      // W_ss, s = 0..7
     K += (size_t)blockIdx.y * k_stride;
     Linv += (size_t)blockIdx.y * linv_stride;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -821,28 +821,24 @@ __global__ __launch_bounds__(256) void potrf_panel_kernel(double* __restrict__ K
         const double2 lo = p[0], hi = p[1];
         y[s] = v4d{lo.x, lo.y, hi.x, hi.y};
     }
-    // stage L_kk (36 blocks) and the eight W_ss, two adjacent columns per thread and step, rows and columns permuted
+    // stage the strictly lower blocks of L_kk and, in the slots of its diagonal blocks (which the substitution never
+    // reads), the eight W_ss: two adjacent columns per thread and step, rows and columns permuted
     {
         const int half = tid >> 7, pr = tid & 127, r = pr >> 3, c = (pr & 7) * 2;
         const int pos0 = bidx(pi16(r), pi16(c)), pos1 = bidx(pi16(r), pi16(c + 1));
-        double2 v[(NBLK + NSB) / 2];
+        double2 v[NBLK / 2];
 #pragma unroll
-        for (int e = 0; e < (NBLK + NSB) / 2; ++e) {
+        for (int e = 0; e < NBLK / 2; ++e) {
             const int b0 = 2 * e, b1 = 2 * e + 1;        // this step's two blocks (threads 0..127 / 128..255)
-            const double* src;
-            if (b0 < NBLK) {
-                const int bi0 = tri_row(b0), bj0 = b0 - bi0 * (bi0 + 1) / 2, bi1 = tri_row(b1), bj1 = b1 - bi1 * (bi1 + 1) / 2;
-                const int bi = half ? bi1 : bi0, bj = half ? bj1 : bj0;
-                src = Kd + (size_t)(bi * SB + r) * ld + bj * SB + c;
-            } else {
-                const int sblk = (half ? b1 : b0) - NBLK;
-                src = Wg + (sblk * SB + r) * NB + sblk * SB + c;
-            }
+            const int bi0 = tri_row(b0), bj0 = b0 - bi0 * (bi0 + 1) / 2, bi1 = tri_row(b1), bj1 = b1 - bi1 * (bi1 + 1) / 2;
+            const int bi = half ? bi1 : bi0, bj = half ? bj1 : bj0;
+            const double* src = bi == bj ? Wg + (bi * SB + r) * NB + bi * SB + c
+                                         : Kd + (size_t)(bi * SB + r) * ld + bj * SB + c;
             v[e] = *reinterpret_cast<const double2*>(src);
         }
 #pragma unroll
-        for (int e = 0; e < (NBLK + NSB) / 2; ++e) {
-            double* dst = smem + (2 * e + half) * BLK;     // blocks 36..43 are the W_ss: sWd = smem + 36 BLK
+        for (int e = 0; e < NBLK / 2; ++e) {
+            double* dst = smem + (2 * e + half) * BLK;
             dst[pos0] = v[e].x;
             dst[pos1] = v[e].y;
         }
@@ -858,7 +854,7 @@ __global__ __launch_bounds__(256) void potrf_panel_kernel(double* __restrict__ K
 #pragma unroll
             for (int r = 0; r < 4; ++r) t = mfma_f64(-a.v[r], y[c][r], t);
         }
-        const Frag4 w = frag_row(sWd + s * BLK, lane);
+        const Frag4 w = frag_row(sL + blk_off(s, s), lane);
         v4d o = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
         for (int r = 0; r < 4; ++r) o = mfma_f64(w.v[r], t[r], o);
@@ -1288,7 +1284,10 @@ template <int TM, bool FUSED>
 __global__ __launch_bounds__(256) void potrf_step_kernel(double* __restrict__ K, size_t k_stride, int ld, int k,
                                                          int n_real, double* __restrict__ Linv, size_t linv_stride,
                                                          int* __restrict__ fail, int kop, int depth, int first_col,
-                                                         int ntiles) {
+                                                         int ntiles, int thin_row) {
+    // thin_row (batched updates only, else -1): the block row that holds nothing but the augmented row (n a multiple of
+    // 128: row n is the first row of the last block, the rows below it are identity rows whose updates are zero) -- its
+    // tiles are computed 32 rows high instead of 128
     // k: trailing base (tiles cover block rows/columns > k); kop: first block column of the panel
     // operand(s); depth: contraction length (128, or 256 = two panels at once, see launch_potrf);
     // first_col != 0: block column k+1 only
@@ -1353,6 +1352,21 @@ __global__ __launch_bounds__(256) void potrf_step_kernel(double* __restrict__ K,
     const double* A = K + row0 * ld + (size_t)kop * NB;
     const double* B = K + ((size_t)j * NB) * ld + (size_t)kop * NB;
     double* C = K + row0 * ld + (size_t)j * NB;
+    if (!FUSED && i == thin_row) {
+        // the augmented row's block: rows 0..31 of the tile (row n is its row 0), same products in the same order
+        if (h != 0) return;
+        AccT<1> acc1;
+#pragma unroll
+        for (int tn = 0; tn < 4; ++tn)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc1.t[0][tn][r] = C[(size_t)acc_row<1>(0, r) * ld + acc_col(tn)];
+        gemm_nt<1, true>(A, ld, B, ld, 0, depth, acc1, smem);
+#pragma unroll
+        for (int tn = 0; tn < 4; ++tn)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) C[(size_t)acc_row<1>(0, r) * ld + acc_col(tn)] = acc1.t[0][tn][r];
+        return;
+    }
     AccT<TM> acc;
 #pragma unroll
     for (int tm = 0; tm < TM; ++tm)
@@ -1467,9 +1481,11 @@ int launch_potrf(robo_gp* gp, const FitBuffers& fb) {
 #define ROBO_STEP(TM, F, ST, S0, NS, GRID, BASE, KOP, DEPTH, FIRST, NT)                                              \
     hipLaunchKernelGGL((potrf_step_kernel<TM, F>), dim3((GRID), (NS)), dim3(256), 0, (ST),                            \
                        fb.K + (size_t)(S0)*fb.k_stride, fb.k_stride, ld, (BASE), gp->n,                               \
-                       fb.Linv + (size_t)(S0)*fb.linv_stride, fb.linv_stride, fb.fail + (S0), (KOP), (DEPTH), (FIRST), (NT))
+                       fb.Linv + (size_t)(S0)*fb.linv_stride, fb.linv_stride, fb.fail + (S0), (KOP), (DEPTH), (FIRST), (NT),  \
+                       (F) ? -1 : thin_row)
     // tile height, measured (N = 4096, S = 1): 128-row tiles 43 us/step at 384..528 blocks, 64-row tiles
     // slower (55 us: B panel re-read twice), 32-row tiles 16 us vs 21 us once blocks < 96
+    const int thin_row = (nbf < nb && tune.potrf_thin_last != 0) ? nb - 1 : -1;   // the augmented row's own block (r05)
     auto update = [&](hipStream_t st, int s0, int ns, int tiles, int base, int kop, int depth, int first) {
         if (tiles * ns >= 96) ROBO_STEP(4, false, st, s0, ns, tiles, base, kop, depth, first, 0);
         else if (tiles > 0) ROBO_STEP(1, false, st, s0, ns, tiles * 4, base, kop, depth, first, 0);
@@ -1510,47 +1526,51 @@ int launch_potrf(robo_gp* gp, const FitBuffers& fb) {
         const int G = tune.potrf_group < 1 ? 1 : (tune.potrf_group > 16 ? 16 : tune.potrf_group);
         // `lead` = size of the FIRST group (1..G); all later groups hold G panels.  Where the group boundaries fall
         // changes which launches carry which products, never the order in which an element accumulates them.
-        auto chain = [&](hipStream_t st, int s0, int ns, int lead) {
-            int k0 = 0;
-            while (k0 < nb) {
-                const int want = k0 == 0 ? lead : G;
-                const int g = nb - k0 < want ? nb - k0 : want;        // panels in this group
-                for (int kk = k0; kk < k0 + g; ++kk) {
-                    if (kk >= nbf) break;         // the augmented row's own block
-                    // left-looking inside the group: block column kk <- panels k0 .. kk-1, all rows >= kk
-                    if (kk > k0) update(st, s0, ns, nb - kk, kk - 1, k0, (kk - k0) * NB, 1);
-                    diag(st, s0, ns, kk);
-                    if (kk + 1 < nb) panel(st, s0, ns, kk);
-                }
-                const int rem = nb - (k0 + g);                    // block rows/columns beyond the group
-                if (rem > 0) update(st, s0, ns, rem * (rem + 1) / 2, k0 + g - 1, k0, g * NB, 0);
-                k0 += g;
+        auto group = [&](hipStream_t st, int s0, int ns, int k0, int g) {
+            for (int kk = k0; kk < k0 + g; ++kk) {
+                if (kk >= nbf) break;         // the augmented row's own block
+                // left-looking inside the group: block column kk <- panels k0 .. kk-1, all rows >= kk
+                if (kk > k0) update(st, s0, ns, nb - kk, kk - 1, k0, (kk - k0) * NB, 1);
+                diag(st, s0, ns, kk);
+                if (kk + 1 < nb) panel(st, s0, ns, kk);
             }
+            const int rem = nb - (k0 + g);                    // block rows/columns beyond the group
+            if (rem > 0) update(st, s0, ns, rem * (rem + 1) / 2, k0 + g - 1, k0, g * NB, 0);
         };
         // Sub-batches on their own streams (potrf_split, r05): the latency-bound phases of a group (diagonal blocks on
-        // S of 256 CUs, panels, the left-looking column updates) of one sub-batch can run beside the chip-wide trailing
-        // update of another IF their group boundaries do not coincide -- hence a different first-group size per
-        // sub-batch (sub-batch j leads with G - j G / splits panels).
+        // S of 256 CUs, panels, the left-looking column updates) of one sub-batch run beside the chip-wide trailing
+        // update of another IF their group boundaries do not coincide -- hence a different FIRST group per sub-batch
+        // (sub-batch j leads with G - j G / splits panels; all later groups hold G).  Where the group boundaries fall
+        // changes which launch carries which products, never the order in which an element accumulates them: same bits.
+        // The host hands the groups out round-robin so that no stream's queue runs dry behind another's launches.
         int splits = tune.potrf_split < 1 ? 1 : (tune.potrf_split > ROBO_AUX_STREAMS + 1 ? ROBO_AUX_STREAMS + 1 : tune.potrf_split);
         if (S < 2 * splits || nb < 2 * G) splits = 1;
-        if (splits == 1) {
-            chain(ctx->stream, 0, S, G);
-        } else {
+        if (splits > 1) {
             ROBO_TRY(ctx_aux_streams(ctx));
             ROBO_HIP_CHECK(hipEventRecord(ctx->ev_fork, ctx->stream));
+            for (int j = 1; j < splits; ++j) ROBO_HIP_CHECK(hipStreamWaitEvent(ctx->aux[j - 1], ctx->ev_fork, 0));
+        }
+        int next_k0[ROBO_AUX_STREAMS + 1] = {0, 0, 0, 0};
+        for (bool more = true; more;) {
+            more = false;
             for (int j = 0; j < splits; ++j) {
+                const int k0 = next_k0[j];
+                if (k0 >= nb) continue;
                 const int s0 = (int)((long long)S * j / splits), s1 = (int)((long long)S * (j + 1) / splits);
-                hipStream_t st = j == 0 ? ctx->stream : ctx->aux[j - 1];
-                if (j > 0) ROBO_HIP_CHECK(hipStreamWaitEvent(st, ctx->ev_fork, 0));
-                int lead = tune.potrf_lead > 0 && j > 0 ? tune.potrf_lead * j : G - (G * j) / splits;
-                if (lead < 1) lead = 1;
-                if (lead > G) lead = G;
-                chain(st, s0, s1 - s0, lead);
-                if (j > 0) {
-                    ROBO_HIP_CHECK(hipEventRecord(ctx->ev_join[j - 1], st));
-                    ROBO_HIP_CHECK(hipStreamWaitEvent(ctx->stream, ctx->ev_join[j - 1], 0));
+                int want = G;
+                if (k0 == 0 && j > 0) {
+                    want = tune.potrf_lead > 0 ? G - tune.potrf_lead * j : G - (G * j) / splits;
+                    if (want < 1) want = 1;
                 }
+                const int g = nb - k0 < want ? nb - k0 : want;
+                group(j == 0 ? ctx->stream : ctx->aux[j - 1], s0, s1 - s0, k0, g);
+                next_k0[j] = k0 + g;
+                more = more || next_k0[j] < nb;
             }
+        }
+        for (int j = 1; j < splits; ++j) {
+            ROBO_HIP_CHECK(hipEventRecord(ctx->ev_join[j - 1], ctx->aux[j - 1]));
+            ROBO_HIP_CHECK(hipStreamWaitEvent(ctx->stream, ctx->ev_join[j - 1], 0));
         }
     }
 #undef ROBO_STEP

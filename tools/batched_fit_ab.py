@@ -21,6 +21,10 @@ spec = os.environ.get("BATCH_AB", "4,1,-1;6,1,-1;8,1,-1;12,1,-1;6,2,-1;6,2,1;6,2
 variants = [tuple(int(v) for v in item.split(",")) for item in spec.split(";") if item]
 
 ctx = _lib.Context(0)
+for item in os.environ.get("BATCH_TUNE", "").split(","):          # e.g. BATCH_TUNE="potrf_thin_last=0"
+    if "=" in item:
+        key, val = item.split("=")
+        ctx.set_tuning(key.strip(), int(val))
 X = np.random.RandomState(0).rand(N, D)
 y = np.sinc(X * 10 - 5).sum(axis=1)
 y = (y - y.mean()) / y.std()
