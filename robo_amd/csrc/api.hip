@@ -49,7 +49,8 @@ static const TuneKey TUNE_KEYS[] = {
     {"potrf_group", nullptr, &Tuning::potrf_group, 4},
     {"potrf_tail_split", nullptr, &Tuning::potrf_tail_split, 1},
     {"potrf_thin_last", nullptr, &Tuning::potrf_thin_last, 1},
-    {"potrf_split", nullptr, &Tuning::potrf_split, 1},
+    {"potrf_split", nullptr, &Tuning::potrf_split, 3},
+    {"potrf_split_min", nullptr, &Tuning::potrf_split_min, 12},
     {"potrf_lead", nullptr, &Tuning::potrf_lead, -1},
     {"gram_persistent", nullptr, &Tuning::gram_persistent, 0},
     {"gram_mfma", nullptr, &Tuning::gram_mfma, 0},

@@ -102,6 +102,7 @@ struct Tuning {
     int potrf_tm4_min, potrf_max_wg, potrf_group;
     int potrf_thin_last;         // batched fit: 32-row tiles for the block row that holds only the augmented row (1; 0 = A/B)
     int potrf_split;             // batched fit: sub-batches on their own streams with staggered group boundaries (1: one stream)
+    int potrf_split_min;         // ... from this many panels on (default 12: N >= 1408)
     int potrf_lead;              // ... first-group size step between sub-batches (-1: G / splits)
     int potrf_tail_split;        // fused step: the ragged last round of 128-row tiles as half / quarter tiles on more workgroups
     int mcmc_block_step;         // ensemble half-step in ONE launch: 2 (default) every one-block problem, 1 only N <= 63, 0 never

@@ -1544,7 +1544,9 @@ int launch_potrf(robo_gp* gp, const FitBuffers& fb) {
         // changes which launch carries which products, never the order in which an element accumulates them: same bits.
         // The host hands the groups out round-robin so that no stream's queue runs dry behind another's launches.
         int splits = tune.potrf_split < 1 ? 1 : (tune.potrf_split > ROBO_AUX_STREAMS + 1 ? ROBO_AUX_STREAMS + 1 : tune.potrf_split);
-        if (S < 2 * splits || nb < 2 * G) splits = 1;
+        // measured (r05b, 27 thetas, ms per theta, one stream -> three): N = 4096 0.512 -> 0.470, N = 2048 0.104 -> 0.092,
+        // N = 1024 0.0293 -> 0.0316 (nine panels: the chains are too short to interleave); four streams: 0.58 at N = 4096
+        if (S < 2 * splits || nb < tune.potrf_split_min) splits = 1;
         if (splits > 1) {
             ROBO_TRY(ctx_aux_streams(ctx));
             ROBO_HIP_CHECK(hipEventRecord(ctx->ev_fork, ctx->stream));

@@ -582,7 +582,7 @@ def check_batched_likelihoods(ctx, sizes=((60, 3), (300, 4))):
         g.close()
 
 
-def check_batched_split(ctx, N=520, D=3, S=5, variants=((2, 2, -1), (2, 3, -1), (2, 2, 1), (3, 1, -1), (16, 1, -1))):
+def check_batched_split(ctx, N=520, D=3, S=6, variants=((2, 2, -1), (2, 3, -1), (2, 2, 1), (3, 1, -1), (16, 1, -1)), split_min=4):
     """The batched factorisation with its sub-batches on separate streams and staggered group boundaries
     (potrf_split / potrf_group / potrf_lead, potrf.hip launch_potrf): likelihoods AND kept factors bit-identical to the
     one-stream schedule -- every element accumulates the same products in the same order whatever launch carries them."""
@@ -599,6 +599,7 @@ def check_batched_split(ctx, N=520, D=3, S=5, variants=((2, 2, -1), (2, 3, -1), 
     try:
         ctx.set_tuning("potrf_split", 1)
         ctx.set_tuning("potrf_group", 1)
+        ctx.set_tuning("potrf_split_min", split_min)
         ref, st = g.loglik_batch(thetas, mean_c)
         assert np.all(st == _lib.OK)
         ll, st = _lib.fit_batch(gps, thetas, mean_c)
@@ -619,7 +620,7 @@ def check_batched_split(ctx, N=520, D=3, S=5, variants=((2, 2, -1), (2, 3, -1), 
             for gp, L in zip(gps, L_ref):
                 np.testing.assert_array_equal(gp.factor(), L)
     finally:
-        for key in ("potrf_split", "potrf_group", "potrf_lead"):
+        for key in ("potrf_split", "potrf_group", "potrf_lead", "potrf_split_min"):
             ctx.set_tuning(key, None)
         g.close()
         for gp in gps:
