@@ -348,6 +348,65 @@ int32_t robo_acq_eval_marginal_cand_sharded(robo_comm* comm, robo_gp* const* gps
                                             double* out_acq, double* out_max, int64_t* out_argmax,
                                             uint32_t* out_flags);
 
+/* ---- multi-GPU, ONE process: G contexts of the calling process, one per device (SURVEY.md 8b "Threading: single process,
+ * one context per device") ------------------------------------------------------------------------------------------------
+ * The reference is one process with one objective evaluation per iteration (robo/solver/bayesian_optimization.py:156-203).
+ * A robo_multi fans the shards of the same two axes as the _sharded entry points above -- candidates
+ * (robo/maximizers/random_sampling.py:42-50) and hyper-parameter samples (robo/acquisition_functions/marginalization.py:
+ * 115-121, robo/models/gaussian_process_mcmc.py:149-164,235-247) -- over its contexts: one worker thread per device runs the
+ * ordinary single-device entry point on that device's context and stream, all devices concurrently, and the G results are
+ * reduced -- candidate shards on the host (32 bytes per device arrive through each context's pinned read-back anyway; np.argmax
+ * tie-break: NaN maximal, larger value, lower global index), sample shards on the FIRST context's device (peer copies over
+ * xGMI, then the rank-ordered sum / mixture kernels of the single-device and _sharded forms: same bits as those).
+ * No collective is involved: a failing device cannot hang the others; every call waits for all devices and returns the
+ * first failing device's status.  Arrays indexed "[G]" have one entry per context, in the order given to robo_multi_create;
+ * every handle of slot g must live on context g.  Several contexts may share a device (tests on a one-GPU box).
+ * ROBO_MULTI_THREADS=0 (read at creation) runs the per-device halves one after the other on the caller's thread.        */
+typedef struct robo_multi robo_multi;
+int32_t robo_multi_create(robo_ctx* const* ctxs, int32_t n_ctx, robo_multi** out);
+int32_t robo_multi_destroy(robo_multi* multi);
+/* out_devices[G] (nullable): HIP device of every slot; out_threads: worker threads in use (0 = caller's thread)            */
+int32_t robo_multi_info(robo_multi* multi, int32_t* out_n, int32_t* out_devices, int32_t* out_threads);
+/* the same training data / the same fit on every device (a replica per device; the fit is deterministic: replicas whose
+ * status or log-likelihood bits differ are reported as ROBO_RUNTIME_ERROR).  gaussian_process.py:119,122,155          */
+int32_t robo_gp_set_data_multi(robo_multi* multi, robo_gp* const* gps, const double* X, const double* y, int32_t n);
+int32_t robo_gp_fit_multi(robo_multi* multi, robo_gp* const* gps, const double* theta, double mean_c, double* out_loglik,
+                          int32_t* out_fail_col);
+/* robo_gp_loglik_batch with the S thetas split contiguously over the devices (the first S % G devices take one more):
+ * the walkers of an ensemble half-step (gaussian_process_mcmc.py:114-142,168-202).  gps[G]: one handle per device, each
+ * holding the data.                                                                                                       */
+int32_t robo_gp_loglik_batch_multi(robo_multi* multi, robo_gp* const* gps, const double* thetas, int32_t S, double mean_c,
+                                   double* out_loglik, int32_t* out_status);
+/* robo_gp_fit_batch per device: gps[S_total] in device order (S_dev[0] handles of slot 0 first, ...), thetas / outputs in
+ * the same order; the FIRST handle of every device's group holds the training data on that device.
+ * gaussian_process_mcmc.py:149-164                                                                                         */
+int32_t robo_gp_fit_batch_multi(robo_multi* multi, robo_gp* const* gps, const int32_t* S_dev, const double* thetas,
+                                double mean_c, double* out_loglik, int32_t* out_status);
+/* candidate shard: robo_acq_eval_cand on every device's shard (cands[g] NULL = empty shard), gps[g] = that device's replica;
+ * global index of candidate c of slot g = global_offsets[g] + c.  out_acq (nullable): the values of all shards, slot after
+ * slot.  out_owner: the slot whose shard holds the maximum; out_flags: OR over the devices.                              */
+int32_t robo_acq_eval_cand_multi(robo_multi* multi, robo_gp* const* gps, int32_t acq_kind, double par, double eta,
+                                 robo_cand* const* cands, const int64_t* global_offsets, double* out_acq, double* out_max,
+                                 int64_t* out_argmax, int32_t* out_owner, uint32_t* out_flags);
+/* candidate shard of robo_ig_eval_per_cost_cand (BASELINE config 4); reps / cost_gps / cost_cands: per-device replicas     */
+int32_t robo_ig_eval_per_cost_cand_multi(robo_multi* multi, robo_gp* const* gps, robo_cand* const* cands,
+                                         robo_cand* const* reps, int32_t n_outcomes, double sn2, const double* logP,
+                                         const double* lmb, const double* W, const double* dlogPdMu,
+                                         const double* dlogPdSigma, const double* dlogPdMudMu, robo_gp* const* cost_gps,
+                                         robo_cand* const* cost_cands, double overhead, const int64_t* global_offsets,
+                                         double* out_values, double* out_max, int64_t* out_argmax, int32_t* out_owner);
+/* sample shard of robo_acq_eval_marginal_cand: gps / etas [S_total] in device order, cands[g] = ALL m candidates on device g
+ * (NULL allowed where S_dev[g] == 0, g > 0).  Partial sums are formed per device and added in device order: the result equals
+ * robo_acq_eval_marginal_cand_sharded with the same shards bit for bit, and the single-device accumulation up to fp64
+ * re-association.                                                                                                          */
+int32_t robo_acq_eval_marginal_cand_multi(robo_multi* multi, robo_gp* const* gps, const int32_t* S_dev, int32_t acq_kind,
+                                          double par, const double* etas, robo_cand* const* cands, double* out_acq,
+                                          double* out_max, int64_t* out_argmax, uint32_t* out_flags);
+/* sample shard of robo_gp_predict_mixture_cand: the per-sample posteriors are gathered on the first device in sample order
+ * and mixed there by the same kernel: identical to the single-device mixture bit for bit.                                  */
+int32_t robo_gp_predict_mixture_cand_multi(robo_multi* multi, robo_gp* const* gps, const int32_t* S_dev,
+                                           robo_cand* const* cands, double* out_mean, double* out_var);
+
 #ifdef __cplusplus
 }
 #endif

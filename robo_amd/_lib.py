@@ -38,6 +38,9 @@ SYMBOLS = [
     "robo_ig_eval_cand", "robo_ig_eval_per_cost_cand", "robo_ig_eval_moments", "robo_gp_cross_cov",
     "robo_comm_create_id", "robo_comm_init", "robo_comm_destroy", "robo_comm_info", "robo_comm_allgather",
     "robo_acq_eval_cand_sharded", "robo_acq_eval_marginal_cand_sharded", "robo_ig_eval_per_cost_cand_sharded",
+    "robo_multi_create", "robo_multi_destroy", "robo_multi_info", "robo_gp_set_data_multi", "robo_gp_fit_multi",
+    "robo_gp_loglik_batch_multi", "robo_gp_fit_batch_multi", "robo_acq_eval_cand_multi",
+    "robo_ig_eval_per_cost_cand_multi", "robo_acq_eval_marginal_cand_multi", "robo_gp_predict_mixture_cand_multi",
 ]
 COMM_ID_BYTES = 128
 # include/robo_hip_diag.h (librobo_hip_diag.so: tests, bench.py's roofline block, tools/)
@@ -79,11 +82,13 @@ def _f64(a, shape=None):
 
 def use_library(path):
     """Point the binding at another build of the same C ABI (test hook)."""
-    global _lib, _lib_path, _default_ctx, _diag
+    global _lib, _lib_path, _default_ctx, _diag, _extra_ctx, _multis
     _lib = None
     _diag = None
     _lib_path = path
     _default_ctx = {}
+    _extra_ctx = {}
+    _multis = {}
 
 
 def library_path():
@@ -169,6 +174,20 @@ def lib():
                                        C.POINTER(C.c_uint32)],
         "robo_acq_eval_marginal_cand_sharded": [vp, pp, i32, i32, i32, dbl, _dp, vp, _dp, _dp, C.POINTER(i64),
                                                 C.POINTER(C.c_uint32)],
+        "robo_multi_create": [pp, i32, pp],
+        "robo_multi_destroy": [vp],
+        "robo_multi_info": [vp, C.POINTER(i32), C.POINTER(i32), C.POINTER(i32)],
+        "robo_gp_set_data_multi": [vp, pp, _dp, _dp, i32],
+        "robo_gp_fit_multi": [vp, pp, _dp, dbl, _dp, C.POINTER(i32)],
+        "robo_gp_loglik_batch_multi": [vp, pp, _dp, i32, dbl, _dp, C.POINTER(i32)],
+        "robo_gp_fit_batch_multi": [vp, pp, C.POINTER(i32), _dp, dbl, _dp, C.POINTER(i32)],
+        "robo_acq_eval_cand_multi": [vp, pp, i32, dbl, dbl, pp, C.POINTER(i64), _dp, _dp, C.POINTER(i64), C.POINTER(i32),
+                                     C.POINTER(C.c_uint32)],
+        "robo_ig_eval_per_cost_cand_multi": [vp, pp, pp, pp, i32, dbl, _dp, _dp, _dp, _dp, _dp, _dp, pp, pp, dbl,
+                                             C.POINTER(i64), _dp, _dp, C.POINTER(i64), C.POINTER(i32)],
+        "robo_acq_eval_marginal_cand_multi": [vp, pp, C.POINTER(i32), i32, dbl, _dp, pp, _dp, _dp, C.POINTER(i64),
+                                              C.POINTER(C.c_uint32)],
+        "robo_gp_predict_mixture_cand_multi": [vp, pp, C.POINTER(i32), pp, _dp, _dp],
     }
     for name, args in sig.items():
         fn = getattr(L, name)
@@ -343,6 +362,57 @@ def default_context(device=None):
     if device not in _default_ctx:
         _default_ctx[device] = Context(device)
     return _default_ctx[device]
+
+
+_extra_ctx = {}        # (device, k): the k-th additional context on a device that appears more than once in a device list
+_multis = {}           # tuple(devices) -> Multi
+
+
+def resolve_devices(devices=None, n_gpus=None):
+    """the device list of a single-process multi-device run, or None for the ordinary one-device case:
+    ``devices`` = explicit HIP device ids (a device may appear twice: two contexts on it, for tests on a one-GPU box),
+    ``n_gpus`` = G -> devices 0 .. G-1"""
+    if devices is None and n_gpus is not None and int(n_gpus) > 1:
+        devices = list(range(int(n_gpus)))
+    if devices is None:
+        return None
+    devices = [int(d) for d in devices]
+    n = device_count()
+    if any(d < 0 or d >= n for d in devices):
+        raise ValueError("devices %r: this process sees %d HIP device(s)" % (devices, n))
+    return devices if len(devices) > 1 else None
+
+
+def contexts_for(devices):
+    """one Context per entry of ``devices``: the process-wide default context of a device for its first occurrence, an
+    extra one (kept for the life of the process) for every further occurrence"""
+    seen = {}
+    out = []
+    for d in devices:
+        k = seen.get(d, 0)
+        seen[d] = k + 1
+        if k == 0:
+            out.append(default_context(d))
+        else:
+            if (d, k) not in _extra_ctx:
+                _extra_ctx[(d, k)] = Context(d)
+            out.append(_extra_ctx[(d, k)])
+    return out
+
+
+def multi_for(devices):
+    """the process-wide Multi of a device list (every model / acquisition function given the same list shares it)"""
+    key = tuple(int(d) for d in devices)
+    if key not in _multis:
+        _multis[key] = Multi(contexts_for(key))
+    return _multis[key]
+
+
+def shard_range(n_items, slot, n_slots):
+    """contiguous [begin, end) of a slot's shard; the first n_items % n_slots slots hold one more (the library's rule)"""
+    base, rem = divmod(int(n_items), int(n_slots))
+    begin = slot * base + min(slot, rem)
+    return begin, begin + base + (1 if slot < rem else 0)
 
 
 class Candidates(object):
@@ -657,6 +727,164 @@ class Comm(object):
                                                         _arr(etas), cand._h, _arr(out) if want_values else None,
                                                         C.byref(mx), C.byref(am), C.byref(fl)))
         return out, mx.value, am.value, fl.value
+
+
+class CandidateShards(object):
+    """the candidate batch of ONE maximisation split over the contexts of a Multi: shards[g] is a Candidates on context g
+    (or None: empty shard), offsets[g] the global index of its first row"""
+
+    def __init__(self, shards, offsets):
+        self.shards, self.offsets = list(shards), [int(o) for o in offsets]
+        self.m = sum(c.m for c in self.shards if c is not None)
+
+    @classmethod
+    def split(cls, ctxs, Xn):
+        """contiguous shards of the host matrix Xn (already in the model's input space), one upload per device"""
+        Xn = _f64(Xn)
+        shards, offsets = [], []
+        for g, ctx in enumerate(ctxs):
+            b, e = shard_range(Xn.shape[0], g, len(ctxs))
+            offsets.append(b)
+            shards.append(Candidates(ctx, Xn[b:e]) if e > b else None)
+        return cls(shards, offsets)
+
+    def owner_point(self, owner, global_index):
+        return self.shards[owner].point(int(global_index) - self.offsets[owner])
+
+    def close(self):
+        for c in self.shards:
+            if c is not None:
+                c.close()
+
+
+class Multi(object):
+    """robo_multi: G contexts of THIS process, one per device; every method fans its shards out to all devices at once
+    (one worker thread per device inside the library) and returns the reduced result (include/robo_hip.h)."""
+
+    def __init__(self, ctxs):
+        self.ctxs = list(ctxs)
+        self.n = len(self.ctxs)
+        arr = (C.c_void_p * self.n)(*[c._h for c in self.ctxs])
+        self._h = C.c_void_p()
+        check(lib().robo_multi_create(arr, self.n, C.byref(self._h)))
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h:
+            lib().robo_multi_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def info(self):
+        """(number of contexts, their HIP devices, worker threads in use)"""
+        n, t = C.c_int32(0), C.c_int32(0)
+        dev = (C.c_int32 * self.n)()
+        check(lib().robo_multi_info(self._h, C.byref(n), dev, C.byref(t)))
+        return int(n.value), [int(d) for d in dev], int(t.value)
+
+    def _handles(self, objs):
+        return (C.c_void_p * max(len(objs), 1))(*[(o._h if o is not None else None) for o in objs])
+
+    @staticmethod
+    def _flatten(groups):
+        flat = [g for grp in groups for g in grp]
+        counts = (C.c_int32 * len(groups))(*[len(grp) for grp in groups])
+        return flat, counts
+
+    def set_data(self, gps, X, y):
+        X, y = _f64(X), _f64(y)
+        assert len(gps) == self.n and X.ndim == 2 and y.shape == (X.shape[0],)
+        check(lib().robo_gp_set_data_multi(self._h, self._handles(gps), _arr(X), _arr(y), X.shape[0]))
+        for g in gps:
+            g.n = X.shape[0]
+
+    def fit(self, gps, theta, mean_c):
+        """the same fit on every device's replica -> log-likelihood; raises np.linalg.LinAlgError like DeviceGP.fit"""
+        assert len(gps) == self.n
+        theta = _f64(theta, (gps[0].n_theta,))
+        ll, col = C.c_double(0), C.c_int32(0)
+        check(lib().robo_gp_fit_multi(self._h, self._handles(gps), _arr(theta), float(mean_c), C.byref(ll), C.byref(col)))
+        return ll.value
+
+    def loglik_batch(self, gps, thetas, mean_c):
+        """DeviceGP.loglik_batch with the thetas split over the devices (gps: one data-holding handle per device)"""
+        assert len(gps) == self.n
+        thetas = _f64(thetas)
+        S = thetas.shape[0]
+        ll = np.empty(S)
+        st = np.empty(S, dtype=np.int32)
+        check(lib().robo_gp_loglik_batch_multi(self._h, self._handles(gps), _arr(thetas), S, float(mean_c), _arr(ll),
+                                               st.ctypes.data_as(C.POINTER(C.c_int32))))
+        return ll, st
+
+    def fit_batch(self, gp_groups, thetas, mean_c):
+        """fit_batch per device: gp_groups[g] = the handles of device g (its first one holds the data), thetas in the
+        flattened order -> (loglik, status)"""
+        assert len(gp_groups) == self.n
+        flat, counts = self._flatten(gp_groups)
+        thetas = _f64(thetas)
+        assert thetas.shape[0] == len(flat)
+        ll = np.empty(len(flat))
+        st = np.empty(len(flat), dtype=np.int32)
+        check(lib().robo_gp_fit_batch_multi(self._h, self._handles(flat), counts, _arr(thetas), float(mean_c), _arr(ll),
+                                            st.ctypes.data_as(C.POINTER(C.c_int32))))
+        n = next((grp[0].n for grp in gp_groups if grp), 0)
+        for g in flat:
+            g.n = n
+        return ll, st
+
+    def acq(self, gps, kind, par, eta, shards, want_values=False):
+        """candidate shard -> (values of all shards in slot order or None, max, GLOBAL argmax, owner slot, flags OR-ed)"""
+        assert len(gps) == self.n and len(shards.shards) == self.n
+        out = np.empty(shards.m) if want_values else None
+        mx, am, own, fl = C.c_double(0), C.c_int64(0), C.c_int32(0), C.c_uint32(0)
+        offs = (C.c_int64 * self.n)(*shards.offsets)
+        check(lib().robo_acq_eval_cand_multi(self._h, self._handles(gps), ACQ_KINDS[kind], float(par), float(eta),
+                                             self._handles(shards.shards), offs, _arr(out) if want_values else None,
+                                             C.byref(mx), C.byref(am), C.byref(own), C.byref(fl)))
+        return out, mx.value, am.value, own.value, fl.value
+
+    def ig_per_cost(self, gps, shards, reps, ep, sn2, cost_gps, cost_shards, overhead, want_values=False):
+        """candidate shard of the information gain per unit cost -> (values or None, max, GLOBAL argmax, owner slot)"""
+        assert all(len(x) == self.n for x in (gps, shards.shards, reps, cost_gps, cost_shards.shards))
+        out = np.empty(shards.m) if want_values else None
+        mx, am, own = C.c_double(0), C.c_int64(0), C.c_int32(0)
+        offs = (C.c_int64 * self.n)(*shards.offsets)
+        check(lib().robo_ig_eval_per_cost_cand_multi(self._h, self._handles(gps), self._handles(shards.shards),
+                                                     self._handles(reps), ep.W.size, float(sn2), *ep.args(),
+                                                     self._handles(cost_gps), self._handles(cost_shards.shards),
+                                                     float(overhead), offs, _arr(out) if want_values else None,
+                                                     C.byref(mx), C.byref(am), C.byref(own)))
+        return out, mx.value, am.value, own.value
+
+    def acq_marginal(self, gp_groups, kind, par, eta_groups, cands, want_values=True):
+        """sample shard: gp_groups[g] / eta_groups[g] = the fitted handles of device g and their incumbent values,
+        cands[g] = ALL candidates on device g (None where a device has no sample, g > 0) -> (mean over all samples or
+        None, max, argmax, flags)"""
+        assert len(gp_groups) == self.n and len(cands) == self.n
+        flat, counts = self._flatten(gp_groups)
+        etas = _f64(np.concatenate([np.asarray(e, dtype=np.float64).reshape(-1) for e in eta_groups] or [np.zeros(0)]))
+        assert etas.shape[0] == len(flat)
+        out = np.empty(cands[0].m) if want_values else None
+        mx, am, fl = C.c_double(0), C.c_int64(0), C.c_uint32(0)
+        check(lib().robo_acq_eval_marginal_cand_multi(self._h, self._handles(flat), counts, ACQ_KINDS[kind], float(par),
+                                                      _arr(etas), self._handles(cands),
+                                                      _arr(out) if want_values else None, C.byref(mx), C.byref(am),
+                                                      C.byref(fl)))
+        return out, mx.value, am.value, fl.value
+
+    def predict_mixture(self, gp_groups, cands):
+        """GaussianProcessMCMC.predict over samples that live on several devices -> (mean (M,), var (M,))"""
+        assert len(gp_groups) == self.n and len(cands) == self.n
+        flat, counts = self._flatten(gp_groups)
+        mean, var = np.empty(cands[0].m), np.empty(cands[0].m)
+        check(lib().robo_gp_predict_mixture_cand_multi(self._h, self._handles(flat), counts, self._handles(cands),
+                                                       _arr(mean), _arr(var)))
+        return mean, var
 
 
 def fit_batch(gps, thetas, mean_c):

@@ -1102,28 +1102,35 @@ int32_t robo_gp_predict_cand(robo_gp* g, robo_cand* k, double* out_mean, double*
     return ROBO_OK;
 }
 
-int32_t robo_gp_predict_mixture_cand(robo_gp* const* gps, int32_t S, robo_cand* k, double* out_mean,
-                                     double* out_var) {
-    if (!gps || S < 1 || !k) return ROBO_BAD_ARGUMENT;
+// per-sample posteriors of S fitted GPs on one candidate handle -> rows 0 .. S - 1 of the handle's (>= cap) x m_pad
+// sample tables d_mu_all / d_var_all (asynchronous)
+static int predict_samples(robo_gp* const* gps, int32_t S, robo_cand* k, int cap) {
     ROBO_HIP_CHECK(hipSetDevice(k->ctx->device));
     const size_t mp = (size_t)k->m_pad;
-    if (k->s_cap < S) {
+    if (cap < S) cap = S;
+    if (k->s_cap < cap) {
         if (k->d_mu_all) ROBO_HIP_CHECK(hipFree(k->d_mu_all));
         if (k->d_var_all) ROBO_HIP_CHECK(hipFree(k->d_var_all));
         k->d_mu_all = k->d_var_all = nullptr;
         k->s_cap = 0;
-        ROBO_TRY(dev_alloc(&k->d_mu_all, (size_t)S * mp));
-        ROBO_TRY(dev_alloc(&k->d_var_all, (size_t)S * mp));
-        k->s_cap = S;
+        ROBO_TRY(dev_alloc(&k->d_mu_all, (size_t)cap * mp));
+        ROBO_TRY(dev_alloc(&k->d_var_all, (size_t)cap * mp));
+        k->s_cap = cap;
     }
     hipStream_t st = k->ctx->stream;
     for (int s = 0; s < S; ++s) {
         ROBO_TRY(predict_core(gps[s], k, false));
-        ROBO_HIP_CHECK(hipMemcpyAsync(k->d_mu_all + (size_t)s * mp, k->d_mean, mp * sizeof(double),
-                                      hipMemcpyDeviceToDevice, st));
-        ROBO_HIP_CHECK(hipMemcpyAsync(k->d_var_all + (size_t)s * mp, k->d_var, mp * sizeof(double),
-                                      hipMemcpyDeviceToDevice, st));
+        ROBO_HIP_CHECK(hipMemcpyAsync(k->d_mu_all + (size_t)s * mp, k->d_mean, mp * sizeof(double), hipMemcpyDeviceToDevice, st));
+        ROBO_HIP_CHECK(hipMemcpyAsync(k->d_var_all + (size_t)s * mp, k->d_var, mp * sizeof(double), hipMemcpyDeviceToDevice, st));
     }
+    return ROBO_OK;
+}
+
+int32_t robo_gp_predict_mixture_cand(robo_gp* const* gps, int32_t S, robo_cand* k, double* out_mean,
+                                     double* out_var) {
+    if (!gps || S < 1 || !k) return ROBO_BAD_ARGUMENT;
+    ROBO_TRY(predict_samples(gps, S, k, S));
+    hipStream_t st = k->ctx->stream;
     ROBO_TRY(launch_mixture(k, S));
     if (out_mean)
         ROBO_HIP_CHECK(hipMemcpyAsync(out_mean, k->d_mean, (size_t)k->m * sizeof(double), hipMemcpyDeviceToHost, st));
@@ -1615,4 +1622,5 @@ int api_acq_read_back(robo_cand* k, const double* d_vec, double* out_vec, double
     return acq_read_back(k, d_vec, out_vec, out_max, out_argmax, out_flags);
 }
 int api_clear_flags(robo_cand* k, int status) { return clear_flags_on_error(k, status); }
+int api_predict_samples(robo_gp* const* gps, int S, robo_cand* k, int cap) { return predict_samples(gps, S, k, cap); }
 }  // namespace robo

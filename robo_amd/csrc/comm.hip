@@ -185,6 +185,22 @@ __global__ __launch_bounds__(256) void comm_ordered_sum_kernel(const double* __r
     }
 }
 
+// the two halves of the sample shard's exchange for callers outside this file (multi.hip: several devices of ONE process)
+int launch_comm_pack_sum(hipStream_t st, const double* d_part, long long m, int have, const unsigned* d_flags, int status,
+                         double* d_send) {
+    hipLaunchKernelGGL(comm_pack_sum_kernel, dim3((unsigned)((m + 1 + 255) / 256)), dim3(256), 0, st, d_part, m, have, d_flags,
+                       status, d_send);
+    ROBO_LAUNCH_CHECK();
+    return ROBO_OK;
+}
+int launch_comm_ordered_sum(hipStream_t st, const double* d_recv, long long stride, int world, long long m, double* d_total,
+                            unsigned* d_flags, int* h_status) {
+    hipLaunchKernelGGL(comm_ordered_sum_kernel, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, st, d_recv, stride, world, m,
+                       d_total, d_flags, h_status);
+    ROBO_LAUNCH_CHECK();
+    return ROBO_OK;
+}
+
 }  // namespace robo
 
 struct robo_comm {

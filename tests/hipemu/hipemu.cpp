@@ -4,6 +4,8 @@
 #include <sys/mman.h>
 
 #include <chrono>
+#include <cstdlib>
+#include <mutex>
 #include <vector>
 
 // ---------------------------------------------------------------------------------------
@@ -184,7 +186,12 @@ static void init_fiber(Fiber& f) {
     f.state = READY;
 }
 
+// One interpreter for every emulated device and host thread: launches are serialised (the library's multi-device entry
+// points launch from one worker thread per device, multi.hip).
+static std::mutex g_launch_mu;
+
 void launch(std::function<void()> body, dim3 grid, dim3 block, size_t shmem) {
+    std::lock_guard<std::mutex> lock(g_launch_mu);
     if (g_cur) { std::fprintf(stderr, "hipemu: nested launch\n"); std::abort(); }
     size_t nt = (size_t)block.x * block.y * block.z;
     if (nt == 0 || nt > 1024) { std::fprintf(stderr, "hipemu: bad block size %zu\n", nt); std::abort(); }
@@ -261,10 +268,23 @@ hipError_t hipStreamDestroy(hipStream_t s) { delete s; return hipSuccess; }
 hipError_t hipStreamSynchronize(hipStream_t) { return hipSuccess; }
 hipError_t hipStreamWaitEvent(hipStream_t, hipEvent_t, unsigned) { return hipSuccess; }
 hipError_t hipDeviceSynchronize() { return hipSuccess; }
-hipError_t hipSetDevice(int) { return hipSuccess; }
-hipError_t hipGetDevice(int* d) { *d = 0; return hipSuccess; }
-hipError_t hipGetDeviceCount(int* n) { *n = 1; return hipSuccess; }
-hipError_t hipGetDeviceProperties(hipDeviceProp_t* p, int) {
+// HIPEMU_DEVICES=G: G emulated devices sharing the host's memory (tests of the single-process multi-device entry points)
+static int emu_device_count() {
+    const char* e = std::getenv("HIPEMU_DEVICES");
+    const int n = e ? std::atoi(e) : 1;
+    return n < 1 ? 1 : n;
+}
+static thread_local int t_device = 0;
+hipError_t hipSetDevice(int d) {
+    if (d < 0 || d >= emu_device_count()) return hipErrorInvalidDevice;
+    t_device = d;
+    return hipSuccess;
+}
+hipError_t hipGetDevice(int* d) { *d = t_device; return hipSuccess; }
+hipError_t hipGetDeviceCount(int* n) { *n = emu_device_count(); return hipSuccess; }
+hipError_t hipMemcpyPeerAsync(void* d, int, const void* s, int, size_t n, hipStream_t) { std::memmove(d, s, n); return hipSuccess; }
+hipError_t hipGetDeviceProperties(hipDeviceProp_t* p, int d) {
+    if (d < 0 || d >= emu_device_count()) return hipErrorInvalidDevice;
     std::memset(p, 0, sizeof(*p));
     std::snprintf(p->name, sizeof(p->name), "hipemu (CPU lockstep interpreter, test only)");
     std::snprintf(p->gcnArchName, sizeof(p->gcnArchName), "hipemu");

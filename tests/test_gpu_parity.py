@@ -492,3 +492,17 @@ def test_host_array_handle_reuse(ctx):
 def test_device_resident_chain(ctx):
     P.check_device_chain(ctx)
     P.check_device_chain(ctx, cases=(("matern52", 300, 16, 36, 20),))
+
+
+# ---- single-process multi-device entry points (multi.hip): two contexts on the one MI355X of the test box --------------
+@pytest.mark.gpu
+def test_multi_device_candidate_and_sample_shards(ctx):
+    """robo_acq_eval_cand_multi / robo_acq_eval_marginal_cand_multi / robo_gp_predict_mixture_cand_multi /
+    robo_ig_eval_per_cost_cand_multi with worker threads, peer copies and the ordered-sum kernel on real hardware
+    (both contexts on device 0; more devices than one cannot be tested on this box): the single-device results"""
+    import multi_checks as MC
+    MC.check_candidate_shard([0, 0], sizes=((900, 6, 4001), (300, 3, 1)))
+    MC.check_sample_shard([0, 0], N=700, D=5, M=3000, S=7)
+    MC.check_per_cost_shard([0, 0], N=500, D=5, M=2000, Nb=30, Np=100)
+    MC.check_fits_and_mixture([0, 0], N=1500, D=6, S=9)
+    MC.check_failing_device([0, 0])
