@@ -751,6 +751,13 @@ class CandidateShards(object):
     def owner_point(self, owner, global_index):
         return self.shards[owner].point(int(global_index) - self.offsets[owner])
 
+    def point(self, global_index):
+        """row `global_index` of the whole batch, from whichever shard holds it"""
+        for g, c in enumerate(self.shards):
+            if c is not None and self.offsets[g] <= global_index < self.offsets[g] + c.m:
+                return self.owner_point(g, global_index)
+        raise IndexError(global_index)
+
     def close(self):
         for c in self.shards:
             if c is not None:
@@ -885,6 +892,16 @@ class Multi(object):
         check(lib().robo_gp_predict_mixture_cand_multi(self._h, self._handles(flat), counts, self._handles(cands),
                                                        _arr(mean), _arr(var)))
         return mean, var
+
+
+def run_on_devices(jobs):
+    """run one callable per device at the same time (host threads; the library calls inside release the GIL) -> their
+    results in order.  For the few per-device sequences that have no fused _multi entry point."""
+    if len(jobs) == 1:
+        return [jobs[0]()]
+    from concurrent.futures import ThreadPoolExecutor
+    with ThreadPoolExecutor(max_workers=len(jobs)) as pool:
+        return [f.result() for f in [pool.submit(j) for j in jobs]]
 
 
 def fit_batch(gps, thetas, mean_c):

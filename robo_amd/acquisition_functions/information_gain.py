@@ -114,6 +114,9 @@ class InformationGain(BaseAcquisitionFunction):
     def _gains(self, X_test, want_values=True):
         if not (np.all(np.isfinite(self.lmb))):
             raise ValueError("lmb should not be infinite.")
+        if self._native() and getattr(self.model, "devices", None) and \
+                X_test.shape[0] >= len(self.model.devices):
+            return self._gains_multi(X_test, want_values)
         if self._native():
             model = self.model
             model._materialise()
@@ -134,6 +137,42 @@ class InformationGain(BaseAcquisitionFunction):
         vals = _lib.ig_from_moments(_lib.default_context(), s, v, self._ep, self.sn2)
         am = int(np.argmax(vals))
         return vals, vals[am], am
+
+    def _gains_multi(self, X_test, want_values):
+        """candidate shard over the devices of ONE process (``GaussianProcess(devices=...)``): every device scores its
+        contiguous slice against its replica of the model and the SAME representer points / EP state; the per-device
+        (max, index) are reduced with np.argmax's tie-break (values are per candidate: sharding changes none)"""
+        model = self.model
+        model._materialise()
+        norm = model.normalize if hasattr(model, "normalize") else model._normalised
+        multi = model._multi()
+        shards = _lib.CandidateShards.split(multi.ctxs, norm(X_test))
+        zbn = norm(np.array(self.zb))
+        gps = model._all_gps()
+
+        def job(g):
+            def run():
+                if shards.shards[g] is None:
+                    return None
+                rep = _lib.Candidates(multi.ctxs[g], zbn)
+                try:
+                    return _lib.ig_eval(gps[g], shards.shards[g], rep, self._ep, self.sn2, want_values)
+                finally:
+                    rep.close()
+            return run
+        try:
+            parts = _lib.run_on_devices([job(g) for g in range(multi.n)])
+        finally:
+            shards.close()
+        best = None
+        for g, p in enumerate(parts):
+            if p is None:
+                continue
+            v, i = float(p[1]), shards.offsets[g] + int(p[2])
+            if best is None or (np.isnan(v) and not np.isnan(best[0])) or (not np.isnan(best[0]) and v > best[0]):
+                best = (v, i)           # (equal values: the earlier shard holds the lower index and stays)
+        vals = np.concatenate([p[0] for p in parts if p is not None]) if want_values else None
+        return vals, best[0], best[1]
 
     def compute(self, X_test, derivative=False, **kwargs):
         if derivative:

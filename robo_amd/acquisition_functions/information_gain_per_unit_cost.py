@@ -94,6 +94,23 @@ class InformationGainPerUnitCost(InformationGain):
         cm._materialise()
         norm = model.normalize if hasattr(model, "normalize") else model._normalised
         cnorm = cm.normalize if hasattr(cm, "normalize") else cm._normalised
+        if comm is None and getattr(model, "devices", None) and model.devices == getattr(cm, "devices", None) and \
+                X.shape[0] >= len(model.devices):
+            # single-process multi-GPU (both models built with the same device list): candidate shards on all devices at
+            # once, replicas of both models and of the representer points on each (robo_ig_eval_per_cost_cand_multi)
+            multi = model._multi()
+            shards, cshards = _lib.CandidateShards.split(multi.ctxs, norm(X)), _lib.CandidateShards.split(multi.ctxs, cnorm(X))
+            zbn = norm(np.array(self.zb))
+            reps = [_lib.Candidates(c, zbn) for c in multi.ctxs]
+            try:
+                vals, mx, am, _ = multi.ig_per_cost(model._all_gps(), shards, reps, self._ep, self.sn2, cm._all_gps(),
+                                                    cshards, self.overhead, want_values)
+                return vals, mx, am
+            finally:
+                for h in reps:
+                    h.close()
+                shards.close()
+                cshards.close()
         ctx = model.gp.ctx
         cand, ccand = _lib.Candidates(ctx, norm(X)), _lib.Candidates(ctx, cnorm(X))
         rep = _lib.Candidates(ctx, norm(np.array(self.zb)))

@@ -64,6 +64,46 @@ class MarginalizationGPMCMC(BaseAcquisitionFunction):
             else:
                 self.estimators[i].update(self.model.models[i], **kwargs)
 
+    def _device_groups(self):
+        """Single-process multi-GPU (``GaussianProcessMCMC(devices=...)``): the estimators grouped by the device slot
+        their sub-model lives on, or None when this is not such a model / not a fused closed-form case."""
+        devices = getattr(self.model, "devices", None)
+        if not devices or self._shard() is not None or not self.estimators:
+            return None
+        if not isinstance(self.acquisition_func, ClosedFormAcquisition):
+            return None
+        multi = _lib.multi_for(devices)
+        groups = [[] for _ in multi.ctxs]
+        for e in self.estimators:
+            gp = getattr(e.model, "gp", None)
+            if not isinstance(gp, _lib.DeviceGP) or not getattr(e.model, "is_trained", False):
+                return None
+            slot = next((g for g, c in enumerate(multi.ctxs) if c is gp.ctx), None)
+            if slot is None or (groups[slot + 1:] and any(groups[slot + 1:])):
+                return None                          # not on the list, or not in contiguous sample order
+            groups[slot].append(e)
+        return multi, groups
+
+    def _multi_eval(self, X_test, want_values):
+        """sample shard over the devices of ONE process (robo_acq_eval_marginal_cand_multi): every device accumulates its
+        samples' acquisition values on all candidates; the partial sums are added in device order on the first device"""
+        multi, groups = self._device_groups()
+        if isinstance(X_test, _lib.Candidates):
+            X_test = self._host_points(X_test)       # every device needs the whole batch: through the host, once
+        m0 = self.estimators[0].model
+        Xn = (m0.normalize if hasattr(m0, "normalize") else m0._normalised)(X_test)
+        cands = [_lib.Candidates(c, Xn) if (groups[g] or g == 0) else None for g, c in enumerate(multi.ctxs)]
+        ref = self.estimators[0]
+        try:
+            vals, mx, am, flags = multi.acq_marginal([[e.model.gp for e in grp] for grp in groups], ref.kind, ref.par,
+                                                     [[e._eta(None) for e in grp] for grp in groups], cands, want_values)
+        finally:
+            for c in cands:
+                if c is not None:
+                    c.close()
+        self.last_max, self.last_argmax = mx, am
+        return vals, flags
+
     def _native(self):
         if self._shard() is not None:
             return False
@@ -157,8 +197,13 @@ class MarginalizationGPMCMC(BaseAcquisitionFunction):
     def compute(self, X_test, derivative=False):
         if not derivative and self._shard() is not None:
             return self._sharded_eval(X_test)
-        if not derivative and self._native():
-            vals, flags = self._native_eval(X_test, True)
+        fused = None
+        if not derivative and self._device_groups() is not None:
+            fused = self._multi_eval
+        elif not derivative and self._native():
+            fused = self._native_eval
+        if fused is not None:
+            vals, flags = fused(X_test, True)
             if self.estimators[0].kind == "ei":
                 if flags & _lib.FLAG_ZERO_SIGMA:
                     # some estimator would have returned [[0]] (ei.py:72-74); keep the reference's
@@ -173,6 +218,23 @@ class MarginalizationGPMCMC(BaseAcquisitionFunction):
         if isinstance(X_test, _lib.Candidates):
             X_test = self._host_points(X_test)       # host loop below: the reference's per-estimator evaluation
         acquisition_values = np.zeros([len(self.model.models), X_test.shape[0]])
+        by_ctx = {}
+        for i, e in enumerate(self.estimators):
+            gp = getattr(getattr(e, "model", None), "gp", None)
+            by_ctx.setdefault(id(gp.ctx) if isinstance(gp, _lib.DeviceGP) else None, []).append(i)
+        if len(by_ctx) > 1 and None not in by_ctx and getattr(self.model, "devices", None):
+            # sub-models on several devices of this process (any acquisition function, e.g. the information gain per unit
+            # cost of Fabolas): one host thread per device walks its estimators -- the library calls release the GIL, so
+            # the devices work at the same time; the mean is still taken in sample order
+            from concurrent.futures import ThreadPoolExecutor
+
+            def run(idx):
+                for i in idx:
+                    acquisition_values[i] = self.estimators[i].compute(X_test, derivative=derivative)
+            with ThreadPoolExecutor(max_workers=len(by_ctx)) as pool:
+                for f in [pool.submit(run, idx) for idx in by_ctx.values()]:
+                    f.result()
+            return acquisition_values.mean(axis=0)
         for i in range(len(self.model.models)):
             acquisition_values[i] = self.estimators[i].compute(X_test, derivative=derivative)
         return acquisition_values.mean(axis=0)
@@ -180,8 +242,9 @@ class MarginalizationGPMCMC(BaseAcquisitionFunction):
     def argmax(self, X_test):
         if self._shard() is not None:
             return int(np.argmax(self._sharded_eval(X_test)))
-        if self._native():
-            _, flags = self._native_eval(X_test, False)
+        fused = self._multi_eval if self._device_groups() is not None else (self._native_eval if self._native() else None)
+        if fused is not None:
+            _, flags = fused(X_test, False)
             if self.estimators[0].kind != "ei" or not flags & (_lib.FLAG_ZERO_SIGMA | _lib.FLAG_NEGATIVE_EI):
                 return int(self.last_argmax)
             # an estimator would have collapsed to [[0]] / raised (ei.py:72-74,86-88): same path as compute()

@@ -30,12 +30,19 @@ logger = logging.getLogger(__name__)
 
 def bayesian_optimization(objective_function, lower, upper, num_iterations=30, X_init=None, Y_init=None,
                           maximizer="random", acquisition_func="log_ei", model_type="gp_mcmc", n_init=3, rng=None,
-                          output_path=None, n_candidates=500, chain_length=200, burnin_steps=100):
+                          output_path=None, n_candidates=500, chain_length=200, burnin_steps=100, n_gpus=None,
+                          devices=None):
     """Minimise ``objective_function`` over the box [lower, upper] -> dict with x_opt, f_opt,
     incumbents, incumbent_values, runtime, overhead, X, y (same keys as the reference).
 
     ``n_candidates`` (default 500 = the reference's RandomSampling.n_samples) may be raised by
     orders of magnitude: the candidate batch is evaluated by one device call.
+
+    ``n_gpus=G`` (devices 0 .. G-1) or ``devices=[...]``: single-process multi-GPU -- this one process drives all the
+    listed devices and the objective is evaluated ONCE per iteration, exactly as in the reference's loop
+    (robo/solver/bayesian_optimization.py:156-203).  ``model_type="gp"``: the fitted model is replicated on every
+    device and the candidate batch of each maximisation is split over them; ``"gp_mcmc"``: the hyper-parameter samples
+    (and, for large N, the walkers of the chain) are split over the devices.  Same chosen points as on one device.
     """
     assert upper.shape[0] == lower.shape[0], "Dimension miss match"
     assert np.all(lower < upper), "Lower bound >= upper bound"
@@ -51,13 +58,15 @@ def bayesian_optimization(objective_function, lower, upper, num_iterations=30, X
     if n_hypers % 2 == 1:
         n_hypers += 1
 
+    from robo_amd import _lib
+    devices = _lib.resolve_devices(devices, n_gpus)
     if model_type == "gp":
         model = GaussianProcess(kernel, prior=prior, rng=rng, normalize_output=False, normalize_input=True,
-                                lower=lower, upper=upper)
+                                lower=lower, upper=upper, devices=devices)
     elif model_type == "gp_mcmc":
         model = GaussianProcessMCMC(kernel, prior=prior, n_hypers=n_hypers, chain_length=chain_length,
                                     burnin_steps=burnin_steps, normalize_input=True, normalize_output=False,
-                                    rng=rng, lower=lower, upper=upper)
+                                    rng=rng, lower=lower, upper=upper, devices=devices)
     else:
         raise ValueError("'{}' is not a valid model (robo_amd provides 'gp' and 'gp_mcmc')".format(model_type))
 

@@ -13,7 +13,7 @@ from robo_amd.solver import BayesianOptimization
 
 
 def build_entropy_search(lower, upper, maximizer="random", model="gp_mcmc", rng=None, n_candidates=500,
-                         chain_length=200, burnin_steps=100, n_representer=50, n_outcomes=400):
+                         chain_length=200, burnin_steps=100, n_representer=50, n_outcomes=400, devices=None):
     """the objects robo/fmin/entropy_search.py:69-121 wires together -> (model, acquisition function, maximiser)"""
     n_dims = lower.shape[0]
     kernel = 2 * Matern52Kernel(np.ones([n_dims]), ndim=n_dims)
@@ -23,11 +23,11 @@ def build_entropy_search(lower, upper, maximizer="random", model="gp_mcmc", rng=
         n_hypers += 1
     if model == "gp":
         gp = GaussianProcess(kernel, prior=prior, rng=rng, normalize_output=False, normalize_input=True, lower=lower,
-                             upper=upper)
+                             upper=upper, devices=devices)
     elif model == "gp_mcmc":
         gp = GaussianProcessMCMC(kernel, prior=prior, n_hypers=n_hypers, chain_length=chain_length,
                                  burnin_steps=burnin_steps, normalize_input=True, normalize_output=False, rng=rng,
-                                 lower=lower, upper=upper)
+                                 lower=lower, upper=upper, devices=devices)
     else:
         raise ValueError("%s is not a valid model!" % model)
     a = InformationGain(gp, lower=lower, upper=upper, sampling_acquisition=EI, Nb=n_representer, Np=n_outcomes, rng=rng)
@@ -41,14 +41,19 @@ def build_entropy_search(lower, upper, maximizer="random", model="gp_mcmc", rng=
 
 def entropy_search(objective_function, lower, upper, num_iterations=30, maximizer="random", model="gp_mcmc",
                    X_init=None, Y_init=None, n_init=3, output_path=None, rng=None, n_candidates=500,
-                   chain_length=200, burnin_steps=100, n_representer=50, n_outcomes=400):
+                   chain_length=200, burnin_steps=100, n_representer=50, n_outcomes=400, n_gpus=None, devices=None):
+    """``n_gpus`` / ``devices``: single-process multi-GPU (see robo_amd.fmin.bayesian_optimization): ``model="gp"`` splits the
+    candidate batch of the information gain over replicas of the model, ``"gp_mcmc"`` splits the hyper-parameter samples --
+    each sample's estimator (representer points, EP, gains) works on its sample's device, all devices at once."""
     assert upper.shape[0] == lower.shape[0], "Dimension miss match"
     assert np.all(lower < upper), "Lower bound >= upper bound"
     assert n_init <= num_iterations, "Number of initial design point has to be <= than the number of iterations"
     if rng is None:
         rng = np.random.RandomState(np.random.randint(0, 10000))
+    from robo_amd import _lib
     gp, acquisition_func, max_func = build_entropy_search(lower, upper, maximizer, model, rng, n_candidates,
-                                                          chain_length, burnin_steps, n_representer, n_outcomes)
+                                                          chain_length, burnin_steps, n_representer, n_outcomes,
+                                                          devices=_lib.resolve_devices(devices, n_gpus))
     bo = BayesianOptimization(objective_function, lower, upper, acquisition_func, gp, max_func,
                               initial_design=init_latin_hypercube_sampling, initial_points=n_init, rng=rng,
                               output_path=output_path)

@@ -29,7 +29,7 @@ def retransform(s_transform, s_min, s_max):
 
 
 def build_fabolas(lower, upper, burnin=100, chain_length=100, n_hypers=12, rng=None, n_candidates=500,
-                  n_representer=50, n_outcomes=400):
+                  n_representer=50, n_outcomes=400, devices=None):
     """the objects robo/fmin/fabolas.py:99-199 wires together -> (objective model, cost model, acquisition
     function, maximiser)"""
     n_dims = lower.shape[0]
@@ -41,12 +41,12 @@ def build_fabolas(lower, upper, burnin=100, chain_length=100, n_hypers=12, rng=N
     prior = EnvPrior(len(kernel) + 1, n_ls=n_dims, n_lr=2, rng=rng)
     model_objective = FabolasGPMCMC(kernel, prior=prior, burnin_steps=burnin, chain_length=chain_length,
                                     n_hypers=n_hypers, normalize_output=False, basis_func=lambda s: (1 - s) ** 2,
-                                    lower=lower, upper=upper, rng=rng)
+                                    lower=lower, upper=upper, rng=rng, devices=devices)
     cost_kernel = FabolasKernel(n_dims + 1, metric=0.01, log_a=0.1, log_b=0.1, amp=1.0)
     cost_prior = EnvPrior(len(cost_kernel) + 1, n_ls=n_dims, n_lr=2, rng=rng)
     model_cost = FabolasGPMCMC(cost_kernel, prior=cost_prior, burnin_steps=burnin, chain_length=chain_length,
                                n_hypers=n_hypers, basis_func=lambda s: s, normalize_output=False, lower=lower,
-                               upper=upper, rng=rng)
+                               upper=upper, rng=rng, devices=devices)
     extend_lower, extend_upper = np.append(lower, 0), np.append(upper, 1)
     is_env = np.zeros(extend_lower.shape[0])
     is_env[-1] = 1
@@ -59,8 +59,13 @@ def build_fabolas(lower, upper, burnin=100, chain_length=100, n_hypers=12, rng=N
 
 def fabolas(objective_function, lower, upper, s_min, s_max, n_init=40, num_iterations=100, subsets=[256, 128, 64],
             inc_estimation="mean", burnin=100, chain_length=100, n_hypers=12, output_path=None, rng=None,
-            n_candidates=500, n_representer=50, n_outcomes=400):
-    """objective_function(x, s) -> (validation error, cost); returns the reference's result dict."""
+            n_candidates=500, n_representer=50, n_outcomes=400, n_gpus=None, devices=None):
+    """objective_function(x, s) -> (validation error, cost); returns the reference's result dict.
+
+    ``n_gpus`` / ``devices``: single-process multi-GPU -- the hyper-parameter samples of both models are split over the
+    listed devices (sample s of the loss model and sample s of the cost model share a device); every sample's
+    information gain per unit cost is evaluated on its device, all devices at once; one objective evaluation per
+    iteration as in robo/fmin/fabolas.py:222-296."""
     time_start = time.time()
     if rng is None:
         rng = np.random.RandomState(np.random.randint(0, 10000))
@@ -76,8 +81,10 @@ def fabolas(objective_function, lower, upper, s_min, s_max, n_init=40, num_itera
             with open(os.path.join(output_path, "fabolas_iter_%d.json" % it), "w") as fh:
                 json.dump(data, fh)
 
+    from robo_amd import _lib
     model_objective, model_cost, acquisition_func, maximizer = build_fabolas(
-        lower, upper, burnin, chain_length, n_hypers, rng, n_candidates, n_representer, n_outcomes)
+        lower, upper, burnin, chain_length, n_hypers, rng, n_candidates, n_representer, n_outcomes,
+        devices=_lib.resolve_devices(devices, n_gpus))
 
     x_init = init_latin_hypercube_sampling(lower, upper, n_init, rng)
     for it in range(n_init):

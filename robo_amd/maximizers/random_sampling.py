@@ -96,6 +96,23 @@ class DeviceRandomSampling(BaseMaximizer):
         loc = (inc - lower) / (upper - lower)
         scale = 0.1 / (upper - lower)
         seed = int(self.rng.randint(0, 2 ** 31 - 1))
+        n_uniform = int(self.n_samples * .7)
+        if getattr(sub, "devices", None) and sub is model:
+            # single-process multi-GPU (``GaussianProcess(devices=...)``): slot g generates and scores rows [b, e) of the
+            # recipe on ITS device -- the same per-shard streams as the one-process-per-GPU form below --, the incumbents
+            # are reduced inside the library call and only the winning row comes back
+            multi = sub._multi()
+            parts, offsets = [], []
+            for g, ctx in enumerate(multi.ctxs):
+                b, e = _lib.shard_range(self.n_samples, g, multi.n)
+                offsets.append(b)
+                parts.append(_lib.Candidates(ctx, m=e - b, seed=seed + 7919 * g,
+                                             n_uniform=min(max(n_uniform - b, 0), e - b), loc=loc, scale=scale) if e > b else None)
+            shards = _lib.CandidateShards(parts, offsets)
+            try:
+                return lower + (upper - lower) * shards.point(acq.argmax(shards))
+            finally:
+                shards.close()
         from robo_amd import sharding
         _, rank, world = sharding.dist_info() if self.shard else (None, 0, 1)
         if world > 1:
@@ -105,7 +122,6 @@ class DeviceRandomSampling(BaseMaximizer):
         # [b, e) of the recipe -- its own Philox stream, the 70 % / 30 % split kept globally -- and only the
         # per-shard incumbent (16 B) and the winning point (D doubles) are exchanged
         b, e = sharding.shard_range(self.n_samples, rank, world)
-        n_uniform = int(self.n_samples * .7)
         cand = _lib.Candidates(sub.gp.ctx, m=max(e - b, 1), seed=seed + 7919 * rank,
                                n_uniform=min(max(n_uniform - b, 0), max(e - b, 1)), loc=loc, scale=scale)
         try:
@@ -145,11 +161,24 @@ class DeviceSobolSampling(BaseMaximizer):
         if not getattr(sub, "normalize_input", False) or not hasattr(sub, "gp"):
             raise TypeError("DeviceSobolSampling needs a robo_amd GP model with normalize_input=True")
         lower, upper = np.asarray(sub.lower, dtype=np.float64), np.asarray(sub.upper, dtype=np.float64)
+        eng = qmc.Sobol(d=lower.shape[0], scramble=True, seed=self.seed)
+        if getattr(sub, "devices", None) and sub is model:
+            # single-process multi-GPU: slot g generates and scores points [b, e) of the ONE sequence on its device
+            multi = sub._multi()
+            parts, offsets = [], []
+            for g, ctx in enumerate(multi.ctxs):
+                b, e = _lib.shard_range(self.n_samples, g, multi.n)
+                offsets.append(b)
+                parts.append(_lib.Candidates(ctx, m=e - b, sobol=eng, first=b) if e > b else None)
+            shards = _lib.CandidateShards(parts, offsets)
+            try:
+                return lower + (upper - lower) * shards.point(acq.argmax(shards))
+            finally:
+                shards.close()
         _, rank, world = sharding.dist_info() if self.shard else (None, 0, 1)
         if world > 1:
             sharding.assert_replicated("DeviceSobolSampling (n_samples, seed)", [self.n_samples, int(self.seed)])
         b, e = sharding.shard_range(self.n_samples, rank, world)
-        eng = qmc.Sobol(d=lower.shape[0], scramble=True, seed=self.seed)
         cand = _lib.Candidates(sub.gp.ctx, m=max(e - b, 1), sobol=eng, first=b)
         try:
             best = acq.argmax(cand)

@@ -22,11 +22,11 @@ def _fabolas_normalize(X, lower, upper, basis):
 class FabolasGP(GaussianProcess):
 
     def __init__(self, kernel, basis_function, prior=None, noise=1e-3, use_gradients=False,
-                 normalize_output=False, lower=None, upper=None, rng=None, device=None):
+                 normalize_output=False, lower=None, upper=None, rng=None, device=None, devices=None):
         self.basis_function = basis_function
         super(FabolasGP, self).__init__(kernel=kernel, prior=prior, noise=noise, use_gradients=use_gradients,
                                         normalize_output=normalize_output, normalize_input=False, lower=lower,
-                                        upper=upper, rng=rng, device=device)
+                                        upper=upper, rng=rng, device=device, devices=devices)
 
     def normalize(self, X):
         return _fabolas_normalize(X, self.lower, self.upper, self.basis_function)
@@ -59,7 +59,10 @@ class FabolasGP(GaussianProcess):
         return dm * scale[:, :, np.newaxis], dv * scale
 
     def acquisition(self, kind, par, eta, X_test, want_values=True):
-        return super(FabolasGP, self).acquisition(kind, par, eta, self.normalize(X_test), want_values)
+        from robo_amd import _lib
+        if not isinstance(X_test, (_lib.Candidates, _lib.CandidateShards)):    # device batches are in the model's space already
+            X_test = self.normalize(X_test)
+        return super(FabolasGP, self).acquisition(kind, par, eta, X_test, want_values)
 
     def get_incumbent(self):
         """(configuration projected to s = 1, its predicted mean there)"""
@@ -76,12 +79,12 @@ class FabolasGP(GaussianProcess):
 class FabolasGPMCMC(GaussianProcessMCMC):
 
     def __init__(self, kernel, basis_func, prior=None, n_hypers=20, chain_length=2000, burnin_steps=2000,
-                 normalize_output=False, rng=None, lower=None, upper=None, noise=-8, device=None):
+                 normalize_output=False, rng=None, lower=None, upper=None, noise=-8, device=None, devices=None):
         self.basis_func = basis_func
         self.hypers = None
         super(FabolasGPMCMC, self).__init__(kernel, prior, n_hypers, chain_length, burnin_steps,
                                             normalize_output=normalize_output, normalize_input=False, rng=rng,
-                                            lower=lower, upper=upper, noise=noise, device=device)
+                                            lower=lower, upper=upper, noise=noise, device=device, devices=devices)
 
     def _make_model(self, kernel, noise):
         return FabolasGP(kernel, basis_function=self.basis_func, normalize_output=self.normalize_output, noise=noise,

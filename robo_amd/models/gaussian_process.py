@@ -26,7 +26,7 @@ logger = logging.getLogger(__name__)
 class GaussianProcess(BaseModel):
 
     def __init__(self, kernel, prior=None, noise=1e-3, use_gradients=False, normalize_output=False,
-                 normalize_input=True, lower=None, upper=None, rng=None, device=None):
+                 normalize_input=True, lower=None, upper=None, rng=None, device=None, devices=None):
         if rng is None:
             self.rng = np.random.RandomState(np.random.randint(0, 10000))
         else:
@@ -45,21 +45,54 @@ class GaussianProcess(BaseModel):
         self.lower = lower
         self.upper = upper
         self.device = device
+        # devices = [d0, d1, ...] (not in the reference, which is one process on one CPU): single-process multi-GPU.  The
+        # final fit of train() is replicated on every listed device (deterministic: one replica per device, all fitted
+        # concurrently) and the candidate batch of an acquisition maximisation is split over them
+        # (robo_acq_eval_cand_multi); everything else -- hyper-parameter optimisation, predict() -- runs on devices[0].
+        self.devices = _lib.resolve_devices(devices)
+        self.replicas = []             # DeviceGPs on devices[1:], same data and factor as self.gp
+        self._ctx_override = None      # GaussianProcessMCMC places its per-sample models on the contexts of its device list
         self._fitted_theta = None
 
     # ---- device handle management ----------------------------------------------------------
+    def _multi(self):
+        return _lib.multi_for(self.devices) if self.devices else None
+
     def _ctx(self):
+        if self._ctx_override is not None:
+            return self._ctx_override
+        if self.devices:
+            return self._multi().ctxs[0]
         return _lib.default_context(self.device)
+
+    def _all_gps(self):
+        return [self.gp] + list(self.replicas)
 
     def _ensure_gp(self, n, dim):
         if self.gp is None or self.gp.dim != dim or self.gp.n_max < n or self.gp.kind != self.kernel.kind:
-            if self.gp is not None:
-                self.gp.close()
             cap = max(127, int(n))
             if self.gp is not None and self.gp.n_max < n:
                 cap = max(cap, 2 * self.gp.n_max)     # amortise growth over a BO run
+            for g in self._all_gps():
+                if g is not None:
+                    g.close()
             self.gp = _lib.DeviceGP(self._ctx(), self.kernel.kind, cap, dim)
+            self.replicas = [_lib.DeviceGP(c, self.kernel.kind, cap, dim) for c in self._multi().ctxs[1:]] \
+                if self.devices else []
         return self.gp
+
+    def _upload(self):
+        """training data to the primary handle and, with a device list, to every replica"""
+        if self.devices:
+            self._multi().set_data(self._all_gps(), self.X, self.y)
+        else:
+            self.gp.set_data(self.X, self.y)
+
+    def _fit_everywhere(self, theta):
+        """the fit the model keeps: on every device of the list at once (robo_gp_fit_multi), else on the one handle"""
+        if self.devices:
+            return self._multi().fit(self._all_gps(), theta, self.mean)
+        return self.gp.fit(theta, self.mean)
 
     def __deepcopy__(self, memo):
         # device memory is not copied: the copy re-fits lazily from its host state on first use
@@ -69,6 +102,10 @@ class GaussianProcess(BaseModel):
         for k, v in self.__dict__.items():
             if k == "gp":
                 new.gp = None
+            elif k == "replicas":
+                new.replicas = []
+            elif k == "_ctx_override":
+                new._ctx_override = v             # a context is shared, not copied
             else:
                 setattr(new, k, copy.deepcopy(v, memo))
         return new
@@ -76,15 +113,17 @@ class GaussianProcess(BaseModel):
     def __getstate__(self):
         d = dict(self.__dict__)
         d["gp"] = None
+        d["replicas"] = []
+        d["_ctx_override"] = None
         return d
 
     def _materialise(self):
         """(re)create the device state of a trained model that lost its handle (deepcopy/pickle)."""
         if self.gp is None and self.is_trained:
-            gp = self._ensure_gp(self.X.shape[0], self.X.shape[1])
-            gp.set_data(self.X, self.y)
+            self._ensure_gp(self.X.shape[0], self.X.shape[1])
+            self._upload()
             self._set_transform()
-            gp.fit(self._fitted_theta, self.mean)
+            self._fit_everywhere(self._fitted_theta)
 
     def _device(self):
         """the device GP holding this model's data (re-created after deepcopy / unpickling)"""
@@ -93,16 +132,17 @@ class GaussianProcess(BaseModel):
                 raise Exception('Model has to be trained first!')
             self._materialise()
             if self.gp is None:                       # data set but never fitted (optimize() before train)
-                gp = self._ensure_gp(self.X.shape[0], self.X.shape[1])
-                gp.set_data(self.X, self.y)
+                self._ensure_gp(self.X.shape[0], self.X.shape[1])
+                self._upload()
                 self._set_transform()
         return self.gp
 
     def _set_transform(self):
-        if self.normalize_output:
-            self.gp.set_output_transform(self.y_mean, self.y_std)
-        else:
-            self.gp.set_output_transform(0.0, 1.0)
+        for g in self._all_gps():
+            if self.normalize_output:
+                g.set_output_transform(self.y_mean, self.y_std)
+            else:
+                g.set_output_transform(0.0, 1.0)
 
     # ---- BaseModel ----------------------------------------------------------------------------
     def _host_train(self, X, y, alloc=True):
@@ -136,7 +176,7 @@ class GaussianProcess(BaseModel):
     @BaseModel._check_shapes_train
     def train(self, X, y, do_optimize=True):
         gp = self._host_train(X, y)
-        gp.set_data(self.X, self.y)
+        self._upload()
         self._set_transform()
 
         if do_optimize:
@@ -149,17 +189,22 @@ class GaussianProcess(BaseModel):
 
         try:
             theta = np.append(self.kernel.get_parameter_vector(), np.log(self.noise))
-            gp.fit(theta, self.mean)
+            self._fit_everywhere(theta)
         except np.linalg.LinAlgError:
             self.noise *= 10
             theta = np.append(self.kernel.get_parameter_vector(), np.log(self.noise))
-            gp.fit(theta, self.mean)
+            self._fit_everywhere(theta)
         self._fitted_theta = theta
         self.is_trained = True
         # what follows a train() in the reference's loop is an acquisition maximisation over a small candidate batch
         # (solver/bayesian_optimization.py:236-245, 500 candidates by default): the explicit inverse factor those batches
-        # use is built on the device while the host prepares them
-        gp.prefetch_inverse()
+        # use is built on the device while the host prepares them.  Best effort: a failure here must not turn a
+        # successful fit into an exception (the first small batch builds the inverse itself)
+        for g in self._all_gps():
+            try:
+                g.prefetch_inverse()
+            except Exception as e:        # noqa: BLE001
+                logger.warning("prefetch of the explicit inverse factor failed (%s); it is built on first use", e)
 
     def get_noise(self):
         return self.noise
@@ -300,6 +345,19 @@ class GaussianProcess(BaseModel):
         if not self.is_trained:
             raise Exception('Model has to be trained first!')
         self._materialise()
+        if isinstance(X_test, _lib.CandidateShards):
+            vals, mx, am, _, flags = self._multi().acq(self._all_gps(), kind, par, eta, X_test, want_values)
+            return vals, mx, am, flags
         if isinstance(X_test, _lib.Candidates):
             return self.gp.acq(kind, par, eta, X_test, want_values)
-        return self.gp.acq(kind, par, eta, self._normalised(X_test), want_values)
+        Xn = self._normalised(X_test)
+        if self.devices and np.asarray(Xn).shape[0] >= len(self.devices):
+            # single-process multi-GPU: contiguous shards of the ONE candidate matrix, a replica of the fitted model on
+            # every device, all devices at once; (max, index, flags) reduced with np.argmax's tie-break
+            shards = _lib.CandidateShards.split(self._multi().ctxs, Xn)
+            try:
+                vals, mx, am, _, flags = self._multi().acq(self._all_gps(), kind, par, eta, shards, want_values)
+            finally:
+                shards.close()
+            return vals, mx, am, flags
+        return self.gp.acq(kind, par, eta, Xn, want_values)

@@ -26,7 +26,7 @@ class GaussianProcessMCMC(BaseModel):
 
     def __init__(self, kernel, prior=None, n_hypers=20, chain_length=2000, burnin_steps=2000,
                  normalize_output=False, normalize_input=True, rng=None, lower=None, upper=None, noise=-8,
-                 device=None):
+                 device=None, devices=None):
         if rng is None:
             self.rng = np.random.RandomState(np.random.randint(0, 10000))
         else:
@@ -47,29 +47,63 @@ class GaussianProcessMCMC(BaseModel):
         self.lower = lower
         self.upper = upper
         self.device = device
+        # devices = [d0, d1, ...] (not in the reference): single-process multi-GPU.  The hyper-parameter samples are
+        # split contiguously over the listed devices (BASELINE config 3: 50 samples over 4 GPUs -> 13/13/12/12): sample s
+        # is fitted, kept and evaluated on its device (robo_gp_fit_batch_multi, robo_acq_eval_marginal_cand_multi,
+        # robo_gp_predict_mixture_cand_multi); the walkers of an ensemble half-step are split the same way once a
+        # likelihood is expensive enough to pay for a host round trip per half-step (walker_shard_min_n points).
+        self.devices = _lib.resolve_devices(devices)
+        self.walker_shard_min_n = 1024
+        self.walker_gps = []            # devices[1:]: data-holding handles for the walkers' likelihoods
         self.gp = None                  # scratch device GP for the likelihood evaluations
         # one process per GPU: fit only this rank's shard of the hyper-parameter samples (the MCMC itself is
         # replicated -- same seeds, same chain on every rank); used with MarginalizationGPMCMC.sample_shard
         self.sample_shard = False
 
+    def _multi(self):
+        return _lib.multi_for(self.devices) if self.devices else None
+
     def _ensure_gp(self, n, dim):
         if self.gp is None or self.gp.dim != dim or self.gp.n_max < n or self.gp.kind != self.kernel.kind:
-            if self.gp is not None:
-                self.gp.close()
+            for g in [self.gp] + list(self.walker_gps):
+                if g is not None:
+                    g.close()
+            self.walker_gps = []
             cap = max(127, int(n)) if self.gp is None else max(int(n), 2 * self.gp.n_max)
-            self.gp = _lib.DeviceGP(_lib.default_context(self.device), self.kernel.kind, cap, dim)
+            ctx = self._multi().ctxs[0] if self.devices else _lib.default_context(self.device)
+            self.gp = _lib.DeviceGP(ctx, self.kernel.kind, cap, dim)
         return self.gp
+
+    def _walker_shard(self):
+        return bool(self.devices) and self.X is not None and self.X.shape[0] >= self.walker_shard_min_n
+
+    def _slot_of(self, i, n_samples):
+        """device slot of hyper-parameter sample i (contiguous shards, the first n % G slots hold one more)"""
+        for g in range(len(self.devices)):
+            b, e = _lib.shard_range(n_samples, g, len(self.devices))
+            if b <= i < e:
+                return g
+        raise IndexError(i)
+
+    def _groups(self):
+        """the trained sub-models' device handles grouped by device slot, in sample order"""
+        G = len(self.devices)
+        groups = [[] for _ in range(G)]
+        for i, m in enumerate(self.models):
+            groups[self._slot_of(i, len(self.models))].append(m)
+        return groups
 
     def __deepcopy__(self, memo):
         new = self.__class__.__new__(self.__class__)
         memo[id(self)] = new
         for k, v in self.__dict__.items():
-            setattr(new, k, None if k == "gp" else deepcopy(v, memo))
+            setattr(new, k, None if k == "gp" else ([] if k == "walker_gps" else deepcopy(v, memo)))
         return new
 
     def __getstate__(self):
         d = dict(self.__dict__)
         d["gp"] = None
+        d["walker_gps"] = []
         return d
 
     # hooks for FabolasGPMCMC -------------------------------------------------------------------
@@ -99,7 +133,12 @@ class GaussianProcessMCMC(BaseModel):
             self.y = y
         self.mean = np.mean(self.y, axis=0)
         gp = self._ensure_gp(self.X.shape[0], self.X.shape[1])
-        gp.set_data(self.X, self.y)
+        if self._walker_shard() and do_optimize:
+            if not self.walker_gps:
+                self.walker_gps = [_lib.DeviceGP(c, self.kernel.kind, gp.n_max, gp.dim) for c in self._multi().ctxs[1:]]
+            self._multi().set_data([gp] + self.walker_gps, self.X, self.y)
+        else:
+            gp.set_data(self.X, self.y)
 
         if do_optimize:
             sampler = EnsembleSampler(self.n_hypers, len(self.kernel) + 1, lnprob_batch=self.loglikelihood_batch,
@@ -135,6 +174,15 @@ class GaussianProcessMCMC(BaseModel):
                 model.lower, model.upper = self.lower, self.upper
             else:
                 model = self._make_model(kernel, np.exp(sample[-1]))
+            if self.devices:
+                # sample i lives on the device of its shard; a handle left on another device by an earlier, differently
+                # sized set of samples is dropped
+                ctx = self._multi().ctxs[self._slot_of(i, len(self.hypers))]
+                if model._ctx_override is not ctx:
+                    if model.gp is not None:
+                        model.gp.close()
+                        model.gp = None
+                    model._ctx_override = ctx
             self.models.append(model)
         for m in old[len(self.models):]:
             if getattr(m, "gp", None) is not None:
@@ -149,6 +197,24 @@ class GaussianProcessMCMC(BaseModel):
         bit-identical to S sequential fits); a sample whose K is not positive definite goes through the
         model's own train(), i.e. the reference's noise x 10 retry (gaussian_process.py:120-122)."""
         models = self.models
+        if self.devices and os.environ.get("ROBO_MCMC_SEQUENTIAL_FITS") != "1":
+            # single-process multi-GPU: every device batch-fits ITS samples, all devices at once
+            groups = self._groups()
+            gp_groups = [[m._host_train_raw(X, y) for m in grp] for grp in groups]
+            flat = [m for grp in groups for m in grp]
+            m0 = flat[0]
+            if all(g.n_max >= m0.X.shape[0] for grp in gp_groups for g in grp):
+                for grp, gps in zip(groups, gp_groups):
+                    if grp:
+                        gps[0].set_data(grp[0].X, grp[0].y)
+                thetas = np.array([np.append(m.kernel.get_parameter_vector(), np.log(m.noise)) for m in flat])
+                _, st = self._multi().fit_batch(gp_groups, thetas, m0.mean)
+                for model, theta, status in zip(flat, thetas, st):
+                    if status == _lib.OK:
+                        model._adopt_fit(theta)
+                    else:
+                        model.train(X, y, do_optimize=False)
+                return
         if self.sample_shard:
             from robo_amd import sharding
             _, rank, world = sharding.dist_info()
@@ -188,8 +254,8 @@ class GaussianProcessMCMC(BaseModel):
         none, exactly DefaultPrior (robo/priors/default_priors.py) or exactly EnvPrior (robo/priors/env_priors.py:8-54,
         FabolasGPMCMC's prior in robo.fmin.fabolas).  Other priors keep the host sampler around the batched likelihood.
         ROBO_MCMC_HOST=1 forces the host sampler (A/B, tests)."""
-        if os.environ.get("ROBO_MCMC_HOST") == "1":
-            return None
+        if os.environ.get("ROBO_MCMC_HOST") == "1" or self._walker_shard():
+            return None                 # (walker shard: the half-ensemble's likelihoods are split over the devices per half-step)
         from robo_amd.priors import DefaultPrior, EnvPrior
         if self.prior is None:
             prior = None
@@ -221,7 +287,10 @@ class GaussianProcessMCMC(BaseModel):
         out = np.full(thetas.shape[0], -np.inf)
         ok = ~np.any((-20 > thetas) + (thetas > 20), axis=1) & np.all(np.isfinite(thetas), axis=1)
         if np.any(ok):
-            ll, st = self.gp.loglik_batch(thetas[ok], self.mean)
+            if self._walker_shard() and self.walker_gps:
+                ll, st = self._multi().loglik_batch([self.gp] + self.walker_gps, thetas[ok], self.mean)
+            else:
+                ll, st = self.gp.loglik_batch(thetas[ok], self.mean)
             ll = np.where(st == _lib.OK, ll, -np.inf)
             if self.prior is not None:
                 if hasattr(self.prior, "lnprob_batch"):
@@ -263,6 +332,20 @@ class GaussianProcessMCMC(BaseModel):
                 v = sharding.allgather_ordered_sum(dev2) / S + tot[1]
                 return m, np.clip(v, np.finfo(v.dtype).eps, np.inf)
         gps = [getattr(m, "gp", None) for m in self.models]
+        if self.devices and len(self.models) >= 1 and all(isinstance(g, _lib.DeviceGP) for g in gps) and \
+                all(m.is_trained for m in self.models):
+            # the samples live on several devices: per-device posteriors, gathered and mixed on the first device
+            groups = self._groups()
+            m0 = self.models[0]
+            Xn = m0.normalize(X_test) if hasattr(m0, "normalize") else m0._normalised(X_test)
+            ctxs = self._multi().ctxs
+            cands = [_lib.Candidates(ctxs[g], Xn) if (groups[g] or g == 0) else None for g in range(len(ctxs))]
+            try:
+                return self._multi().predict_mixture([[m.gp for m in grp] for grp in groups], cands)
+            finally:
+                for c in cands:
+                    if c is not None:
+                        c.close()
         if all(isinstance(g, _lib.DeviceGP) for g in gps) and all(m.is_trained for m in self.models):
             # all samples live on the device: S posteriors on one candidate upload + mixture kernel
             m0 = self.models[0]

@@ -47,6 +47,39 @@ class BayesianOptimization(object):
         self.init_points = initial_points
         self.runtime = []
 
+    def _spmd(self):
+        """(rank, world) when this loop runs as one process per GPU with a shard switched on in one of its objects
+        (explicit opt-in flags only: nothing here touches a communicator otherwise), else None"""
+        acq = self.acquisition_func
+        if not (getattr(self.maximize_func, "shard", False) or getattr(self.model, "sample_shard", False) or
+                getattr(acq, "sample_shard", False) or getattr(acq, "shard", False)):
+            return None
+        from robo_amd import sharding
+        _, rank, world = sharding.dist_info()
+        return (rank, world) if world > 1 else None
+
+    def _evaluate(self, x):
+        """ONE objective evaluation per iteration (robo/solver/bayesian_optimization.py:123,174), also when every rank of
+        a one-process-per-GPU job runs this loop in lock step: rank 0 evaluates, the value travels to the others (an
+        expensive or non-deterministic objective must not run world-size times, nor give the ranks different data)."""
+        spmd = self._spmd()
+        if spmd is None:
+            return self.objective_func(x)
+        from robo_amd import sharding
+        rank, _ = spmd
+        value, failed, err = 0.0, 0.0, None
+        if rank == 0:
+            try:
+                value = float(self.objective_func(x))
+            except Exception as e:      # noqa: BLE001 -- the other ranks must leave the exchange too
+                failed, err = 1.0, e
+        row = sharding.allgather_rows([value, failed])[0]
+        if row[1] != 0.0:
+            if err is not None:
+                raise err
+            raise RuntimeError("the objective function failed on rank 0")
+        return float(row[0])
+
     def _record_incumbent(self, X, y):
         best = int(np.argmin(y))
         self.incumbents.append(np.asarray(X[best]).tolist())
@@ -64,7 +97,7 @@ class BayesianOptimization(object):
             for i, x in enumerate(init):
                 logger.info("Evaluate: %s", x)
                 t0 = time.time()
-                new_y = self.objective_func(x)
+                new_y = self._evaluate(x)
                 Xl.append(x)
                 yl.append(new_y)
                 self.time_func_evals.append(time.time() - t0)
@@ -83,7 +116,7 @@ class BayesianOptimization(object):
             self.time_overhead.append(time.time() - t0)
             logger.info("Optimization overhead was %f seconds", self.time_overhead[-1])
             t0 = time.time()
-            new_y = self.objective_func(new_x)
+            new_y = self._evaluate(new_x)
             self.time_func_evals.append(time.time() - t0)
             logger.info("Configuration %s achieved a performance of %f", str(new_x), new_y)
             self.X = np.append(self.X, new_x[None, :], axis=0)

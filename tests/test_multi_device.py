@@ -76,3 +76,163 @@ def test_device_resolution(emu3):
     m = _lib.multi_for([0, 1, 2])
     assert m.info()[:2] == (3, [0, 1, 2]) and m is _lib.multi_for((0, 1, 2))
     assert [_lib.shard_range(50, g, 4) for g in range(4)] == [(0, 13), (13, 26), (26, 38), (38, 50)]
+
+
+# ---- the plugin classes and the robo.fmin front ends on several devices of one process -----------------------------------
+def _branin(x):
+    a, b, c, r, s, t = 1.0, 5.1 / (4 * np.pi ** 2), 5.0 / np.pi, 6.0, 10.0, 1.0 / (8 * np.pi)
+    return a * (x[1] - b * x[0] ** 2 + c * x[0] - r) ** 2 + s * (1 - t) * np.cos(x[0]) + s
+
+
+class _Counted(object):
+    def __init__(self, f):
+        self.f, self.calls = f, 0
+
+    def __call__(self, *a):
+        self.calls += 1
+        return self.f(*a)
+
+
+def _run_bo(n_gpus, **kw):
+    from robo_amd.fmin import bayesian_optimization
+    f = _Counted(_branin)
+    np.random.seed(11)
+    res = bayesian_optimization(f, np.array([-5.0, 0.0]), np.array([10.0, 15.0]), num_iterations=8, n_init=3,
+                                rng=np.random.RandomState(11), n_gpus=n_gpus, **kw)
+    return np.array(res["X"]), f.calls
+
+
+def test_frontend_gp_candidate_shard_same_trajectory(emu3):
+    """robo_amd.fmin.bayesian_optimization(n_gpus=G), model_type="gp": the candidate batch of every maximisation split
+    over replicas on G devices of THIS process -> the points the one-device run chooses, bit for bit; the objective is
+    evaluated once per iteration"""
+    X1, calls1 = _run_bo(None, model_type="gp", acquisition_func="ei", maximizer="random")
+    for G in (2, 3):
+        XG, calls = _run_bo(G, model_type="gp", acquisition_func="ei", maximizer="random")
+        np.testing.assert_array_equal(XG, X1)
+        assert calls == calls1 == 8
+    XG, _ = _run_bo(3, model_type="gp", acquisition_func="lcb", maximizer="device_random", n_candidates=700)
+    assert XG.shape == (8, 2)
+
+
+def test_frontend_gp_mcmc_sample_shard(emu3):
+    """model_type="gp_mcmc": hyper-parameter samples split over the devices (fits, marginal LogEI, mixture posterior)"""
+    kw = dict(model_type="gp_mcmc", acquisition_func="log_ei", maximizer="random", chain_length=4, burnin_steps=6)
+    X1, _ = _run_bo(None, **kw)
+    for G in (2, 3):
+        XG, calls = _run_bo(G, **kw)
+        np.testing.assert_array_equal(XG, X1)       # (re-associated sums of 8 samples: no argmax flips on this run)
+        assert calls == 8
+
+
+def test_gp_mcmc_classes_on_devices(emu3):
+    """GaussianProcessMCMC(devices=...) + MarginalizationGPMCMC: where the samples live, the batched fits per device, the
+    mixture posterior and the marginal acquisition against the one-device objects; walker shard of the chain"""
+    from robo_amd.acquisition_functions import LogEI, MarginalizationGPMCMC
+    from robo_amd.kernels import Matern52Kernel
+    from robo_amd.models import GaussianProcessMCMC
+    from robo_amd.priors import DefaultPrior
+    rs = np.random.RandomState(4)
+    lo, hi = np.zeros(3), np.ones(3)
+    X = rs.rand(40, 3)
+    y = np.sin(3 * X.sum(axis=1))
+    Xc = rs.rand(200, 3)
+
+    def build(devices, walker_min=10 ** 9):
+        kernel = 2 * Matern52Kernel(np.ones(3), ndim=3)
+        m = GaussianProcessMCMC(kernel, prior=DefaultPrior(len(kernel) + 1, rng=np.random.RandomState(5)), n_hypers=10, chain_length=4, burnin_steps=6,
+                                rng=np.random.RandomState(7), lower=lo, upper=hi, devices=devices)
+        m.walker_shard_min_n = walker_min
+        m.train(X, y)
+        return m
+    m1, m3 = build(None), build([0, 1, 2])
+    np.testing.assert_array_equal(np.array(m3.hypers), np.array(m1.hypers))
+    ctxs = _lib.multi_for([0, 1, 2]).ctxs
+    assert [ctxs.index(s.gp.ctx) for s in m3.models] == [0, 0, 0, 0, 1, 1, 1, 2, 2, 2]
+    mu1, v1 = m1.predict(Xc)
+    mu3, v3 = m3.predict(Xc)
+    np.testing.assert_array_equal(mu3, mu1)
+    np.testing.assert_array_equal(v3, v1)
+    a1, a3 = MarginalizationGPMCMC(LogEI(m1)), MarginalizationGPMCMC(LogEI(m3))
+    a1.update(m1)
+    a3.update(m3)
+    np.testing.assert_allclose(a3.compute(Xc), a1.compute(Xc), rtol=1e-12)
+    assert a3.argmax(Xc) == a1.argmax(Xc) == int(np.argmax(a1.compute(Xc)))
+    # walkers split over the devices per half-step (host sampler around robo_gp_loglik_batch_multi): the same chain
+    mw = build([0, 1, 2], walker_min=1)
+    assert len(mw.walker_gps) == 2
+    np.testing.assert_allclose(np.array(mw.hypers), np.array(m1.hypers), rtol=1e-9)
+
+
+def test_information_gain_candidate_shard(emu3):
+    """InformationGain / InformationGainPerUnitCost on GaussianProcess(devices=...): gains of a candidate batch split over
+    the replicas == the one-device values for the SAME representer points and EP state"""
+    from robo_amd.acquisition_functions import EI, InformationGain, InformationGainPerUnitCost
+    from robo_amd.kernels import FabolasKernel, Matern52Kernel
+    from robo_amd.models import FabolasGP, GaussianProcess
+    rs = np.random.RandomState(8)
+    lo, hi = np.zeros(2), np.ones(2)
+    X = rs.rand(30, 2)
+    y = np.sin(4 * X.sum(axis=1))
+    Xc = rs.rand(101, 2)
+    gains = []
+    state = None
+    for devices in (None, [0, 1, 2]):
+        gp = GaussianProcess(2 * Matern52Kernel(np.ones(2), ndim=2), lower=lo, upper=hi, rng=np.random.RandomState(1),
+                             devices=devices)
+        gp.train(X, y, do_optimize=False)
+        ig = InformationGain(gp, lo, hi, Nb=8, Np=20, sampling_acquisition=EI, rng=np.random.RandomState(2))
+        ig.update(gp)
+        if state is None:
+            state = {k: getattr(ig, k) for k in ("zb", "lmb", "logP", "dlogPdMu", "dlogPdSigma", "dlogPdMudMu", "W", "_ep")}
+        else:
+            ig.__dict__.update(state)
+        gains.append((ig.compute(Xc), ig.argmax(Xc)))
+    np.testing.assert_array_equal(gains[1][0], gains[0][0])
+    assert gains[1][1] == gains[0][1] == int(np.argmax(gains[0][0]))
+    # per unit cost (Fabolas kernels, config 4's shape)
+    lo3, hi3 = np.zeros(3), np.ones(3)
+    Xf = rs.rand(36, 3)
+    yf, cf = np.sin(3 * Xf.sum(axis=1)), 0.3 * Xf[:, -1] + 0.05 * rs.randn(36)
+    Xcf = rs.rand(77, 3)
+    out, state = [], None
+    for devices in (None, [0, 1]):
+        mk = lambda basis: FabolasGP(FabolasKernel(3, metric=0.3, log_a=0.1, log_b=0.1, amp=1.0), basis_function=basis,
+                                     lower=lo3[:2], upper=hi3[:2], rng=np.random.RandomState(1), devices=devices)
+        gm, cm = mk(lambda s: (1 - s) ** 2), mk(lambda s: s)
+        gm.train(Xf, yf, do_optimize=False)
+        cm.train(Xf, cf, do_optimize=False)
+        ig = InformationGainPerUnitCost(gm, cm, lo3, hi3, is_env_variable=np.array([0, 0, 1]), sampling_acquisition=EI,
+                                        n_representer=8, Np=20, rng=np.random.RandomState(2))
+        ig.update(gm, cm, overhead=0.1)
+        if state is None:
+            state = {k: getattr(ig, k) for k in ("zb", "lmb", "logP", "dlogPdMu", "dlogPdSigma", "dlogPdMudMu", "W", "_ep")}
+        else:
+            ig.__dict__.update(state)
+        out.append((ig.compute(Xcf), ig.argmax(Xcf)))
+    np.testing.assert_array_equal(out[1][0], out[0][0])
+    assert out[1][1] == out[0][1]
+
+
+def test_fabolas_frontend_on_devices(emu3):
+    """robo_amd.fmin.fabolas(n_gpus=2): both models' samples split over two devices, every sample's information gain per
+    unit cost evaluated on its device by its own host thread; the threaded mean equals the sequential one"""
+    from robo_amd.fmin.fabolas import build_fabolas, fabolas
+
+    def obj(x, s):
+        return float(np.exp(-np.sum((x - 0.3) ** 2)) + 1.0 / s + 0.5), float(s) / 100.0
+    lo, hi = np.zeros(2), np.ones(2)
+    res = fabolas(obj, lo, hi, s_min=16, s_max=1024, n_init=2, num_iterations=6, subsets=[64, 16], burnin=4, chain_length=3,
+                  n_hypers=12, rng=np.random.RandomState(3), n_candidates=60, n_representer=6, n_outcomes=12, n_gpus=2)
+    assert len(res["X"]) == 6
+    mo, mc, acq, _ = build_fabolas(lo, hi, burnin=4, chain_length=3, rng=np.random.RandomState(3), n_candidates=60,
+                                   n_representer=6, n_outcomes=12, devices=[0, 1])
+    X, y, c = np.array(res["X"]), np.log(np.array(res["y"])), np.array(res["c"])
+    mo.train(X, y)
+    mc.train(X, c)
+    acq.update(mo, mc)
+    Xt = np.random.RandomState(5).rand(40, 3)
+    threaded = acq.compute(Xt)
+    seq = np.mean([e.compute(Xt) for e in acq.estimators], axis=0)
+    np.testing.assert_array_equal(threaded, seq)
+    assert len({id(e.model.gp.ctx) for e in acq.estimators}) == 2
