@@ -957,12 +957,9 @@ def run_c3(args, D_, _lib, sharding):
 # ----------------------------------------------------------------------------------------------------
 # config 4: Fabolas kernel, information gain per unit cost, candidate shard
 # ----------------------------------------------------------------------------------------------------
-def run_c4(args, D_, _lib, sharding):
-    from robo_amd.util import epmgp
-    from scipy.stats import norm
-    rank, world = D_.rank, D_.world
-    ctx = _lib.Context(D_.device_ordinal())
-    N, D, Nb, Np = args.n, args.d, 50, 400
+def c4_problem(N, D):
+    """BASELINE config 4's training data: (X with basis (1 - s)^2 on the fidelity column, y, X with the linear basis for
+    the cost model, log cost, theta, mean of y)"""
     rs = np.random.RandomState(3)
     X = np.random.RandomState(0).rand(N, D)
     s = rs.rand(N)
@@ -971,24 +968,38 @@ def run_c4(args, D_, _lib, sharding):
     y = (y - y.mean()) / y.std() + 0.5 * X[:, -1]
     cost = np.log(0.2 + 3.0 * s)
     theta = default_theta(D - 1, extra=2)                          # [amp, D-1 metrics, log_a, log_b, noise]
-    mean_c = float(np.mean(y))
+    Xcost = X.copy()
+    Xcost[:, -1] = s                                               # linear basis for the cost model
+    return X, y, Xcost, cost, theta, float(np.mean(y))
+
+
+def c4_ep_state(_lib, gp, D, Nb=50, Np=400):
+    """representer points on the s = 1 subspace and the EP state of config 4 -> (zb, lmb, EPState, arrays for the CPU port)"""
+    from robo_amd.util import epmgp
+    from scipy.stats import norm
+    zb = np.random.RandomState(4).rand(Nb, D)
+    zb[:, -1] = 0.0
+    lmb = np.random.RandomState(5).randn(Nb)
+    mu_b, cov_b = gp.predict_cov(zb)
+    logP, dMu, dSig, dMM = epmgp.joint_min(mu_b, np.clip(cov_b, np.finfo(float).eps, np.inf), with_derivatives=True)
+    W = norm.ppf(np.linspace(1. / (Np + 1), 1 - 1. / (Np + 1), Np))[np.newaxis, :]
+    return zb, lmb, _lib.EPState(logP, lmb, W, dMu, dSig, dMM), (logP, lmb, dMu, dSig, dMM), W
+
+
+def run_c4(args, D_, _lib, sharding):
+    rank, world = D_.rank, D_.world
+    ctx = _lib.Context(D_.device_ordinal())
+    N, D, Nb, Np = args.n, args.d, 50, 400
+    X, y, Xcost, cost, theta, mean_c = c4_problem(N, D)
     gp, gc = _lib.DeviceGP(ctx, "fabolas", N, D), _lib.DeviceGP(ctx, "fabolas", N, D)
     gp.set_data(X, y)
     gp.fit(theta, mean_c)
-    Xcost = X.copy()
-    Xcost[:, -1] = s                                               # linear basis for the cost model
     gc.set_data(Xcost, cost)
     gc.fit(theta, float(np.mean(cost)))
     Xc, M, offset, M_total = synthetic_candidates(args, D_, sharding)
     Xc_cost = Xc.copy()
     Xc[:, -1] = (1.0 - Xc[:, -1]) ** 2
-    zb = np.random.RandomState(4).rand(Nb, D)
-    zb[:, -1] = 0.0                                                # representers on the s = 1 subspace
-    lmb = np.random.RandomState(5).randn(Nb)
-    mu_b, cov_b = gp.predict_cov(zb)
-    logP, dMu, dSig, dMM = epmgp.joint_min(mu_b, np.clip(cov_b, np.finfo(float).eps, np.inf), with_derivatives=True)
-    W = norm.ppf(np.linspace(1. / (Np + 1), 1 - 1. / (Np + 1), Np))[np.newaxis, :]
-    ep = _lib.EPState(logP, lmb, W, dMu, dSig, dMM)
+    zb, lmb, ep, ep_arrays, W = c4_ep_state(_lib, gp, D, Nb, Np)
     cand, cand_cost, rep = _lib.Candidates(ctx, Xc), _lib.Candidates(ctx, Xc_cost), _lib.Candidates(ctx, zb)
     sn2 = float(np.exp(theta[-1]))
     comm = D_.make_comm(_lib, ctx)
@@ -1029,7 +1040,7 @@ def run_c4(args, D_, _lib, sharding):
             "note": "roofline: the block-row solve of the LAST posterior of a step (the cost model's); at this batch "
                     "size the step is latency-bound, not MFMA-bound (see small_batch_latency_ms of the headline line)"})
     if world == 1 and not args.no_cpu_baseline:
-        cb = cpu_baseline_c4(N, D, theta, X, y, Xcost, cost, Xc, Xc_cost, zb, (logP, lmb, dMu, dSig, dMM), W, sn2)
+        cb = cpu_baseline_c4(N, D, theta, X, y, Xcost, cost, Xc, Xc_cost, zb, ep_arrays, W, sn2)
         # the sampled candidates double as a live check of the device's values against the restated reference loop
         cpu_vals = np.array(cb.pop("_values"))
         dev_vals, _, _ = _lib.ig_eval_per_cost(gp, cand, rep, ep, sn2, gc, cand_cost, 0.0, want_values=True)
@@ -1101,6 +1112,187 @@ def run_c5(args, D_, _lib, sharding):
     return out
 
 
+# ----------------------------------------------------------------------------------------------------
+# --launcher inproc: ONE process drives all the GPUs (robo_amd/csrc/multi.hip) -- the form a robo.fmin caller uses
+# (robo_amd.fmin.*(n_gpus=G)); same workloads, same line shape as the one-process-per-GPU forms above
+# ----------------------------------------------------------------------------------------------------
+def run_inproc(args, _lib):
+    from scipy.stats import qmc
+    devices = [int(d) for d in args.devices.split(",")] if args.devices else list(range(args.gpus))
+    if len(devices) != args.gpus:
+        raise SystemExit("bench.py: --devices names %d devices, --gpus is %d" % (len(devices), args.gpus))
+    ctxs = _lib.contexts_for(devices)
+    multi = _lib.multi_for(devices) if len(devices) > 1 else _lib.Multi(ctxs)
+    G, ctx0 = multi.n, ctxs[0]
+    N, D = args.n, args.d
+    info = multi.info()
+    ranks = {"ranks": list(range(G)), "devices": info[1], "comm_world": G, "launcher": "inproc",
+             "worker_threads": info[2]}
+    exchange = ("none between processes: %d contexts of one process, one worker thread per device inside librobo_hip; "
+                "candidate shards: host reduce of (max, index, flags) per device; sample shards: peer copies to device %d "
+                "+ the rank-ordered sum kernel" % (G, info[1][0]))
+
+    def timed(step, steps, warmup, ev_ctx=ctx0):
+        for _ in range(warmup):
+            step()
+        for c in ctxs:
+            c.synchronize()
+        t0 = time.perf_counter()
+        last, trsm = None, 0.0
+        for _ in range(steps):
+            last = step()
+            trsm += ev_ctx.elapsed_ms(25, 26)
+        for c in ctxs:
+            c.synchronize()
+        return time.perf_counter() - t0, last, trsm / steps
+
+    def shard_sizes(total):
+        return [_lib.shard_range(total, g, G)[1] - _lib.shard_range(total, g, G)[0] for g in range(G)]
+
+    base = {"metric": METRIC, "n_gpus": G, "steps": args.steps, "warmup": args.warmup, "higher_is_better": True,
+            "vs_baseline": None, "data": "synthetic", "device": ctx0.name, "exchange": exchange}
+    base.update(ranks)
+
+    if args.config in ("headline", "c2", "c5"):
+        kind, par, fp32 = ("lcb", 1.0, True) if args.config == "c5" else (args.acq, 0.0, False)
+        X, y, theta, _ = synthetic(N, D, 1, 0)
+        mean_c, eta = float(np.mean(y)), float(y.min())
+        gps = [_lib.DeviceGP(c, "matern52", N, D) for c in ctxs]
+        for g in gps:
+            g.set_precision(fp32)
+        fit_ms = []
+        for _ in range(4):
+            t0 = time.perf_counter()
+            multi.set_data(gps, X, y)
+            multi.fit(gps, theta, mean_c)          # replicated on every device, all devices at once
+            fit_ms.append((time.perf_counter() - t0) * 1e3)
+
+        def shards_for(scaling):
+            total = args.m if scaling == "strong" else args.m * G
+            parts, offs = [], []
+            for g, c in enumerate(ctxs):
+                b, e = _lib.shard_range(total, g, G) if scaling == "strong" else (g * args.m, (g + 1) * args.m)
+                offs.append(b)
+                if args.config == "c5":
+                    n_pad = (N + 1 + 127) // 128 * 128
+                    if "ROBO_WS_BYTES" not in os.environ:
+                        c.set_tuning("ws_bytes", max(12 << 30, min((e - b) * n_pad * 8 + (1 << 20), 160 << 30)))
+                    parts.append(_lib.Candidates(c, m=e - b, sobol=qmc.Sobol(d=D, scramble=True, seed=0), first=b))
+                elif scaling == "strong":
+                    parts.append(_lib.Candidates(c, np.ascontiguousarray(np.random.RandomState(1).rand(total, D)[b:e])))
+                else:
+                    parts.append(_lib.Candidates(c, np.random.RandomState(1 + g).rand(args.m, D)))
+            return _lib.CandidateShards(parts, offs), total
+
+        results = {}
+        for scaling in ([args.scaling] + (["weak" if args.scaling == "strong" else "strong"] if G > 1 else [])):
+            shards, total = shards_for(scaling)
+            for c in ctxs:
+                c.set_phase_events(total // G <= 16384)
+
+            def step(shards=shards):
+                _, mx, am, _, _ = multi.acq(gps, kind, par, eta, shards)
+                return mx, am
+            el, best, trsm_ms = timed(step, args.steps, args.warmup)
+            results[scaling] = {"scaling": scaling, "value": total * args.steps / el, "ms_per_step": el / args.steps * 1e3,
+                                "candidates_total": total, "candidates_per_device": shard_sizes(total), "argmax": list(best),
+                                "trsm_ms": trsm_ms, "solve_kernel": shards.shards[0].solve_kernel(),
+                                "chunk": shards.shards[0].chunk()}
+            shards.close()
+        for c in ctxs:
+            c.set_phase_events(False)
+        main_r = results[args.scaling]
+        M0 = main_r["candidates_per_device"][0]
+        roof = roofline_trsm(ctx0, N, M0, main_r["trsm_ms"], passes=max(1, -(-M0 // max(main_r["chunk"], 1))),
+                             kernel=main_r["solve_kernel"])
+        unit = "LCB evals/s" if args.config == "c5" else "EI evals/s"
+        out = dict(base, value=main_r["value"], unit=unit, ms_per_step=main_r["ms_per_step"], scaling=args.scaling,
+                   dtype="f64 (covariance entries f32)" if fp32 else "f64",
+                   config={"workload": "GP Matern-5/2 ARD N=%d D=%d, %d candidates in total over %d devices of ONE process, %s, "
+                                       "%s" % (N, D, main_r["candidates_total"], G, kind.upper(),
+                                               "fp32 K-build + fp64 Cholesky/solve, scrambled-Sobol candidates"
+                                               if fp32 else "fp64"),
+                           "n_train": N, "dim": D, "candidates_per_gpu": M0, "candidates_total": main_r["candidates_total"],
+                           "acquisition": kind, "parallelism": "candidate-shard x%d, replicated fit, single process" % G},
+                   algorithmic_tflops_whole_step=main_r["value"] * flops_ei(N, D) / 1e12,
+                   gp_fit_ms=float(np.median(fit_ms)), gp_fit_ms_min=float(np.min(fit_ms)),
+                   gp_fit_what="robo_gp_set_data_multi + robo_gp_fit_multi: the same fit on all %d devices at once, incl. H2D" % G,
+                   argmax=main_r["argmax"], roofline=roof)
+        other = [r for k, r in results.items() if k != args.scaling]
+        if other:
+            o = other[0]
+            out["other_scaling"] = {"scaling": o["scaling"], "value": o["value"], "unit": unit, "ms_per_step": o["ms_per_step"],
+                                    "candidates_total": o["candidates_total"], "argmax": o["argmax"]}
+        return out
+
+    if args.config == "c3":
+        S, M = 50, args.m
+        X, y, theta, Xc = synthetic(N, D, M, 0)
+        thetas = theta[None, :] + 0.3 * np.random.RandomState(2).randn(S, theta.size)
+        mean_c, eta = float(np.mean(y)), float(y.min())
+        groups = []
+        for g, c in enumerate(ctxs):
+            b, e = _lib.shard_range(S, g, G)
+            grp = [_lib.DeviceGP(c, "matern52", N, D) for _ in range(b, e)]
+            if grp:
+                grp[0].set_data(X, y)
+            groups.append(grp)
+        cands = [_lib.Candidates(c, Xc) if (groups[g] or g == 0) else None for g, c in enumerate(ctxs)]
+        etas = [np.full(len(grp), eta) for grp in groups]
+        fit_s = []
+
+        def step():
+            t0 = time.perf_counter()
+            _, st = multi.fit_batch(groups, thetas, mean_c)       # every device batch-fits ITS samples, all at once
+            assert np.all(st == _lib.OK)
+            fit_s.append(time.perf_counter() - t0)
+            _, mx, am, _ = multi.acq_marginal(groups, "log_ei", 0.0, etas, cands, want_values=False)
+            return float(mx), int(am)
+        el, best, trsm_ms = timed(step, args.steps, args.warmup)
+        ms = el / args.steps * 1e3
+        return dict(base, value=S * M * args.steps / el, unit="LogEI sample-evals/s", ms_per_step=ms, scaling="strong", dtype="f64",
+                    config={"workload": "BASELINE config 3: 50 hyper-parameter samples, N=%d D=%d, marginal LogEI over %d "
+                                        "candidates; a step = batched fits of every device's samples + their posteriors + peer "
+                                        "copies + ordered sum + argmax, ONE process" % (N, D, M),
+                            "n_train": N, "dim": D, "candidates": M, "samples": S, "acquisition": "log_ei",
+                            "parallelism": "sample-shard x%d (%s), single process" % (G, "/".join(str(len(g)) for g in groups))},
+                    end_to_end_ms=ms, fit_batch_ms=float(np.median(fit_s)) * 1e3,
+                    algorithmic_tflops_whole_step=S * M * flops_ei(N, D) / (ms * 1e-3) / 1e12, argmax=list(best),
+                    roofline=roofline_trsm(ctx0, N, M, trsm_ms, kernel=cands[0].solve_kernel()))
+
+    # config 4: information gain per unit cost, candidate shard
+    X, y, Xcost, cost, theta, mean_c = c4_problem(N, D)
+    gps, gcs = [_lib.DeviceGP(c, "fabolas", N, D) for c in ctxs], [_lib.DeviceGP(c, "fabolas", N, D) for c in ctxs]
+    multi.set_data(gps, X, y)
+    multi.fit(gps, theta, mean_c)
+    multi.set_data(gcs, Xcost, cost)
+    multi.fit(gcs, theta, float(np.mean(cost)))
+    zb, lmb, ep, _, _ = c4_ep_state(_lib, gps[0], D)
+    total = args.m if args.scaling == "strong" else args.m * G
+    Xc_cost = np.random.RandomState(1).rand(total, D)
+    Xc = Xc_cost.copy()
+    Xc[:, -1] = (1.0 - Xc[:, -1]) ** 2
+    shards, cshards = _lib.CandidateShards.split(ctxs, Xc), _lib.CandidateShards.split(ctxs, Xc_cost)
+    reps = [_lib.Candidates(c, zb) for c in ctxs]
+    sn2 = float(np.exp(theta[-1]))
+    for c in ctxs:
+        c.set_phase_events(True)
+
+    def step():
+        _, mx, am, _ = multi.ig_per_cost(gps, shards, reps, ep, sn2, gcs, cshards, 0.0)
+        return float(mx), int(am)
+    el, best, trsm_ms = timed(step, args.steps, args.warmup)
+    ms = el / args.steps * 1e3
+    return dict(base, value=total * args.steps / el, unit="information gains/s", ms_per_step=ms, scaling=args.scaling, dtype="f64",
+                config={"workload": "BASELINE config 4: Fabolas product kernel N=%d D=%d, information gain per unit cost (Nb=50, "
+                                    "Np=400, objective + cost GP), %d candidates over %d devices of ONE process" % (N, D, total, G),
+                        "n_train": N, "dim": D, "candidates_per_gpu": shard_sizes(total)[0], "candidates_total": total,
+                        "acquisition": "information_gain_per_unit_cost",
+                        "parallelism": "candidate-shard x%d, replicated fits, single process" % G},
+                argmax=list(best),
+                roofline=roofline_trsm(ctx0, N, shard_sizes(total)[0], trsm_ms, kernel=cshards.shards[0].solve_kernel()))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -1116,6 +1308,11 @@ def main():
     ap.add_argument("--scaling", default=None, choices=["weak", "strong"],
                     help="weak (default): --m candidates per GPU; strong: --m candidates in TOTAL, split over the ranks "
                          "(SURVEY 8(d)'s headline; config 3 shards its 50 samples and is always strong)")
+    ap.add_argument("--launcher", default=None, choices=["inproc"],
+                    help="inproc: ONE process drives all --gpus devices (robo_amd/csrc/multi.hip), the form robo_amd.fmin.*("
+                         "n_gpus=G) uses; default: one process per GPU (this script starts them, or torchrun did)")
+    ap.add_argument("--devices", default=None, help="inproc: comma-separated HIP device ids (default 0..gpus-1; a device "
+                                                    "may repeat: several contexts on it)")
     ap.add_argument("--lean", action="store_true",
                     help="the timed region and the fit only: no side measurements (phases, micro-benchmarks, small batches)")
     args = ap.parse_args()
@@ -1126,7 +1323,9 @@ def main():
         sys.stderr.write("bench.py: --gpus %d but the launcher started WORLD_SIZE=%s ranks; refusing to report a line "
                          "for a job that is not the one asked for\n" % (args.gpus, env_world))
         sys.exit(2)
-    if env_world is None and args.gpus > 1:
+    if args.launcher == "inproc" and env_world is not None and int(env_world) > 1:
+        ap.error("--launcher inproc is ONE process; it cannot run under a multi-rank launcher")
+    if env_world is None and args.gpus > 1 and args.launcher != "inproc":
         # no launcher around this process: be the launcher (one rank process per GPU), pass rank 0's line through
         sys.exit(launch_ranks(args.gpus, sys.argv[1:]))
     if args.config == "c3":
@@ -1140,6 +1339,13 @@ def main():
     args.d = args.d or defaults[1]
     args.m = args.m or defaults[2]
 
+    if args.launcher == "inproc":
+        from robo_amd import _lib
+        if args.lib:
+            _lib.use_library(os.path.abspath(args.lib))
+        sys.stdout.write(json.dumps(run_inproc(args, _lib)) + "\n")
+        sys.stdout.flush()
+        return
     D_ = Dist()
     from robo_amd import _lib, sharding
     if args.lib:
