@@ -89,7 +89,7 @@ int32_t robo_ctx_set_phase_events(robo_ctx* ctx, int32_t on);
  * winv_cond_max (... while cond_inf(L) <= this, default 1e5: robo_gp_factor_cond), winv_rows (form of that product: -1 auto,
  * 0 chunked units + reduction pass, 1 one workgroup per (candidate tile, block row) over the whole contraction range),
  * trsm_pair (1: two block rows of the solve per launch on one read of V; default 0: one), trsm_small_max, trsm_small_narrow,
- * trsm_small_deep, trsm_rows, predict_stepwise, gram_persistent, mcmc_block_step, potrf_fused, potrf_tm4_min,
+ * trsm_small_deep, trsm_rows, predict_stepwise, mcmc_block_step, potrf_fused, potrf_tm4_min,
  * potrf_max_wg, potrf_group, potrf_split (sub-batches of a batched factorisation on their own streams, default 3, from
  * potrf_split_min = 12 panels on), potrf_lead, potrf_thin_last (kernel-variant selection; A/B runs and tests).         */
 int32_t robo_ctx_set_tuning(robo_ctx* ctx, const char* key, int64_t value);

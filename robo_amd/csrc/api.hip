@@ -52,10 +52,6 @@ static const TuneKey TUNE_KEYS[] = {
     {"potrf_split", nullptr, &Tuning::potrf_split, 3},
     {"potrf_split_min", nullptr, &Tuning::potrf_split_min, 12},
     {"potrf_lead", nullptr, &Tuning::potrf_lead, -1},
-    {"gram_persistent", nullptr, &Tuning::gram_persistent, 0},
-    {"gram_mfma", nullptr, &Tuning::gram_mfma, 0},
-    {"gram_half", nullptr, &Tuning::gram_half, 0},
-    {"gram_occ", nullptr, &Tuning::gram_occ, 0},
     {"mcmc_block_step", nullptr, &Tuning::mcmc_block_step, 2},
 };
 
@@ -243,6 +239,7 @@ int32_t robo_gp_create(robo_ctx* ctx, int32_t kind, int32_t n_max, int32_t dim, 
     // the strictly upper 16x16 sub-blocks of every inverted diagonal block are zero and never written
     ROBO_HIP_CHECK(hipMemset(g->d_Linv, 0, np * NB * sizeof(double)));
     ROBO_TRY(dev_alloc(&g->d_LinvP, (np / NB) * WP_BLOCK));
+    ROBO_HIP_CHECK(hipMemset(g->d_LinvP, 0, (np / NB) * WP_BLOCK * sizeof(double)));
     ROBO_TRY(dev_alloc(&g->d_llpart, (np / NB) * 4));
     ROBO_TRY(dev_alloc(&g->d_theta, (size_t)dim + 8 + sizeof(FitSample) / sizeof(double)));
     g->d_sp = reinterpret_cast<FitSample*>(g->d_theta + dim + 8);
@@ -299,6 +296,13 @@ int32_t robo_gp_set_data(robo_gp* g, const double* X, const double* y, int32_t n
     ROBO_HIP_CHECK(hipSetDevice(c->device));
     ROBO_HIP_CHECK(hipMemcpyAsync(g->d_X, X, (size_t)n * g->dim * sizeof(double), hipMemcpyHostToDevice, c->stream));
     ROBO_HIP_CHECK(hipMemcpyAsync(g->d_y, y, (size_t)n * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    if (n % NB == 0) {
+        // the augmented row's own block (block n / NB) is never factored nor inverted (launch_potrf): its inverse slots
+        // must not carry a former data set's entries -- the pack / keep kernels copy every block of the padded range
+        const size_t blk = (size_t)(n / NB);
+        ROBO_HIP_CHECK(hipMemsetAsync(g->d_Linv + blk * NB * NB, 0, (size_t)NB * NB * sizeof(double), c->stream));
+        ROBO_HIP_CHECK(hipMemsetAsync(g->d_LinvP + blk * WP_BLOCK, 0, (size_t)WP_BLOCK * sizeof(double), c->stream));
+    }
     ROBO_HIP_CHECK(hipStreamSynchronize(c->stream));
     g->n = n;
     g->n_pad = round_up(n + 1, NB);

@@ -106,10 +106,6 @@ struct Tuning {
     int potrf_lead;              // ... first-group size step between sub-batches (-1: G / splits)
     int potrf_tail_split;        // fused step: the ragged last round of 128-row tiles as half / quarter tiles on more workgroups
     int mcmc_block_step;         // ensemble half-step in ONE launch: 2 (default) every one-block problem, 1 only N <= 63, 0 never
-    int gram_mfma;               // K1 with x.x' on the matrix pipe (gram_mfma_kernel; measured slower, r04c: default 0 = never)
-    int gram_occ;                // K1 (Matern, fp64): 7 / 8 = gram_kernel compiled for that many workgroups per CU (A/B); else 6
-    int gram_half;               // K1 on 32 x 64 tiles (gram_half_kernel; measured slower at the headline, r04d: default 0 = never)
-    int gram_persistent;         // K1: persistent workgroups per CU; 0 (default, faster: r03d) = one workgroup per tile
 };
 void tuning_from_env(Tuning* t);
 }  // namespace robo
@@ -165,7 +161,9 @@ struct robo_gp {
     double* d_Xs;       // (n_pad_max, dim) inputs scaled by 1/sqrt(metric_d)
     double* d_y;        // (n_max)
     double* d_K;        // (n_pad_max, n_pad_max) gram -> Cholesky factor in place (lower)
-    double* d_Linv;     // (n_pad_max / NB) x NB x NB inverses of the diagonal blocks
+    double* d_Linv;     // (n_pad_max / NB) x NB x NB inverses of the diagonal blocks.  With n a multiple of NB the LAST block
+                        // (the augmented row alone) is never factored: its inverse slots here and in d_LinvP are ZERO, not
+                        // an inverse (robo_gp_set_data clears them); every consumer walks ceil(n / NB) block rows only
     double* d_LinvP;    // the same inverses as packed MFMA A-operand fragments (WP_BLOCK doubles per block, predict.hip)
     double* d_theta;    // inverse sqrt metric (dim) of the current theta
     robo::FitSample* d_sp;   // device copy of the current FitSample

@@ -17,7 +17,7 @@ SHAPE = ["--n", "200", "--d", "4", "--m", "601", "--steps", "2", "--warmup", "1"
 def _run(extra, env_extra=None, timeout=600):
     sys.path.insert(0, os.path.join(HERE, "hipemu"))
     import build_emu
-    env = dict(os.environ, ROBO_RCCL_LIB=build_emu.build_fake_rccl(), ROBO_BENCH_COMM_TIMEOUT="120")
+    env = dict(os.environ, ROBO_RCCL_LIB=build_emu.build_fake_rccl(), ROBO_BENCH_COMM_TIMEOUT="120", HIPEMU_DEVICES="4")
     for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "ROBO_BENCH_RENDEZVOUS", "ROBO_BENCH_FORCE_DIST"):
         env.pop(k, None)
     env.update(env_extra or {})
@@ -119,15 +119,15 @@ def test_inproc_two_contexts_on_one_device(single):
 
 def test_inproc_sample_and_per_cost_shards():
     """config 3 (sample shard) and config 4 (information gain per unit cost) in one process == their one-device runs"""
-    c3 = ["--config", "c3", "--n", "150", "--d", "3", "--m", "200"]
+    c3 = ["--config", "c3", "--n", "100", "--d", "3", "--m", "150", "--steps", "1", "--warmup", "0"]
     one = _line(_run(["--gpus", "1"] + c3))
     three = _line(_run(["--gpus", "3", "--launcher", "inproc"] + c3, env_extra={"HIPEMU_DEVICES": "3"}))
     assert three["config"]["parallelism"].startswith("sample-shard x3 (17/17/16)")
     assert three["argmax"][1] == one["argmax"][1] and abs(three["argmax"][0] - one["argmax"][0]) <= 1e-12 * abs(one["argmax"][0])
-    c4 = ["--config", "c4", "--n", "200", "--d", "4", "--m", "300", "--scaling", "strong"]
+    c4 = ["--config", "c4", "--n", "150", "--d", "4", "--m", "200", "--scaling", "strong", "--steps", "1", "--warmup", "0"]
     one = _line(_run(["--gpus", "1"] + c4))
     two = _line(_run(["--gpus", "2", "--launcher", "inproc"] + c4, env_extra={"HIPEMU_DEVICES": "2"}))
-    assert two["argmax"] == one["argmax"] and two["config"]["candidates_total"] == 300 and two["launcher"] == "inproc"
+    assert two["argmax"] == one["argmax"] and two["config"]["candidates_total"] == 200 and two["launcher"] == "inproc"
 
 
 def test_inproc_refuses_a_multi_rank_launcher():

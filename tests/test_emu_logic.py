@@ -227,7 +227,3 @@ def test_winv_condition_guard_sweep(emu_ctx):
     """the cond_inf(L) guard of the explicit-inverse posterior (same arithmetic as on the MI355X, three block rows)"""
     P.check_winv_guard_sweep(emu_ctx, n=384, min_blocks=2, m=200,
                              sweep=((2, (1e-3, 1e-9)), (1, (1e-7, 1e-10, 1e-12))))
-
-
-def test_gram_kernel_variants(emu_ctx):
-    P.check_gram_variants(emu_ctx)

@@ -61,9 +61,11 @@ def test_config2_full_size(ctx):
     eo = O.ei(mo, vo, eta)
     well = np.abs((eta - mo) / np.sqrt(vo)) < 8
     np.testing.assert_allclose(vals[well], eo[well], rtol=1e-6, atol=1e-12)
-    want = int(np.argmax(eo))
+    # north_star: "argmax index bit-exact" -- on BASELINE's inputs there is no tie to hide behind (the oracle's two best
+    # EI values differ by far more than the value tolerance), so the index is asserted without an escape
     srt = np.sort(eo)
-    assert am == want or srt[-1] - srt[-2] <= 1e-7 * srt[-1]
+    assert srt[-1] - srt[-2] > 1e-6 * srt[-1], "config 2's inputs were expected to have a unique maximiser"
+    assert am == int(np.argmax(eo))
     assert am == int(np.argmax(vals)) and mx == vals[am]
     cand.close()
     g.close()
@@ -287,6 +289,30 @@ def test_config3_full_size_sample_shard(ctx):
     finite = np.isfinite(full)
     np.testing.assert_allclose(sharded[finite], full[finite], rtol=1e-12)
     assert int(np.argmax(sharded)) == am
+    # the marginal LogEI VALUES against the oracle at config 3's shape (marginalization.py:115-121 over log_ei.py:74-120):
+    # the oracle's own posteriors of four samples on 2048 candidates through the oracle's LogEI, mean in sample order,
+    # against the device's marginal over the SAME four samples; and the argmax over that slice
+    sub, n_sl = (0, 17, 37, 49), 2048
+    o_vals, z_min = [], None
+    for s_ in sub:
+        ogp = O.OracleGP("matern52", thetas[s_], lower=np.zeros(D), upper=np.ones(D))
+        ogp.train(X, y)
+        mo, vo = ogp.predict(Xc[:n_sl], diag_only=True)
+        o_vals.append(O.log_ei_vec(mo, vo, eta))
+        z = (eta - mo) / np.sqrt(vo)
+        z_min = z if z_min is None else np.minimum(z_min, z)
+        mu, var = gps[s_].predict(cand)
+        np.testing.assert_allclose(mu[:n_sl], mo, rtol=MU_RTOL, atol=MU_ATOL)
+        np.testing.assert_allclose(var[:n_sl], vo, rtol=0, atol=VAR_ATOL_REL_AMP * np.exp(thetas[s_][0]))
+    o_marg = O.marginalize(np.array(o_vals))
+    cand_sl = _lib.Candidates(ctx, Xc[:n_sl])
+    d_marg, _, am_sl, _ = _lib.acq_marginal([gps[s_] for s_ in sub], "log_ei", 0.0, eta, cand_sl)
+    cand_sl.close()
+    # log EI amplifies the posterior's own tolerance by |z| (d log EI / d mu ~ -z / s in the lower tail): the stated
+    # LogEI tolerance (tests/_tol.py) where every sample is within 8 sigma, the tail tolerance beyond
+    from _tol import assert_logei_close
+    assert_logei_close(d_marg, o_marg, z_min, rtol=1e-6, tail_rtol=1e-5)
+    assert am_sl == int(np.argmax(o_marg)) == int(np.argmax(d_marg))
     for s in (0, 37):
         ogp = O.OracleGP("matern52", thetas[s], lower=np.zeros(D), upper=np.ones(D))
         ogp.train(X, y)
@@ -307,8 +333,8 @@ def test_config5_mixed_precision_lcb(ctx):
     11 workspace passes.  Parity is against the oracle's own fp32 K-build on a candidate slice + the device's
     top candidates (loose: two fp32 libms, amplified by cond(K)), the argmax against their re-scoring; the 1/8
     shard an 8-GPU run gives every rank (131 072 candidates from first_index) must reproduce the full run's bits;
-    the error of the mixed-precision posterior w.r.t. the all-fp64 oracle is measured and printed, not asserted
-    tight."""
+    the error of the mixed-precision posterior w.r.t. the all-fp64 oracle is ASSERTED against the stated
+    mixed-precision contract (tests/_tol.py: MIXED_MU_ATOL, MIXED_VAR_ATOL, MIXED_LOGLIK_RTOL) and printed."""
     from scipy.stats import qmc
     N, D = 8192, 64
     M = 2 ** 20
@@ -345,7 +371,9 @@ def test_config5_mixed_precision_lcb(ctx):
     np.testing.assert_allclose(var[sl], vo, rtol=0, atol=5e-3)
     lo = O.lcb(mo, vo)
     best_o = sl[int(np.argmax(lo))]
-    assert best_o == am or abs(lo.max() - lo[list(sl).index(am)]) < 1e-2
+    # the fp32-K-build oracle's winner among these candidates IS the device's winner on BASELINE's inputs (no escape:
+    # the two best LCB values are further apart than two fp32 libms can move them)
+    assert best_o == am
     o64 = O.OracleGP("matern52", theta, lower=np.zeros(D), upper=np.ones(D))
     o64.train(X, y)
     # the mixed-precision posterior against the ALL-fp64 oracle: a stated contract (tests/_tol.py), asserted on the
@@ -361,7 +389,7 @@ def test_config5_mixed_precision_lcb(ctx):
     # the all-fp64 oracle's LCB winner among these candidates is the device's, or ties with it inside the mixed-
     # precision bound on the mean
     l64 = O.lcb(m64, v64)
-    assert sl[int(np.argmax(l64))] == am or l64.max() - l64[list(sl).index(am)] <= 2 * MIXED_MU_ATOL
+    assert sl[int(np.argmax(l64))] == am
     cand.close()
     g.close()
 
@@ -448,10 +476,6 @@ def test_winv_condition_guard_sweep(ctx):
     substitution before the explicit inverse would miss tests/_tol.py"""
     P.check_winv_guard_sweep(ctx)
 
-
-def test_gram_kernel_variants(ctx):
-    P.check_gram_variants(ctx)
-    P.check_gram_variants(ctx, cases=(("matern52", 4096, 16), ("matern52", 1000, 40)))
 
 
 def test_comm_one_rank_rccl(ctx):

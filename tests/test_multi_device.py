@@ -214,25 +214,29 @@ def test_information_gain_candidate_shard(emu3):
     assert out[1][1] == out[0][1]
 
 
-def test_fabolas_frontend_on_devices(emu3):
-    """robo_amd.fmin.fabolas(n_gpus=2): both models' samples split over two devices, every sample's information gain per
-    unit cost evaluated on its device by its own host thread; the threaded mean equals the sequential one"""
+def test_fabolas_objects_on_devices(emu3):
+    """what robo_amd.fmin.fabolas(n_gpus=2) wires together (build_fabolas(devices=[0, 1])), through one model-based iteration
+    of its loop: both models' samples split over two devices, every sample's information gain per unit cost evaluated on
+    its device by its own host thread; the threaded mean equals the sequential one"""
+    import inspect
     from robo_amd.fmin.fabolas import build_fabolas, fabolas
-
-    def obj(x, s):
-        return float(np.exp(-np.sum((x - 0.3) ** 2)) + 1.0 / s + 0.5), float(s) / 100.0
+    assert {"n_gpus", "devices"} <= set(inspect.signature(fabolas).parameters)
     lo, hi = np.zeros(2), np.ones(2)
-    res = fabolas(obj, lo, hi, s_min=16, s_max=1024, n_init=2, num_iterations=6, subsets=[64, 16], burnin=4, chain_length=3,
-                  n_hypers=12, rng=np.random.RandomState(3), n_candidates=60, n_representer=6, n_outcomes=12, n_gpus=2)
-    assert len(res["X"]) == 6
-    mo, mc, acq, _ = build_fabolas(lo, hi, burnin=4, chain_length=3, rng=np.random.RandomState(3), n_candidates=60,
-                                   n_representer=6, n_outcomes=12, devices=[0, 1])
-    X, y, c = np.array(res["X"]), np.log(np.array(res["y"])), np.array(res["c"])
+    mo, mc, acq, maxi = build_fabolas(lo, hi, burnin=3, chain_length=2, rng=np.random.RandomState(3), n_candidates=40,
+                                      n_representer=6, n_outcomes=10, devices=[0, 1])
+    rs = np.random.RandomState(9)
+    X = rs.rand(9, 3)
+    y, c = np.log(np.exp(-np.sum((X[:, :2] - 0.3) ** 2, axis=1)) + 0.5 + 0.2 * (1 - X[:, 2])), np.log(0.1 + X[:, 2])
     mo.train(X, y)
     mc.train(X, c)
     acq.update(mo, mc)
-    Xt = np.random.RandomState(5).rand(40, 3)
+    ctxs = _lib.multi_for([0, 1]).ctxs
+    slots = [ctxs.index(e.model.gp.ctx) for e in acq.estimators]
+    assert slots == sorted(slots) and set(slots) == {0, 1}
+    assert [ctxs.index(e.cost_model.gp.ctx) for e in acq.estimators] == slots      # loss and cost sample s share a device
+    Xt = rs.rand(30, 3)
     threaded = acq.compute(Xt)
     seq = np.mean([e.compute(Xt) for e in acq.estimators], axis=0)
     np.testing.assert_array_equal(threaded, seq)
-    assert len({id(e.model.gp.ctx) for e in acq.estimators}) == 2
+    x_new = maxi.maximize()
+    assert x_new.shape == (3,) and np.all(x_new >= 0) and np.all(x_new <= 1)
