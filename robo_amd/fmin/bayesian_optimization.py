@@ -7,11 +7,11 @@ without george, pybnn and pyrfr: :2,5,8,11), wired to the MI355X GP path:
     n_hypers 3 * len(kernel), made even                      (:85-87)
     model    GaussianProcess | GaussianProcessMCMC(chain_length=200, burnin_steps=100)  (:89-100)
     acq      EI | LogEI | PI | LCB, wrapped in MarginalizationGPMCMC for gp_mcmc       (:114-129)
-    maximiser RandomSampling                                  (:131-139)
 
-Model types other than the two GP ones (rf / bohamiann / dngo) and the single-point
-maximisers (scipy / differential_evolution) are outside this project's hot path
-(SURVEY.md section 2, rows 6, 8, 17).
+    maximiser RandomSampling | SciPyOptimizer | DifferentialEvolution                    (:131-139)
+
+Model types other than the two GP ones (rf / bohamiann / dngo) are outside this project's hot path
+(SURVEY.md section 2, rows 6, 8).
 """
 import logging
 
@@ -20,7 +20,7 @@ import numpy as np
 from robo_amd.acquisition_functions import EI, LCB, PI, LogEI, MarginalizationGPMCMC
 from robo_amd.initial_design import init_latin_hypercube_sampling
 from robo_amd.kernels import Matern52Kernel
-from robo_amd.maximizers import DeviceRandomSampling, RandomSampling
+from robo_amd.maximizers import DeviceRandomSampling, DifferentialEvolution, RandomSampling, SciPyOptimizer
 from robo_amd.models import GaussianProcess, GaussianProcessMCMC
 from robo_amd.priors import DefaultPrior
 from robo_amd.solver import BayesianOptimization
@@ -81,9 +81,12 @@ def bayesian_optimization(objective_function, lower, upper, num_iterations=30, X
     elif maximizer == "device_random":
         # same recipe, candidates generated and scored on the device, only x* comes back
         max_func = DeviceRandomSampling(acq, lower, upper, n_samples=n_candidates, rng=rng)
+    elif maximizer == "scipy":
+        max_func = SciPyOptimizer(acq, lower, upper, rng=rng)
+    elif maximizer == "differential_evolution":
+        max_func = DifferentialEvolution(acq, lower, upper, rng=rng)
     else:
-        raise ValueError("'{}' is not a valid function to maximize the acquisition function "
-                         "(robo_amd provides 'random' and 'device_random')".format(maximizer))
+        raise ValueError("'{}' is not a valid function to maximize the acquisition function".format(maximizer))
 
     bo = BayesianOptimization(objective_function, lower, upper, acq, model, max_func, initial_points=n_init, rng=rng,
                               initial_design=init_latin_hypercube_sampling, output_path=output_path)

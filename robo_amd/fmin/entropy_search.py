@@ -6,7 +6,7 @@ import numpy as np
 from robo_amd.acquisition_functions import EI, InformationGain, MarginalizationGPMCMC
 from robo_amd.initial_design import init_latin_hypercube_sampling
 from robo_amd.kernels import Matern52Kernel
-from robo_amd.maximizers import RandomSampling
+from robo_amd.maximizers import DifferentialEvolution, RandomSampling, SciPyOptimizer
 from robo_amd.models import GaussianProcess, GaussianProcessMCMC
 from robo_amd.priors import DefaultPrior
 from robo_amd.solver import BayesianOptimization
@@ -32,10 +32,15 @@ def build_entropy_search(lower, upper, maximizer="random", model="gp_mcmc", rng=
         raise ValueError("%s is not a valid model!" % model)
     a = InformationGain(gp, lower=lower, upper=upper, sampling_acquisition=EI, Nb=n_representer, Np=n_outcomes, rng=rng)
     acquisition_func = MarginalizationGPMCMC(a) if model == "gp_mcmc" else a
-    if maximizer != "random":
-        raise ValueError("%s is not a valid function to maximize the acquisition function (robo_amd: 'random')"
-                         % maximizer)
-    max_func = RandomSampling(acquisition_func, lower, upper, n_samples=n_candidates, rng=rng)
+    if maximizer == "random":
+        max_func = RandomSampling(acquisition_func, lower, upper, n_samples=n_candidates, rng=rng)
+    elif maximizer == "scipy":
+        max_func = SciPyOptimizer(acquisition_func, lower, upper, rng=rng)
+    elif maximizer == "differential_evolution":
+        max_func = DifferentialEvolution(acquisition_func, lower, upper, rng=rng)
+    else:
+        # (the reference prints an error and returns None here, entropy_search.py:110-112; a ValueError is kinder)
+        raise ValueError("%s is not a valid function to maximize the acquisition function" % maximizer)
     return gp, acquisition_func, max_func
 
 

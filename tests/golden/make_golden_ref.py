@@ -531,9 +531,48 @@ def make_fabolas_frontend(R, seed=6, n_init=3, subsets=(64, 16), n_model_based=3
     _save("ref_fabolas_frontend", **out)
 
 
+# ------------------------------------------------------------------------------------------------
+# (7) the reference's single-point maximisers behind its front end: robo.fmin.bayesian_optimization(maximizer="scipy" /
+#     "differential_evolution") on Branin (robo/fmin/bayesian_optimization.py:131-139, robo/maximizers/scipy_optimizer.py,
+#     differential_evolution.py), everything the loop decides logged for a replay (tests/ref_checks.py)
+# ------------------------------------------------------------------------------------------------
+def make_branin_single_point(R, seed=4, n_iter=11):
+    _placeholder_optional_models()
+    from robo.fmin import bayesian_optimization as fmin_bo
+    GP = R.GaussianProcess
+    orig_train = GP.train
+    lo, hi = np.array([-5.0, 0.0]), np.array([10.0, 15.0])
+    out = {"seed": seed}
+    for name in ("scipy", "differential_evolution"):
+        log = []
+
+        def train(self, X, y, do_optimize=True):
+            orig_train(self, X, y, do_optimize)
+            st = np.random.get_state()
+            log.append(dict(n=X.shape[0], hypers=np.array(self.hypers, dtype=np.float64), noise=float(self.noise),
+                            keys=st[1].copy(), pos=st[2], has_gauss=st[3], cached=st[4]))
+
+        GP.train = train
+        try:
+            np.random.seed(seed)
+            res = fmin_bo(branin, lo, hi, num_iterations=n_iter, n_init=3, model_type="gp", acquisition_func="ei",
+                          maximizer=name, rng=np.random.RandomState(seed))
+        finally:
+            GP.train = orig_train
+        out.update({name + "_X": np.array(res["X"]), name + "_y": np.array(res["y"]), name + "_f_opt": res["f_opt"],
+                    name + "_n": np.array([l["n"] for l in log]), name + "_hypers": np.array([l["hypers"] for l in log]),
+                    name + "_noise": np.array([l["noise"] for l in log]),
+                    name + "_rng_keys": np.array([l["keys"] for l in log]), name + "_rng_pos": np.array([l["pos"] for l in log]),
+                    name + "_rng_has_gauss": np.array([l["has_gauss"] for l in log]),
+                    name + "_rng_cached": np.array([l["cached"] for l in log])})
+        print("branin", name, "f_opt", res["f_opt"], "model-based iterations", len(log))
+    _save("ref_branin_single_point", **out)
+
+
 MAKERS = dict(gp=make_gp, mcmc=make_mcmc, fabolas=make_fabolas, infogain=make_infogain,
               infogain_config4=make_infogain_config4, branin=make_branin,
-              entropy_search=make_entropy_search, fabolas_frontend=make_fabolas_frontend)
+              entropy_search=make_entropy_search, fabolas_frontend=make_fabolas_frontend,
+              branin_single_point=make_branin_single_point)
 
 if __name__ == "__main__":
     R = reference()

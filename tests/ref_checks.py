@@ -392,6 +392,53 @@ def check_ref_branin_free_run(device=None):
     return same, float(res["f_opt"]), float(gold["f_opt"])
 
 
+def check_ref_single_point_replay(device=None, which=("scipy", "differential_evolution"), max_iters=None):
+    """At every model-based iteration of the reference's own runs of robo.fmin.bayesian_optimization(maximizer="scipy" /
+    "differential_evolution") on Branin (fixture ref_branin_single_point, tests/golden/make_golden_ref.py): same data so far,
+    the hyper-parameters the reference found, the global RNG state it had before maximising -> robo_amd's
+    SciPyOptimizer / DifferentialEvolution over robo_amd's EI.  L-BFGS-B differentiates the acquisition by finite
+    differences of 1e-8, so a trajectory cannot be bit-identical across two implementations of EI (a relative 1e-9 in a value is
+    10 % of such a difference); what is pinned: the start points are the reference's (same stream consumption: checked
+    through the end state of the global stream where the search itself draws nothing), the point found scores at least
+    (1 - 1e-3) of what the reference's point scores under the SAME acquisition function, and in most iterations it IS the
+    reference's point to 1e-3 of the box.  -> (iterations checked, iterations landing on the reference's point)"""
+    from robo_amd.maximizers import DifferentialEvolution, SciPyOptimizer
+    gold = load("ref_branin_single_point")
+    lo, hi = np.array([-5.0, 0.0]), np.array([10.0, 15.0])
+    checked = same = 0
+    for name in which:
+        X, y = gold[name + "_X"], gold[name + "_y"]
+        np.testing.assert_array_equal(y, np.array([G.branin(x) for x in X]))
+        kernel = 2 * Matern52Kernel(np.ones(2), ndim=2)
+        gp = GaussianProcess(kernel, lower=lo, upper=hi, rng=np.random.RandomState(0), device=device)
+        acq = A.EI(gp)
+        cls = SciPyOptimizer if name == "scipy" else DifferentialEvolution
+        maxi = cls(acq, lo, hi, rng=np.random.RandomState(0))
+        for it, n in enumerate(gold[name + "_n"][:max_iters]):
+            h = gold[name + "_hypers"][it]
+            gp.kernel.set_parameter_vector(h[:-1])
+            gp.noise = np.exp(h[-1])
+            gp.train(X[:n], y[:n], do_optimize=False)
+            np.testing.assert_allclose(gp.noise, gold[name + "_noise"][it], rtol=1e-12)
+            acq.update(gp)
+            np.random.set_state(("MT19937", gold[name + "_rng_keys"][it], int(gold[name + "_rng_pos"][it]),
+                                 int(gold[name + "_rng_has_gauss"][it]), float(gold[name + "_rng_cached"][it])))
+            x_new = maxi.maximize()
+            x_ref = X[n]
+            assert np.all(x_new >= lo) and np.all(x_new <= hi)
+            a_new, a_ref = float(acq(x_new[None, :])[0]), float(acq(x_ref[None, :])[0])
+            assert a_new >= (1.0 - 1e-3) * a_ref - 1e-12, (name, it, a_new, a_ref)
+            same += bool(np.all(np.abs(x_new - x_ref) <= 1e-3 * (hi - lo)))
+            if name == "scipy" and it + 1 < len(gold[name + "_n"]):
+                # the search draws nothing: the global stream must stand where the reference's stood after ITS maximisation,
+                # i.e. before the (deterministic) objective call and the next train -- which draw nothing either
+                st = np.random.get_state()
+                assert int(st[2]) == int(gold[name + "_rng_pos"][it + 1]) and \
+                    np.array_equal(st[1], gold[name + "_rng_keys"][it + 1]), "start points consumed another stream"
+            checked += 1
+    return checked, same
+
+
 # ------------------------------------------------------------------------------------------------
 # (6) the other two front ends replayed: robo/fmin/entropy_search.py:20-131 (model="gp") and
 #     robo/fmin/fabolas.py:31-312, objects wired by robo_amd's own front-end builders

@@ -63,6 +63,12 @@ def test_branin_replay_emulated(emu):
     R.check_ref_branin_replay()
 
 
+def test_single_point_maximizers_replay_emulated(emu):
+    """robo.fmin.bayesian_optimization(maximizer="scipy" / "differential_evolution"): the reference's own two runs replayed"""
+    checked, same = R.check_ref_single_point_replay(max_iters=3)       # (the interpreter is slow; all 16 on the MI355X)
+    assert checked == 6 and same >= 4, (checked, same)
+
+
 def test_entropy_search_replay_emulated(emu):
     assert R.check_ref_entropy_search_replay() == 6
 
@@ -126,6 +132,12 @@ def test_branin_free_run(gpu):
 
 
 @pytest.mark.gpu
+def test_single_point_maximizers_trajectory_replay(gpu):
+    checked, same = R.check_ref_single_point_replay()
+    print("single-point maximisers: %d iterations replayed, %d on the reference's point to 1e-3 of the box" % (checked, same))
+    assert checked == 16 and same >= 12, (checked, same)
+
+
 def test_entropy_search_trajectory_replay(gpu):
     """robo.fmin.entropy_search's own run (model="gp"): same choice at all 6 model-based iterations"""
     assert R.check_ref_entropy_search_replay() == 6
