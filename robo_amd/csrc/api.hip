@@ -50,6 +50,7 @@ static const TuneKey TUNE_KEYS[] = {
     {"potrf_tail_split", nullptr, &Tuning::potrf_tail_split, 1},
     {"potrf_thin_last", nullptr, &Tuning::potrf_thin_last, 1},
     {"potrf_split", nullptr, &Tuning::potrf_split, 3},
+    {"potrf_gram_split", nullptr, &Tuning::potrf_gram_split, 1},
     {"potrf_split_min", nullptr, &Tuning::potrf_split_min, 12},
     {"potrf_lead", nullptr, &Tuning::potrf_lead, -1},
     {"mcmc_block_step", nullptr, &Tuning::mcmc_block_step, 2},
@@ -526,8 +527,7 @@ static int fit_batch_core(robo_gp* g, const double* thetas, int32_t S, double me
         fb.want_inverse = (bool)keep;      // likelihoods only: the posterior's inverse blocks are not formed
         fb.S = ns;
         ROBO_TRY(launch_scale_inputs(c, g->d_X, g->d_bXs, g->d_bism, g->n, g->n_pad, D, ns, np * D, (size_t)D));
-        ROBO_TRY(launch_gram(g, fb));
-        ROBO_TRY(launch_potrf(g, fb));   // its tail kernel also reduces the log-likelihood terms into fb.out
+        ROBO_TRY(launch_potrf(g, fb, true));   // gram + factorisation; its tail kernel also reduces the log-likelihood terms into fb.out
         ROBO_HIP_CHECK(hipStreamSynchronize(c->stream));   // the finishing kernel wrote hout (pinned) itself
         for (int s = 0; s < ns; ++s) {
             double ll = -HUGE_VAL;
@@ -655,8 +655,7 @@ int32_t robo_gp_mcmc_run(robo_gp* g, double mean_c, int32_t prior_kind, const do
     auto half_step = [&](int start, int first, int h, int it) -> int {
         if (one_block) return launch_mcmc_block_step(g, st, start, first, h, it);
         ROBO_TRY(launch_mcmc_propose_scale(c, st, start, first, h, it, g->d_X, g->d_bXs, g->n, g->n_pad, np * D));
-        ROBO_TRY(launch_gram(g, fb));
-        ROBO_TRY(launch_potrf(g, fb));
+        ROBO_TRY(launch_potrf(g, fb, true));        // gram + factorisation
         return launch_mcmc_accept(c, st, start, first, h, it);
     };
     if (eval_start) {

@@ -102,6 +102,7 @@ struct Tuning {
     int potrf_tm4_min, potrf_max_wg, potrf_group;
     int potrf_thin_last;         // batched fit: 32-row tiles for the block row that holds only the augmented row (1; 0 = A/B)
     int potrf_split;             // batched fit: sub-batches on their own streams with staggered group boundaries (1: one stream)
+    int potrf_gram_split;        // ... with every sub-batch's gram kernel on its own stream (1) or one launch for all (0)
     int potrf_split_min;         // ... from this many panels on (default 12: N >= 1408)
     int potrf_lead;              // ... first-group size step between sub-batches (-1: G / splits)
     int potrf_tail_split;        // fused step: the ragged last round of 128-row tiles as half / quarter tiles on more workgroups
@@ -262,7 +263,7 @@ struct KeepDst {
     int ok;
 };
 int launch_batch_keep(robo_gp* g0, const KeepDst* d_dst, int ns);
-int launch_gram(robo_gp* gp, const FitBuffers& fb);
+int launch_gram(robo_gp* gp, const FitBuffers& fb, hipStream_t stream = nullptr, int s0 = 0, int ns = -1);
 // the device-resident hyper-parameter chain (mcmc.hip): everything the two kernels around the batched fit need
 struct McmcState {
     int k, P, D, kind, n, n_steps, ns_eval, prior_kind;
@@ -283,7 +284,8 @@ int launch_mcmc_propose_scale(robo_ctx* ctx, const McmcState& st, int start, int
                               double* d_Xs, int64_t rows_real, int64_t rows_pad, size_t xs_stride);
 int launch_mcmc_accept(robo_ctx* ctx, const McmcState& st, int start, int first, int h, int it);
 int launch_mcmc_block_step(robo_gp* gp, const McmcState& st, int start, int first, int h, int it);
-int launch_potrf(robo_gp* gp, const FitBuffers& fb);
+// with_gram: the gram matrices are built here too, every sub-batch's on the stream its factorisation runs on
+int launch_potrf(robo_gp* gp, const FitBuffers& fb, bool with_gram = false);
 int launch_diag_timeline(robo_gp* gp, long long* d_stamps);
 int launch_cross_gram(robo_gp* gp, robo_cand* cand, int64_t c0, int64_t cn, double* d_out = nullptr);
 // posterior of a chunk through W = L^-1 (winv.hip): fills cand->d_q / d_mu (and d_V when store_v)

@@ -253,12 +253,16 @@ int launch_scale_inputs(robo_ctx* ctx, const double* d_in, double* d_out, const 
         }                                                                          \
     } while (0)
 
-int launch_gram(robo_gp* gp, const FitBuffers& fb) {
+// samples s0 .. s0 + ns - 1 of the batch (default: all of it) on `stream` (default: the context's)
+int launch_gram(robo_gp* gp, const FitBuffers& fb, hipStream_t stream, int s0, int ns) {
     const int T = gp->n_pad / GT;
     const int tiles = T * (T + 1) / 2;
+    if (!stream) stream = gp->ctx->stream;
+    if (ns < 0) ns = fb.S - s0;
 #define ROBO_GRAM_CALL(TYPE, KIND)                                                                              \
-    hipLaunchKernelGGL((gram_kernel<TYPE, KIND>), dim3(tiles, fb.S), dim3(256), 0, gp->ctx->stream, fb.Xs,      \
-                       fb.xs_stride, (const double*)gp->d_y, fb.K, fb.k_stride, gp->n, gp->n_pad, fb.sp, fb.fail)
+    hipLaunchKernelGGL((gram_kernel<TYPE, KIND>), dim3(tiles, ns), dim3(256), 0, stream,                        \
+                       fb.Xs + (size_t)s0 * fb.xs_stride, fb.xs_stride, (const double*)gp->d_y,                 \
+                       fb.K + (size_t)s0 * fb.k_stride, fb.k_stride, gp->n, gp->n_pad, fb.sp + s0, fb.fail + s0)
     ROBO_DISPATCH_COV(gp->fp32_gram, gp->kind, ROBO_GRAM_CALL);
 #undef ROBO_GRAM_CALL
     ROBO_LAUNCH_CHECK();

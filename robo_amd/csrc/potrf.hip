@@ -1455,12 +1455,13 @@ int launch_pack_linv(robo_gp* gp) {
     return ROBO_OK;
 }
 
-int launch_potrf(robo_gp* gp, const FitBuffers& fb) {
+int launch_potrf(robo_gp* gp, const FitBuffers& fb, bool with_gram) {
     robo_ctx* ctx = gp->ctx;
     const int ld = gp->n_pad, nb = gp->n_pad / NB, S = fb.S;
-    // fb.fail[0 .. S) was zeroed by the gram kernel (launch_gram always precedes this)
+    // fb.fail[0 .. S) is zeroed by the gram kernel, which always precedes the factorisation of its samples
     const Tuning& tune = ctx->tune;
     const bool fused = S <= 2 && tune.potrf_fused != 0;
+    bool gram_done = !with_gram;
     // n a multiple of 128 (every BASELINE size): the last block holds the augmented row ALONE.  Its diagonal entry is never
     // read -- z = L^-1 (y - mean) is complete once the last REAL panel has passed over row n, the likelihood needs z.z and the
     // real pivots only -- so that block is neither updated nor factored nor inverted: one link less in the chain
@@ -1492,6 +1493,7 @@ int launch_potrf(robo_gp* gp, const FitBuffers& fb) {
     };
     if (nb == 1 && !fb.want_inverse) {
         // one block, likelihood only: factor and reduce in one launch
+        if (!gram_done) ROBO_TRY(launch_gram(gp, fb));
         hipLaunchKernelGGL(potrf_diag_kernel, dim3(S), dim3(256), 0, ctx->stream, fb.K, fb.k_stride, ld, 0, gp->n, fb.Linv,
                            fb.linv_stride, fb.fail, (long long*)nullptr, fb.out, fb.host_out);
         ROBO_LAUNCH_CHECK();
@@ -1503,6 +1505,7 @@ int launch_potrf(robo_gp* gp, const FitBuffers& fb) {
     if (fused) {
         // single theta: trailing update of step k + diagonal block k+1 (workgroup 0) in one launch
         hipStream_t st = ctx->stream;
+        if (!gram_done) ROBO_TRY(launch_gram(gp, fb));
         diag(st, 0, S, 0);
         for (int k = 0; k + 1 < nb; ++k) {
             const int rem = nb - k - 1, tiles = rem * (rem + 1) / 2;
@@ -1551,6 +1554,16 @@ int launch_potrf(robo_gp* gp, const FitBuffers& fb) {
             ROBO_TRY(ctx_aux_streams(ctx));
             ROBO_HIP_CHECK(hipEventRecord(ctx->ev_fork, ctx->stream));
             for (int j = 1; j < splits; ++j) ROBO_HIP_CHECK(hipStreamWaitEvent(ctx->aux[j - 1], ctx->ev_fork, 0));
+        }
+        if (!gram_done) {
+            // K of every sub-batch on ITS stream: the first sub-batch starts factoring after a third of the covariance work
+            // and the others' fp64-VALU-bound gram kernels run beside its matrix-pipe phases (potrf_gram_split = 0: one launch)
+            if (splits == 1 || tune.potrf_gram_split == 0) ROBO_TRY(launch_gram(gp, fb));
+            else
+                for (int j = 0; j < splits; ++j) {
+                    const int s0 = (int)((long long)S * j / splits), s1 = (int)((long long)S * (j + 1) / splits);
+                    ROBO_TRY(launch_gram(gp, fb, j == 0 ? ctx->stream : ctx->aux[j - 1], s0, s1 - s0));
+                }
         }
         int next_k0[ROBO_AUX_STREAMS + 1] = {0, 0, 0, 0};
         for (bool more = true; more;) {
