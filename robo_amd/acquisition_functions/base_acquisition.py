@@ -113,18 +113,9 @@ class ClosedFormAcquisition(BaseAcquisitionFunction):
         if not model.is_trained:
             raise Exception('Model has to be trained first!')
         if n_here == 0:
-            # an empty shard takes part in the SAME collective the other ranks issue inside
-            # robo_acq_eval_cand_sharded (an all-gather of four doubles: max, global index or -1, flag word, status)
-            # and applies the same tie-break to what comes back
+            # an empty shard takes part in the SAME collective the other ranks issue inside robo_acq_eval_cand_sharded
             from robo_amd import sharding
-            rows = comm.allgather([0.0, -1.0, 0.0, 0.0])
-            best = sharding.reduce_argmax((float(r[0]), int(r[1])) for r in rows)
-            flags = 0
-            for r in rows:
-                flags |= int(r[2])
-                if int(r[3]) != _lib.OK:
-                    _lib.check(int(r[3]), "the local half of another rank's shard failed (status %d)" % int(r[3]))
-            mx, am = best if best is not None else (0.0, -1)
+            mx, am, flags = sharding.exchange_best(comm, lambda: None)
         else:
             model._materialise()
             norm = model.normalize if hasattr(model, "normalize") else model._normalised

@@ -61,20 +61,18 @@ class InformationGainPerUnitCost(InformationGain):
             vals = np.asarray(self.compute(X_slice), dtype=np.float64).reshape(-1)
             j = int(np.argmax(vals))
             return sharding.allgather_argmax(float(vals[j]), global_offset + j)[1]
+        # whether a slice has out-of-box candidates is a property of THAT slice; both forms issue the same four-double
+        # all-gather (the library's comm_pack_best_kernel / sharding.exchange_best build the same message), so ranks may
+        # take different forms within one call
         if n_here == 0 or np.any(self._outside(X_slice)):
-            # the rare forms (an empty shard; candidates outside the box get np.spacing(1) / cost): values on the host,
-            # the SAME four-double message the library's exchange carries
-            if n_here:
+            # the rare forms (an empty shard; candidates outside the box get np.spacing(1) / cost): values on the host
+            def local():
+                if not n_here:
+                    return None
                 vals = np.asarray(self.compute(X_slice), dtype=np.float64).reshape(-1)
                 j = int(np.argmax(vals))
-                msg = [float(vals[j]), float(global_offset + j), 0.0, 0.0]
-            else:
-                msg = [0.0, -1.0, 0.0, 0.0]
-            rows = comm.allgather(msg)
-            for r in rows:
-                if int(r[3]) != _lib.OK:
-                    _lib.check(int(r[3]), "the local half of another rank's shard failed (status %d)" % int(r[3]))
-            return sharding.reduce_argmax((float(r[0]), int(r[1])) for r in rows)[1]
+                return float(vals[j]), global_offset + j
+            return sharding.exchange_best(comm, local)[1]
         return int(self._per_cost(X_slice, False, comm, global_offset)[2])
 
     def _outside(self, X):

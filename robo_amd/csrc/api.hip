@@ -50,7 +50,7 @@ static const TuneKey TUNE_KEYS[] = {
     {"potrf_tail_split", nullptr, &Tuning::potrf_tail_split, 1},
     {"potrf_thin_last", nullptr, &Tuning::potrf_thin_last, 1},
     {"potrf_split", nullptr, &Tuning::potrf_split, 3},
-    {"potrf_gram_split", nullptr, &Tuning::potrf_gram_split, 1},
+    {"potrf_gram_split", nullptr, &Tuning::potrf_gram_split, 0},
     {"potrf_split_min", nullptr, &Tuning::potrf_split_min, 12},
     {"potrf_lead", nullptr, &Tuning::potrf_lead, -1},
     {"mcmc_block_step", nullptr, &Tuning::mcmc_block_step, 2},

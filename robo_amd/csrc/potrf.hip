@@ -1556,8 +1556,10 @@ int launch_potrf(robo_gp* gp, const FitBuffers& fb, bool with_gram) {
             for (int j = 1; j < splits; ++j) ROBO_HIP_CHECK(hipStreamWaitEvent(ctx->aux[j - 1], ctx->ev_fork, 0));
         }
         if (!gram_done) {
-            // K of every sub-batch on ITS stream: the first sub-batch starts factoring after a third of the covariance work
-            // and the others' fp64-VALU-bound gram kernels run beside its matrix-pipe phases (potrf_gram_split = 0: one launch)
+            // potrf_gram_split = 1: K of every sub-batch on ITS stream (the first sub-batch starts factoring after a third of
+            // the covariance work, the others' fp64-VALU-bound gram kernels run beside its matrix-pipe phases).  MEASURED
+            // (r05d, 27 thetas): no gain -- N = 4096 0.4711 vs 0.4700 ms per theta, N = 2048 0.0934 vs 0.0923 -- so the
+            // default stays one gram launch for the whole batch
             if (splits == 1 || tune.potrf_gram_split == 0) ROBO_TRY(launch_gram(gp, fb));
             else
                 for (int j = 0; j < splits; ++j) {

@@ -214,6 +214,7 @@ class GaussianProcessMCMC(BaseModel):
                         model._adopt_fit(theta)
                     else:
                         model.train(X, y, do_optimize=False)
+                self._prefetch_inverses(flat)
                 return
         if self.sample_shard:
             from robo_amd import sharding
@@ -242,6 +243,19 @@ class GaussianProcessMCMC(BaseModel):
                 model._adopt_fit(theta)
             else:
                 model.train(X, y, do_optimize=False)
+        self._prefetch_inverses(models)
+
+    @staticmethod
+    def _prefetch_inverses(models):
+        """launch every sample's explicit-inverse build now (asynchronous, best effort): the marginal acquisition over a
+        small candidate batch that follows (500 candidates by default) then finds S inverses in place instead of building
+        -- and waiting for -- one per sample inside its loop"""
+        for m in models:
+            try:
+                if m.gp is not None:
+                    m.gp.prefetch_inverse()
+            except Exception as e:        # noqa: BLE001
+                logger.warning("prefetch of the explicit inverse factor failed (%s); it is built on first use", e)
 
     def _keep_hypers_without_optimize(self):
         # FabolasGPMCMC keeps the previous samples when do_optimize=False (fabolas_gp.py:80-84);

@@ -111,6 +111,39 @@ def allgather_argmax(local_max, local_global_index):
     return reduce_argmax((float(r[0]), int(r[1])) for r in rows)
 
 
+BEST_MSG_LEN = 4        # (max, global index or -1, flag word, status of the sender's local half): comm.hip BEST_MSG
+
+
+def exchange_best(comm, compute_local):
+    """The host-side form of the candidate shard's exchange, for the cases the fused library call does not cover (an
+    empty shard, out-of-box candidates, a non-device model): ``compute_local()`` -> (value, global index) or None for an
+    empty shard.  ONE place builds and parses the four-double message the library's own exchange carries (comm.hip
+    comm_pack_best_kernel / comm_best_kernel); a rank whose compute_local() raises still joins the collective with its
+    status set -- the other ranks get an error instead of a hang -- and then re-raises.
+    -> (global max, global argmax, flags OR-ed)"""
+    from robo_amd import _lib
+    msg, err = [0.0, -1.0, 0.0, 0.0], None
+    try:
+        local = compute_local()
+        if local is not None:
+            msg[0], msg[1] = float(local[0]), float(local[1])
+            if len(local) > 2:
+                msg[2] = float(local[2])
+    except Exception as e:      # noqa: BLE001 -- the collective below must be issued on every rank
+        msg, err = [0.0, -1.0, 0.0, float(_lib.RUNTIME_ERROR)], e
+    rows = comm.allgather(msg)
+    if err is not None:
+        raise err
+    flags = 0
+    for r in rows:
+        flags |= int(r[2])
+        if int(r[3]) != _lib.OK:
+            _lib.check(int(r[3]), "the local half of another rank's shard failed (status %d)" % int(r[3]))
+    best = reduce_argmax((float(r[0]), int(r[1])) for r in rows)
+    mx, am = best if best is not None else (0.0, -1)
+    return mx, am, flags
+
+
 def allgather_ordered_sum(partial_sum):
     """Sum per-rank partial vectors in rank order (deterministic on every rank) -- the generic form for quantities
     that are not acquisition sums (the mixture posterior of GaussianProcessMCMC.predict)."""
