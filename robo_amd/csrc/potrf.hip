@@ -1550,22 +1550,23 @@ int launch_potrf(robo_gp* gp, const FitBuffers& fb, bool with_gram) {
         // measured (r05b, 27 thetas, ms per theta, one stream -> three): N = 4096 0.512 -> 0.470, N = 2048 0.104 -> 0.092,
         // N = 1024 0.0293 -> 0.0316 (nine panels: the chains are too short to interleave); four streams: 0.58 at N = 4096
         if (S < 2 * splits || nb < tune.potrf_split_min) splits = 1;
+        const bool gram_per_stream = !gram_done && splits > 1 && tune.potrf_gram_split != 0;
+        // one gram launch for the whole batch goes IN FRONT of the fork: the side streams must not start before it is done
+        if (!gram_done && !gram_per_stream) ROBO_TRY(launch_gram(gp, fb));
         if (splits > 1) {
             ROBO_TRY(ctx_aux_streams(ctx));
             ROBO_HIP_CHECK(hipEventRecord(ctx->ev_fork, ctx->stream));
             for (int j = 1; j < splits; ++j) ROBO_HIP_CHECK(hipStreamWaitEvent(ctx->aux[j - 1], ctx->ev_fork, 0));
         }
-        if (!gram_done) {
+        if (gram_per_stream) {
             // potrf_gram_split = 1: K of every sub-batch on ITS stream (the first sub-batch starts factoring after a third of
             // the covariance work, the others' fp64-VALU-bound gram kernels run beside its matrix-pipe phases).  MEASURED
             // (r05d, 27 thetas): no gain -- N = 4096 0.4711 vs 0.4700 ms per theta, N = 2048 0.0934 vs 0.0923 -- so the
             // default stays one gram launch for the whole batch
-            if (splits == 1 || tune.potrf_gram_split == 0) ROBO_TRY(launch_gram(gp, fb));
-            else
-                for (int j = 0; j < splits; ++j) {
-                    const int s0 = (int)((long long)S * j / splits), s1 = (int)((long long)S * (j + 1) / splits);
-                    ROBO_TRY(launch_gram(gp, fb, j == 0 ? ctx->stream : ctx->aux[j - 1], s0, s1 - s0));
-                }
+            for (int j = 0; j < splits; ++j) {
+                const int s0 = (int)((long long)S * j / splits), s1 = (int)((long long)S * (j + 1) / splits);
+                ROBO_TRY(launch_gram(gp, fb, j == 0 ? ctx->stream : ctx->aux[j - 1], s0, s1 - s0));
+            }
         }
         int next_k0[ROBO_AUX_STREAMS + 1] = {0, 0, 0, 0};
         for (bool more = true; more;) {

@@ -39,8 +39,9 @@ for rnd in range(2):                       # two rounds: the second sees the par
         ctx.set_tuning("potrf_group", group)
         ctx.set_tuning("potrf_split", split)
         ctx.set_tuning("potrf_lead", lead)
-        ll, st = g.loglik_batch(thetas, 0.0)          # warm-up (workspace, streams)
-        assert np.all(st == _lib.OK)
+        g.loglik_batch(thetas + 0.01, 0.0)            # other gram matrices in the workspace first (a schedule that reads K
+        ll, st = g.loglik_batch(thetas, 0.0)          # too early must not find the right ones left over); warm-up
+        assert np.all(st == _lib.OK), st
         if ref is None:
             ref = ll.copy()
         same = bool(np.array_equal(ll, ref))
