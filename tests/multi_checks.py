@@ -210,3 +210,40 @@ def check_failing_device(devices):
         broken.close()
         for g in gps:
             g.close()
+
+
+# ---- the front ends on several devices of one process ----------------------------------------------------------------------
+def branin(x):
+    a, b, c, r, s, t = 1.0, 5.1 / (4 * np.pi ** 2), 5.0 / np.pi, 6.0, 10.0, 1.0 / (8 * np.pi)
+    return a * (x[1] - b * x[0] ** 2 + c * x[0] - r) ** 2 + s * (1 - t) * np.cos(x[0]) + s
+
+
+class Counted(object):
+    def __init__(self, f):
+        self.f, self.calls = f, 0
+
+    def __call__(self, *a):
+        self.calls += 1
+        return self.f(*a)
+
+
+def run_bo(devices=None, n_gpus=None, num_iterations=8, **kw):
+    """robo_amd.fmin.bayesian_optimization on Branin with fixed seeds -> (X trajectory, objective calls)"""
+    from robo_amd.fmin import bayesian_optimization
+    f = Counted(branin)
+    np.random.seed(11)
+    res = bayesian_optimization(f, np.array([-5.0, 0.0]), np.array([10.0, 15.0]), num_iterations=num_iterations, n_init=3,
+                                rng=np.random.RandomState(11), n_gpus=n_gpus, devices=devices, **kw)
+    return np.array(res["X"]), f.calls
+
+
+def check_front_end_trajectories(device_lists, num_iterations=8, mcmc=dict(chain_length=4, burnin_steps=6)):
+    """bayesian_optimization(devices=...) == the one-device run, point for point, for model_type gp (candidate shard over
+    replicas) and gp_mcmc (sample shard); the objective is evaluated once per iteration"""
+    for kw in (dict(model_type="gp", acquisition_func="ei", maximizer="random"),
+               dict(model_type="gp_mcmc", acquisition_func="log_ei", maximizer="random", **mcmc)):
+        X1, calls1 = run_bo(None, num_iterations=num_iterations, **kw)
+        for devices in device_lists:
+            XG, calls = run_bo(devices, num_iterations=num_iterations, **kw)
+            np.testing.assert_array_equal(XG, X1, err_msg="%r on devices %r" % (kw["model_type"], devices))
+            assert calls == calls1 == num_iterations

@@ -530,3 +530,11 @@ def test_multi_device_candidate_and_sample_shards(ctx):
     MC.check_per_cost_shard([0, 0], N=500, D=5, M=2000, Nb=30, Np=100)
     MC.check_fits_and_mixture([0, 0], N=1500, D=6, S=9)
     MC.check_failing_device([0, 0])
+
+
+@pytest.mark.gpu
+def test_multi_device_front_ends(ctx):
+    """robo_amd.fmin.bayesian_optimization(devices=[0, 0]) on the MI355X (two contexts of this process on device 0): the
+    one-device trajectory for gp (candidate shard) and gp_mcmc (sample shard), 12 iterations, objective called once each"""
+    import multi_checks as MC
+    MC.check_front_end_trajectories([[0, 0]], num_iterations=12, mcmc=dict(chain_length=20, burnin_steps=20))

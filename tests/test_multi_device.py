@@ -79,50 +79,14 @@ def test_device_resolution(emu3):
 
 
 # ---- the plugin classes and the robo.fmin front ends on several devices of one process -----------------------------------
-def _branin(x):
-    a, b, c, r, s, t = 1.0, 5.1 / (4 * np.pi ** 2), 5.0 / np.pi, 6.0, 10.0, 1.0 / (8 * np.pi)
-    return a * (x[1] - b * x[0] ** 2 + c * x[0] - r) ** 2 + s * (1 - t) * np.cos(x[0]) + s
-
-
-class _Counted(object):
-    def __init__(self, f):
-        self.f, self.calls = f, 0
-
-    def __call__(self, *a):
-        self.calls += 1
-        return self.f(*a)
-
-
-def _run_bo(n_gpus, **kw):
-    from robo_amd.fmin import bayesian_optimization
-    f = _Counted(_branin)
-    np.random.seed(11)
-    res = bayesian_optimization(f, np.array([-5.0, 0.0]), np.array([10.0, 15.0]), num_iterations=8, n_init=3,
-                                rng=np.random.RandomState(11), n_gpus=n_gpus, **kw)
-    return np.array(res["X"]), f.calls
-
-
-def test_frontend_gp_candidate_shard_same_trajectory(emu3):
-    """robo_amd.fmin.bayesian_optimization(n_gpus=G), model_type="gp": the candidate batch of every maximisation split
-    over replicas on G devices of THIS process -> the points the one-device run chooses, bit for bit; the objective is
-    evaluated once per iteration"""
-    X1, calls1 = _run_bo(None, model_type="gp", acquisition_func="ei", maximizer="random")
-    for G in (2, 3):
-        XG, calls = _run_bo(G, model_type="gp", acquisition_func="ei", maximizer="random")
-        np.testing.assert_array_equal(XG, X1)
-        assert calls == calls1 == 8
-    XG, _ = _run_bo(3, model_type="gp", acquisition_func="lcb", maximizer="device_random", n_candidates=700)
-    assert XG.shape == (8, 2)
-
-
-def test_frontend_gp_mcmc_sample_shard(emu3):
-    """model_type="gp_mcmc": hyper-parameter samples split over the devices (fits, marginal LogEI, mixture posterior)"""
-    kw = dict(model_type="gp_mcmc", acquisition_func="log_ei", maximizer="random", chain_length=4, burnin_steps=6)
-    X1, _ = _run_bo(None, **kw)
-    for G in (2, 3):
-        XG, calls = _run_bo(G, **kw)
-        np.testing.assert_array_equal(XG, X1)       # (re-associated sums of 8 samples: no argmax flips on this run)
-        assert calls == 8
+def test_front_ends_same_trajectory_on_2_and_3_devices(emu3):
+    """robo_amd.fmin.bayesian_optimization(n_gpus / devices): model_type="gp" splits the candidate batch of every
+    maximisation over replicas on G devices of THIS process, "gp_mcmc" splits the hyper-parameter samples (fits, marginal
+    LogEI, mixture posterior) -> the points the one-device run chooses, bit for bit; the objective is evaluated once per
+    iteration (robo/solver/bayesian_optimization.py:156-203)"""
+    MC.check_front_end_trajectories([[0, 1], [0, 1, 2]])
+    XG, calls = MC.run_bo(n_gpus=3, model_type="gp", acquisition_func="lcb", maximizer="device_random", n_candidates=700)
+    assert XG.shape == (8, 2) and calls == 8
 
 
 def test_gp_mcmc_classes_on_devices(emu3):

@@ -43,14 +43,14 @@ dist)
   timeout 300 python bench.py --gpus 2 --lean --no-cpu-baseline > $OUT/gpus2_on_one_gpu.json 2> $OUT/gpus2_on_one_gpu.err; echo "gpus2-on-1-gpu rc=$? (expected non-zero)" >> $OUT/summary.txt
   cut -c1-260 $OUT/forcedist_weak.json $OUT/forcedist_strong.json $OUT/spawn1_strong.json $OUT/forcedist_c3.json >> $OUT/summary.txt; tail -3 $OUT/forcedist_strong.err >> $OUT/summary.txt ;;
 prof)
-  timeout 900 rocprofv3 --kernel-trace --stats -d $OUT/prof -o bench -- python bench.py --gpus 1 --no-cpu-baseline > $OUT/prof_bench.json 2> $OUT/prof.err; echo "rocprof rc=$?" >> $OUT/summary.txt
+  timeout 600 rocprofv3 --kernel-trace --stats -d $OUT/prof -o bench -- python bench.py --gpus 1 --no-cpu-baseline --lean > $OUT/prof_bench.json 2> $OUT/prof.err; echo "rocprof rc=$?" >> $OUT/summary.txt
   python tools/rocpd_stats.py $OUT/prof/bench_results.db > $OUT/bench_kernel_stats.csv 2>> $OUT/prof.err
   find $OUT/prof -size +20M -delete
   head -16 $OUT/bench_kernel_stats.csv >> $OUT/summary.txt ;;
 pmc)
   for C in FETCH_SIZE WRITE_SIZE "SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE"; do
     name=$(echo $C | tr ' ' '_')
-    timeout 600 rocprofv3 --kernel-trace --pmc $C -d $OUT/pmc/$name -o pmc -- python bench.py --gpus 1 --steps 1 --warmup 0 --no-cpu-baseline > $OUT/pmc_$name.json 2> $OUT/pmc_$name.err
+    timeout 300 rocprofv3 --kernel-trace --pmc $C -d $OUT/pmc/$name -o pmc -- python bench.py --gpus 1 --steps 1 --warmup 0 --no-cpu-baseline --lean > $OUT/pmc_$name.json 2> $OUT/pmc_$name.err
     echo "pmc $C rc=$?" >> $OUT/summary.txt
   done
   python tools/rocpd_pmc.py $OUT/pmc > $OUT/pmc_summary.txt 2>&1
