@@ -138,6 +138,7 @@ def test_single_point_maximizers_trajectory_replay(gpu):
     assert checked == 16 and same >= 12, (checked, same)
 
 
+@pytest.mark.gpu
 def test_entropy_search_trajectory_replay(gpu):
     """robo.fmin.entropy_search's own run (model="gp"): same choice at all 6 model-based iterations"""
     assert R.check_ref_entropy_search_replay() == 6
