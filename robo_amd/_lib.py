@@ -83,6 +83,8 @@ def _f64(a, shape=None):
 def use_library(path):
     """Point the binding at another build of the same C ABI (test hook)."""
     global _lib, _lib_path, _default_ctx, _diag, _extra_ctx, _multis
+    for m in list(_multis.values()):       # worker threads of the outgoing library end here, not at garbage collection
+        m.close()
     _lib = None
     _diag = None
     _lib_path = path
@@ -773,11 +775,12 @@ class Multi(object):
         self.n = len(self.ctxs)
         arr = (C.c_void_p * self.n)(*[c._h for c in self.ctxs])
         self._h = C.c_void_p()
-        check(lib().robo_multi_create(arr, self.n, C.byref(self._h)))
+        self._lib = lib()            # the library that owns the handle (tests switch libraries: use_library)
+        check(self._lib.robo_multi_create(arr, self.n, C.byref(self._h)))
 
     def close(self):
         if getattr(self, "_h", None) is not None and self._h:
-            lib().robo_multi_destroy(self._h)
+            self._lib.robo_multi_destroy(self._h)      # joins the worker threads
             self._h = None
 
     def __del__(self):

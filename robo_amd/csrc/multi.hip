@@ -431,7 +431,10 @@ int32_t robo_acq_eval_marginal_cand_multi(robo_multi* m, robo_gp* const* gps, co
     });
     if (st != ROBO_OK) {
         for (int g = 0; g < m->G; ++g)
-            if (cands[g]) api_clear_flags(cands[g], st);
+            if (cands[g]) {
+                hipSetDevice(m->ctx[(size_t)g]->device);
+                api_clear_flags(cands[g], st);
+            }
         hipSetDevice(m->ctx[0]->device);
         hipStreamSynchronize(m->ctx[0]->stream);
         return st;

@@ -582,7 +582,7 @@ def check_batched_likelihoods(ctx, sizes=((60, 3), (300, 4))):
         g.close()
 
 
-def check_batched_split(ctx, N=520, D=3, S=6, variants=((2, 2, -1), (2, 3, 1)), split_min=4):
+def check_batched_split(ctx, N=400, D=3, S=6, variants=((2, 2, -1), (2, 3, 1)), split_min=4):
     """The batched factorisation with its sub-batches on separate streams and staggered group boundaries
     (potrf_split / potrf_group / potrf_lead, potrf.hip launch_potrf): likelihoods AND kept factors bit-identical to the
     one-stream schedule -- every element accumulates the same products in the same order whatever launch carries them."""

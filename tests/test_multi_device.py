@@ -185,12 +185,12 @@ def test_fabolas_objects_on_devices(emu3):
     import inspect
     from robo_amd.fmin.fabolas import build_fabolas, fabolas
     assert {"n_gpus", "devices"} <= set(inspect.signature(fabolas).parameters)
-    lo, hi = np.zeros(2), np.ones(2)
+    lo, hi = np.zeros(1), np.ones(1)
     mo, mc, acq, maxi = build_fabolas(lo, hi, burnin=3, chain_length=2, rng=np.random.RandomState(3), n_candidates=40,
                                       n_representer=6, n_outcomes=10, devices=[0, 1])
     rs = np.random.RandomState(9)
-    X = rs.rand(9, 3)
-    y, c = np.log(np.exp(-np.sum((X[:, :2] - 0.3) ** 2, axis=1)) + 0.5 + 0.2 * (1 - X[:, 2])), np.log(0.1 + X[:, 2])
+    X = rs.rand(8, 2)
+    y, c = np.log(np.exp(-np.sum((X[:, :1] - 0.3) ** 2, axis=1)) + 0.5 + 0.2 * (1 - X[:, 1])), np.log(0.1 + X[:, 1])
     mo.train(X, y)
     mc.train(X, c)
     acq.update(mo, mc)
@@ -198,9 +198,9 @@ def test_fabolas_objects_on_devices(emu3):
     slots = [ctxs.index(e.model.gp.ctx) for e in acq.estimators]
     assert slots == sorted(slots) and set(slots) == {0, 1}
     assert [ctxs.index(e.cost_model.gp.ctx) for e in acq.estimators] == slots      # loss and cost sample s share a device
-    Xt = rs.rand(30, 3)
+    Xt = rs.rand(30, 2)
     threaded = acq.compute(Xt)
     seq = np.mean([e.compute(Xt) for e in acq.estimators], axis=0)
     np.testing.assert_array_equal(threaded, seq)
     x_new = maxi.maximize()
-    assert x_new.shape == (3,) and np.all(x_new >= 0) and np.all(x_new <= 1)
+    assert x_new.shape == (2,) and np.all(x_new >= 0) and np.all(x_new <= 1)

@@ -65,8 +65,8 @@ def test_branin_replay_emulated(emu):
 
 def test_single_point_maximizers_replay_emulated(emu):
     """robo.fmin.bayesian_optimization(maximizer="scipy" / "differential_evolution"): the reference's own two runs replayed"""
-    checked, same = R.check_ref_single_point_replay(max_iters=3)       # (the interpreter is slow; all 16 on the MI355X)
-    assert checked == 6 and same >= 4, (checked, same)
+    checked, same = R.check_ref_single_point_replay(max_iters=2)       # (the interpreter is slow; all 16 on the MI355X)
+    assert checked == 4 and same >= 3, (checked, same)
 
 
 def test_entropy_search_replay_emulated(emu):
