@@ -80,6 +80,19 @@ class BayesianOptimization(object):
             raise RuntimeError("the objective function failed on rank 0")
         return float(row[0])
 
+    def _replicate_representer_points(self):
+        """One process per GPU with a shard switched on somewhere in this loop: an entropy-search acquisition (or the
+        per-sample estimators of a marginalised one) draws its representer points from an OS-seeded sampler, as in the
+        reference (information_gain.py:139-142) -- they differ from rank to rank unless ``shard`` is set on it too, and ranks
+        that score candidates against different p_min beliefs pick different points.  Forgetting that flag must not split
+        the job: it is switched on here (rank 0's points on every rank), with a warning."""
+        acq = self.acquisition_func
+        for a in [acq] + list(getattr(acq, "estimators", [])):
+            if hasattr(a, "sample_representer_points") and not getattr(a, "shard", False):
+                logger.warning("%s.shard was off in a one-process-per-GPU run: switched on (rank 0's representer points "
+                               "on every rank)", type(a).__name__)
+                a.shard = True
+
     def _record_incumbent(self, X, y):
         best = int(np.argmin(y))
         self.incumbents.append(np.asarray(X[best]).tolist())
@@ -138,6 +151,8 @@ class BayesianOptimization(object):
         except Exception:
             logger.error("Model could not be trained!")
             raise
+        if self._spmd() is not None:
+            self._replicate_representer_points()
         self.acquisition_func.update(self.model)
         t0 = time.time()
         x = self.maximize_func.maximize()

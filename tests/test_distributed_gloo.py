@@ -265,6 +265,31 @@ def _class_worker(rank, world, port, out_dir):
     assert igc._native_cost() and igc.argmax(Xq) == int(np.argmax(want))
     assert sharding.sharded_argmax(igc, Xq) == int(np.argmax(want))
     assert sharding.sharded_argmax(igc, Xq[:1]) == 0                 # one candidate, two ranks: an empty shard joins
+    # the solver loop in this form (every rank runs it in lock step): the objective is evaluated on rank 0 ONLY -- a
+    # rank-dependent (non-deterministic) objective would otherwise give the ranks different data -- and an entropy-search
+    # acquisition whose `shard` flag was forgotten is switched on by the loop (rank 0's representer points everywhere)
+    from robo_amd.solver import BayesianOptimization
+    from robo_amd.initial_design import init_latin_hypercube_sampling
+    calls = []
+
+    def objective(x):
+        calls.append(1)
+        return float(np.sum((x - 1.0) ** 2)) + 1000.0 * rank          # what rank 1 would return must never be seen
+
+    kernel2 = 2 * Matern52Kernel(np.ones(2), ndim=2)
+    gp2 = GaussianProcess(kernel2, lower=lo[:2], upper=hi[:2], rng=np.random.RandomState(40))
+    ig2 = A.InformationGain(gp2, lo[:2], hi[:2], Nb=8, Np=20, sampling_acquisition=A.EI, rng=np.random.RandomState(41))
+    assert ig2.shard is False
+    np.random.seed(42)
+    bo = BayesianOptimization(objective, lo[:2], hi[:2], ig2, gp2,
+                              RandomSampling(ig2, lo[:2], hi[:2], n_samples=60, rng=np.random.RandomState(43), shard=True),
+                              initial_design=init_latin_hypercube_sampling, initial_points=3, rng=np.random.RandomState(44))
+    bo.run(5)
+    assert len(calls) == (5 if rank == 0 else 0), (rank, len(calls))
+    assert ig2.shard is True
+    rows = sharding.allgather_rows(np.concatenate([bo.X.ravel(), bo.y.ravel(), np.asarray(ig2.zb).ravel()]))
+    np.testing.assert_array_equal(rows[0], rows[-1])
+    assert np.all(bo.y < 500.0)
     dist.barrier()
     sharding.close_comm()
     dist.destroy_process_group()
