@@ -163,6 +163,8 @@ int32_t robo_ctx_destroy(robo_ctx* c) {
 }
 
 int32_t robo_ctx_synchronize(robo_ctx* c) {
+    if (!c) return ROBO_BAD_ARGUMENT;
+    ROBO_HIP_CHECK(hipSetDevice(c->device));
     ROBO_HIP_CHECK(hipStreamSynchronize(c->stream));
     return ROBO_OK;
 }
@@ -175,6 +177,7 @@ int32_t robo_ctx_device_name(robo_ctx* c, char* buf, int32_t len) {
 
 int32_t robo_ctx_event_record(robo_ctx* c, int32_t slot) {
     if (slot < 0 || slot >= 32) return ROBO_BAD_ARGUMENT;
+    ROBO_HIP_CHECK(hipSetDevice(c->device));
     ROBO_HIP_CHECK(hipEventRecord(c->events[slot], c->stream));
     return ROBO_OK;
 }
@@ -767,6 +770,7 @@ int32_t robo_gp_fit_batch(robo_gp* const* gps, int32_t S, const double* thetas, 
 int32_t robo_gp_get_factor(robo_gp* g, double* out_L) {
     if (!g || !out_L) return ROBO_BAD_ARGUMENT;
     if (!g->fitted) return ROBO_NOT_FITTED;
+    ROBO_HIP_CHECK(hipSetDevice(g->ctx->device));     // (a process may drive several devices: multi.hip)
     const size_t np = (size_t)g->n_pad;
     std::vector<double> h(np * np);
     ROBO_HIP_CHECK(hipMemcpyAsync(h.data(), g->d_K, np * np * sizeof(double), hipMemcpyDeviceToHost, g->ctx->stream));
@@ -943,6 +947,7 @@ int32_t robo_cand_get_point(robo_cand* k, int64_t index, double* out_x) {
         set_error("candidate index %lld outside [0, %lld)", (long long)index, (long long)k->m);
         return ROBO_BAD_SHAPE;
     }
+    ROBO_HIP_CHECK(hipSetDevice(k->ctx->device));
     ROBO_HIP_CHECK(hipMemcpyAsync(out_x, k->d_Xc + (size_t)index * k->dim, (size_t)k->dim * sizeof(double),
                                   hipMemcpyDeviceToHost, k->ctx->stream));
     ROBO_HIP_CHECK(hipStreamSynchronize(k->ctx->stream));
@@ -963,6 +968,7 @@ int32_t robo_cand_last_solve_kernel(robo_cand* k, char* buf, int32_t buf_len) {
 
 int32_t robo_cand_get_points(robo_cand* k, double* out_Xc) {
     if (!k || !out_Xc) return ROBO_BAD_ARGUMENT;
+    ROBO_HIP_CHECK(hipSetDevice(k->ctx->device));
     ROBO_HIP_CHECK(hipMemcpyAsync(out_Xc, k->d_Xc, (size_t)k->m * k->dim * sizeof(double), hipMemcpyDeviceToHost,
                                   k->ctx->stream));
     ROBO_HIP_CHECK(hipStreamSynchronize(k->ctx->stream));
