@@ -795,16 +795,18 @@ int32_t robo_gp_get_gram(robo_gp* g, const double* theta, double* out_K) {
     return ROBO_OK;
 }
 
+static bool winv_factor_ok(const robo_gp* g, int min_blocks);
+static int winv_min_blocks_for(const robo_gp* g, long long m);
+
 int32_t robo_gp_prefetch_inverse(robo_gp* g) {
     if (!g) return ROBO_BAD_ARGUMENT;
     if (!g->fitted) {
         set_error("Model has to be trained first!");
         return ROBO_NOT_FITTED;
     }
-    const Tuning& t = g->ctx->tune;
-    // the same conditions under which a small batch would ask for W (decide_winv), minus the batch size
-    if (g->fp32_gram || t.predict_stepwise || t.winv_max <= 0 || (g->n + NB - 1) / NB < t.winv_min_blocks) return ROBO_OK;
-    if (!(g->diag_min > 0.0 && g->diag_max <= (double)t.winv_cond_max * g->diag_min)) return ROBO_OK;
+    // the same conditions under which a small batch would ask for W (winv_candidate), for the smallest batch that could
+    // come (a handful of candidates: from three block rows on)
+    if (!winv_factor_ok(g, winv_min_blocks_for(g, 1))) return ROBO_OK;
     // only for handles that HAVE served a small batch through W before (its buffers exist): a model that is only ever asked
     // for large batches never pays the two n_pad^2 buffers or the build
     if (!g->d_Winv) return ROBO_OK;
@@ -1034,14 +1036,26 @@ static int cand_ensure_workspace(robo_cand* k, int n_pad, bool single_chunk) {
 // <= 1.1e-10 = the stated absolute tolerance of the mean; tests/parity_checks.py check_winv_guard_sweep); beyond it the
 // substitution stays.  The diagonal ratio
 // max L_ii / min L_ii <= cond_2(L) is only the cheap pre-filter that avoids building a W that would be rejected.
-static bool winv_candidate(const robo_gp* g, const robo_cand* k) {
+// the factor-side half of the decision (everything but the batch size): shared by winv_candidate and
+// robo_gp_prefetch_inverse, so that a prefetch is launched exactly for the factors a small batch would use W on.
+// min_blocks: 3 for a handful of candidates (matrix-vector form), winv_min_blocks otherwise
+static bool winv_factor_ok(const robo_gp* g, int min_blocks) {
     const Tuning& t = g->ctx->tune;
     if (g->fp32_gram || t.predict_stepwise || t.winv_max <= 0) return false;
+    if ((g->n + NB - 1) / NB < min_blocks) return false;
+    return g->diag_min > 0.0 && g->diag_max <= (double)t.winv_cond_max * g->diag_min;
+}
+
+static int winv_min_blocks_for(const robo_gp* g, long long m) {
+    const Tuning& t = g->ctx->tune;
     // a handful of candidates (the matrix-vector form, winv.hip) pays from three block rows on: N = 300 0.044 vs 0.065 ms,
     // N = 500 0.053 vs 0.086 ms against the 32-candidate substitution (r04x); larger batches from winv_min_blocks on
-    const int min_blocks = (k->m <= 8 && t.winv_gemv != 0 && t.winv_min_blocks > 3) ? 3 : t.winv_min_blocks;
-    if (k->m_pad > t.winv_max || (g->n + NB - 1) / NB < min_blocks) return false;
-    return g->diag_min > 0.0 && g->diag_max <= (double)t.winv_cond_max * g->diag_min;
+    return (m <= 8 && t.winv_gemv != 0 && t.winv_min_blocks > 3) ? 3 : t.winv_min_blocks;
+}
+
+static bool winv_candidate(const robo_gp* g, const robo_cand* k) {
+    if (k->m_pad > g->ctx->tune.winv_max) return false;
+    return winv_factor_ok(g, winv_min_blocks_for(g, k->m));
 }
 
 static int decide_winv(robo_gp* g, const robo_cand* k, bool* use) {
