@@ -1363,8 +1363,10 @@ def run_inproc(args, _lib):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=None,
+                    help="timed steps (default 5; config c2: 100, c4: 50 -- their steps last 1.3 / 5.3 ms, and a 5-step run "
+                         "ends before the part has left its idle power state)")
+    ap.add_argument("--warmup", type=int, default=None, help="untimed steps in front (default 2; c2 / c4: 5)")
     ap.add_argument("--config", default="headline", choices=["headline", "c2", "c3", "c4", "c5"])
     ap.add_argument("--n", type=int, default=None)
     ap.add_argument("--d", type=int, default=None)
@@ -1395,6 +1397,11 @@ def main():
     if env_world is None and args.gpus > 1 and args.launcher != "inproc":
         # no launcher around this process: be the launcher (one rank process per GPU), pass rank 0's line through
         sys.exit(launch_ranks(args.gpus, sys.argv[1:]))
+    short_steps = args.config in ("c2", "c4")
+    if args.steps is None:
+        args.steps = {"c2": 100, "c4": 50}.get(args.config, 5)
+    if args.warmup is None:
+        args.warmup = 5 if short_steps else 2
     if args.config == "c3":
         args.scaling = "strong"
     args.scaling = args.scaling or "weak"

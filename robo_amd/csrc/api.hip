@@ -48,6 +48,7 @@ static const TuneKey TUNE_KEYS[] = {
     {"potrf_max_wg", nullptr, &Tuning::potrf_max_wg, 0},
     {"potrf_group", nullptr, &Tuning::potrf_group, 4},
     {"potrf_tail_split", nullptr, &Tuning::potrf_tail_split, 1},
+    {"potrf_batch_tm4_min", nullptr, &Tuning::potrf_batch_tm4_min, 96},
     {"potrf_thin_last", nullptr, &Tuning::potrf_thin_last, 1},
     {"potrf_split", nullptr, &Tuning::potrf_split, 3},
     {"potrf_gram_split", nullptr, &Tuning::potrf_gram_split, 0},

@@ -100,6 +100,8 @@ struct Tuning {
     long long winv_cond_max;     // ... while cond_inf(L) = |L|_inf |W|_inf stays below this (default 1e5)
     int potrf_fused;             // 0: never fuse the next diagonal block into the trailing update
     int potrf_tm4_min, potrf_max_wg, potrf_group;
+    int potrf_batch_tm4_min;     // batched updates: 128-row tiles from this many (tiles x samples) on, 32-row tiles below (96;
+                                 // tests lower it so that the interpreter reaches the 128-row form at small N)
     int potrf_thin_last;         // batched fit: 32-row tiles for the block row that holds only the augmented row (1; 0 = A/B)
     int potrf_split;             // batched fit: sub-batches on their own streams with staggered group boundaries (1: one stream)
     int potrf_gram_split;        // ... with every sub-batch's gram kernel on its own stream (1) or one launch for all (0)

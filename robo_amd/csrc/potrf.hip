@@ -1488,7 +1488,7 @@ int launch_potrf(robo_gp* gp, const FitBuffers& fb, bool with_gram) {
     // slower (55 us: B panel re-read twice), 32-row tiles 16 us vs 21 us once blocks < 96
     const int thin_row = (nbf < nb && tune.potrf_thin_last != 0) ? nb - 1 : -1;   // the augmented row's own block (r05)
     auto update = [&](hipStream_t st, int s0, int ns, int tiles, int base, int kop, int depth, int first) {
-        if (tiles * ns >= 96) ROBO_STEP(4, false, st, s0, ns, tiles, base, kop, depth, first, 0);
+        if (tiles * ns >= tune.potrf_batch_tm4_min) ROBO_STEP(4, false, st, s0, ns, tiles, base, kop, depth, first, 0);
         else if (tiles > 0) ROBO_STEP(1, false, st, s0, ns, tiles * 4, base, kop, depth, first, 0);
     };
     if (nb == 1 && !fb.want_inverse) {

@@ -638,6 +638,48 @@ def check_batched_split(ctx, N=400, D=3, S=6, variants=((2, 2, -1), (2, 3, 1)), 
             gp.close()
 
 
+def check_batched_multiple_of_128(ctx, sizes=((256, 3), (384, 2)), S=5, tm4_min=None):
+    """N a multiple of 128: the augmented row sits alone in the last block, which is never factored, and its block row is
+    updated on 32-row tiles (thin_row) -- inside the 128-row update kernel too (tm4_min lowers the threshold so that the
+    interpreter reaches that form at small N).  Batched likelihoods and kept factors == sequential single fits, bit for
+    bit, with the thin tiles on and off and on one / three streams."""
+    rs = np.random.RandomState(77)
+    for N, D in sizes:
+        X = rs.rand(N, D)
+        y = np.sin(3 * X.sum(axis=1))
+        base = np.concatenate([[0.0], np.full(D, np.log(0.3 * D)), [np.log(1e-2)]])
+        thetas = base[None, :] + 0.3 * rs.randn(S, base.size)
+        mean_c = float(y.mean())
+        g = _lib.DeviceGP(ctx, "matern52", N, D)
+        g.set_data(X, y)
+        seq, L_seq = [], []
+        for th in thetas:
+            seq.append(g.fit(th, mean_c))
+            L_seq.append(g.factor().copy())
+        gps = [_lib.DeviceGP(ctx, "matern52", N, D) for _ in range(S)]
+        gps[0].set_data(X, y)
+        try:
+            if tm4_min is not None:
+                ctx.set_tuning("potrf_batch_tm4_min", tm4_min)
+            for thin, split in ((1, 1), (0, 1), (1, 3)):
+                ctx.set_tuning("potrf_thin_last", thin)
+                ctx.set_tuning("potrf_split", split)
+                ctx.set_tuning("potrf_split_min", 2)
+                ll, st = g.loglik_batch(thetas, mean_c)
+                assert np.all(st == _lib.OK)
+                np.testing.assert_array_equal(ll, np.array(seq), err_msg="N %d thin %d split %d" % (N, thin, split))
+                ll, st = _lib.fit_batch(gps, thetas, mean_c)
+                np.testing.assert_array_equal(ll, np.array(seq))
+                for gp, L in zip(gps, L_seq):
+                    np.testing.assert_array_equal(gp.factor(), L)
+        finally:
+            for key in ("potrf_batch_tm4_min", "potrf_thin_last", "potrf_split", "potrf_split_min"):
+                ctx.set_tuning(key, None)
+            g.close()
+            for gp in gps:
+                gp.close()
+
+
 def check_fit_batch(ctx, sizes=((60, 3), (300, 4)), kind="matern52"):
     """robo_gp_fit_batch (the per-sample model fits of GaussianProcessMCMC.train in one batched pass that keeps
     the factors) == S sequential robo_gp_fit calls on S handles: log-likelihood, Cholesky factor and posterior bit

@@ -104,6 +104,12 @@ def test_batched_split_streams(emu_ctx):
     P.check_batched_split(emu_ctx)
 
 
+def test_batched_fit_multiple_of_128(emu_ctx):
+    """the thin tiles of the augmented row's block row, in the 32-row and (threshold lowered) the 128-row update kernel"""
+    P.check_batched_multiple_of_128(emu_ctx, sizes=((256, 3),))
+    P.check_batched_multiple_of_128(emu_ctx, sizes=((384, 2),), S=4, tm4_min=1)
+
+
 def test_grad_loglik(emu_ctx):
     P.check_grad_loglik(emu_ctx)
 

@@ -105,6 +105,13 @@ def test_batched_likelihoods(ctx):
     P.check_batched_likelihoods(ctx, sizes=((60, 3), (300, 4), (1500, 8)))
 
 
+def test_batched_fit_multiple_of_128(ctx):
+    """N = 1024 / 2048 (every BASELINE size is a multiple of 128): batched likelihoods and kept factors == sequential fits,
+    thin tiles of the augmented row's block row on and off, one and three streams"""
+    P.check_batched_multiple_of_128(ctx, sizes=((1024, 8), (2048, 16)), S=7)
+    P.check_batched_multiple_of_128(ctx, sizes=((384, 2),), S=4, tm4_min=1)
+
+
 def test_batched_split_streams(ctx):
     """sub-batches of a batched factorisation on side streams with staggered group boundaries: likelihoods and kept
     factors bit-identical to the one-stream schedule (17 panels, 9 thetas; 2 / 3 / 4 streams, groups of 2 .. 6)"""

@@ -26,10 +26,10 @@ configs)
   : > $OUT/configs.jsonl
   # c2 / c4 steps last 1.4 / 5.4 ms: the default 5 timed steps (7 / 27 ms behind 2 warm-up steps) end before the part has
   # left its idle power state (c2: 0.59 of peak over 5 steps, 0.65 over 20, 0.69 over 100) -- sustained runs for those two
-  for c in "c2 --steps 100 --warmup 5" "c3" "c4 --steps 50 --warmup 5" "c5"; do
+  for c in "c2" "c3" "c4" "c5"; do          # (c2 / c4 default to 100 / 50 timed steps: sustained rates)
     timeout 900 python bench.py --gpus 1 --config $c >> $OUT/configs.jsonl 2>> $OUT/configs.err; echo "$c rc=$?" >> $OUT/summary.txt
   done
-  timeout 300 python bench.py --gpus 1 --config c2 --no-cpu-baseline > $OUT/c2_default_5_steps.json 2>> $OUT/configs.err
+  timeout 300 python bench.py --gpus 1 --config c2 --steps 5 --warmup 2 --no-cpu-baseline > $OUT/c2_default_5_steps.json 2>> $OUT/configs.err
   timeout 900 python bench.py --gpus 1 --config c5 --m 1048576 --steps 2 --warmup 1 --no-cpu-baseline >> $OUT/configs.jsonl 2>> $OUT/configs.err; echo "c5 full rc=$?" >> $OUT/summary.txt
   cut -c1-300 $OUT/configs.jsonl >> $OUT/summary.txt ;;
 dist)
