@@ -46,7 +46,7 @@ static const TuneKey TUNE_KEYS[] = {
     {"potrf_fused", nullptr, &Tuning::potrf_fused, 1},
     {"potrf_tm4_min", nullptr, &Tuning::potrf_tm4_min, 96},
     {"potrf_max_wg", nullptr, &Tuning::potrf_max_wg, 0},
-    {"potrf_group", nullptr, &Tuning::potrf_group, 4},
+    {"potrf_group", nullptr, &Tuning::potrf_group, 0},
     {"potrf_tail_split", nullptr, &Tuning::potrf_tail_split, 1},
     {"potrf_batch_tm4_min", nullptr, &Tuning::potrf_batch_tm4_min, 96},
     {"potrf_thin_last", nullptr, &Tuning::potrf_thin_last, 1},

@@ -1525,8 +1525,11 @@ int launch_potrf(robo_gp* gp, const FitBuffers& fb, bool with_gram) {
         // factored (left-looking, one update of growing depth), and the rest of the trailing matrix
         // receives all G panels in ONE (128 G)-deep update -- 1/G of the C traffic.  Bitwise the same
         // factor: every element still accumulates its products in ascending k on top of the stored value.
-        // measured, 27 thetas at N = 4096 (ms per theta): G=1 0.668, 2 0.596, 4 0.574, 6 0.566
-        const int G = tune.potrf_group < 1 ? 1 : (tune.potrf_group > 16 ? 16 : tune.potrf_group);
+        // measured in round 1, 27 thetas at N = 4096 on one stream (ms per theta): G=1 0.668, 2 0.596, 4 0.574, 6 0.566
+        // potrf_group = 0 (default): by size -- measured with three streams (r05h, 26-27 thetas, ms per theta for groups of
+        // 2 / 3 / 4 / 5): N = 1024 0.0290 / 0.0289 / 0.0300 / 0.0293, 1536 0.0535 / 0.0529 / 0.0538 / 0.0546, 2048 0.0946 /
+        // 0.0927 / 0.0954 / 0.0942, 3072 0.2393 / 0.2307 / 0.2320 / 0.2322, 4096 0.4918 / 0.4791 / 0.4761 / 0.4708
+        const int G = tune.potrf_group < 1 ? (nb <= 25 ? 3 : 5) : (tune.potrf_group > 16 ? 16 : tune.potrf_group);
         // `lead` = size of the FIRST group (1..G); all later groups hold G panels.  Where the group boundaries fall
         // changes which launches carry which products, never the order in which an element accumulates them.
         auto group = [&](hipStream_t st, int s0, int ns, int k0, int g) {

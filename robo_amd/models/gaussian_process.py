@@ -81,6 +81,23 @@ class GaussianProcess(BaseModel):
                 if self.devices else []
         return self.gp
 
+    def _shards_for(self, Xn):
+        """per-device candidate handles for a host batch: kept between calls of one batch size (a BO loop maximises over
+        the same number of candidates every iteration) and only re-uploaded, like the single-device host-array path"""
+        Xn = np.ascontiguousarray(Xn, dtype=np.float64)
+        old = getattr(self, "_shard_cache", None)
+        if old is not None and old[0] == Xn.shape and old[0][0] <= 16384 * len(self.devices):
+            shards = old[1]
+            for g, c in enumerate(shards.shards):
+                if c is not None:
+                    c.set_points(Xn[shards.offsets[g]:shards.offsets[g] + c.m])
+            return shards
+        if old is not None:
+            old[1].close()
+        shards = _lib.CandidateShards.split(self._multi().ctxs, Xn)
+        self._shard_cache = (Xn.shape, shards)
+        return shards
+
     def _upload(self):
         """training data to the primary handle and, with a device list, to every replica"""
         if self.devices:
@@ -104,6 +121,8 @@ class GaussianProcess(BaseModel):
                 new.gp = None
             elif k == "replicas":
                 new.replicas = []
+            elif k == "_shard_cache":
+                new._shard_cache = None
             elif k == "_ctx_override":
                 new._ctx_override = v             # a context is shared, not copied
             else:
@@ -114,6 +133,7 @@ class GaussianProcess(BaseModel):
         d = dict(self.__dict__)
         d["gp"] = None
         d["replicas"] = []
+        d["_shard_cache"] = None
         d["_ctx_override"] = None
         return d
 
@@ -354,10 +374,7 @@ class GaussianProcess(BaseModel):
         if self.devices and np.asarray(Xn).shape[0] >= len(self.devices):
             # single-process multi-GPU: contiguous shards of the ONE candidate matrix, a replica of the fitted model on
             # every device, all devices at once; (max, index, flags) reduced with np.argmax's tie-break
-            shards = _lib.CandidateShards.split(self._multi().ctxs, Xn)
-            try:
-                vals, mx, am, _, flags = self._multi().acq(self._all_gps(), kind, par, eta, shards, want_values)
-            finally:
-                shards.close()
+            shards = self._shards_for(Xn)
+            vals, mx, am, _, flags = self._multi().acq(self._all_gps(), kind, par, eta, shards, want_values)
             return vals, mx, am, flags
         return self.gp.acq(kind, par, eta, Xn, want_values)
