@@ -388,6 +388,13 @@ int32_t robo_gp_fit_batch_multi(robo_multi* multi, robo_gp* const* gps, const in
 int32_t robo_acq_eval_cand_multi(robo_multi* multi, robo_gp* const* gps, int32_t acq_kind, double par, double eta,
                                  robo_cand* const* cands, const int64_t* global_offsets, double* out_acq, double* out_max,
                                  int64_t* out_argmax, int32_t* out_owner, uint32_t* out_flags);
+/* candidate shard of robo_ig_eval_cand (InformationGain.compute, information_gain.py:87-125,253-272): reps[g] = the
+ * representer points on device g, the EP state is the same host input for every device                                     */
+int32_t robo_ig_eval_cand_multi(robo_multi* multi, robo_gp* const* gps, robo_cand* const* cands, robo_cand* const* reps,
+                                int32_t n_outcomes, double sn2, const double* logP, const double* lmb, const double* W,
+                                const double* dlogPdMu, const double* dlogPdSigma, const double* dlogPdMudMu,
+                                const int64_t* global_offsets, double* out_dh, double* out_max, int64_t* out_argmax,
+                                int32_t* out_owner);
 /* candidate shard of robo_ig_eval_per_cost_cand (BASELINE config 4); reps / cost_gps / cost_cands: per-device replicas     */
 int32_t robo_ig_eval_per_cost_cand_multi(robo_multi* multi, robo_gp* const* gps, robo_cand* const* cands,
                                          robo_cand* const* reps, int32_t n_outcomes, double sn2, const double* logP,

@@ -40,7 +40,8 @@ SYMBOLS = [
     "robo_acq_eval_cand_sharded", "robo_acq_eval_marginal_cand_sharded", "robo_ig_eval_per_cost_cand_sharded",
     "robo_multi_create", "robo_multi_destroy", "robo_multi_info", "robo_gp_set_data_multi", "robo_gp_fit_multi",
     "robo_gp_loglik_batch_multi", "robo_gp_fit_batch_multi", "robo_acq_eval_cand_multi",
-    "robo_ig_eval_per_cost_cand_multi", "robo_acq_eval_marginal_cand_multi", "robo_gp_predict_mixture_cand_multi",
+    "robo_ig_eval_cand_multi", "robo_ig_eval_per_cost_cand_multi", "robo_acq_eval_marginal_cand_multi",
+    "robo_gp_predict_mixture_cand_multi",
 ]
 COMM_ID_BYTES = 128
 # include/robo_hip_diag.h (librobo_hip_diag.so: tests, bench.py's roofline block, tools/)
@@ -185,6 +186,8 @@ def lib():
         "robo_gp_fit_batch_multi": [vp, pp, C.POINTER(i32), _dp, dbl, _dp, C.POINTER(i32)],
         "robo_acq_eval_cand_multi": [vp, pp, i32, dbl, dbl, pp, C.POINTER(i64), _dp, _dp, C.POINTER(i64), C.POINTER(i32),
                                      C.POINTER(C.c_uint32)],
+        "robo_ig_eval_cand_multi": [vp, pp, pp, pp, i32, dbl, _dp, _dp, _dp, _dp, _dp, _dp, C.POINTER(i64), _dp, _dp,
+                                    C.POINTER(i64), C.POINTER(i32)],
         "robo_ig_eval_per_cost_cand_multi": [vp, pp, pp, pp, i32, dbl, _dp, _dp, _dp, _dp, _dp, _dp, pp, pp, dbl,
                                              C.POINTER(i64), _dp, _dp, C.POINTER(i64), C.POINTER(i32)],
         "robo_acq_eval_marginal_cand_multi": [vp, pp, C.POINTER(i32), i32, dbl, _dp, pp, _dp, _dp, C.POINTER(i64),
@@ -857,6 +860,17 @@ class Multi(object):
                                              self._handles(shards.shards), offs, _arr(out) if want_values else None,
                                              C.byref(mx), C.byref(am), C.byref(own), C.byref(fl)))
         return out, mx.value, am.value, own.value, fl.value
+
+    def ig(self, gps, shards, reps, ep, sn2, want_values=True):
+        """candidate shard of the information gain -> (values of all shards in slot order or None, max, GLOBAL argmax, owner)"""
+        assert all(len(x) == self.n for x in (gps, shards.shards, reps))
+        out = np.empty(shards.m) if want_values else None
+        mx, am, own = C.c_double(0), C.c_int64(0), C.c_int32(0)
+        offs = (C.c_int64 * self.n)(*shards.offsets)
+        check(lib().robo_ig_eval_cand_multi(self._h, self._handles(gps), self._handles(shards.shards), self._handles(reps),
+                                            ep.W.size, float(sn2), *ep.args(), offs, _arr(out) if want_values else None,
+                                            C.byref(mx), C.byref(am), C.byref(own)))
+        return out, mx.value, am.value, own.value
 
     def ig_per_cost(self, gps, shards, reps, ep, sn2, cost_gps, cost_shards, overhead, want_values=False):
         """candidate shard of the information gain per unit cost -> (values or None, max, GLOBAL argmax, owner slot)"""

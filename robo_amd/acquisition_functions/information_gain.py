@@ -140,39 +140,23 @@ class InformationGain(BaseAcquisitionFunction):
 
     def _gains_multi(self, X_test, want_values):
         """candidate shard over the devices of ONE process (``GaussianProcess(devices=...)``): every device scores its
-        contiguous slice against its replica of the model and the SAME representer points / EP state; the per-device
-        (max, index) are reduced with np.argmax's tie-break (values are per candidate: sharding changes none)"""
+        contiguous slice against its replica of the model and the SAME representer points / EP state
+        (robo_ig_eval_cand_multi); the per-device (max, index) are reduced with np.argmax's tie-break (values are per
+        candidate: sharding changes none)"""
         model = self.model
         model._materialise()
         norm = model.normalize if hasattr(model, "normalize") else model._normalised
         multi = model._multi()
         shards = _lib.CandidateShards.split(multi.ctxs, norm(X_test))
         zbn = norm(np.array(self.zb))
-        gps = model._all_gps()
-
-        def job(g):
-            def run():
-                if shards.shards[g] is None:
-                    return None
-                rep = _lib.Candidates(multi.ctxs[g], zbn)
-                try:
-                    return _lib.ig_eval(gps[g], shards.shards[g], rep, self._ep, self.sn2, want_values)
-                finally:
-                    rep.close()
-            return run
+        reps = [_lib.Candidates(c, zbn) for c in multi.ctxs]
         try:
-            parts = _lib.run_on_devices([job(g) for g in range(multi.n)])
+            vals, mx, am, _ = multi.ig(model._all_gps(), shards, reps, self._ep, self.sn2, want_values)
         finally:
+            for h in reps:
+                h.close()
             shards.close()
-        best = None
-        for g, p in enumerate(parts):
-            if p is None:
-                continue
-            v, i = float(p[1]), shards.offsets[g] + int(p[2])
-            if best is None or (np.isnan(v) and not np.isnan(best[0])) or (not np.isnan(best[0]) and v > best[0]):
-                best = (v, i)           # (equal values: the earlier shard holds the lower index and stays)
-        vals = np.concatenate([p[0] for p in parts if p is not None]) if want_values else None
-        return vals, best[0], best[1]
+        return vals, mx, am
 
     def compute(self, X_test, derivative=False, **kwargs):
         if derivative:

@@ -391,6 +391,35 @@ int32_t robo_ig_eval_per_cost_cand_multi(robo_multi* m, robo_gp* const* gps, rob
     return reduce_best(m, mx, am, fl, have, global_offsets, out_max, out_argmax, out_owner, nullptr);
 }
 
+int32_t robo_ig_eval_cand_multi(robo_multi* m, robo_gp* const* gps, robo_cand* const* cands, robo_cand* const* reps,
+                                int32_t n_outcomes, double sn2, const double* logP, const double* lmb, const double* W,
+                                const double* dlogPdMu, const double* dlogPdSigma, const double* dlogPdMudMu,
+                                const int64_t* global_offsets, double* out_dh, double* out_max, int64_t* out_argmax,
+                                int32_t* out_owner) {
+    if (!m || !gps || !cands || !reps || !global_offsets) return ROBO_BAD_ARGUMENT;
+    std::vector<int64_t> pos((size_t)m->G + 1, 0);
+    std::vector<char> have((size_t)m->G, 0);
+    for (int g = 0; g < m->G; ++g) {
+        pos[(size_t)g + 1] = pos[(size_t)g];
+        if (!cands[g]) continue;
+        if (!gps[g] || !reps[g]) return ROBO_BAD_ARGUMENT;
+        ROBO_TRY(check_on(m, g, gps[g]->ctx, "robo_ig_eval_cand_multi", "the GP"));
+        ROBO_TRY(check_on(m, g, cands[g]->ctx, "robo_ig_eval_cand_multi", "the candidate shard"));
+        ROBO_TRY(check_on(m, g, reps[g]->ctx, "robo_ig_eval_cand_multi", "the representer points"));
+        have[(size_t)g] = 1;
+        pos[(size_t)g + 1] += cands[g]->m;
+    }
+    std::vector<double> mx((size_t)m->G, 0.0);
+    std::vector<int64_t> am((size_t)m->G, -1);
+    std::vector<uint32_t> fl((size_t)m->G, 0u);
+    ROBO_TRY(multi_run(m, [&](int g) -> int {
+        if (!have[(size_t)g]) return (int)ROBO_OK;
+        return (int)robo_ig_eval_cand(gps[g], cands[g], reps[g], n_outcomes, sn2, logP, lmb, W, dlogPdMu, dlogPdSigma, dlogPdMudMu,
+                                      out_dh ? out_dh + pos[(size_t)g] : nullptr, &mx[(size_t)g], &am[(size_t)g]);
+    }));
+    return reduce_best(m, mx, am, fl, have, global_offsets, out_max, out_argmax, out_owner, nullptr);
+}
+
 int32_t robo_acq_eval_marginal_cand_multi(robo_multi* m, robo_gp* const* gps, const int32_t* S_dev, int32_t acq_kind,
                                           double par, const double* etas, robo_cand* const* cands, double* out_acq,
                                           double* out_max, int64_t* out_argmax, uint32_t* out_flags) {
