@@ -911,16 +911,6 @@ class Multi(object):
         return mean, var
 
 
-def run_on_devices(jobs):
-    """run one callable per device at the same time (host threads; the library calls inside release the GIL) -> their
-    results in order.  For the few per-device sequences that have no fused _multi entry point."""
-    if len(jobs) == 1:
-        return [jobs[0]()]
-    from concurrent.futures import ThreadPoolExecutor
-    with ThreadPoolExecutor(max_workers=len(jobs)) as pool:
-        return [f.result() for f in [pool.submit(j) for j in jobs]]
-
-
 def fit_batch(gps, thetas, mean_c):
     """GaussianProcessMCMC.train's per-sample fits in one batched pass that keeps the factors:
     gps[0] holds the data; afterwards gps[s] is fitted at thetas[s] wherever status[s] == OK.
