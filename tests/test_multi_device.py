@@ -204,3 +204,55 @@ def test_fabolas_objects_on_devices(emu3):
     np.testing.assert_array_equal(threaded, seq)
     x_new = maxi.maximize()
     assert x_new.shape == (2,) and np.all(x_new >= 0) and np.all(x_new <= 1)
+
+
+def test_more_devices_than_samples_and_copies(emu3):
+    """edge cases of the device lists: fewer hyper-parameter samples than devices (a device without a sample), a model
+    trained without hyper-parameter inference (ONE sample), fewer candidates than devices, and deepcopy / pickle of models
+    that hold replicas (the copies re-create their device state on first use, on the same device list)"""
+    import copy
+    import pickle
+    from robo_amd.acquisition_functions import EI, LogEI, MarginalizationGPMCMC
+    from robo_amd.kernels import Matern52Kernel
+    from robo_amd.models import GaussianProcess, GaussianProcessMCMC
+    from robo_amd.priors import DefaultPrior
+    rs = np.random.RandomState(12)
+    lo, hi = np.zeros(2), np.ones(2)
+    X = rs.rand(25, 2)
+    y = np.cos(4 * X.sum(axis=1))
+    Xc = rs.rand(57, 2)
+
+    def mcmc(devices, n_hypers):
+        kernel = 2 * Matern52Kernel(np.ones(2), ndim=2)
+        return GaussianProcessMCMC(kernel, prior=DefaultPrior(len(kernel) + 1, rng=np.random.RandomState(5)), n_hypers=n_hypers,
+                                   chain_length=3, burnin_steps=3, rng=np.random.RandomState(7), lower=lo, upper=hi,
+                                   devices=devices)
+    for n_hypers, optimise in ((8, True), (8, False)):       # 3 / 3 / 2 samples; ONE sample on three devices
+        m1, m3 = mcmc(None, n_hypers), mcmc([0, 1, 2], n_hypers)
+        m1.train(X, y, do_optimize=optimise)
+        m3.train(X, y, do_optimize=optimise)
+        assert len(m3.models) == (n_hypers if optimise else 1)
+        for a, b in zip(m3.predict(Xc), m1.predict(Xc)):
+            np.testing.assert_array_equal(a, b)
+        a1, a3 = MarginalizationGPMCMC(LogEI(m1)), MarginalizationGPMCMC(LogEI(m3))
+        a1.update(m1)
+        a3.update(m3)
+        np.testing.assert_allclose(a3.compute(Xc), a1.compute(Xc), rtol=1e-12)
+        assert a3.argmax(Xc) == a1.argmax(Xc)
+    # candidate shard with fewer candidates than devices, and copies of a model with replicas
+    gp1 = GaussianProcess(2 * Matern52Kernel(np.ones(2), ndim=2), lower=lo, upper=hi, rng=np.random.RandomState(1))
+    gp3 = GaussianProcess(2 * Matern52Kernel(np.ones(2), ndim=2), lower=lo, upper=hi, rng=np.random.RandomState(1),
+                          devices=[0, 1, 2])
+    gp1.train(X, y, do_optimize=False)
+    gp3.train(X, y, do_optimize=False)
+    assert len(gp3.replicas) == 2
+    for n in (1, 2, 3, 57):
+        np.testing.assert_array_equal(EI(gp3).compute(Xc[:n]), EI(gp1).compute(Xc[:n]))
+        assert EI(gp3).argmax(Xc[:n]) == EI(gp1).argmax(Xc[:n])
+    for clone in (copy.deepcopy(gp3), pickle.loads(pickle.dumps(gp3))):
+        assert clone.devices == [0, 1, 2] and clone.gp is None and clone.replicas == []
+        np.testing.assert_array_equal(EI(clone).compute(Xc), EI(gp1).compute(Xc))
+        assert len(clone.replicas) == 2
+    clone = pickle.loads(pickle.dumps(m3))
+    for a, b in zip(clone.predict(Xc), m1.predict(Xc)):
+        np.testing.assert_array_equal(a, b)
