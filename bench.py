@@ -3,7 +3,10 @@
 
     python bench.py --gpus 1 --steps 5 --warmup 2
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
-           --master-port P bench.py --gpus N --steps K --warmup W
+           --master-port P bench.py --gpus N --steps K --warmup W          # one process per GPU (the driver's form)
+    python bench.py --gpus N                      # the same without a launcher: starts its N rank processes itself
+    python bench.py --gpus N --launcher inproc    # ONE process drives all N GPUs (robo_amd/csrc/multi.hip): the form
+                                                  # robo_amd.fmin.*(n_gpus=N) runs; same line shape
 
 A "step" is one pass of the hot path over one candidate batch: from raw candidate
 coordinates (already resident in HBM) through cross-gram, blocked triangular solve,

@@ -51,6 +51,7 @@ class GaussianProcess(BaseModel):
         # (robo_acq_eval_cand_multi); everything else -- hyper-parameter optimisation, predict() -- runs on devices[0].
         self.devices = _lib.resolve_devices(devices)
         self.replicas = []             # DeviceGPs on devices[1:], same data and factor as self.gp
+        self._shard_cache = None       # per-device candidate handles of the last host batch (kept between maximisations)
         self._ctx_override = None      # GaussianProcessMCMC places its per-sample models on the contexts of its device list
         self._fitted_theta = None
 
@@ -85,7 +86,7 @@ class GaussianProcess(BaseModel):
         """per-device candidate handles for a host batch: kept between calls of one batch size (a BO loop maximises over
         the same number of candidates every iteration) and only re-uploaded, like the single-device host-array path"""
         Xn = np.ascontiguousarray(Xn, dtype=np.float64)
-        old = getattr(self, "_shard_cache", None)
+        old = self._shard_cache
         if old is not None and old[0] == Xn.shape and old[0][0] <= 16384 * len(self.devices):
             shards = old[1]
             for g, c in enumerate(shards.shards):

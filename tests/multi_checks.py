@@ -179,6 +179,12 @@ def check_per_cost_shard(devices, N=60, D=4, M=97, Nb=10, Np=30):
         np.testing.assert_array_equal(v2, vals)
         assert (mx2, am2) == (mx, am) and am == int(np.argmax(vals))
         assert _lib.shard_range(M, owner, multi.n)[0] <= am2 < _lib.shard_range(M, owner, multi.n)[1]
+        # the plain information gain (robo_ig_eval_cand_multi) on the same shards
+        g_vals, g_mx, g_am = _lib.ig_eval(gps[0], cand, rep, ep, sn2)
+        v3, mx3, am3, _ = multi.ig(gps, shards, reps, ep, sn2, want_values=True)
+        np.testing.assert_array_equal(v3, g_vals)
+        assert (mx3, am3) == (g_mx, g_am)
+        assert multi.ig(gps, shards, reps, ep, sn2, want_values=False)[1:3] == (g_mx, g_am)
     finally:
         for h in [cand, ccand, rep] + reps:
             h.close()
@@ -247,3 +253,30 @@ def check_front_end_trajectories(device_lists, num_iterations=8, mcmc=dict(chain
             XG, calls = run_bo(devices, num_iterations=num_iterations, **kw)
             np.testing.assert_array_equal(XG, X1, err_msg="%r on devices %r" % (kw["model_type"], devices))
             assert calls == calls1 == num_iterations
+
+
+def check_walker_shard(devices, N=60, D=3, n_hypers=10):
+    """GaussianProcessMCMC(devices=...) with the walkers of every ensemble half-step split over the devices (host sampler
+    around robo_gp_loglik_batch_multi) against the single-device chain (robo_gp_mcmc_run on the device): the same hyper-
+    parameter samples (per-theta likelihoods are bit-identical; the host and the device sampler agree to rounding)"""
+    from robo_amd.kernels import Matern52Kernel
+    from robo_amd.models import GaussianProcessMCMC
+    from robo_amd.priors import DefaultPrior
+    rs = np.random.RandomState(4)
+    X = rs.rand(N, D)
+    y = np.sin(3 * X.sum(axis=1))
+
+    def build(devs, walker_min):
+        kernel = 2 * Matern52Kernel(np.ones(D), ndim=D)
+        m = GaussianProcessMCMC(kernel, prior=DefaultPrior(len(kernel) + 1, rng=np.random.RandomState(5)), n_hypers=n_hypers,
+                                chain_length=4, burnin_steps=6, rng=np.random.RandomState(7), lower=np.zeros(D),
+                                upper=np.ones(D), devices=devs)
+        m.walker_shard_min_n = walker_min
+        m.train(X, y)
+        return m
+    one, many = build(None, 10 ** 9), build(devices, 1)
+    assert len(many.walker_gps) == len(devices) - 1
+    np.testing.assert_allclose(np.array(many.hypers), np.array(one.hypers), rtol=1e-9)
+    Xc = rs.rand(50, D)
+    for a, b in zip(many.predict(Xc), one.predict(Xc)):
+        np.testing.assert_allclose(a, b, rtol=1e-8, atol=1e-12)

@@ -537,6 +537,7 @@ def test_multi_device_candidate_and_sample_shards(ctx):
     MC.check_per_cost_shard([0, 0], N=500, D=5, M=2000, Nb=30, Np=100)
     MC.check_fits_and_mixture([0, 0], N=1500, D=6, S=9)
     MC.check_failing_device([0, 0])
+    MC.check_walker_shard([0, 0], N=300, D=4, n_hypers=12)
 
 
 @pytest.mark.gpu

@@ -123,9 +123,7 @@ def test_gp_mcmc_classes_on_devices(emu3):
     np.testing.assert_allclose(a3.compute(Xc), a1.compute(Xc), rtol=1e-12)
     assert a3.argmax(Xc) == a1.argmax(Xc) == int(np.argmax(a1.compute(Xc)))
     # walkers split over the devices per half-step (host sampler around robo_gp_loglik_batch_multi): the same chain
-    mw = build([0, 1, 2], walker_min=1)
-    assert len(mw.walker_gps) == 2
-    np.testing.assert_allclose(np.array(mw.hypers), np.array(m1.hypers), rtol=1e-9)
+    MC.check_walker_shard([0, 1, 2])
 
 
 def test_information_gain_candidate_shard(emu3):
