@@ -1,4 +1,4 @@
-"""Same-session A/B of the batched factorisation's schedules (potrf_group / potrf_split / potrf_lead):
+"""Same-session A/B of the batched factorisation's schedules (potrf_group -- 0 = by size, the default -- / potrf_split / potrf_lead):
 S likelihoods of ONE robo_gp_loglik_batch call at N x D, per-theta time and fraction of the fp64 MFMA peak
 (S N^3 / 3 flops), likelihoods compared bit for bit with the first variant.
 

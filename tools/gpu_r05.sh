@@ -104,7 +104,7 @@ batched)
   # the batched factorisation: one stream vs three sub-batch streams, same session, several N
   : > $OUT/batched_fit_ab.txt
   for cfg in "4096 16 27 7" "3072 16 26 7" "2048 16 26 9" "1536 16 26 9" "1024 8 26 9"; do
-    BATCH_AB="4,1,-1;4,3,-1" timeout 600 python tools/batched_fit_ab.py $cfg >> $OUT/batched_fit_ab.txt 2>&1
+    BATCH_AB="4,1,-1;4,3,-1;0,3,-1" timeout 600 python tools/batched_fit_ab.py $cfg >> $OUT/batched_fit_ab.txt 2>&1
   done
   grep "batched fit\|round 1" $OUT/batched_fit_ab.txt >> $OUT/summary.txt
   for v in "4,1,-1" "4,3,-1"; do
