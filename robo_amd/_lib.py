@@ -8,8 +8,10 @@ first use raises :class:`RoboHipUnavailable`.
 the same sources (tests/hipemu) to exercise host logic in the GPU-less build container; the
 product never calls it.
 """
+import atexit
 import ctypes as C
 import os
+import weakref
 
 import numpy as np
 
@@ -84,8 +86,7 @@ def _f64(a, shape=None):
 def use_library(path):
     """Point the binding at another build of the same C ABI (test hook)."""
     global _lib, _lib_path, _default_ctx, _diag, _extra_ctx, _multis
-    for m in list(_multis.values()):       # worker threads of the outgoing library end here, not at garbage collection
-        m.close()
+    _close_multis()                        # worker threads of the outgoing library end here, not at garbage collection
     _lib = None
     _diag = None
     _lib_path = path
@@ -371,6 +372,23 @@ def default_context(device=None):
 
 _extra_ctx = {}        # (device, k): the k-th additional context on a device that appears more than once in a device list
 _multis = {}           # tuple(devices) -> Multi
+_live_multis = weakref.WeakSet()
+
+
+def _close_multis():
+    """End every Multi's worker threads while the interpreter and the HIP runtime are fully alive.  Registered with atexit:
+    left to garbage collection during interpreter finalisation, the join of a worker thread (whose exit runs the HIP
+    runtime's thread-local destructors) was seen to hang or abort the process on the MI355X (r05: a test process whose last
+    test had used a device list)."""
+    for m in list(_live_multis):
+        try:
+            m.close()
+        except Exception:      # noqa: BLE001
+            pass
+    _multis.clear()
+
+
+atexit.register(_close_multis)
 
 
 def resolve_devices(devices=None, n_gpus=None):
@@ -780,6 +798,7 @@ class Multi(object):
         self._h = C.c_void_p()
         self._lib = lib()            # the library that owns the handle (tests switch libraries: use_library)
         check(self._lib.robo_multi_create(arr, self.n, C.byref(self._h)))
+        _live_multis.add(self)
 
     def close(self):
         if getattr(self, "_h", None) is not None and self._h:
