@@ -68,7 +68,12 @@ int32_t robo_device_count(int32_t* out_n);
 /* hip_stream: an existing hipStream_t to launch on (e.g. torch's current stream), or NULL
  * to let the library create its own non-blocking stream.                                  */
 int32_t robo_ctx_create(int32_t device, void* hip_stream, robo_ctx** out);
+/* Handles created on a context (robo_gp, robo_cand, robo_comm, robo_multi) keep it alive: robo_ctx_destroy on a context
+ * that still has such handles only marks it; its stream, events and scratch are released with the last of them.  (A
+ * garbage-collected binding cannot promise to finalise a context after everything that lives on it.)                     */
 int32_t robo_ctx_destroy(robo_ctx* ctx);
+/* contexts whose resources are still held (created and not yet released): diagnostics / tests                            */
+int32_t robo_ctx_live_count(int32_t* out_n);
 int32_t robo_ctx_synchronize(robo_ctx* ctx);
 int32_t robo_ctx_device_name(robo_ctx* ctx, char* buf, int32_t buf_len);
 /* HIP-event timing on the context's stream (what bench.py uses).  Slots 0..19 are the

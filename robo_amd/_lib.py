@@ -26,7 +26,7 @@ FLAG_ZERO_SIGMA, FLAG_NEGATIVE_EI, FLAG_NAN = 1, 2, 4
 
 # every symbol include/robo_hip.h declares (tests check the library exports all of them)
 SYMBOLS = [
-    "robo_device_count", "robo_ctx_create", "robo_ctx_destroy", "robo_ctx_synchronize",
+    "robo_device_count", "robo_ctx_create", "robo_ctx_destroy", "robo_ctx_live_count", "robo_ctx_synchronize",
     "robo_ctx_device_name", "robo_ctx_event_record", "robo_ctx_event_elapsed_ms", "robo_ctx_set_phase_events",
     "robo_ctx_set_tuning",
     "robo_last_error_string", "robo_version_string",
@@ -118,6 +118,7 @@ def lib():
         "robo_device_count": [C.POINTER(i32)],
         "robo_ctx_create": [i32, vp, pp],
         "robo_ctx_destroy": [vp],
+        "robo_ctx_live_count": [C.POINTER(i32)],
         "robo_ctx_synchronize": [vp],
         "robo_ctx_device_name": [vp, C.c_char_p, i32],
         "robo_ctx_event_record": [vp, i32],
@@ -253,6 +254,13 @@ def check(status, msg=None):
     if status == BAD_ARGUMENT:
         raise ValueError(msg)
     raise RoboHipError(msg)
+
+
+def live_contexts():
+    """contexts whose device resources are still held by the library (robo_ctx_live_count)"""
+    n = C.c_int32(0)
+    lib().robo_ctx_live_count(C.byref(n))
+    return n.value
 
 
 def device_count():

@@ -7,6 +7,7 @@
 #include <cstdarg>
 #include <cstdlib>
 #include <functional>
+#include <mutex>
 #include <vector>
 
 #include "common.h"
@@ -74,6 +75,43 @@ void tuning_from_env(Tuning* t) {
     if (t->ws_bytes < 1) t->ws_bytes = (long long)6 << 30;   // callers round down to whole 128-candidate blocks
 }
 
+static std::mutex g_ctx_life;
+static std::atomic<int> g_ctx_live{0};
+
+static void ctx_free(robo_ctx* c) {
+    hipSetDevice(c->device);
+    hipStreamSynchronize(c->stream);
+    for (int i = 0; i < 32; ++i) hipEventDestroy(c->events[i]);
+    if (c->aux_ready) {
+        hipEventDestroy(c->ev_fork);
+        for (int i = 0; i < ROBO_AUX_STREAMS; ++i) {
+            hipStreamSynchronize(c->aux[i]);
+            hipStreamDestroy(c->aux[i]);
+            hipEventDestroy(c->ev_join[i]);
+        }
+    }
+    hipFree(c->d_scalars);
+    hipFree(c->d_fail);
+    hipHostFree(c->h_pinned);
+    if (c->own_stream) hipStreamDestroy(c->stream);
+    delete c;
+    --g_ctx_live;
+}
+
+void ctx_retain(robo_ctx* c) {
+    std::lock_guard<std::mutex> lock(g_ctx_life);
+    ++c->users;
+}
+
+void ctx_release(robo_ctx* c) {
+    bool last;
+    {
+        std::lock_guard<std::mutex> lock(g_ctx_life);
+        last = --c->users == 0 && c->closing;
+    }
+    if (last) ctx_free(c);
+}
+
 int ctx_aux_streams(robo_ctx* c) {
     if (c->aux_ready) return ROBO_OK;
     ROBO_HIP_CHECK(hipSetDevice(c->device));
@@ -138,28 +176,26 @@ int32_t robo_ctx_create(int32_t device, void* hip_stream, robo_ctx** out) {
     ROBO_TRY(dev_alloc(&c->d_scalars, 8));
     ROBO_TRY(dev_alloc(&c->d_fail, 4));
     ROBO_HIP_CHECK(hipHostMalloc((void**)&c->h_pinned, (MAX_DIM + 64) * sizeof(double), 0));
+    ++g_ctx_live;
     *out = c;
     return ROBO_OK;
 }
 
 int32_t robo_ctx_destroy(robo_ctx* c) {
     if (!c) return ROBO_OK;
-    hipSetDevice(c->device);
-    hipStreamSynchronize(c->stream);
-    for (int i = 0; i < 32; ++i) hipEventDestroy(c->events[i]);
-    if (c->aux_ready) {
-        hipEventDestroy(c->ev_fork);
-        for (int i = 0; i < ROBO_AUX_STREAMS; ++i) {
-            hipStreamSynchronize(c->aux[i]);
-            hipStreamDestroy(c->aux[i]);
-            hipEventDestroy(c->ev_join[i]);
-        }
+    bool now;
+    {
+        std::lock_guard<std::mutex> lock(g_ctx_life);
+        c->closing = true;
+        now = c->users == 0;
     }
-    hipFree(c->d_scalars);
-    hipFree(c->d_fail);
-    hipHostFree(c->h_pinned);
-    if (c->own_stream) hipStreamDestroy(c->stream);
-    delete c;
+    if (now) ctx_free(c);        // otherwise with the last handle that lives on it (ctx_release)
+    return ROBO_OK;
+}
+
+int32_t robo_ctx_live_count(int32_t* out_n) {
+    if (!out_n) return ROBO_BAD_ARGUMENT;
+    *out_n = g_ctx_live.load();
     return ROBO_OK;
 }
 
@@ -248,6 +284,7 @@ int32_t robo_gp_create(robo_ctx* ctx, int32_t kind, int32_t n_max, int32_t dim, 
     ROBO_TRY(dev_alloc(&g->d_llpart, (np / NB) * 4));
     ROBO_TRY(dev_alloc(&g->d_theta, (size_t)dim + 8 + sizeof(FitSample) / sizeof(double)));
     g->d_sp = reinterpret_cast<FitSample*>(g->d_theta + dim + 8);
+    ctx_retain(ctx);
     *out = g;
     return ROBO_OK;
 }
@@ -287,7 +324,9 @@ int32_t robo_gp_destroy(robo_gp* g) {
     hipFree(g->d_bsp);
     hipFree(g->d_bfail);
     if (g->h_bstage) hipHostFree(g->h_bstage);
+    robo_ctx* ctx = g->ctx;
     delete g;
+    ctx_release(ctx);
     return ROBO_OK;
 }
 
@@ -859,6 +898,7 @@ static int cand_alloc(robo_ctx* ctx, int64_t m, int32_t dim, robo_cand** out) {
     ROBO_TRY(dev_alloc(&k->d_part_idx, (size_t)k->n_part + 1));
     ROBO_TRY(dev_alloc(&k->d_flags, 4));
     ROBO_HIP_CHECK(hipMemset(k->d_flags, 0, 4 * sizeof(unsigned)));   // cleared again by every read-back
+    ctx_retain(ctx);
     *out = k;
     return ROBO_OK;
 }
@@ -1005,7 +1045,9 @@ int32_t robo_cand_destroy(robo_cand* k) {
     hipFree(k->d_part_val);
     hipFree(k->d_part_idx);
     hipFree(k->d_flags);
+    robo_ctx* ctx = k->ctx;
     delete k;
+    ctx_release(ctx);
     return ROBO_OK;
 }
 

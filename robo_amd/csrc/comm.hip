@@ -259,6 +259,7 @@ int32_t robo_comm_init(robo_ctx* ctx, int32_t rank, int32_t world, const void* i
     }
     int st = comm_reserve(c, 64);
     if (st == ROBO_OK && hipHostMalloc((void**)&c->h_pinned, 8 * sizeof(double), 0) != hipSuccess) st = ROBO_RUNTIME_ERROR;
+    ctx_retain(ctx);             // (released by robo_comm_destroy, also on the failure path right below)
     if (st != ROBO_OK) {
         robo_comm_destroy(c);
         return st;
@@ -275,7 +276,9 @@ int32_t robo_comm_destroy(robo_comm* c) {
     hipFree(c->d_send);
     hipFree(c->d_recv);
     if (c->h_pinned) hipHostFree(c->h_pinned);
+    robo_ctx* ctx = c->ctx;
     delete c;
+    ctx_release(ctx);
     return ROBO_OK;
 }
 

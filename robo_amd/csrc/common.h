@@ -115,6 +115,8 @@ void tuning_from_env(Tuning* t);
 struct robo_ctx;
 namespace robo {
 int ctx_aux_streams(robo_ctx* ctx);   // api.hip: create ctx->aux / ev_fork / ev_join once
+void ctx_retain(robo_ctx* ctx);        // a handle was created on ctx
+void ctx_release(robo_ctx* ctx);       // ... destroyed: frees a closing context with its last handle
 }
 
 constexpr int ROBO_AUX_STREAMS = 3;
@@ -126,6 +128,12 @@ struct robo_ctx {
     hipStream_t aux[ROBO_AUX_STREAMS];
     hipEvent_t ev_fork, ev_join[ROBO_AUX_STREAMS];
     bool aux_ready;
+    // lifetime: handles created on this context (robo_gp, robo_cand, robo_comm, robo_multi) keep it alive.  robo_ctx_destroy
+    // marks it `closing`; stream, events and scratch are released when the last such handle is destroyed (api.hip
+    // ctx_retain / ctx_release).  A binding whose garbage collector finalises a context before the objects that live on it
+    // (Python's cyclic GC gives no order) therefore cannot make a later robo_gp_destroy touch a dead stream.
+    int users;
+    bool closing;
     hipEvent_t events[32];
     bool phase_events;   // record the internal phase events of robo_gp_fit (robo_ctx_set_phase_events, default off)
     char name[256];

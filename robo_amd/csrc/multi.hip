@@ -198,6 +198,7 @@ int32_t robo_multi_create(robo_ctx* const* ctxs, int32_t n_ctx, robo_multi** out
             w->th = std::thread([w] { w->loop(); });
             m->w.push_back(w);
         }
+    for (int g = 0; g < n_ctx; ++g) ctx_retain(ctxs[g]);      // the contexts outlive this object (common.h: lifetime)
     *out = m;
     return ROBO_OK;
 }
@@ -221,7 +222,9 @@ int32_t robo_multi_destroy(robo_multi* m) {
     hipSetDevice(m->ctx[0]->device);
     if (m->d_recv) hipFree(m->d_recv);
     if (m->h_pinned) hipHostFree(m->h_pinned);
+    const std::vector<robo_ctx*> ctxs = m->ctx;
     delete m;
+    for (robo_ctx* c : ctxs) ctx_release(c);
     return ROBO_OK;
 }
 

@@ -110,6 +110,39 @@ def test_batched_fit_multiple_of_128(emu_ctx):
     P.check_batched_multiple_of_128(emu_ctx, sizes=((384, 2),), S=4, tm4_min=1)
 
 
+def test_context_lifetime(emu_ctx):
+    """a context closed BEFORE the handles that live on it (what a garbage collector may do: Python's cyclic GC finalises
+    an unreachable group in no particular order) stays usable until the last of them is destroyed, then goes"""
+    n0 = _lib.live_contexts()
+    ctx = _lib.Context(0)
+    rs = np.random.RandomState(0)
+    X, y, Xc = rs.rand(30, 2), rs.rand(30), rs.rand(9, 2)
+    theta = np.array([0.0, -0.5, -0.5, np.log(1e-2)])
+    gp = _lib.DeviceGP(ctx, "matern52", 30, 2)
+    gp.set_data(X, y)
+    cand = _lib.Candidates(ctx, Xc)
+    want = (gp.fit(theta, 0.0), gp.predict(cand))
+    assert _lib.live_contexts() == n0 + 1
+    ctx.close()                                         # marked, not released: two handles live on it
+    assert _lib.live_contexts() == n0 + 1
+    assert gp.fit(theta, 0.0) == want[0]
+    np.testing.assert_array_equal(gp.predict(cand)[0], want[1][0])
+    gp.close()
+    assert _lib.live_contexts() == n0 + 1
+    cand.close()                                        # the last handle takes the context with it
+    assert _lib.live_contexts() == n0
+    # the ordinary order, and a Multi over two contexts closed before it
+    a, b = _lib.Context(0), _lib.Context(0)
+    g2 = _lib.DeviceGP(a, "matern52", 30, 2)
+    g2.close()
+    multi = _lib.Multi([a, b])
+    a.close()
+    b.close()
+    assert _lib.live_contexts() == n0 + 2
+    multi.close()
+    assert _lib.live_contexts() == n0
+
+
 def test_grad_loglik(emu_ctx):
     P.check_grad_loglik(emu_ctx)
 
