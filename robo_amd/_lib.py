@@ -292,12 +292,13 @@ class Context(object):
 
     def __init__(self, device=0, stream=None):
         self._h = C.c_void_p()
-        check(lib().robo_ctx_create(int(device), C.c_void_p(stream) if stream else None, C.byref(self._h)))
+        self._owner = lib()          # the library that owns the handle (tests switch libraries: use_library)
+        check(self._owner.robo_ctx_create(int(device), C.c_void_p(stream) if stream else None, C.byref(self._h)))
         self.device = int(device)
 
     def close(self):
         if getattr(self, "_h", None) is not None and self._h:
-            lib().robo_ctx_destroy(self._h)
+            self._owner.robo_ctx_destroy(self._h)
             self._h = None
 
     def __del__(self):
@@ -453,6 +454,7 @@ class Candidates(object):
                  first=0):
         self.ctx = ctx
         self._h = C.c_void_p()
+        self._owner = lib()
         if sobol is not None:
             # sobol: a scipy.stats.qmc.Sobol engine (its direction numbers and digital shift are read, the engine is
             # not advanced) or a (sv (dim, bits), shift (dim,), bits) triple; points first .. first + m - 1
@@ -515,7 +517,7 @@ class Candidates(object):
 
     def close(self):
         if getattr(self, "_h", None) is not None and self._h:
-            lib().robo_cand_destroy(self._h)
+            self._owner.robo_cand_destroy(self._h)
             self._h = None
 
     def __del__(self):
@@ -531,7 +533,8 @@ class DeviceGP(object):
     def __init__(self, ctx, kind, n_max, dim):
         self.ctx, self.kind, self.n_max, self.dim = ctx, kind, int(n_max), int(dim)
         self._h = C.c_void_p()
-        check(lib().robo_gp_create(ctx._h, KERNEL_KINDS[kind], self.n_max, self.dim, C.byref(self._h)))
+        self._owner = lib()
+        check(self._owner.robo_gp_create(ctx._h, KERNEL_KINDS[kind], self.n_max, self.dim, C.byref(self._h)))
         self.n = 0
         self.n_theta = lib().robo_theta_size(KERNEL_KINDS[kind], self.dim)
 
@@ -540,7 +543,7 @@ class DeviceGP(object):
 
     def close(self):
         if getattr(self, "_h", None) is not None and self._h:
-            lib().robo_gp_destroy(self._h)
+            self._owner.robo_gp_destroy(self._h)
             self._h = None
 
     def __del__(self):
@@ -704,11 +707,12 @@ class Comm(object):
         assert len(comm_id) == COMM_ID_BYTES
         self.ctx, self.rank, self.world = ctx, int(rank), int(world)
         self._h = C.c_void_p()
-        check(lib().robo_comm_init(ctx._h, self.rank, self.world, bytes(comm_id), C.byref(self._h)))
+        self._owner = lib()
+        check(self._owner.robo_comm_init(ctx._h, self.rank, self.world, bytes(comm_id), C.byref(self._h)))
 
     def close(self):
         if getattr(self, "_h", None) is not None and self._h:
-            lib().robo_comm_destroy(self._h)
+            self._owner.robo_comm_destroy(self._h)
             self._h = None
 
     def info(self):
