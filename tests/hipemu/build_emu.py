@@ -46,5 +46,20 @@ def build_fake_rccl(force=False):
     return FAKE_RCCL
 
 
+SCHED_SELFTEST = os.path.join(HERE, "_build", "libsched_selftest.so")
+
+
+def build_sched_selftest(force=False):
+    """sched_selftest.cpp + its own copy of the interpreter: the deferred stream schedules checked on a known race"""
+    srcs = [os.path.join(HERE, "sched_selftest.cpp"), os.path.join(HERE, "hipemu.cpp")]
+    deps = srcs + [os.path.join(HERE, "hip", "hip_runtime.h")]
+    if not force and os.path.exists(SCHED_SELFTEST) and all(os.path.getmtime(d) <= os.path.getmtime(SCHED_SELFTEST) for d in deps):
+        return SCHED_SELFTEST
+    os.makedirs(os.path.dirname(SCHED_SELFTEST), exist_ok=True)
+    subprocess.check_call(["g++", "-O1", "-g", "-std=c++17", "-fPIC", "-shared", "-Wno-psabi", "-I", HERE] + srcs +
+                          ["-o", SCHED_SELFTEST])
+    return SCHED_SELFTEST
+
+
 if __name__ == "__main__":
     print(build(force=True))

@@ -65,6 +65,7 @@ dim3& cur_bdim();
 dim3& cur_gdim();
 void* dyn_smem();
 void launch(std::function<void()> body, dim3 grid, dim3 block, size_t shmem);
+void launch_on(hipStream_t st, std::function<void()> body, dim3 grid, dim3 block, size_t shmem);
 void barrier();
 // generic wave64 collective: every live lane of the wave deposits `in` (nbytes) and gets
 // `out` back once all arrived; `op` is evaluated once per rendezvous.
@@ -80,7 +81,7 @@ int lane_id();
 static const int warpSize = 64;
 
 #define hipLaunchKernelGGL(kernel, grid, block, shmem, stream, ...) \
-    hipemu::launch([=]() mutable { kernel(__VA_ARGS__); }, dim3(grid), dim3(block), (size_t)(shmem))
+    hipemu::launch_on((hipStream_t)(stream), [=]() mutable { kernel(__VA_ARGS__); }, dim3(grid), dim3(block), (size_t)(shmem))
 
 // ---- runtime API --------------------------------------------------------------------
 hipError_t hipMalloc(void** p, size_t n);

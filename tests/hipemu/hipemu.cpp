@@ -5,6 +5,10 @@
 
 #include <chrono>
 #include <cstdlib>
+#include <algorithm>
+#include <deque>
+#include <map>
+#include <memory>
 #include <mutex>
 #include <vector>
 
@@ -188,10 +192,11 @@ static void init_fiber(Fiber& f) {
 
 // One interpreter for every emulated device and host thread: launches are serialised (the library's multi-device entry
 // points launch from one worker thread per device, multi.hip).
-static std::mutex g_launch_mu;
+// The same lock guards the stream queues of the deferred modes below.
+std::recursive_mutex g_rt_mu;
 
 void launch(std::function<void()> body, dim3 grid, dim3 block, size_t shmem) {
-    std::lock_guard<std::mutex> lock(g_launch_mu);
+    std::lock_guard<std::recursive_mutex> lock(g_rt_mu);
     if (g_cur) { std::fprintf(stderr, "hipemu: nested launch\n"); std::abort(); }
     size_t nt = (size_t)block.x * block.y * block.z;
     if (nt == 0 || nt > 1024) { std::fprintf(stderr, "hipemu: bad block size %zu\n", nt); std::abort(); }
@@ -245,29 +250,199 @@ void launch(std::function<void()> body, dim3 grid, dim3 block, size_t shmem) {
 // ---------------------------------------------------------------------------------------
 // runtime API
 // ---------------------------------------------------------------------------------------
-struct hipemuStream { int dummy; };
-struct hipemuEvent { std::chrono::steady_clock::time_point t; };
+// Streams and events.  Three schedules, all LEGAL orders of the work the host enqueued (in-stream order and
+// hipStreamWaitEvent edges are always honoured), chosen by HIPEMU_ASYNC / hipemu_set_async():
+//   0  every call executes at once, in issue order (the default);
+//   1  deferred, "others first": a synchronisation point runs every runnable operation of the OTHER streams before the
+//      stream it waits for -- a side stream that forgot to wait for its producer on the main stream reads stale data;
+//   2  deferred, "others last": a synchronisation point runs only what the awaited stream (or event) transitively
+//      depends on -- a main stream that forgot to join its side streams reads their output before it exists.
+// The null stream executes at once in every mode (the library's streams are hipStreamNonBlocking: no implicit
+// ordering with it).  hipFree / hipHostFree / hipDeviceSynchronize drain everything, as the runtime does.
+struct hipemuEvent {
+    std::chrono::steady_clock::time_point t;
+    uint64_t enqueued = 0, completed = 0;
+    int refs = 0;
+    bool destroyed = false;
+};
+struct EmuOp {
+    enum Kind { RUN, RECORD, WAIT } kind;
+    std::function<void()> fn;
+    hipemuEvent* ev;
+    uint64_t seq;
+};
+struct hipemuStream { std::deque<EmuOp> q; };
+
+using hipemu::g_rt_mu;
+typedef std::lock_guard<std::recursive_mutex> RtLock;
+static std::vector<hipemuStream*> g_streams;
+static std::map<uintptr_t, size_t> g_allocs;            // every hipMalloc / hipHostMalloc range (device or pinned)
+static int g_async = -1;
+
+static int async_mode() {
+    if (g_async < 0) {
+        const char* e = std::getenv("HIPEMU_ASYNC");
+        g_async = e ? std::atoi(e) : 0;
+        if (g_async < 0 || g_async > 2) g_async = 0;
+    }
+    return g_async;
+}
+static bool tracked(const void* p) {
+    auto it = g_allocs.upper_bound((uintptr_t)p);
+    if (it == g_allocs.begin()) return false;
+    --it;
+    return (uintptr_t)p < it->first + it->second;
+}
+static void unref(hipemuEvent* e) { if (--e->refs == 0 && e->destroyed) delete e; }
+static bool runnable(hipemuStream* s) {
+    if (s->q.empty()) return false;
+    const EmuOp& op = s->q.front();
+    return op.kind != EmuOp::WAIT || op.ev->completed >= op.seq;
+}
+static void exec_head(hipemuStream* s) {
+    EmuOp op = std::move(s->q.front());
+    s->q.pop_front();
+    switch (op.kind) {
+    case EmuOp::RUN: op.fn(); break;
+    case EmuOp::RECORD:
+        op.ev->t = std::chrono::steady_clock::now();
+        if (op.ev->completed < op.seq) op.ev->completed = op.seq;
+        unref(op.ev);
+        break;
+    case EmuOp::WAIT: unref(op.ev); break;
+    }
+}
+static void satisfy(hipemuEvent* e, uint64_t seq, int depth);
+static void step(hipemuStream* s, int depth) {           // the head of s, after whatever it waits for
+    const EmuOp& op = s->q.front();
+    if (op.kind == EmuOp::WAIT && op.ev->completed < op.seq) satisfy(op.ev, op.seq, depth + 1);
+    exec_head(s);
+}
+static void satisfy(hipemuEvent* e, uint64_t seq, int depth) {
+    if (depth > 256) { std::fprintf(stderr, "hipemu: event wait cycle\n"); std::abort(); }
+    while (e->completed < seq) {
+        hipemuStream* r = nullptr;
+        for (hipemuStream* s : g_streams) {
+            for (const EmuOp& op : s->q)
+                if (op.kind == EmuOp::RECORD && op.ev == e && op.seq >= seq) { r = s; break; }
+            if (r) break;
+        }
+        if (!r) { std::fprintf(stderr, "hipemu: wait for an event whose record is queued nowhere\n"); std::abort(); }
+        step(r, depth);
+    }
+}
+static void drain_stream(hipemuStream* s) { while (!s->q.empty()) step(s, 0); }
+template <class Done> static void others_first_until(Done done, hipemuStream* target) {
+    while (!done()) {
+        hipemuStream* pick = nullptr;
+        for (auto it = g_streams.rbegin(); it != g_streams.rend(); ++it)
+            if (*it != target && runnable(*it)) { pick = *it; break; }
+        if (!pick && target && runnable(target)) pick = target;
+        if (!pick) { std::fprintf(stderr, "hipemu: deadlock: nothing runnable at a synchronisation point\n"); std::abort(); }
+        exec_head(pick);
+    }
+}
+static void drain_all() {
+    if (async_mode() == 1)
+        others_first_until([] { for (hipemuStream* s : g_streams) if (!s->q.empty()) return false; return true; }, nullptr);
+    else
+        for (hipemuStream* s : g_streams) drain_stream(s);
+}
+static bool deferred(hipStream_t s) { return s != nullptr && async_mode() != 0; }
+static long g_deferred_total = 0;
+static void enqueue(hipStream_t s, std::function<void()> fn) { ++g_deferred_total; s->q.push_back(EmuOp{EmuOp::RUN, std::move(fn), nullptr, 0}); }
+
+namespace hipemu {
+void launch_on(hipStream_t st, std::function<void()> body, dim3 grid, dim3 block, size_t shmem) {
+    RtLock lock(g_rt_mu);
+    if (!deferred(st)) { launch(std::move(body), grid, block, shmem); return; }
+    enqueue(st, [body, grid, block, shmem]() { launch(body, grid, block, shmem); });
+}
+}  // namespace hipemu
+
+extern "C" void hipemu_set_async(int mode) {
+    RtLock lock(g_rt_mu);
+    async_mode();
+    drain_all();
+    g_async = mode < 0 || mode > 2 ? 0 : mode;
+}
+extern "C" long hipemu_deferred_total() { RtLock lock(g_rt_mu); return g_deferred_total; }
+extern "C" int hipemu_pending_ops() {
+    RtLock lock(g_rt_mu);
+    size_t n = 0;
+    for (hipemuStream* s : g_streams) n += s->q.size();
+    return (int)n;
+}
 
 hipError_t hipMalloc(void** p, size_t n) {
     void* q = nullptr;
     if (posix_memalign(&q, 256, n ? n : 1)) return hipErrorOutOfMemory;
     std::memset(q, 0xCD, n);  // poison: uninitialised reads show up as garbage
     *p = q;
+    RtLock lock(g_rt_mu);
+    g_allocs[(uintptr_t)q] = n ? n : 1;
     return hipSuccess;
 }
-hipError_t hipFree(void* p) { std::free(p); return hipSuccess; }
+hipError_t hipFree(void* p) {
+    RtLock lock(g_rt_mu);
+    drain_all();                                         // the runtime synchronises the device before it frees
+    g_allocs.erase((uintptr_t)p);
+    std::free(p);
+    return hipSuccess;
+}
 hipError_t hipHostMalloc(void** p, size_t n, unsigned) { return hipMalloc(p, n); }
-hipError_t hipHostFree(void* p) { std::free(p); return hipSuccess; }
+hipError_t hipHostFree(void* p) { return hipFree(p); }
 hipError_t hipMemcpy(void* d, const void* s, size_t n, hipMemcpyKind) { std::memmove(d, s, n); return hipSuccess; }
-hipError_t hipMemcpyAsync(void* d, const void* s, size_t n, hipMemcpyKind, hipStream_t) { std::memmove(d, s, n); return hipSuccess; }
+static hipError_t copy_async(void* d, const void* s, size_t n, hipStream_t st) {
+    RtLock lock(g_rt_mu);
+    if (!deferred(st)) { std::memmove(d, s, n); return hipSuccess; }
+    if (!tracked(s)) {
+        // pageable host source: staged before the call returns (the caller may reuse the buffer at once)
+        auto snap = std::make_shared<std::vector<char>>((const char*)s, (const char*)s + n);
+        enqueue(st, [d, snap, n]() { std::memcpy(d, snap->data(), n); });
+    } else {
+        enqueue(st, [d, s, n]() { std::memmove(d, s, n); });
+    }
+    return hipSuccess;
+}
+hipError_t hipMemcpyAsync(void* d, const void* s, size_t n, hipMemcpyKind, hipStream_t st) { return copy_async(d, s, n, st); }
 hipError_t hipMemset(void* d, int v, size_t n) { std::memset(d, v, n); return hipSuccess; }
-hipError_t hipMemsetAsync(void* d, int v, size_t n, hipStream_t) { std::memset(d, v, n); return hipSuccess; }
-hipError_t hipStreamCreate(hipStream_t* s) { *s = new hipemuStream(); return hipSuccess; }
+hipError_t hipMemsetAsync(void* d, int v, size_t n, hipStream_t st) {
+    RtLock lock(g_rt_mu);
+    if (!deferred(st)) { std::memset(d, v, n); return hipSuccess; }
+    enqueue(st, [d, v, n]() { std::memset(d, v, n); });
+    return hipSuccess;
+}
+hipError_t hipStreamCreate(hipStream_t* s) {
+    RtLock lock(g_rt_mu);
+    *s = new hipemuStream();
+    g_streams.push_back(*s);
+    return hipSuccess;
+}
 hipError_t hipStreamCreateWithFlags(hipStream_t* s, unsigned) { return hipStreamCreate(s); }
-hipError_t hipStreamDestroy(hipStream_t s) { delete s; return hipSuccess; }
-hipError_t hipStreamSynchronize(hipStream_t) { return hipSuccess; }
-hipError_t hipStreamWaitEvent(hipStream_t, hipEvent_t, unsigned) { return hipSuccess; }
-hipError_t hipDeviceSynchronize() { return hipSuccess; }
+hipError_t hipStreamDestroy(hipStream_t s) {
+    RtLock lock(g_rt_mu);
+    drain_stream(s);
+    g_streams.erase(std::find(g_streams.begin(), g_streams.end(), s));
+    delete s;
+    return hipSuccess;
+}
+hipError_t hipStreamSynchronize(hipStream_t s) {
+    RtLock lock(g_rt_mu);
+    if (!s) return hipSuccess;
+    if (async_mode() == 1) others_first_until([s] { return s->q.empty(); }, s);
+    else drain_stream(s);
+    return hipSuccess;
+}
+hipError_t hipStreamWaitEvent(hipStream_t s, hipEvent_t e, unsigned) {
+    RtLock lock(g_rt_mu);
+    if (e->completed >= e->enqueued) return hipSuccess;  // nothing outstanding (or never recorded): no dependency
+    if (!s) { satisfy(e, e->enqueued, 0); return hipSuccess; }
+    ++e->refs;
+    s->q.push_back(EmuOp{EmuOp::WAIT, nullptr, e, e->enqueued});
+    return hipSuccess;
+}
+hipError_t hipDeviceSynchronize() { RtLock lock(g_rt_mu); drain_all(); return hipSuccess; }
 // HIPEMU_DEVICES=G: G emulated devices sharing the host's memory (tests of the single-process multi-device entry points)
 static int emu_device_count() {
     const char* e = std::getenv("HIPEMU_DEVICES");
@@ -282,7 +457,7 @@ hipError_t hipSetDevice(int d) {
 }
 hipError_t hipGetDevice(int* d) { *d = t_device; return hipSuccess; }
 hipError_t hipGetDeviceCount(int* n) { *n = emu_device_count(); return hipSuccess; }
-hipError_t hipMemcpyPeerAsync(void* d, int, const void* s, int, size_t n, hipStream_t) { std::memmove(d, s, n); return hipSuccess; }
+hipError_t hipMemcpyPeerAsync(void* d, int, const void* s, int, size_t n, hipStream_t st) { return copy_async(d, s, n, st); }
 hipError_t hipGetDeviceProperties(hipDeviceProp_t* p, int d) {
     if (d < 0 || d >= emu_device_count()) return hipErrorInvalidDevice;
     std::memset(p, 0, sizeof(*p));
@@ -295,10 +470,34 @@ hipError_t hipGetDeviceProperties(hipDeviceProp_t* p, int d) {
 }
 hipError_t hipEventCreate(hipEvent_t* e) { *e = new hipemuEvent(); return hipSuccess; }
 hipError_t hipEventCreateWithFlags(hipEvent_t* e, unsigned) { return hipEventCreate(e); }
-hipError_t hipEventDestroy(hipEvent_t e) { delete e; return hipSuccess; }
-hipError_t hipEventRecord(hipEvent_t e, hipStream_t) { e->t = std::chrono::steady_clock::now(); return hipSuccess; }
-hipError_t hipEventSynchronize(hipEvent_t) { return hipSuccess; }
+hipError_t hipEventDestroy(hipEvent_t e) {
+    RtLock lock(g_rt_mu);
+    if (e->refs > 0) e->destroyed = true;                // released when the queued record / waits have run
+    else delete e;
+    return hipSuccess;
+}
+hipError_t hipEventRecord(hipEvent_t e, hipStream_t s) {
+    RtLock lock(g_rt_mu);
+    ++e->enqueued;
+    if (!deferred(s) && (!s || s->q.empty())) {
+        e->t = std::chrono::steady_clock::now();
+        e->completed = e->enqueued;
+        return hipSuccess;
+    }
+    ++e->refs;
+    s->q.push_back(EmuOp{EmuOp::RECORD, nullptr, e, e->enqueued});
+    return hipSuccess;
+}
+hipError_t hipEventSynchronize(hipEvent_t e) {
+    RtLock lock(g_rt_mu);
+    const uint64_t seq = e->enqueued;
+    if (async_mode() == 1) others_first_until([e, seq] { return e->completed >= seq; }, nullptr);
+    else satisfy(e, seq, 0);
+    return hipSuccess;
+}
 hipError_t hipEventElapsedTime(float* ms, hipEvent_t a, hipEvent_t b) {
+    RtLock lock(g_rt_mu);
+    if (a->completed < a->enqueued || b->completed < b->enqueued) return hipErrorNotReady;
     *ms = std::chrono::duration<float, std::milli>(b->t - a->t).count();
     return hipSuccess;
 }
