@@ -374,20 +374,47 @@ extern "C" int hipemu_pending_ops() {
     return (int)n;
 }
 
+// HIPEMU_GUARD=1: every allocation ends (to 32 bytes) against an inaccessible page and starts behind one, so that a
+// kernel reading or writing past its buffer faults at the access instead of silently touching a neighbour.
+struct GuardedAlloc { void* base; size_t len; };
+static std::map<uintptr_t, GuardedAlloc> g_guarded;
+static bool guard_mode() {
+    static const bool on = [] { const char* e = std::getenv("HIPEMU_GUARD"); return e && std::atoi(e) != 0; }();
+    return on;
+}
 hipError_t hipMalloc(void** p, size_t n) {
     void* q = nullptr;
-    if (posix_memalign(&q, 256, n ? n : 1)) return hipErrorOutOfMemory;
+    const size_t want = n ? n : 1;
+    if (guard_mode()) {
+        const size_t page = 4096, body = (want + 31) & ~(size_t)31, pages = (body + page - 1) / page;
+        const size_t len = (pages + 2) * page;
+        char* base = (char*)mmap(nullptr, len, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS, -1, 0);
+        if (base == (char*)MAP_FAILED) return hipErrorOutOfMemory;
+        mprotect(base, page, PROT_NONE);
+        mprotect(base + (pages + 1) * page, page, PROT_NONE);
+        q = base + (pages + 1) * page - body;
+        RtLock lock(g_rt_mu);
+        g_guarded[(uintptr_t)q] = GuardedAlloc{base, len};
+    } else if (posix_memalign(&q, 256, want)) {
+        return hipErrorOutOfMemory;
+    }
     std::memset(q, 0xCD, n);  // poison: uninitialised reads show up as garbage
     *p = q;
     RtLock lock(g_rt_mu);
-    g_allocs[(uintptr_t)q] = n ? n : 1;
+    g_allocs[(uintptr_t)q] = want;
     return hipSuccess;
 }
 hipError_t hipFree(void* p) {
     RtLock lock(g_rt_mu);
     drain_all();                                         // the runtime synchronises the device before it frees
     g_allocs.erase((uintptr_t)p);
-    std::free(p);
+    auto it = g_guarded.find((uintptr_t)p);
+    if (it != g_guarded.end()) {
+        munmap(it->second.base, it->second.len);
+        g_guarded.erase(it);
+    } else {
+        std::free(p);
+    }
     return hipSuccess;
 }
 hipError_t hipHostMalloc(void** p, size_t n, unsigned) { return hipMalloc(p, n); }

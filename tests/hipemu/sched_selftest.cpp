@@ -43,3 +43,14 @@ extern "C" int sched_selftest(int mode, int with_fork_wait, int with_join_wait, 
     hipemu_set_async(0);
     return 0;
 }
+
+// HIPEMU_GUARD=1: a kernel that stores one element past its buffer must fault at the store (tests/test_emu_schedules.py
+// runs this in a child process and expects SIGSEGV with overrun = 1, a clean return with overrun = 0).
+extern "C" int guard_probe(int overrun) {
+    const int n = 100;                                   // 800 bytes: the buffer ends exactly at the guard page
+    double* A;
+    hipMalloc(&A, n * sizeof(double));
+    hipLaunchKernelGGL(sched_fill, dim3(2), dim3(64), 0, (hipStream_t)0, A, 1.0, n + (overrun ? 1 : 0));
+    hipFree(A);
+    return 0;
+}

@@ -70,3 +70,33 @@ def test_multi_stream_paths_under_deferred_schedules(emu, mode, monkeypatch):
     finally:
         emu.hipemu_set_async(0)
     assert emu.hipemu_deferred_total() > before + 100    # the work really went through the stream queues
+
+
+def _child(code_or_args, env_extra, timeout=900):
+    import subprocess
+    env = dict(os.environ, **env_extra)
+    env["PYTHONPATH"] = os.pathsep.join([os.path.dirname(HERE), env.get("PYTHONPATH", "")])
+    return subprocess.run([sys.executable] + code_or_args, env=env, cwd=os.path.dirname(HERE), capture_output=True,
+                          text=True, timeout=timeout)
+
+
+def test_guard_pages_fault_on_an_overrun():
+    """HIPEMU_GUARD=1: one element past the end of a device buffer is a fault at the store, not a silent neighbour write"""
+    import build_emu
+    lib = build_emu.build_sched_selftest()
+    probe = "import ctypes,sys; sys.exit(ctypes.CDLL(%r).guard_probe(int(sys.argv[1])))" % lib
+    assert _child(["-c", probe, "0"], {"HIPEMU_GUARD": "1"}).returncode == 0
+    assert _child(["-c", probe, "1"], {"HIPEMU_GUARD": "1"}).returncode == -11       # SIGSEGV
+    assert _child(["-c", probe, "1"], {"HIPEMU_GUARD": "0"}).returncode == 0         # (unnoticed without the guard)
+
+
+def test_kernels_stay_inside_their_buffers():
+    """a broad, fast subset of the interpreter tests again with every device buffer fenced by inaccessible pages: ragged
+    and edge sizes, multi-panel factorisation, chunked workspaces, batched likelihoods, the mixture and the argmax paths"""
+    pick = ("edge_sizes or shape_sweep or golden_cases or multi_panel or chunked_workspace or mcmc_marginal or "
+            "batched_likelihoods or fit_batch_keeps or ill_conditioned or fabolas_kernel or candidate_reupload or "
+            "argmax_semantics or model_gradients or small_and_large_candidate")
+    r = _child(["-m", "pytest", os.path.join(HERE, "test_emu_logic.py"), "-x", "-q", "-p", "no:cacheprovider", "-k", pick],
+               {"HIPEMU_GUARD": "1"})
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert " passed" in r.stdout and "failed" not in r.stdout
