@@ -201,6 +201,8 @@ void launch(std::function<void()> body, dim3 grid, dim3 block, size_t shmem) {
     size_t nt = (size_t)block.x * block.y * block.z;
     if (nt == 0 || nt > 1024) { std::fprintf(stderr, "hipemu: bad block size %zu\n", nt); std::abort(); }
     if (g_fibers.size() < nt) g_fibers.resize(nt);
+    static const int order = [] { const char* e = std::getenv("HIPEMU_ORDER"); return e ? std::atoi(e) : 0; }();
+    unsigned long long rot = 0x9E3779B97F4A7C15ull;
     g_body = std::move(body);
     g_bdim = block; g_gdim = grid;
     g_dyn.assign(shmem + 64, 0);
@@ -221,7 +223,14 @@ void launch(std::function<void()> body, dim3 grid, dim3 block, size_t shmem) {
         for (int w = 0; w < nw; ++w) { int a = (int)nt - w * 64; g_wave_alive[w] = a > 64 ? 64 : a; g_wave_wait[w] = 0; }
         while (g_live > 0) {
             bool progressed = false;
-            for (size_t i = 0; i < nt; ++i) {
+            rot = rot * 6364136223846793005ull + 1442695040888963407ull;
+            for (size_t k = 0; k < nt; ++k) {
+                // HIPEMU_ORDER: which work-item runs next between two rendezvous points.  0: ascending (default);
+                // 1: descending -- a consumer wave now runs BEFORE the producer wave it forgot to __syncthreads with;
+                // 2: a different pseudo-random rotation and direction every pass
+                size_t i = k;
+                if (order == 1) i = nt - 1 - k;
+                else if (order == 2) i = (rot & 1) ? (nt - 1 - (k + (size_t)(rot >> 1)) % nt) : (k + (size_t)(rot >> 1)) % nt;
                 Fiber& f = F[i];
                 if (f.state != READY) continue;
                 progressed = true;

@@ -54,3 +54,24 @@ extern "C" int guard_probe(int overrun) {
     hipFree(A);
     return 0;
 }
+
+// HIPEMU_ORDER: wave 1 consumes what wave 0 produced in LDS; without the barrier the result depends on which wave's
+// work-items the interpreter runs first.  Returns the number of stale elements wave 1 saw.
+__global__ void lds_handoff(double* out, int with_barrier) {
+    __shared__ double buf[64];
+    const int t = threadIdx.x;
+    if (t < 64) buf[t] = 0.0;
+    __syncthreads();
+    if (t < 64) buf[t] = t + 1.0;
+    if (with_barrier) __syncthreads();
+    if (t >= 64) out[t - 64] = buf[t - 64];
+}
+extern "C" int order_probe(int with_barrier) {
+    double* out;
+    hipMalloc(&out, 64 * sizeof(double));
+    hipLaunchKernelGGL(lds_handoff, dim3(1), dim3(128), 0, (hipStream_t)0, out, with_barrier);
+    int stale = 0;
+    for (int i = 0; i < 64; ++i) stale += out[i] != i + 1.0;
+    hipFree(out);
+    return stale;
+}

@@ -100,3 +100,28 @@ def test_kernels_stay_inside_their_buffers():
                {"HIPEMU_GUARD": "1"})
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert " passed" in r.stdout and "failed" not in r.stdout
+
+
+def test_work_item_order_exposes_a_missing_barrier():
+    """HIPEMU_ORDER=1 (descending) / 2 (rotating): a wave that reads LDS another wave wrote, without __syncthreads in
+    between, sees stale data; the default ascending order hides it.  With the barrier every order agrees."""
+    import build_emu
+    lib = build_emu.build_sched_selftest()
+    probe = "import ctypes,sys; sys.exit(ctypes.CDLL(%r).order_probe(int(sys.argv[1])))" % lib
+    for order in ("0", "1", "2"):
+        assert _child(["-c", probe, "1"], {"HIPEMU_ORDER": order}).returncode == 0
+    # ascending order hides it (all but the work-item that arrived last at the previous barrier and runs on first)
+    assert _child(["-c", probe, "0"], {"HIPEMU_ORDER": "0"}).returncode <= 1
+    assert _child(["-c", probe, "0"], {"HIPEMU_ORDER": "1"}).returncode >= 63         # (nearly) every element stale
+
+
+@pytest.mark.parametrize("order", ["1", "2"])
+def test_kernels_do_not_depend_on_work_item_order(order):
+    """the fast subset of the interpreter tests with the work-items of a workgroup run in descending / rotating order"""
+    pick = ("edge_sizes or shape_sweep or golden_cases or multi_panel or chunked_workspace or mcmc_marginal or "
+            "batched_likelihoods or fit_batch_keeps or ill_conditioned or fabolas_kernel or candidate_reupload or "
+            "argmax_semantics or model_gradients or small_and_large_candidate")
+    r = _child(["-m", "pytest", os.path.join(HERE, "test_emu_logic.py"), "-x", "-q", "-p", "no:cacheprovider", "-k", pick],
+               {"HIPEMU_ORDER": order})
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert " passed" in r.stdout and "failed" not in r.stdout
