@@ -64,7 +64,7 @@ def test_multi_stream_paths_under_deferred_schedules(emu, mode, monkeypatch):
     emu.hipemu_set_async(mode)
     try:
         ctx = _lib.Context(0)
-        P.check_batched_split(ctx)
+        P.check_batched_split(ctx, N=300, variants=((2, 2, -1),))
         M.check_sample_shard([0, 1])
         M.check_candidate_shard([0, 1])
     finally:
@@ -90,14 +90,19 @@ def test_guard_pages_fault_on_an_overrun():
     assert _child(["-c", probe, "1"], {"HIPEMU_GUARD": "0"}).returncode == 0         # (unnoticed without the guard)
 
 
-def test_kernels_stay_inside_their_buffers():
-    """a broad, fast subset of the interpreter tests again with every device buffer fenced by inaccessible pages: ragged
-    and edge sizes, multi-panel factorisation, chunked workspaces, batched likelihoods, the mixture and the argmax paths"""
-    pick = ("edge_sizes or shape_sweep or golden_cases or multi_panel or chunked_workspace or mcmc_marginal or "
-            "batched_likelihoods or fit_batch_keeps or ill_conditioned or fabolas_kernel or candidate_reupload or "
-            "argmax_semantics or model_gradients or small_and_large_candidate")
-    r = _child(["-m", "pytest", os.path.join(HERE, "test_emu_logic.py"), "-x", "-q", "-p", "no:cacheprovider", "-k", pick],
-               {"HIPEMU_GUARD": "1"})
+_FAST_SUBSET = ("edge_sizes or shape_sweep or golden_cases or multi_panel or chunked_workspace or mcmc_marginal or "
+                "batched_likelihoods or fit_batch_keeps or ill_conditioned or fabolas_kernel or candidate_reupload or "
+                "argmax_semantics or model_gradients")
+
+
+@pytest.mark.parametrize("env", [{"HIPEMU_GUARD": "1", "HIPEMU_ORDER": "1"}, {"HIPEMU_ORDER": "2"}],
+                         ids=["fenced+descending", "rotating"])
+def test_kernels_stay_inside_their_buffers_in_any_work_item_order(env):
+    """a broad, fast subset of the interpreter tests again (ragged and edge sizes, multi-panel factorisation, chunked
+    workspaces, batched likelihoods, the mixture and the argmax paths): once with every device buffer fenced by
+    inaccessible pages and the work-items of a workgroup run in descending order, once in rotating order"""
+    r = _child(["-m", "pytest", os.path.join(HERE, "test_emu_logic.py"), "-x", "-q", "-p", "no:cacheprovider",
+                "-k", _FAST_SUBSET], env)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert " passed" in r.stdout and "failed" not in r.stdout
 
@@ -113,15 +118,3 @@ def test_work_item_order_exposes_a_missing_barrier():
     # ascending order hides it (all but the work-item that arrived last at the previous barrier and runs on first)
     assert _child(["-c", probe, "0"], {"HIPEMU_ORDER": "0"}).returncode <= 1
     assert _child(["-c", probe, "0"], {"HIPEMU_ORDER": "1"}).returncode >= 63         # (nearly) every element stale
-
-
-@pytest.mark.parametrize("order", ["1", "2"])
-def test_kernels_do_not_depend_on_work_item_order(order):
-    """the fast subset of the interpreter tests with the work-items of a workgroup run in descending / rotating order"""
-    pick = ("edge_sizes or shape_sweep or golden_cases or multi_panel or chunked_workspace or mcmc_marginal or "
-            "batched_likelihoods or fit_batch_keeps or ill_conditioned or fabolas_kernel or candidate_reupload or "
-            "argmax_semantics or model_gradients or small_and_large_candidate")
-    r = _child(["-m", "pytest", os.path.join(HERE, "test_emu_logic.py"), "-x", "-q", "-p", "no:cacheprovider", "-k", pick],
-               {"HIPEMU_ORDER": order})
-    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
-    assert " passed" in r.stdout and "failed" not in r.stdout
