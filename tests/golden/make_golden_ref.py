@@ -569,10 +569,51 @@ def make_branin_single_point(R, seed=4, n_iter=11):
     _save("ref_branin_single_point", **out)
 
 
+# ------------------------------------------------------------------------------------------------
+# (8) robo.fmin.bayesian_optimization(model_type="gp_mcmc", acquisition_func="log_ei"): the front end's own
+#     MCMC configuration (DefaultPrior, 3 * len(kernel) walkers, 100 burn-in + 200 steps per iteration),
+#     LogEI marginalised over the walkers' last positions (MarginalizationGPMCMC), RandomSampling
+# ------------------------------------------------------------------------------------------------
+def make_branin_gpmcmc(R, seed=7, n_iter=11):
+    _placeholder_optional_models()
+    from robo.fmin import bayesian_optimization as fmin_bo
+    M = R.GaussianProcessMCMC
+    log = []
+    orig_train = M.train
+
+    def train(self, X, y, do_optimize=True, **kw):
+        before = self.rng.get_state()
+        orig_train(self, X, y, do_optimize, **kw)
+        st = np.random.get_state()
+        after = self.rng.get_state()
+        log.append(dict(n=X.shape[0], hypers=np.array(self.hypers, dtype=np.float64), keys=st[1].copy(), pos=st[2],
+                        has_gauss=st[3], cached=st[4], own_keys=after[1].copy(), own_pos=after[2],
+                        own_before_keys=before[1].copy(), own_before_pos=before[2]))
+
+    M.train = train
+    try:
+        lo, hi = np.array([-5.0, 0.0]), np.array([10.0, 15.0])
+        np.random.seed(seed)
+        res = fmin_bo(branin, lo, hi, num_iterations=n_iter, n_init=3, model_type="gp_mcmc", acquisition_func="log_ei",
+                      maximizer="random", rng=np.random.RandomState(seed))
+    finally:
+        M.train = orig_train
+    out = dict(X=np.array(res["X"]), y=np.array(res["y"]), x_opt=np.array(res["x_opt"]), f_opt=res["f_opt"],
+               incumbent_values=np.array(res["incumbent_values"]), seed=seed,
+               n=np.array([l["n"] for l in log]), hypers=np.array([l["hypers"] for l in log]),
+               rng_keys=np.array([l["keys"] for l in log]), rng_pos=np.array([l["pos"] for l in log]),
+               rng_has_gauss=np.array([l["has_gauss"] for l in log]), rng_cached=np.array([l["cached"] for l in log]),
+               own_keys=np.array([l["own_keys"] for l in log]), own_pos=np.array([l["own_pos"] for l in log]),
+               own_before_keys=np.array([l["own_before_keys"] for l in log]),
+               own_before_pos=np.array([l["own_before_pos"] for l in log]))
+    print("branin gp_mcmc f_opt", res["f_opt"], "walkers", out["hypers"].shape)
+    _save("ref_branin_gpmcmc", **out)
+
+
 MAKERS = dict(gp=make_gp, mcmc=make_mcmc, fabolas=make_fabolas, infogain=make_infogain,
               infogain_config4=make_infogain_config4, branin=make_branin,
               entropy_search=make_entropy_search, fabolas_frontend=make_fabolas_frontend,
-              branin_single_point=make_branin_single_point)
+              branin_single_point=make_branin_single_point, branin_gpmcmc=make_branin_gpmcmc)
 
 if __name__ == "__main__":
     R = reference()

@@ -536,3 +536,76 @@ def check_ref_fabolas_replay(device=None, n_iter=None):
     finally:
         InformationGainPerUnitCost.sample_representer_points = orig
     return n_all if n_iter is None else min(n_iter, n_all)
+
+
+def check_ref_branin_gpmcmc_replay(device=None, devices=None, max_iters=None, chain=True):
+    """robo.fmin.bayesian_optimization(model_type="gp_mcmc", acquisition_func="log_ei", maximizer="random") -- the
+    reference's own run on Branin with the front end's MCMC configuration (DefaultPrior, 10 walkers, 100 burn-in + 200
+    steps per iteration; fixture ref_branin_gpmcmc).  At every model-based iteration: the data so far, the walkers' last
+    positions the reference's chain ended on, the global RNG state it had before maximising -> robo_amd's
+    GaussianProcessMCMC (one batched fit of the 10 samples) + MarginalizationGPMCMC(LogEI) + RandomSampling must pick the
+    SAME candidate, bit for bit (= the same argmax of the marginal LogEI over the 500 candidates).
+    ``chain``: additionally robo_amd's OWN chains, started from the reference's generator state before the first training
+    (prior draw + burn-in + 200 steps, then 200 steps from the previous positions at every later iteration), must end on
+    the reference's walkers at EVERY iteration (rtol 1e-6) with the generator standing exactly where the reference's stood.
+    -> (iterations checked, smallest relative gap between the best and the second-best candidate)"""
+    from robo_amd.maximizers import RandomSampling
+    gold = load("ref_branin_gpmcmc")
+    lo, hi = np.array([-5.0, 0.0]), np.array([10.0, 15.0])
+    X, y = gold["X"], gold["y"]
+    np.testing.assert_array_equal(y, np.array([G.branin(x) for x in X]))
+    S = gold["hypers"].shape[1]
+    assert S == 10 and gold["hypers"].shape[2] == 4      # 3 * len(kernel) = 9 -> even (bayesian_optimization.py:86-88)
+
+    class Pinned(GaussianProcessMCMC):
+        def _keep_hypers_without_optimize(self):          # train(do_optimize=False) keeps the samples put in place
+            return True
+
+    def build(cls, rng):
+        kernel = 2 * Matern52Kernel(np.ones(2), ndim=2)
+        kw = dict(devices=devices) if devices is not None else dict(device=device)
+        # the front end gives the prior NO generator (bayesian_optimization.py:84): DefaultPrior seeds its own from the
+        # GLOBAL stream (default_priors.py:11-12) -- the first global draw after the caller's np.random.seed
+        return cls(kernel, prior=DefaultPrior(len(kernel) + 1), n_hypers=S, chain_length=200, burnin_steps=100,
+                   normalize_input=True, normalize_output=False, rng=rng, lower=lo, upper=hi, **kw)
+
+    np.random.seed(int(gold["seed"]))
+    model = build(Pinned, np.random.RandomState(0))
+    acq = A.MarginalizationGPMCMC(A.LogEI(model))
+    rs = RandomSampling(acq, lo, hi, rng=np.random.RandomState(0))
+    n_checked, gap = 0, np.inf
+    for it, n in enumerate(gold["n"]):
+        if max_iters is not None and it >= max_iters:
+            break
+        model.hypers = [h for h in gold["hypers"][it]]
+        model.train(X[:n], y[:n], do_optimize=False)
+        assert len(model.models) == S
+        acq.update(model)
+        _set_global_rng({k: gold[k][it] for k in ("rng_keys", "rng_pos", "rng_has_gauss", "rng_cached")}, "")
+        cand = rs.candidates()
+        vals = np.asarray(acq.compute(cand)).reshape(-1)
+        order = np.argsort(vals)
+        gap = min(gap, float((vals[order[-1]] - vals[order[-2]]) / abs(vals[order[-1]])))
+        _set_global_rng({k: gold[k][it] for k in ("rng_keys", "rng_pos", "rng_has_gauss", "rng_cached")}, "")
+        x_new = rs.maximize()
+        np.testing.assert_array_equal(x_new, X[n], err_msg="iteration %d (n=%d)" % (it, n))
+        np.testing.assert_array_equal(x_new, cand[order[-1]])
+        n_checked += 1
+    if chain:
+        # the chain itself, first training: the reference's generator stood at own_before; robo_amd draws the prior sample,
+        # burns in and runs the chain with the same stream consumption and must end where the reference ended
+        rng = np.random.RandomState(0)
+        rng.set_state(("MT19937", gold["own_before_keys"][0], int(gold["own_before_pos"][0]), 0, 0.0))
+        np.random.seed(int(gold["seed"]))
+        own = build(GaussianProcessMCMC, rng)
+        for it, n in enumerate(gold["n"]):
+            if max_iters is not None and it >= max_iters:
+                break
+            # (nothing else draws from this generator between two trainings: the maximiser uses the global stream)
+            own.train(X[:n], y[:n], do_optimize=True)
+            np.testing.assert_allclose(np.asarray(own.hypers), gold["hypers"][it], rtol=1e-6, atol=1e-8,
+                                       err_msg="chain of iteration %d" % it)
+            st = rng.get_state()
+            np.testing.assert_array_equal(st[1], gold["own_keys"][it])
+            assert int(st[2]) == int(gold["own_pos"][it])
+    return n_checked, gap

@@ -254,3 +254,12 @@ def test_more_devices_than_samples_and_copies(emu3):
     clone = pickle.loads(pickle.dumps(m3))
     for a, b in zip(clone.predict(Xc), m1.predict(Xc)):
         np.testing.assert_array_equal(a, b)
+
+
+def test_reference_gp_mcmc_run_replayed_on_3_devices(emu3):
+    """the REFERENCE'S own robo.fmin.bayesian_optimization(model_type="gp_mcmc") run (fixture ref_branin_gpmcmc): with the
+    10 hyper-parameter samples spread over three devices of this process (4/3/3: batched fits per device, per-device
+    partial sums added in device order) the marginal LogEI still picks the reference's candidate at every iteration"""
+    import ref_checks as R
+    checked, gap = R.check_ref_branin_gpmcmc_replay(devices=[0, 1, 2], chain=False)
+    assert checked == 8 and gap > 1e-7, (checked, gap)

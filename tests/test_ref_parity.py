@@ -69,6 +69,13 @@ def test_single_point_maximizers_replay_emulated(emu):
     assert checked == 4 and same >= 3, (checked, same)
 
 
+def test_gp_mcmc_front_end_replay_emulated(emu):
+    """robo.fmin.bayesian_optimization(model_type="gp_mcmc", acquisition_func="log_ei"): the reference's own run replayed --
+    the candidate chosen at all 8 model-based iterations, and robo_amd's own chains ending on the reference's walkers"""
+    checked, gap = R.check_ref_branin_gpmcmc_replay(max_iters=4)       # (interpreter: half the run; all of it on the MI355X)
+    assert checked == 4 and gap > 1e-7, (checked, gap)
+
+
 def test_entropy_search_replay_emulated(emu):
     assert R.check_ref_entropy_search_replay() == 6
 
@@ -136,6 +143,15 @@ def test_single_point_maximizers_trajectory_replay(gpu):
     checked, same = R.check_ref_single_point_replay()
     print("single-point maximisers: %d iterations replayed, %d on the reference's point to 1e-3 of the box" % (checked, same))
     assert checked == 16 and same >= 12, (checked, same)
+
+
+@pytest.mark.gpu
+def test_gp_mcmc_front_end_trajectory_replay(gpu):
+    """the reference's own gp_mcmc + LogEI run: same choice at all 8 model-based iterations (marginal LogEI over the 10
+    walkers, one batched fit per iteration), and robo_amd's device-resident chains end on the reference's walkers"""
+    checked, gap = R.check_ref_branin_gpmcmc_replay()
+    print("gp_mcmc front end: %d iterations replayed, smallest best-vs-second gap %.2e" % (checked, gap))
+    assert checked == 8 and gap > 1e-7, (checked, gap)
 
 
 @pytest.mark.gpu
