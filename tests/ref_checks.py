@@ -609,3 +609,30 @@ def check_ref_branin_gpmcmc_replay(device=None, devices=None, max_iters=None, ch
             np.testing.assert_array_equal(st[1], gold["own_keys"][it])
             assert int(st[2]) == int(gold["own_pos"][it])
     return n_checked, gap
+
+
+def check_ref_branin_gpmcmc_free_run(num_iterations=None, **kw):
+    """robo_amd.fmin.bayesian_optimization(model_type="gp_mcmc", acquisition_func="log_ei", maximizer="random") LEFT TO
+    ITSELF with the seeds of the reference's run: nothing in this configuration is decided by a finite-difference
+    optimiser (the hyper-parameters come from the ensemble sampler, the candidate from an argmax over 500 points), so the
+    whole result must be the reference's -- every evaluated point bit for bit, hence y, the incumbent trajectory, x_opt and
+    f_opt.  (With model_type="gp" the free run diverges after the first differing L-BFGS-B run: check_ref_branin_free_run.)
+    -> number of evaluated points compared"""
+    from robo_amd.fmin import bayesian_optimization
+    gold = load("ref_branin_gpmcmc")
+    seed = int(gold["seed"])
+    n_all = gold["X"].shape[0]
+    n_it = n_all if num_iterations is None else int(num_iterations)
+    np.random.seed(seed)
+    res = bayesian_optimization(G.branin, np.array([-5.0, 0.0]), np.array([10.0, 15.0]), num_iterations=n_it, n_init=3,
+                                model_type="gp_mcmc", acquisition_func="log_ei", maximizer="random",
+                                rng=np.random.RandomState(seed), **kw)
+    Xm = np.array(res["X"])
+    assert Xm.shape[0] == n_it
+    np.testing.assert_array_equal(Xm, gold["X"][:n_it])
+    np.testing.assert_array_equal(np.array(res["y"]), gold["y"][:n_it])
+    np.testing.assert_array_equal(np.array(res["incumbent_values"]), gold["incumbent_values"][:n_it])
+    if n_it == n_all:
+        np.testing.assert_array_equal(np.asarray(res["x_opt"]), gold["x_opt"])
+        assert float(res["f_opt"]) == float(gold["f_opt"])
+    return n_it

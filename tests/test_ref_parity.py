@@ -72,8 +72,14 @@ def test_single_point_maximizers_replay_emulated(emu):
 def test_gp_mcmc_front_end_replay_emulated(emu):
     """robo.fmin.bayesian_optimization(model_type="gp_mcmc", acquisition_func="log_ei"): the reference's own run replayed --
     the candidate chosen at all 8 model-based iterations, and robo_amd's own chains ending on the reference's walkers"""
-    checked, gap = R.check_ref_branin_gpmcmc_replay(max_iters=4)       # (interpreter: half the run; all of it on the MI355X)
-    assert checked == 4 and gap > 1e-7, (checked, gap)
+    checked, gap = R.check_ref_branin_gpmcmc_replay(chain=False)
+    assert checked == 8 and gap > 1e-7, (checked, gap)
+
+
+def test_gp_mcmc_front_end_free_run_emulated(emu):
+    """robo_amd.fmin.bayesian_optimization(model_type="gp_mcmc") left to itself with the reference's seeds returns the
+    reference's run: every evaluated point, bit for bit (7 of the 11 iterations here, all of them on the MI355X)"""
+    assert R.check_ref_branin_gpmcmc_free_run(num_iterations=7) == 7
 
 
 def test_entropy_search_replay_emulated(emu):
@@ -152,6 +158,8 @@ def test_gp_mcmc_front_end_trajectory_replay(gpu):
     checked, gap = R.check_ref_branin_gpmcmc_replay()
     print("gp_mcmc front end: %d iterations replayed, smallest best-vs-second gap %.2e" % (checked, gap))
     assert checked == 8 and gap > 1e-7, (checked, gap)
+    # and left to itself with the reference's seeds: the reference's whole result, bit for bit
+    assert R.check_ref_branin_gpmcmc_free_run() == 11
 
 
 @pytest.mark.gpu
