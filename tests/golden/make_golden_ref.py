@@ -610,10 +610,28 @@ def make_branin_gpmcmc(R, seed=7, n_iter=11):
     _save("ref_branin_gpmcmc", **out)
 
 
+def make_branin_gpmcmc_acq(R, n_iter=8):
+    """the same front end with the other three acquisition functions under MarginalizationGPMCMC: results only (the free
+    run of robo_amd's front end with the same seeds must return them, tests/ref_checks.py)"""
+    _placeholder_optional_models()
+    from robo.fmin import bayesian_optimization as fmin_bo
+    lo, hi = np.array([-5.0, 0.0]), np.array([10.0, 15.0])
+    out = {}
+    for seed, name in ((8, "ei"), (9, "pi"), (10, "lcb")):
+        np.random.seed(seed)
+        res = fmin_bo(branin, lo, hi, num_iterations=n_iter, n_init=3, model_type="gp_mcmc", acquisition_func=name,
+                      maximizer="random", rng=np.random.RandomState(seed))
+        out.update({name + "_seed": seed, name + "_X": np.array(res["X"]), name + "_y": np.array(res["y"]),
+                    name + "_incumbent_values": np.array(res["incumbent_values"]), name + "_x_opt": np.array(res["x_opt"]),
+                    name + "_f_opt": res["f_opt"]})
+        print("branin gp_mcmc", name, "f_opt", res["f_opt"])
+    _save("ref_branin_gpmcmc_acq", **out)
+
+
 MAKERS = dict(gp=make_gp, mcmc=make_mcmc, fabolas=make_fabolas, infogain=make_infogain,
               infogain_config4=make_infogain_config4, branin=make_branin,
               entropy_search=make_entropy_search, fabolas_frontend=make_fabolas_frontend,
-              branin_single_point=make_branin_single_point, branin_gpmcmc=make_branin_gpmcmc)
+              branin_single_point=make_branin_single_point, branin_gpmcmc=make_branin_gpmcmc, branin_gpmcmc_acq=make_branin_gpmcmc_acq)
 
 if __name__ == "__main__":
     R = reference()

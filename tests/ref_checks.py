@@ -611,7 +611,7 @@ def check_ref_branin_gpmcmc_replay(device=None, devices=None, max_iters=None, ch
     return n_checked, gap
 
 
-def check_ref_branin_gpmcmc_free_run(num_iterations=None, **kw):
+def check_ref_branin_gpmcmc_free_run(num_iterations=None, acquisition_func="log_ei", **kw):
     """robo_amd.fmin.bayesian_optimization(model_type="gp_mcmc", acquisition_func="log_ei", maximizer="random") LEFT TO
     ITSELF with the seeds of the reference's run: nothing in this configuration is decided by a finite-difference
     optimiser (the hyper-parameters come from the ensemble sampler, the candidate from an argmax over 500 points), so the
@@ -619,13 +619,18 @@ def check_ref_branin_gpmcmc_free_run(num_iterations=None, **kw):
     f_opt.  (With model_type="gp" the free run diverges after the first differing L-BFGS-B run: check_ref_branin_free_run.)
     -> number of evaluated points compared"""
     from robo_amd.fmin import bayesian_optimization
-    gold = load("ref_branin_gpmcmc")
+    if acquisition_func == "log_ei":
+        gold = load("ref_branin_gpmcmc")
+    else:
+        # fixture ref_branin_gpmcmc_acq: the reference's runs with EI / PI / LCB under MarginalizationGPMCMC (8 iterations each)
+        full = load("ref_branin_gpmcmc_acq")
+        gold = {k[len(acquisition_func) + 1:]: full[k] for k in full.files if k.startswith(acquisition_func + "_")}
     seed = int(gold["seed"])
     n_all = gold["X"].shape[0]
     n_it = n_all if num_iterations is None else int(num_iterations)
     np.random.seed(seed)
     res = bayesian_optimization(G.branin, np.array([-5.0, 0.0]), np.array([10.0, 15.0]), num_iterations=n_it, n_init=3,
-                                model_type="gp_mcmc", acquisition_func="log_ei", maximizer="random",
+                                model_type="gp_mcmc", acquisition_func=acquisition_func, maximizer="random",
                                 rng=np.random.RandomState(seed), **kw)
     Xm = np.array(res["X"])
     assert Xm.shape[0] == n_it

@@ -263,3 +263,6 @@ def test_reference_gp_mcmc_run_replayed_on_3_devices(emu3):
     import ref_checks as R
     checked, gap = R.check_ref_branin_gpmcmc_replay(devices=[0, 1, 2], chain=False)
     assert checked == 8 and gap > 1e-7, (checked, gap)
+    # and the public entry point itself: bayesian_optimization(model_type="gp_mcmc", n_gpus=3) with the reference's seeds
+    # returns the REFERENCE'S run (first 6 of its 11 points here), not merely its own one-device run
+    assert R.check_ref_branin_gpmcmc_free_run(num_iterations=6, n_gpus=3) == 6

@@ -82,6 +82,13 @@ def test_gp_mcmc_front_end_free_run_emulated(emu):
     assert R.check_ref_branin_gpmcmc_free_run(num_iterations=7) == 7
 
 
+@pytest.mark.parametrize("acq", ["ei", "pi", "lcb"])
+def test_gp_mcmc_front_end_other_acquisitions_free_run_emulated(emu, acq):
+    """the same front end with EI / PI / LCB under MarginalizationGPMCMC: the reference's runs (fixture
+    ref_branin_gpmcmc_acq), first 5 of 8 iterations here, bit for bit"""
+    assert R.check_ref_branin_gpmcmc_free_run(num_iterations=5, acquisition_func=acq) == 5
+
+
 def test_entropy_search_replay_emulated(emu):
     assert R.check_ref_entropy_search_replay() == 6
 
@@ -152,6 +159,20 @@ def test_single_point_maximizers_trajectory_replay(gpu):
 
 
 @pytest.mark.gpu
+def test_entropy_search_trajectory_replay(gpu):
+    """robo.fmin.entropy_search's own run (model="gp"): same choice at all 6 model-based iterations"""
+    assert R.check_ref_entropy_search_replay() == 6
+
+
+@pytest.mark.gpu
+def test_fabolas_trajectory_replay(gpu):
+    """robo.fmin.fabolas's own run: projected incumbents and the choice at all 3 model-based iterations"""
+    assert R.check_ref_fabolas_replay() == 3
+
+
+# (added after the round-5 GPU budget was spent: verified through the interpreter only, hence LAST in the last file --
+# under `-x` a surprise here cannot hide another test)
+@pytest.mark.gpu
 def test_gp_mcmc_front_end_trajectory_replay(gpu):
     """the reference's own gp_mcmc + LogEI run: same choice at all 8 model-based iterations (marginal LogEI over the 10
     walkers, one batched fit per iteration), and robo_amd's device-resident chains end on the reference's walkers"""
@@ -163,12 +184,8 @@ def test_gp_mcmc_front_end_trajectory_replay(gpu):
 
 
 @pytest.mark.gpu
-def test_entropy_search_trajectory_replay(gpu):
-    """robo.fmin.entropy_search's own run (model="gp"): same choice at all 6 model-based iterations"""
-    assert R.check_ref_entropy_search_replay() == 6
-
-
-@pytest.mark.gpu
-def test_fabolas_trajectory_replay(gpu):
-    """robo.fmin.fabolas's own run: projected incumbents and the choice at all 3 model-based iterations"""
-    assert R.check_ref_fabolas_replay() == 3
+@pytest.mark.parametrize("acq", ["ei", "pi", "lcb"])
+def test_gp_mcmc_front_end_other_acquisitions_free_run(gpu, acq):
+    """robo_amd.fmin.bayesian_optimization(model_type="gp_mcmc", acquisition_func=ei|pi|lcb) with the reference's seeds:
+    the reference's whole result, bit for bit"""
+    assert R.check_ref_branin_gpmcmc_free_run(acquisition_func=acq) == 8
