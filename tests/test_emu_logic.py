@@ -65,9 +65,11 @@ def test_mcmc_draws_equal_numpy_legacy_stream(emu_ctx):
 
 
 def test_device_resident_chain(emu_ctx):
-    P.check_device_chain(emu_ctx, cases=(("matern52", 150, 3, 10, 6), ("rbf", 40, 2, 8, 5), ("matern52", 90, 2, 8, 3),
-                                               ("fabolas", 50, 3, 12, 4), ("fabolas", 60, 3, 12, 4, "env"),
-                                               ("fabolas", 150, 4, 14, 3, "env")))
+    # (the small-N chains of the reference's own front-end run are replayed in tests/test_ref_parity.py; here the shapes:
+    # two panels, the three kernel kinds, both priors)
+    P.check_device_chain(emu_ctx, cases=(("matern52", 150, 3, 10, 4), ("rbf", 40, 2, 8, 5),
+                                               ("fabolas", 50, 3, 12, 4), ("fabolas", 60, 3, 12, 3, "env"),
+                                               ("fabolas", 150, 4, 14, 2, "env")))
 
 
 def test_elementwise_and_degenerate_branches(emu_ctx):
@@ -259,7 +261,7 @@ def test_host_array_handle_reuse(emu_ctx):
 
 def test_winv_small_batch_path(emu_ctx):
     """the explicit-inverse posterior for small batches (winv.hip): index arithmetic, unit table, chunk order"""
-    P.check_winv_path(emu_ctx, cases=(("matern52", 300, 5, 300), ("fabolas", 280, 4, 130)))
+    P.check_winv_path(emu_ctx, cases=(("matern52", 300, 5, 200), ("fabolas", 280, 4, 130)))
 
 
 def test_winv_condition_guard_sweep(emu_ctx):
