@@ -266,3 +266,37 @@ def test_reference_gp_mcmc_run_replayed_on_3_devices(emu3):
     # and the public entry point itself: bayesian_optimization(model_type="gp_mcmc", n_gpus=3) with the reference's seeds
     # returns the REFERENCE'S run (first 5 of its 11 points here), not merely its own one-device run
     assert R.check_ref_branin_gpmcmc_free_run(num_iterations=5, n_gpus=3) == 5
+
+
+def test_create_destroy_cycles_leak_nothing(emu3):
+    """40 create / use / destroy cycles of the multi-device handle with random shapes (ragged shards, fewer candidates than
+    devices, two contexts on one device): the candidate shard equals the single-device call every time, no context and
+    no worker thread is left behind"""
+    rng = np.random.default_rng(5)
+    before = _lib.live_contexts()
+    tasks = lambda: len(os.listdir("/proc/self/task"))      # noqa: E731
+    n_tasks = None
+    for cycle in range(40):
+        devs = [[0, 1], [0, 1, 2], [0, 0], [2, 1]][cycle % 4]
+        ctxs = [_lib.Context(d) for d in devs]
+        multi = _lib.Multi(ctxs)
+        N, D, M = int(rng.integers(5, 60)), int(rng.integers(1, 4)), int(rng.integers(1, 90))
+        X, y = rng.random((N, D)), rng.standard_normal(N)
+        gps = [_lib.DeviceGP(c, "matern52", N, D) for c in ctxs]
+        multi.set_data(gps, X, y)
+        multi.fit(gps, np.concatenate([[0.0], np.zeros(D), [-3.0]]), float(y.mean()))
+        Xc = rng.random((M, D))
+        shards = _lib.CandidateShards.split(ctxs, Xc)
+        vals, mx, am, _, _ = multi.acq(gps, "ei", 0.0, float(y.min()), shards, True)
+        one = gps[0].acq("ei", 0.0, float(y.min()), Xc, True)
+        assert np.array_equal(vals, one[0]) and am == one[2] and mx == one[1], cycle
+        shards.close()
+        for g in gps:
+            g.close()
+        multi.close()
+        for c in ctxs:
+            c.close()
+        if cycle == 7:
+            n_tasks = tasks()
+    assert _lib.live_contexts() == before
+    assert tasks() <= n_tasks                                # worker threads end with their handle
