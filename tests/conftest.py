@@ -13,6 +13,29 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+@pytest.hookimpl(tryfirst=True)
+def pytest_cmdline_main(config):
+    """The CPU suite (`-m "not gpu"` on a box without a GPU) is ~9 minutes of single-threaded interpreter work in twelve
+    independent files: run the files on four worker processes (pytest-xdist, --dist loadfile: a file's tests stay together
+    and in order, module fixtures are per worker) unless the caller chose a process count, asked for a serial run
+    (ROBO_TESTS_SERIAL=1) or xdist is absent.  NEVER on a GPU box: the `-m gpu` tests share one device and time things."""
+    try:
+        opt = config.option
+        if os.environ.get("ROBO_TESTS_SERIAL") == "1" or os.environ.get("PYTEST_XDIST_WORKER"):
+            return None
+        if not _no_gpu_hardware() or getattr(opt, "markexpr", "") != "not gpu":
+            return None
+        if not config.pluginmanager.hasplugin("xdist") or getattr(opt, "numprocesses", None) is not None:
+            return None
+        if getattr(opt, "collectonly", False) or getattr(opt, "usepdb", False) or (os.cpu_count() or 1) < 4:
+            return None
+        opt.numprocesses = 4
+        opt.dist = "loadfile"
+    except Exception:        # noqa: BLE001 -- any surprise: the plain serial run
+        pass
+    return None
+
+
 @pytest.fixture(scope="session")
 def golden_dir():
     return os.path.join(ROOT, "tests", "golden")

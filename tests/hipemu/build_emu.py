@@ -4,6 +4,8 @@ The product sources under robo_amd/csrc are compiled unmodified against the stan
 <hip/hip_runtime.h> of this directory.  Output: tests/hipemu/_build/librobo_emu.so.
 Never loaded by robo_amd; only by tests that pass an explicit library path.
 """
+import contextlib
+import fcntl
 import glob
 import os
 import subprocess
@@ -13,7 +15,24 @@ ROOT = os.path.dirname(os.path.dirname(HERE))
 OUT = os.path.join(HERE, "_build", "librobo_emu.so")
 
 
+@contextlib.contextmanager
+def _build_lock():
+    """one builder at a time (several test processes may find the library stale at the same moment)"""
+    os.makedirs(os.path.join(HERE, "_build"), exist_ok=True)
+    with open(os.path.join(HERE, "_build", ".lock"), "w") as f:
+        fcntl.flock(f, fcntl.LOCK_EX)
+        try:
+            yield
+        finally:
+            fcntl.flock(f, fcntl.LOCK_UN)
+
+
 def build(force=False):
+    with _build_lock():
+        return _build(force)
+
+
+def _build(force=False):
     srcs = sorted(glob.glob(os.path.join(ROOT, "robo_amd", "csrc", "*.hip")) +
                   glob.glob(os.path.join(ROOT, "robo_amd", "csrc", "diag", "*.hip")))   # one interpreter library
     deps = srcs + glob.glob(os.path.join(ROOT, "robo_amd", "csrc", "*.h")) + \
@@ -38,6 +57,11 @@ FAKE_RCCL = os.path.join(HERE, "_build", "libfake_rccl.so")
 
 def build_fake_rccl(force=False):
     """the shared-memory stand-in for librccl.so (fake_rccl.cpp): ROBO_RCCL_LIB points comm.hip at it"""
+    with _build_lock():
+        return _build_fake_rccl(force)
+
+
+def _build_fake_rccl(force=False):
     src = os.path.join(HERE, "fake_rccl.cpp")
     if not force and os.path.exists(FAKE_RCCL) and os.path.getmtime(src) <= os.path.getmtime(FAKE_RCCL):
         return FAKE_RCCL
@@ -51,6 +75,11 @@ SCHED_SELFTEST = os.path.join(HERE, "_build", "libsched_selftest.so")
 
 def build_sched_selftest(force=False):
     """sched_selftest.cpp + its own copy of the interpreter: the deferred stream schedules checked on a known race"""
+    with _build_lock():
+        return _build_sched_selftest(force)
+
+
+def _build_sched_selftest(force=False):
     srcs = [os.path.join(HERE, "sched_selftest.cpp"), os.path.join(HERE, "hipemu.cpp")]
     deps = srcs + [os.path.join(HERE, "hip", "hip_runtime.h")]
     if not force and os.path.exists(SCHED_SELFTEST) and all(os.path.getmtime(d) <= os.path.getmtime(SCHED_SELFTEST) for d in deps):
