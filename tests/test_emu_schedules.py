@@ -102,7 +102,7 @@ def test_kernels_stay_inside_their_buffers_in_any_work_item_order(env):
     workspaces, batched likelihoods, the mixture and the argmax paths): once with every device buffer fenced by
     inaccessible pages and the work-items of a workgroup run in descending order, once in rotating order"""
     r = _child(["-m", "pytest", os.path.join(HERE, "test_emu_logic.py"), "-x", "-q", "-p", "no:cacheprovider",
-                "-k", _FAST_SUBSET], env)
+                "-k", _FAST_SUBSET], dict(env, ROBO_TESTS_SERIAL="1"))
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert " passed" in r.stdout and "failed" not in r.stdout
 
