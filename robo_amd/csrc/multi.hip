@@ -17,6 +17,7 @@
 // workers have finished.
 #include <condition_variable>
 #include <cstdlib>
+#include <exception>
 #include <functional>
 #include <mutex>
 #include <string>
@@ -35,6 +36,19 @@ int launch_comm_pack_sum(hipStream_t st, const double* d_part, long long m, int 
                          double* d_send);
 int launch_comm_ordered_sum(hipStream_t st, const double* d_recv, long long stride, int world, long long m, double* d_total,
                             unsigned* d_flags, int* h_status);
+
+// a C++ exception (an allocation failure inside an entry point) must not leave a worker thread: the caller would wait
+// for ever, and an exception escaping a std::thread ends the process
+static int guarded(const std::function<int()>& fn) {
+    try {
+        return fn();
+    } catch (const std::exception& e) {
+        set_error("exception in a device worker: %s", e.what());
+    } catch (...) {
+        set_error("exception in a device worker");
+    }
+    return ROBO_RUNTIME_ERROR;
+}
 
 struct MultiWorker {
     std::thread th;
@@ -55,7 +69,7 @@ struct MultiWorker {
                 fn = std::move(job);
                 has_job = false;
             }
-            const int st = fn();
+            const int st = guarded(fn);
             {
                 std::lock_guard<std::mutex> lock(mu);
                 status = st;
@@ -90,7 +104,7 @@ static int multi_run(robo_multi* m, const std::function<int(int)>& fn, std::vect
     std::vector<std::string> msg((size_t)m->G);
     if (!m->threads) {
         for (int g = 0; g < m->G; ++g) {
-            st[(size_t)g] = fn(g);
+            st[(size_t)g] = guarded([&fn, g] { return fn(g); });
             if (st[(size_t)g] != ROBO_OK) msg[(size_t)g] = robo_last_error_string();
         }
     } else {
