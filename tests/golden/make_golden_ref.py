@@ -628,10 +628,59 @@ def make_branin_gpmcmc_acq(R, n_iter=8):
     _save("ref_branin_gpmcmc_acq", **out)
 
 
+def make_entropy_search_gpmcmc(R, seed=12, n_iter=6):
+    """robo/fmin/entropy_search.py with its DEFAULT model, "gp_mcmc": GaussianProcessMCMC (10 walkers, 100 + 200 steps) +
+    MarginalizationGPMCMC(InformationGain(EI, Nb=50, Np=400)) + RandomSampling(500).  Logged per model-based iteration:
+    the walkers' last positions, EVERY estimator's representer points (its emcee sampler is seeded from OS entropy in the
+    reference: inputs of a replay), the global RNG state right before RandomSampling.maximize, and what it chose."""
+    _placeholder_optional_models()
+    from robo.fmin import entropy_search as fmin_es
+    from robo.maximizers.random_sampling import RandomSampling
+    M, IG = R.GaussianProcessMCMC, R.InformationGain
+    log_t, log_r, log_m = [], [], []
+    o_train, o_rep, o_max = M.train, IG.sample_representer_points, RandomSampling.maximize
+
+    def train(self, X, y, do_optimize=True, **kw):
+        o_train(self, X, y, do_optimize, **kw)
+        log_t.append(dict(n=X.shape[0], hypers=np.array(self.hypers, dtype=np.float64)))
+
+    def rep(self):
+        o_rep(self)
+        log_r.append(dict(zb=np.array(self.zb), lmb=np.array(self.lmb)))
+
+    def maximize(self):
+        st = _rng_state()
+        x = o_max(self)
+        st["x"] = np.array(x)
+        log_m.append(st)
+        return x
+
+    M.train, IG.sample_representer_points, RandomSampling.maximize = train, rep, maximize
+    try:
+        lo, hi = np.array([-5.0, 0.0]), np.array([10.0, 15.0])
+        np.random.seed(seed)
+        res = fmin_es(es_objective, lo, hi, num_iterations=n_iter, n_init=3, maximizer="random", model="gp_mcmc",
+                      rng=np.random.RandomState(seed))
+    finally:
+        M.train, IG.sample_representer_points, RandomSampling.maximize = o_train, o_rep, o_max
+    n_mb = n_iter - 3
+    S = log_t[0]["hypers"].shape[0]
+    assert len(log_t) == len(log_m) == n_mb and len(log_r) == n_mb * S, (len(log_t), len(log_m), len(log_r), S)
+    zb = np.array([l["zb"] for l in log_r]).reshape((n_mb, S) + log_r[0]["zb"].shape)
+    lmb = np.array([l["lmb"] for l in log_r]).reshape((n_mb, S) + log_r[0]["lmb"].shape)
+    _save("ref_entropy_search_gpmcmc", X=np.array(res["X"]), y=np.array(res["y"]), seed=seed,
+          n=np.array([l["n"] for l in log_t]), hypers=np.array([l["hypers"] for l in log_t]), zb=zb, lmb=lmb,
+          x_new=np.array([l["x"] for l in log_m]),
+          rng_keys=np.array([l["keys"] for l in log_m]), rng_pos=np.array([l["pos"] for l in log_m]),
+          rng_has_gauss=np.array([l["has_gauss"] for l in log_m]), rng_cached=np.array([l["cached"] for l in log_m]),
+          incumbents=np.array(res["incumbents"]), incumbent_values=np.array(res["incumbent_values"]))
+
+
 MAKERS = dict(gp=make_gp, mcmc=make_mcmc, fabolas=make_fabolas, infogain=make_infogain,
               infogain_config4=make_infogain_config4, branin=make_branin,
               entropy_search=make_entropy_search, fabolas_frontend=make_fabolas_frontend,
-              branin_single_point=make_branin_single_point, branin_gpmcmc=make_branin_gpmcmc, branin_gpmcmc_acq=make_branin_gpmcmc_acq)
+              branin_single_point=make_branin_single_point, branin_gpmcmc=make_branin_gpmcmc, branin_gpmcmc_acq=make_branin_gpmcmc_acq,
+              entropy_search_gpmcmc=make_entropy_search_gpmcmc)
 
 if __name__ == "__main__":
     R = reference()

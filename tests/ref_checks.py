@@ -641,3 +641,53 @@ def check_ref_branin_gpmcmc_free_run(num_iterations=None, acquisition_func="log_
         np.testing.assert_array_equal(np.asarray(res["x_opt"]), gold["x_opt"])
         assert float(res["f_opt"]) == float(gold["f_opt"])
     return n_it
+
+
+def check_ref_entropy_search_gpmcmc_replay(device=None, devices=None, max_iters=None):
+    """robo.fmin.entropy_search with its DEFAULT model ("gp_mcmc"; fixture ref_entropy_search_gpmcmc): at every model-based
+    iteration of the reference's own run -- the data so far, the 10 walkers the reference's chain ended on, EVERY
+    estimator's representer points (OS-entropy seeded in the reference: inputs), the global RNG state before
+    RandomSampling.maximize -> robo_amd's GaussianProcessMCMC + MarginalizationGPMCMC(InformationGain) + RandomSampling, as
+    robo_amd.fmin.entropy_search wires them, must choose the SAME candidate, bit for bit (the argmax over 500 candidates of
+    the information gain averaged over the 10 samples, each with its own EP and innovations).  -> iterations checked"""
+    from robo_amd.acquisition_functions import InformationGain
+    from robo_amd.fmin.entropy_search import build_entropy_search
+    gold = load("ref_entropy_search_gpmcmc")
+    lo, hi = np.array([-5.0, 0.0]), np.array([10.0, 15.0])
+    X, y = gold["X"], gold["y"]
+    np.testing.assert_array_equal(y, np.array([G.es_objective(x) for x in X]))
+    S = gold["hypers"].shape[1]
+    np.random.seed(int(gold["seed"]))
+    model, acq, rs = build_entropy_search(lo, hi, "random", "gp_mcmc", np.random.RandomState(0), devices=devices)
+    assert model.n_hypers == S
+    if device is not None:
+        model.device = device
+    model._keep_hypers_without_optimize = lambda: True       # train(do_optimize=False) keeps the samples put in place
+    state = {}
+
+    def pinned(self):
+        self.sampling_acquisition.update(self.model)
+        i = [k for k, mdl in enumerate(model.models) if mdl is self.model][0]
+        self.zb, self.lmb = state["zb"][i].copy(), state["lmb"][i].copy()
+
+    orig = InformationGain.sample_representer_points
+    InformationGain.sample_representer_points = pinned
+    n_checked = 0
+    try:
+        for it, n in enumerate(gold["n"]):
+            if max_iters is not None and it >= max_iters:
+                break
+            model.hypers = [h for h in gold["hypers"][it]]
+            model.train(X[:n], y[:n], do_optimize=False)
+            assert len(model.models) == S
+            state["zb"], state["lmb"] = gold["zb"][it], gold["lmb"][it]
+            acq.update(model)
+            assert len(acq.estimators) == S
+            _set_global_rng({k: gold[k][it] for k in ("rng_keys", "rng_pos", "rng_has_gauss", "rng_cached")}, "")
+            x_new = rs.maximize()
+            np.testing.assert_array_equal(x_new, gold["x_new"][it], err_msg="iteration %d (n=%d)" % (it, n))
+            np.testing.assert_array_equal(x_new, X[n])
+            n_checked += 1
+    finally:
+        InformationGain.sample_representer_points = orig
+    return n_checked

@@ -93,6 +93,12 @@ def test_entropy_search_replay_emulated(emu):
     assert R.check_ref_entropy_search_replay() == 6
 
 
+def test_entropy_search_default_model_replay_emulated(emu):
+    """robo.fmin.entropy_search with its DEFAULT model (gp_mcmc): MarginalizationGPMCMC over 10 InformationGain estimators,
+    the reference's choice bit for bit (first of the 3 model-based iterations here; all of them on the MI355X)"""
+    assert R.check_ref_entropy_search_gpmcmc_replay(max_iters=1) == 1
+
+
 def test_fabolas_replay_emulated(emu):
     assert R.check_ref_fabolas_replay(n_iter=1) == 1         # host logic; all three iterations run on the MI355X
 
@@ -189,3 +195,10 @@ def test_gp_mcmc_front_end_other_acquisitions_free_run(gpu, acq):
     """robo_amd.fmin.bayesian_optimization(model_type="gp_mcmc", acquisition_func=ei|pi|lcb) with the reference's seeds:
     the reference's whole result, bit for bit"""
     assert R.check_ref_branin_gpmcmc_free_run(acquisition_func=acq) == 8
+
+
+@pytest.mark.gpu
+def test_entropy_search_default_model_trajectory_replay(gpu):
+    """robo.fmin.entropy_search's DEFAULT configuration (model="gp_mcmc"): the reference's own run, same choice at all 3
+    model-based iterations (best-vs-second gaps of the marginal information gain 12-45 %)"""
+    assert R.check_ref_entropy_search_gpmcmc_replay() == 3
