@@ -629,9 +629,11 @@ def check_ref_branin_gpmcmc_free_run(num_iterations=None, acquisition_func="log_
     n_all = gold["X"].shape[0]
     n_it = n_all if num_iterations is None else int(num_iterations)
     np.random.seed(seed)
-    res = bayesian_optimization(G.branin, np.array([-5.0, 0.0]), np.array([10.0, 15.0]), num_iterations=n_it, n_init=3,
-                                model_type="gp_mcmc", acquisition_func=acquisition_func, maximizer="random",
-                                rng=np.random.RandomState(seed), **kw)
+    # log_ei: every choice left to the front end's DEFAULTS (the reference's: gp_mcmc, log_ei, random, n_init 3)
+    explicit = {} if acquisition_func == "log_ei" else dict(model_type="gp_mcmc", acquisition_func=acquisition_func,
+                                                            maximizer="random", n_init=3)
+    res = bayesian_optimization(G.branin, np.array([-5.0, 0.0]), np.array([10.0, 15.0]), num_iterations=n_it,
+                                rng=np.random.RandomState(seed), **explicit, **kw)
     Xm = np.array(res["X"])
     assert Xm.shape[0] == n_it
     np.testing.assert_array_equal(Xm, gold["X"][:n_it])
