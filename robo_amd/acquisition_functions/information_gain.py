@@ -158,6 +158,38 @@ class InformationGain(BaseAcquisitionFunction):
             shards.close()
         return vals, mx, am
 
+    # ---- the reference's per-candidate building blocks, kept callable ------------------------------------------
+    # compute() never goes through them (one batched device call scores all candidates); they exist because they are
+    # public methods of the reference class (information_gain.py:60-66, :199-252, :253-272) and return what those return.
+    def loss_function(self, logP, lmb, lPred, *args):
+        """entropy change of the belief over the representer points for each predicted outcome (columns of lPred),
+        relative to the current belief logP, both measured against the proposal measure lmb -> array (1, Np)"""
+        p_now, p_new = np.exp(logP), np.exp(lPred)
+        entropy_now = -np.sum(p_now * (logP + lmb))
+        return np.array([-np.sum(p_new * (lPred + lmb), axis=0) - entropy_now])
+
+    def innovations(self, x, rep):
+        """change of the posterior at the representer points ``rep`` (Nb, D) if ``x`` (1, D) were evaluated:
+        (stochastic innovation of the mean (Nb, 1), deterministic innovation of the covariance (Nb, Nb)); the quirks of
+        :257-259 included (the noise is subtracted from an already noise-free predictive variance)"""
+        v = np.asarray(self.model.predict(x)[1], dtype=np.float64).reshape(-1, 1)
+        v_less = v - self.sn2
+        cross = np.asarray(self.model.predict_variance(rep, x), dtype=np.float64)
+        scaled = cross.dot(np.linalg.inv(v_less))
+        return scaled.dot(np.linalg.cholesky(v + 1e-10)), -scaled.dot(cross.T)
+
+    def dh_fun(self, x, derivative=False):
+        """information gain of ONE candidate x (1, D) -> array([dH]) (:199-252; np.spacing(1) outside the box)"""
+        if derivative:
+            raise NotImplementedError("InformationGain.dh_fun: derivative=True (central differences, untested in the "
+                                      "reference) is not provided")
+        x = np.atleast_2d(np.asarray(x, dtype=np.float64))
+        if not np.all(np.isfinite(self.lmb)):
+            raise ValueError("lmb should not be infinite.")
+        if np.any(x < self.lower) or np.any(x > self.upper):
+            return np.array([[np.spacing(1)]]), np.array([[np.zeros((x.shape[1], 1))]])
+        return np.array([self._gains(x[:1])[0][0]])
+
     def compute(self, X_test, derivative=False, **kwargs):
         if derivative:
             raise NotImplementedError("InformationGain: derivative=True (central differences, untested in the "

@@ -1,1 +1,1 @@
-from robo_amd.solver.bayesian_optimization import BayesianOptimization  # noqa: F401
+from robo_amd.solver.bayesian_optimization import BaseSolver, BayesianOptimization  # noqa: F401

@@ -20,7 +20,55 @@ from robo_amd.initial_design import init_random_uniform
 logger = logging.getLogger(__name__)
 
 
-class BayesianOptimization(object):
+class BaseSolver(object):
+    """What robo/solver/base_solver.py:12-139 gives every solver: the four collaborators as attributes, a run directory
+    with results.csv / results.json, and the per-iteration JSON record put together from solver, model, task and
+    acquisition function.  Host control plane; kept because callers subclass it and call its helpers."""
+
+    def __init__(self, acquisition_func=None, model=None, maximize_func=None, task=None, save_dir=None):
+        self.acquisition_func, self.model, self.maximize_func = acquisition_func, model, maximize_func
+        self.task, self.save_dir = task, save_dir
+        if save_dir is not None:
+            self.create_save_dir()
+
+    def create_save_dir(self):
+        os.makedirs(self.save_dir, exist_ok=True)                # an existing directory is reused
+        self.output_file, self.output_file_json = (open(os.path.join(self.save_dir, "results." + ext), "w")
+                                                   for ext in ("csv", "json"))
+        self.csv_writer = self.json_writer = None
+
+    def get_observations(self):
+        # the reference returns ``self.X, self.Y`` (:62-63) although BayesianOptimization keeps its targets in ``y``:
+        # whichever of the two this solver holds
+        return self.X, getattr(self, "Y", getattr(self, "y", None))
+
+    def get_model(self):
+        if self.model is None:
+            logger.info("No model trained yet!")
+        return self.model
+
+    def run(self, num_iterations=10, X=None, y=None):
+        """the optimisation loop -> (incumbent, incumbent value)"""
+
+    def choose_next(self, X=None, y=None):
+        """-> the next point to evaluate"""
+
+    def get_json_data(self, it):
+        """the solver's share of an iteration record; expects ``time_overhead``, ``time_func_eval``, ``incumbent``,
+        ``incumbent_value`` and ``time_start`` on the solver (:112-123)"""
+        record = dict(iteration=it, runtime=time.time() - self.time_start)
+        record["optimization_overhead"], record["time_func_eval"] = self.time_overhead[it], self.time_func_eval[it]
+        record["incumbent"], record["incumbent_fval"] = self.incumbent.tolist(), self.incumbent_value.tolist()
+        return record
+
+    def save_json(self, it, **kwargs):
+        """one line of results.json per call (key spelling 'Acquisiton' as in :131-135)"""
+        parts = (("Solver", self.get_json_data(it)), ("Model", self.model.get_json_data()),
+                 ("Task", self.task.get_json_data()), ("Acquisiton", self.acquisition_func.get_json_data()))
+        self.output_file_json.write(json.dumps(dict(parts)) + "\n")
+
+
+class BayesianOptimization(BaseSolver):
 
     def __init__(self, objective_func, lower, upper, acquisition_func, model, maximize_func,
                  initial_design=init_random_uniform, initial_points=3, output_path=None, train_interval=1,

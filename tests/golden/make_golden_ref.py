@@ -676,11 +676,84 @@ def make_entropy_search_gpmcmc(R, seed=12, n_iter=6):
           incumbents=np.array(res["incumbents"]), incumbent_values=np.array(res["incumbent_values"]))
 
 
+# ------------------------------------------------------------------------------------------------
+# (9) the public surface on the path: names, parameter order and defaults of the reference's classes / functions,
+#     and which public methods each class has (tests/test_api_surface.py holds robo_amd against it)
+# ------------------------------------------------------------------------------------------------
+API_SURFACE = [
+    ("robo.models.gaussian_process", "GaussianProcess"), ("robo.models.gaussian_process_mcmc", "GaussianProcessMCMC"),
+    ("robo.models.fabolas_gp", "FabolasGP"), ("robo.models.fabolas_gp", "FabolasGPMCMC"),
+    ("robo.models.base_model", "BaseModel"),
+    ("robo.acquisition_functions.ei", "EI"), ("robo.acquisition_functions.log_ei", "LogEI"),
+    ("robo.acquisition_functions.pi", "PI"), ("robo.acquisition_functions.lcb", "LCB"),
+    ("robo.acquisition_functions.information_gain", "InformationGain"),
+    ("robo.acquisition_functions.information_gain_per_unit_cost", "InformationGainPerUnitCost"),
+    ("robo.acquisition_functions.marginalization", "MarginalizationGPMCMC"),
+    ("robo.acquisition_functions.base_acquisition", "BaseAcquisitionFunction"),
+    ("robo.maximizers.random_sampling", "RandomSampling"), ("robo.maximizers.scipy_optimizer", "SciPyOptimizer"),
+    ("robo.maximizers.differential_evolution", "DifferentialEvolution"), ("robo.maximizers.base_maximizer", "BaseMaximizer"),
+    ("robo.solver.bayesian_optimization", "BayesianOptimization"), ("robo.solver.base_solver", "BaseSolver"),
+    ("robo.priors.default_priors", "DefaultPrior"), ("robo.priors.env_priors", "EnvPrior"),
+    ("robo.priors.base_prior", "BasePrior"), ("robo.priors.base_prior", "TophatPrior"),
+    ("robo.priors.base_prior", "HorseshoePrior"), ("robo.priors.base_prior", "LognormalPrior"),
+    ("robo.priors.base_prior", "NormalPrior"),
+    ("robo.fmin.bayesian_optimization", "bayesian_optimization"), ("robo.fmin.entropy_search", "entropy_search"),
+    ("robo.fmin.fabolas", "fabolas"),
+    ("robo.initial_design.init_random_uniform", "init_random_uniform"),
+    ("robo.initial_design.init_latin_hypercube_sampling", "init_latin_hypercube_sampling"),
+    ("robo.util.incumbent_estimation", "projected_incumbent_estimation"),
+    ("robo.util.normalization", "zero_one_normalization"), ("robo.util.normalization", "zero_one_unnormalization"),
+    ("robo.util.normalization", "zero_mean_unit_var_normalization"),
+    ("robo.util.normalization", "zero_mean_unit_var_unnormalization"),
+    ("robo.util.epmgp", "joint_min"),
+]
+
+
+def signature_of(f):
+    """[[name, kind, default or None], ...]; callables as defaults by name, everything else by repr"""
+    import inspect
+    try:
+        params = inspect.signature(f).parameters.values()
+    except (TypeError, ValueError):
+        return None
+    out = []
+    for p in params:
+        if p.default is inspect.Parameter.empty:
+            d = None
+        elif callable(p.default):
+            d = "<callable>:" + getattr(p.default, "__name__", "?")
+        else:
+            d = repr(p.default)
+        out.append([p.name, p.kind.name, d])
+    return out
+
+
+def make_api_surface(R):
+    import importlib
+    import inspect
+    import json
+    _placeholder_optional_models()
+    out = {}
+    for mod, name in API_SURFACE:
+        obj = getattr(importlib.import_module(mod), name)
+        if inspect.isclass(obj):
+            entry = {"__init__": signature_of(obj.__init__)}
+            for m, member in inspect.getmembers(obj, predicate=inspect.isfunction):
+                if not m.startswith("_"):
+                    entry[m] = signature_of(member)
+            out[mod + ":" + name] = entry
+        else:
+            out[mod + ":" + name] = {"": signature_of(obj)}
+    with open(os.path.join(HERE, "ref_api_surface.json"), "w") as fh:
+        json.dump(out, fh, indent=1, sort_keys=True)
+    print("wrote ref_api_surface.json:", len(out), "objects,", sum(len(v) for v in out.values()), "callables")
+
+
 MAKERS = dict(gp=make_gp, mcmc=make_mcmc, fabolas=make_fabolas, infogain=make_infogain,
               infogain_config4=make_infogain_config4, branin=make_branin,
               entropy_search=make_entropy_search, fabolas_frontend=make_fabolas_frontend,
               branin_single_point=make_branin_single_point, branin_gpmcmc=make_branin_gpmcmc, branin_gpmcmc_acq=make_branin_gpmcmc_acq,
-              entropy_search_gpmcmc=make_entropy_search_gpmcmc)
+              entropy_search_gpmcmc=make_entropy_search_gpmcmc, api_surface=make_api_surface)
 
 if __name__ == "__main__":
     R = reference()

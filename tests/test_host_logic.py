@@ -184,3 +184,34 @@ def test_marginalization_without_opt_in_never_touches_the_communicator(monkeypat
     acq.sample_shard = False
     acq.estimators = []
     assert acq._shard() is None
+
+
+def test_base_solver_helpers(tmp_path):
+    """robo/solver/base_solver.py:41-139: run directory, observations, the per-iteration JSON record"""
+    import json
+    from robo_amd.solver import BaseSolver, BayesianOptimization
+
+    class Part(object):
+        def __init__(self, tag):
+            self.tag = tag
+
+        def get_json_data(self):
+            return {"tag": self.tag}
+
+    assert issubclass(BayesianOptimization, BaseSolver)
+    s = BaseSolver(acquisition_func=Part("a"), model=Part("m"), maximize_func=None, task=Part("t"),
+                   save_dir=str(tmp_path / "run"))
+    s.create_save_dir()                                   # an existing directory is reused
+    assert s.get_model().tag == "m" and BaseSolver().get_model() is None
+    s.X, s.y = np.zeros((2, 1)), np.ones(2)
+    assert s.get_observations()[1] is s.y
+    s.time_overhead, s.time_func_eval, s.time_start = [0.5], [0.25], 0.0
+    s.incumbent, s.incumbent_value = np.array([0.1]), np.array([2.0])
+    rec = s.get_json_data(0)
+    assert rec["iteration"] == 0 and rec["incumbent"] == [0.1] and rec["incumbent_fval"] == [2.0] and \
+        rec["optimization_overhead"] == 0.5 and rec["time_func_eval"] == 0.25 and rec["runtime"] > 0
+    s.save_json(0)
+    s.output_file_json.close()
+    s.output_file.close()
+    line = json.loads(open(str(tmp_path / "run" / "results.json")).read().strip())
+    assert sorted(line) == ["Acquisiton", "Model", "Solver", "Task"] and line["Model"] == {"tag": "m"}

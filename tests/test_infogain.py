@@ -174,6 +174,24 @@ def test_information_gain_class_emulated(emu_ctx):
     out = a.compute(np.array([[1.5]]))
     assert out[0] == np.spacing(1)
     assert a.argmax(Xt) == int(np.argmax(v))
+    # the reference's per-candidate public methods (information_gain.py:60-66, :199-272): dh_fun of one point is that
+    # point's value in the batch; innovations + loss_function, put together the way the reference's entropy step does
+    # on the host, give the same number as the fused device path
+    for i in range(3):
+        x = Xt[i:i + 1]
+        np.testing.assert_array_equal(a.dh_fun(x), v[i:i + 1])
+        dm, dv = a.innovations(x, a.zb)
+        Nb = a.logP.size
+        assert dm.shape == (Nb, 1) and dv.shape == (Nb, Nb)
+        upper_by_column = dv[np.triu(np.ones((Nb, Nb))).T.astype(bool), np.newaxis]
+        curvature = 0.5 * np.einsum("kij,ij->k", a.dlogPdMudMu, dm @ dm.T)[:, None]
+        pred = a.logP + a.dlogPdSigma @ upper_by_column + curvature + (a.dlogPdMu @ dm) @ a.W
+        top = pred.max(axis=0)
+        pred = pred - (top + np.log(np.exp(pred - top).sum(axis=0)))
+        gain = float(np.mean(-a.loss_function(a.logP, a.lmb, pred, a.zb)))
+        np.testing.assert_allclose(gain, v[i], rtol=1e-6, atol=1e-12)
+    far = a.dh_fun(np.array([[1.5]]))
+    assert isinstance(far, tuple) and far[0][0, 0] == np.spacing(1)      # (the reference returns a pair outside the box)
 
 
 @pytest.mark.gpu
