@@ -728,6 +728,57 @@ def signature_of(f):
     return out
 
 
+def api_attribute_objects(ns, kernel_of, lo, hi, X, y):
+    """one constructed-and-used instance per class, built the same way for the reference (ns = reference()) and for
+    robo_amd (ns = its namespace; tests/test_api_surface.py) -> {class name: object}"""
+    rs = np.random.RandomState
+    objs = {}
+    gp = ns.GaussianProcess(kernel_of(), prior=ns.DefaultPrior(4, rng=rs(1)), rng=rs(2), normalize_input=True, lower=lo,
+                            upper=hi)
+    gp.train(X, y, do_optimize=False)
+    objs["GaussianProcess"] = gp
+    mc = ns.GaussianProcessMCMC(kernel_of(), prior=ns.DefaultPrior(4, rng=rs(1)), n_hypers=8, chain_length=5,
+                                burnin_steps=5, rng=rs(2), lower=lo, upper=hi)
+    mc.train(X, y, do_optimize=True)
+    objs["GaussianProcessMCMC"] = mc
+    for name in ("EI", "LogEI", "PI", "LCB"):
+        a = getattr(ns, name)(gp)
+        a.update(gp)
+        objs[name] = a
+    ig = ns.InformationGain(gp, lo, hi, Nb=6, Np=10)
+    ig.update(gp)
+    objs["InformationGain"] = ig
+    ma = ns.MarginalizationGPMCMC(ns.LogEI(mc))
+    ma.update(mc)
+    objs["MarginalizationGPMCMC"] = ma
+    for name in ("RandomSampling", "SciPyOptimizer", "DifferentialEvolution"):
+        objs[name] = getattr(ns, name)(ns.EI(gp), lo, hi, rng=rs(0))
+    objs["BayesianOptimization"] = ns.BayesianOptimization(lambda x: float(np.sum(x)), lo, hi, ns.EI(gp), gp,
+                                                           ns.RandomSampling(ns.EI(gp), lo, hi), rng=rs(0))
+    objs["DefaultPrior"] = ns.DefaultPrior(4, rng=rs(0))
+    objs["EnvPrior"] = ns.EnvPrior(5, n_ls=2, n_lr=2, rng=rs(0))
+    return objs
+
+
+def api_attribute_data():
+    rs = np.random.RandomState(0)
+    X = rs.rand(12, 2)
+    return np.zeros(2), np.ones(2), X, np.sin(3 * X.sum(axis=1))
+
+
+def _public_attributes(R):
+    """public instance attributes of the reference's objects after construction + train / update"""
+    from robo.maximizers.random_sampling import RandomSampling
+    from robo.maximizers.scipy_optimizer import SciPyOptimizer
+    from robo.maximizers.differential_evolution import DifferentialEvolution
+    from robo.solver.bayesian_optimization import BayesianOptimization
+    R.RandomSampling, R.SciPyOptimizer, R.DifferentialEvolution = RandomSampling, SciPyOptimizer, DifferentialEvolution
+    R.BayesianOptimization = BayesianOptimization
+    lo, hi, X, y = api_attribute_data()
+    objs = api_attribute_objects(R, lambda: george_kernel(R, "matern52", 2, np.log([2.0, 1.0, 1.0])), lo, hi, X, y)
+    return {k: sorted(a for a in vars(o) if not a.startswith("_")) for k, o in objs.items()}
+
+
 def make_api_surface(R):
     import importlib
     import inspect
@@ -744,9 +795,11 @@ def make_api_surface(R):
             out[mod + ":" + name] = entry
         else:
             out[mod + ":" + name] = {"": signature_of(obj)}
+    n_obj, n_call = len(out), sum(len(v) for v in out.values())
+    out["attributes"] = _public_attributes(R)
     with open(os.path.join(HERE, "ref_api_surface.json"), "w") as fh:
         json.dump(out, fh, indent=1, sort_keys=True)
-    print("wrote ref_api_surface.json:", len(out), "objects,", sum(len(v) for v in out.values()), "callables")
+    print("wrote ref_api_surface.json:", n_obj, "objects,", n_call, "callables,", len(out["attributes"]), "attribute sets")
 
 
 MAKERS = dict(gp=make_gp, mcmc=make_mcmc, fabolas=make_fabolas, infogain=make_infogain,

@@ -62,7 +62,7 @@ def _mine(sig_of):
     return out
 
 
-@pytest.mark.parametrize("key", sorted(SURFACE))
+@pytest.mark.parametrize("key", sorted(k for k in SURFACE if k != "attributes"))
 def test_same_call_surface(key):
     mod, name = key.split(":")
     obj = getattr(importlib.import_module(HOME[mod]), name)
@@ -90,3 +90,37 @@ def test_same_call_surface(key):
             if p[2] is None and not p[1].startswith("VAR_"):
                 problems.append("%s.%s: extra parameter %s has no default" % (name, method, p[0]))
     assert not problems, "\n".join(problems)
+
+
+def test_same_public_attributes():
+    """after construction + train / update every object carries (at least) the public attributes the reference's carries
+    (``model.X``, ``model.hypers``, ``model.models``, ``acq.estimators``, ``solver.incumbents`` ...): code that reads them
+    keeps working.  robo_amd's objects are built through the interpreter (host logic only)."""
+    import sys
+    import types
+    import numpy as np
+    sys.path.insert(0, os.path.join(HERE, "hipemu"))
+    import build_emu
+    import make_golden_ref as G
+    from robo_amd import _lib
+    from robo_amd import acquisition_functions as A, maximizers as MX, models as M, priors as P
+    from robo_amd.kernels import Matern52Kernel
+    from robo_amd.solver import BayesianOptimization
+    ns = types.SimpleNamespace(BayesianOptimization=BayesianOptimization)
+    for mod in (A, MX, M, P):
+        for k in dir(mod):
+            if not k.startswith("_"):
+                setattr(ns, k, getattr(mod, k))
+    _lib.use_library(build_emu.build())
+    try:
+        lo, hi, X, y = G.api_attribute_data()
+        objs = G.api_attribute_objects(ns, lambda: 2 * Matern52Kernel(np.ones(2), ndim=2), lo, hi, X, y)
+        problems = []
+        for name, want in SURFACE["attributes"].items():
+            have = {a for a in vars(objs[name]) if not a.startswith("_")}
+            missing = sorted(set(want) - have)
+            if missing:
+                problems.append("%s lacks %s" % (name, missing))
+        assert not problems, "\n".join(problems)
+    finally:
+        _lib.use_library(None)
