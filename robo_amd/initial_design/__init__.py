@@ -28,3 +28,21 @@ def init_latin_hypercube_sampling(lower, upper, n_points, rng=None):
     for i in range(d):
         rng.shuffle(pts[i, :])
     return pts.T
+
+
+def init_grid(lower, upper, n_points):
+    """(n_points ** D, D) full grid with n_points levels per dimension, end points included, in the row order of
+    np.meshgrid's default 'xy' indexing (robo/initial_design/init_grid.py:23-30)."""
+    levels = [np.linspace(lo, hi, n_points) for lo, hi in zip(lower, upper)]
+    return np.stack([axis.ravel() for axis in np.meshgrid(*levels)], axis=1).astype(np.float64)
+
+
+def init_random_normal(lower, upper, n_points, mean=None, std=None, rng=None):
+    """(n_points, D) points from N(mean_d, std_d) per dimension, clipped to the box; defaults: the centre of the box and
+    std 0.1; one draw of n_points numbers per dimension, dimension by dimension (init_random_normal.py:30-43)."""
+    rng = _rng(rng)
+    d = lower.shape[0]
+    mean = 0.5 * (upper + lower) if mean is None else mean
+    std = np.full(d, 0.1) if std is None else std
+    cols = [np.clip(rng.normal(mean[i], std[i], n_points), lower[i], upper[i]) for i in range(d)]
+    return np.stack(cols, axis=1)

@@ -701,6 +701,7 @@ API_SURFACE = [
     ("robo.fmin.fabolas", "fabolas"),
     ("robo.initial_design.init_random_uniform", "init_random_uniform"),
     ("robo.initial_design.init_latin_hypercube_sampling", "init_latin_hypercube_sampling"),
+    ("robo.initial_design.init_grid", "init_grid"), ("robo.initial_design.init_random_normal", "init_random_normal"),
     ("robo.util.incumbent_estimation", "projected_incumbent_estimation"),
     ("robo.util.normalization", "zero_one_normalization"), ("robo.util.normalization", "zero_one_unnormalization"),
     ("robo.util.normalization", "zero_mean_unit_var_normalization"),

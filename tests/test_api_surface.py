@@ -34,6 +34,8 @@ HOME = {
     "robo.fmin.fabolas": "robo_amd.fmin",
     "robo.initial_design.init_random_uniform": "robo_amd.initial_design",
     "robo.initial_design.init_latin_hypercube_sampling": "robo_amd.initial_design",
+    "robo.initial_design.init_grid": "robo_amd.initial_design",
+    "robo.initial_design.init_random_normal": "robo_amd.initial_design",
     "robo.util.incumbent_estimation": "robo_amd.util.incumbent_estimation",
     "robo.util.normalization": "robo_amd.util.normalization", "robo.util.epmgp": "robo_amd.util.epmgp",
 }

@@ -91,6 +91,29 @@ def test_initial_designs_properties():
     assert np.all(U >= lo) and np.all(U <= hi)
 
 
+def test_grid_and_normal_designs():
+    """robo/initial_design/{init_grid,init_random_normal}.py: pinned values (rows in np.meshgrid 'xy' order; a normal draw of
+    n numbers per dimension, dimension by dimension, clipped) and, where the reference tree is present, its own output"""
+    from robo_amd.initial_design import init_grid, init_random_normal
+    lo, hi = np.array([-1.0, 0.0, 2.0]), np.array([1.0, 5.0, 3.0])
+    g = init_grid(lo[:2], hi[:2], 3)
+    np.testing.assert_array_equal(g, [[-1, 0], [0, 0], [1, 0], [-1, 2.5], [0, 2.5], [1, 2.5], [-1, 5], [0, 5], [1, 5]])
+    assert init_grid(lo, hi, 2).shape == (8, 3)
+    r = np.random.RandomState(3)
+    want = np.stack([np.clip(r.normal(m, 0.1, 6), a, b) for m, a, b in zip(0.5 * (lo + hi), lo, hi)], axis=1)
+    np.testing.assert_array_equal(init_random_normal(lo, hi, 6, rng=np.random.RandomState(3)), want)
+    wide = init_random_normal(lo, hi, 200, std=np.full(3, 50.0), rng=np.random.RandomState(4))
+    assert np.all(wide >= lo) and np.all(wide <= hi) and np.any(wide == lo) and np.any(wide == hi)      # clipped
+    if os.path.isdir("/root/reference/robo"):
+        _ref()
+        from robo.initial_design import init_grid as ref_grid, init_random_normal as ref_normal
+        for n in (1, 2, 4):
+            np.testing.assert_array_equal(init_grid(lo, hi, n), ref_grid(lo, hi, n))
+        for kw in ({}, {"mean": np.array([0.0, 4.9, 2.1])}, {"std": np.array([1.0, 2.0, 3.0])}):
+            np.testing.assert_array_equal(init_random_normal(lo, hi, 7, rng=np.random.RandomState(3), **kw),
+                                          ref_normal(lo, hi, 7, rng=np.random.RandomState(3), **kw))
+
+
 @needs_ref
 @pytest.mark.parametrize("D", [2, 3])
 def test_random_sampling_candidates_match_reference(D):
