@@ -706,7 +706,7 @@ API_SURFACE = [
     ("robo.util.normalization", "zero_one_normalization"), ("robo.util.normalization", "zero_one_unnormalization"),
     ("robo.util.normalization", "zero_mean_unit_var_normalization"),
     ("robo.util.normalization", "zero_mean_unit_var_unnormalization"),
-    ("robo.util.epmgp", "joint_min"),
+    ("robo.util.epmgp", "joint_min"), ("robo.util.mc_part", "joint_pmin"),
 ]
 
 

@@ -38,6 +38,7 @@ HOME = {
     "robo.initial_design.init_random_normal": "robo_amd.initial_design",
     "robo.util.incumbent_estimation": "robo_amd.util.incumbent_estimation",
     "robo.util.normalization": "robo_amd.util.normalization", "robo.util.epmgp": "robo_amd.util.epmgp",
+    "robo.util.mc_part": "robo_amd.util.mc_part",
 }
 
 # stated differences (everything else must match)

@@ -45,6 +45,36 @@ def test_pmin_pins():
     assert np.exp(epmgp.joint_min(mu, np.eye(n) * 1e-3))[0] == 1.0
 
 
+def test_pmin_monte_carlo():
+    """robo/util/mc_part.py joint_pmin: the reference's known answer (test/test_util/test_mc_part.py:9-14: two independent
+    unit Gaussians -> [0.5, 0.5] to 10 % with 10 000 samples), agreement with the EP approximation on a correlated belief,
+    the jitter ladder on a singular covariance, and -- where the reference tree is present -- its own numbers, bit for bit"""
+    from robo_amd.util.mc_part import joint_pmin
+    np.random.seed(1)
+    np.testing.assert_allclose(joint_pmin(np.zeros([2, 1]), np.diag(np.ones(2)), 10000), [0.5, 0.5], rtol=1e-1)
+    rs = np.random.RandomState(0)
+    A = rs.randn(6, 6)
+    V, m = A @ A.T / 6 + 0.05 * np.eye(6), rs.randn(6, 1)
+    np.random.seed(2)
+    mc = joint_pmin(m, V, 40000)
+    assert abs(mc.sum() - 1.0) < 1e-12
+    np.testing.assert_allclose(mc, np.exp(epmgp.joint_min(m[:, 0], V)), atol=0.03)
+    singular = np.ones((4, 4))
+    np.random.seed(4)
+    p = joint_pmin(np.zeros((4, 1)), singular, 500)                # rank one: factorable only with the diagonal raised
+    assert abs(p.sum() - 1.0) < 1e-12 and np.all(p > 0.15)
+    dirac = joint_pmin(np.array([[-1e4], [1e4]]), np.eye(2) * 1e-3, 100)
+    np.testing.assert_array_equal(dirac, [1.0, 1e-70])
+    if HAVE_REF:
+        sys.path.insert(0, "/root/reference")
+        from robo.util.mc_part import joint_pmin as ref
+        for seed, (mm, VV) in enumerate(((m, V), (np.zeros((4, 1)), singular))):
+            np.random.seed(seed)
+            want = ref(mm, VV, 1500)
+            np.random.seed(seed)
+            np.testing.assert_array_equal(joint_pmin(mm, VV, 1500), want)
+
+
 def _setup(ctx, N=60, D=3, M=150, Nb=12, Np=40, seed=0, kind="matern52"):
     rs = np.random.RandomState(seed)
     X = rs.rand(N, D)
