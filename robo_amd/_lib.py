@@ -527,16 +527,31 @@ class Candidates(object):
             pass
 
 
+def _full_theta(gp, theta):
+    """the hyper-parameter vector(s) the library takes, from what the caller holds: ``gp.fixed_head`` in front.  A george
+    kernel WITHOUT an amplitude factor has no amplitude parameter (``Matern52Kernel(metric, ndim)`` alone: len = D; with
+    ``amp * kernel`` in front: 1 + D) -- the library's vector always starts with log amp, which such a caller pins at 0."""
+    head = gp.fixed_head
+    if not head:
+        return theta
+    theta = np.asarray(theta, dtype=np.float64)
+    if theta.ndim == 1:
+        return np.concatenate([head, theta])
+    return np.hstack([np.tile(np.asarray(head, dtype=np.float64), (theta.shape[0], 1)), theta])
+
+
 class DeviceGP(object):
     """robo_gp: training data + Cholesky factor + z resident on the device."""
 
-    def __init__(self, ctx, kind, n_max, dim):
+    def __init__(self, ctx, kind, n_max, dim, fixed_head=()):
         self.ctx, self.kind, self.n_max, self.dim = ctx, kind, int(n_max), int(dim)
         self._h = C.c_void_p()
         self._owner = lib()
         check(self._owner.robo_gp_create(ctx._h, KERNEL_KINDS[kind], self.n_max, self.dim, C.byref(self._h)))
         self.n = 0
         self.n_theta = lib().robo_theta_size(KERNEL_KINDS[kind], self.dim)
+        # leading library hyper-parameters the caller does not hold (see _full_theta); () for every kernel with an amplitude
+        self.fixed_head = tuple(float(v) for v in fixed_head)
 
     def set_precision(self, fp32_gram):
         check(lib().robo_gp_set_precision(self._h, 1 if fp32_gram else 0))
@@ -563,7 +578,7 @@ class DeviceGP(object):
 
     def fit(self, theta, mean_c):
         """-> log-likelihood; raises np.linalg.LinAlgError when K is not PD."""
-        theta = _f64(theta, (self.n_theta,))
+        theta = _f64(_full_theta(self, theta), (self.n_theta,))
         ll, col = C.c_double(0), C.c_int32(0)
         check(lib().robo_gp_fit(self._h, _arr(theta), float(mean_c), C.byref(ll), C.byref(col)))
         return ll.value
@@ -571,15 +586,15 @@ class DeviceGP(object):
     def grad_loglik(self, theta, mean_c):
         """(log likelihood, d loglik / d theta) at theta; the GP is fitted at theta afterwards.  The last
         gradient entry is d / d sigma^2, as in the reference's grad_nll (include/robo_hip.h)."""
-        theta = _f64(theta, (self.n_theta,))
+        theta = _f64(_full_theta(self, theta), (self.n_theta,))
         ll = C.c_double()
         col = C.c_int32()
         grad = np.empty(self.n_theta)
         check(lib().robo_gp_grad_loglik(self._h, _arr(theta), float(mean_c), C.byref(ll), _arr(grad), C.byref(col)))
-        return ll.value, grad
+        return ll.value, grad[len(self.fixed_head):]
 
     def loglik_batch(self, thetas, mean_c):
-        thetas = _f64(thetas)
+        thetas = _f64(_full_theta(self, np.atleast_2d(thetas)))
         assert thetas.ndim == 2 and thetas.shape[1] == self.n_theta
         S = thetas.shape[0]
         ll = np.empty(S)
@@ -594,6 +609,7 @@ class DeviceGP(object):
         lnp None = evaluate the start positions.  -> (pos, lnp, chain (k, n_steps, P), lnprob (k, n_steps), accepted (k))"""
         pos = np.array(pos, dtype=np.float64, order="C")
         k = pos.shape[0]
+        assert not self.fixed_head, "the device chain moves every library hyper-parameter: use the host sampler"
         assert pos.shape == (k, self.n_theta)
         eval_start = lnp is None
         lnp = np.zeros(k) if eval_start else np.array(lnp, dtype=np.float64)
@@ -634,7 +650,7 @@ class DeviceGP(object):
         return float(out[0]), float(out[1]), float(out[2])
 
     def gram(self, theta):
-        theta = _f64(theta, (self.n_theta,))
+        theta = _f64(_full_theta(self, theta), (self.n_theta,))
         out = np.empty((self.n, self.n))
         check(lib().robo_gp_get_gram(self._h, _arr(theta), _arr(out)))
         return out
@@ -849,7 +865,7 @@ class Multi(object):
     def fit(self, gps, theta, mean_c):
         """the same fit on every device's replica -> log-likelihood; raises np.linalg.LinAlgError like DeviceGP.fit"""
         assert len(gps) == self.n
-        theta = _f64(theta, (gps[0].n_theta,))
+        theta = _f64(_full_theta(gps[0], theta), (gps[0].n_theta,))
         ll, col = C.c_double(0), C.c_int32(0)
         check(lib().robo_gp_fit_multi(self._h, self._handles(gps), _arr(theta), float(mean_c), C.byref(ll), C.byref(col)))
         return ll.value
@@ -857,7 +873,7 @@ class Multi(object):
     def loglik_batch(self, gps, thetas, mean_c):
         """DeviceGP.loglik_batch with the thetas split over the devices (gps: one data-holding handle per device)"""
         assert len(gps) == self.n
-        thetas = _f64(thetas)
+        thetas = _f64(_full_theta(gps[0], np.atleast_2d(thetas)))
         S = thetas.shape[0]
         ll = np.empty(S)
         st = np.empty(S, dtype=np.int32)
@@ -870,7 +886,7 @@ class Multi(object):
         flattened order -> (loglik, status)"""
         assert len(gp_groups) == self.n
         flat, counts = self._flatten(gp_groups)
-        thetas = _f64(thetas)
+        thetas = _f64(_full_theta(flat[0], np.atleast_2d(thetas))) if flat else _f64(thetas)
         assert thetas.shape[0] == len(flat)
         ll = np.empty(len(flat))
         st = np.empty(len(flat), dtype=np.int32)
@@ -947,7 +963,7 @@ def fit_batch(gps, thetas, mean_c):
     gps[0] holds the data; afterwards gps[s] is fitted at thetas[s] wherever status[s] == OK.
     -> (loglik (S,), status (S,))"""
     S = len(gps)
-    thetas = _f64(thetas)
+    thetas = _f64(_full_theta(gps[0], np.atleast_2d(thetas)))
     assert thetas.shape == (S, gps[0].n_theta)
     arr = (C.c_void_p * S)(*[g._h for g in gps])
     ll = np.empty(S)

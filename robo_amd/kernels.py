@@ -19,33 +19,49 @@ import numpy as np
 class Kernel(object):
     kind = None
 
-    def __init__(self, metric, ndim=None, log_amp=0.0):
+    def __init__(self, metric, ndim=None, log_amp=None, axes=None):
         metric = np.atleast_1d(np.asarray(metric, dtype=np.float64))
         if ndim is None:
             ndim = metric.shape[0]
         if metric.shape[0] == 1 and ndim > 1:
             metric = np.full(ndim, metric[0])
         assert metric.shape[0] == ndim, "metric must have ndim entries"
+        if axes is not None and sorted(np.atleast_1d(axes).tolist()) != list(range(int(ndim))):
+            # george restricts a kernel to a subset of the input columns with ``axes``; the one product of such kernels
+            # RoBO builds is the Fabolas kernel (robo/fmin/fabolas.py:104-117) -- FabolasKernel below
+            raise NotImplementedError("axes=%r with ndim=%d: only kernels over all input columns (or FabolasKernel)"
+                                      % (axes, ndim))
         self.ndim = int(ndim)
-        self._vector = np.concatenate([[float(log_amp)], np.log(metric)])
+        # george: ``Matern52Kernel(metric, ndim)`` ALONE has no amplitude parameter (len = D, amplitude 1); ``b * kernel``
+        # puts a ConstantKernel in front (len = 1 + D).  The library's vector always starts with log amp: a kernel without
+        # the factor pins it at 0 (robo_amd._lib._full_theta) and keeps it out of its own parameter vector.
+        self.has_amp = log_amp is not None
+        self._vector = np.concatenate([[float(log_amp) if self.has_amp else 0.0], np.log(metric)])
+
+    def _public(self):
+        return self._vector if self.has_amp else self._vector[1:]
+
+    def fixed_head(self):
+        """library hyper-parameters in front of this kernel's own vector (see the constructor)"""
+        return () if self.has_amp else (0.0,)
 
     # ---- george API slice -------------------------------------------------------------
     def __len__(self):
-        return self._vector.shape[0]
+        return self._public().shape[0]
 
     def get_parameter_vector(self):
-        return self._vector.copy()
+        return self._public().copy()
 
     def set_parameter_vector(self, v):
         v = np.asarray(v, dtype=np.float64)
-        assert v.shape == self._vector.shape
-        self._vector = v.copy()
+        assert v.shape == self._public().shape
+        self._public()[:] = v
 
     def __getitem__(self, k):
-        return self._vector[k].copy() if isinstance(k, slice) else float(self._vector[k])
+        return self._public()[k].copy() if isinstance(k, slice) else float(self._public()[k])
 
     def __setitem__(self, k, v):
-        self._vector[k] = v
+        self._public()[k] = v
 
     @property
     def vector(self):
@@ -59,21 +75,22 @@ class Kernel(object):
     __mul__ = __rmul__
 
     def get_value(self, X1, X2=None):
-        """k(X1, X2), evaluated by the device cross-gram kernel."""
+        """k(X1, X1) or k(X1, X2), evaluated by the device gram kernel (for two sets: the off-diagonal block of the gram
+        matrix of the stacked points)."""
         from robo_amd import _lib
         X1 = np.ascontiguousarray(X1, dtype=np.float64)
+        n1 = X1.shape[0]
+        pts = X1 if X2 is None else np.concatenate([X1, np.ascontiguousarray(X2, dtype=np.float64)], axis=0)
         ctx = _lib.default_context()
-        if X2 is not None:
-            raise NotImplementedError("get_value(X1, X2) is only provided for X2=None")
-        gp = _lib.DeviceGP(ctx, self.kind, X1.shape[0], self.ndim)
+        gp = _lib.DeviceGP(ctx, self.kind, pts.shape[0], self.ndim)
         try:
-            gp.set_data(X1, np.zeros(X1.shape[0]))
+            gp.set_data(pts, np.zeros(pts.shape[0]))
             theta = np.concatenate([self._vector, [-700.0]])   # exp(-700) = 0 noise
             K = gp.gram(theta)
         finally:
             gp.close()
         K[np.diag_indices_from(K)] -= 1.25e-12
-        return K
+        return K if X2 is None else K[:n1, n1:].copy()
 
     def __repr__(self):
         return "%s(amp=%g, metric=%s)" % (self.__class__.__name__, np.exp(self._vector[0]),
@@ -111,6 +128,7 @@ class FabolasKernel(Kernel):
             metric = np.full(self.ndim - 1, metric[0])
         assert metric.shape[0] == self.ndim - 1
         # cov_amp * kernel: ConstantKernel(log(amp / ndim)) (george __rmul__)
+        self.has_amp = True
         self._vector = np.concatenate([[np.log(float(amp) / self.ndim)], np.log(metric), [log_a, log_b]])
 
     def __rmul__(self, b):

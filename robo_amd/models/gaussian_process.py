@@ -77,8 +77,9 @@ class GaussianProcess(BaseModel):
             for g in self._all_gps():
                 if g is not None:
                     g.close()
-            self.gp = _lib.DeviceGP(self._ctx(), self.kernel.kind, cap, dim)
-            self.replicas = [_lib.DeviceGP(c, self.kernel.kind, cap, dim) for c in self._multi().ctxs[1:]] \
+            head = self.kernel.fixed_head()      # (0.0,) for a george kernel without an amplitude factor, else ()
+            self.gp = _lib.DeviceGP(self._ctx(), self.kernel.kind, cap, dim, fixed_head=head)
+            self.replicas = [_lib.DeviceGP(c, self.kernel.kind, cap, dim, fixed_head=head) for c in self._multi().ctxs[1:]] \
                 if self.devices else []
         return self.gp
 

@@ -71,7 +71,7 @@ class GaussianProcessMCMC(BaseModel):
             self.walker_gps = []
             cap = max(127, int(n)) if self.gp is None else max(int(n), 2 * self.gp.n_max)
             ctx = self._multi().ctxs[0] if self.devices else _lib.default_context(self.device)
-            self.gp = _lib.DeviceGP(ctx, self.kernel.kind, cap, dim)
+            self.gp = _lib.DeviceGP(ctx, self.kernel.kind, cap, dim, fixed_head=self.kernel.fixed_head())
         return self.gp
 
     def _walker_shard(self):
@@ -135,7 +135,8 @@ class GaussianProcessMCMC(BaseModel):
         gp = self._ensure_gp(self.X.shape[0], self.X.shape[1])
         if self._walker_shard() and do_optimize:
             if not self.walker_gps:
-                self.walker_gps = [_lib.DeviceGP(c, self.kernel.kind, gp.n_max, gp.dim) for c in self._multi().ctxs[1:]]
+                self.walker_gps = [_lib.DeviceGP(c, self.kernel.kind, gp.n_max, gp.dim, fixed_head=gp.fixed_head)
+                                   for c in self._multi().ctxs[1:]]
             self._multi().set_data([gp] + self.walker_gps, self.X, self.y)
         else:
             gp.set_data(self.X, self.y)
@@ -270,6 +271,8 @@ class GaussianProcessMCMC(BaseModel):
         ROBO_MCMC_HOST=1 forces the host sampler (A/B, tests)."""
         if os.environ.get("ROBO_MCMC_HOST") == "1" or self._walker_shard():
             return None                 # (walker shard: the half-ensemble's likelihoods are split over the devices per half-step)
+        if self.kernel.fixed_head():
+            return None                 # a kernel without an amplitude parameter: the device chain would move the amplitude
         from robo_amd.priors import DefaultPrior, EnvPrior
         if self.prior is None:
             prior = None

@@ -967,7 +967,7 @@ def check_predictive_gradients(ctx, cases=(("matern52", 70, 3, 9), ("rbf", 150, 
             Xr = np.concatenate((X[:, :-1], X01[:, -1:]), axis=1)
             Xq = np.concatenate((lower[:-1] + (upper[:-1] - lower[:-1]) * Xt01[:, :-1], Xt01[:, -1:]), axis=1)
         else:
-            kern = (Matern52Kernel if kind == "matern52" else ExpSquaredKernel)(np.ones(D), ndim=D)
+            kern = 1.0 * (Matern52Kernel if kind == "matern52" else ExpSquaredKernel)(np.ones(D), ndim=D)
             kern.set_parameter_vector(theta[:-1])
             model = GaussianProcess(kern, noise=np.exp(theta[-1]), normalize_output=(kind == "rbf"), lower=lower,
                                     upper=upper, rng=np.random.RandomState(1), device=device)

@@ -28,7 +28,7 @@ def load(name):
 
 
 def _kernel(kind, D, theta_k):
-    k = {"matern52": Matern52Kernel, "rbf": ExpSquaredKernel}[kind](np.ones(D), ndim=D)
+    k = 1.0 * {"matern52": Matern52Kernel, "rbf": ExpSquaredKernel}[kind](np.ones(D), ndim=D)      # (with the amplitude factor)
     k.set_parameter_vector(theta_k)
     return k
 

@@ -268,3 +268,53 @@ def test_winv_condition_guard_sweep(emu_ctx):
     """the cond_inf(L) guard of the explicit-inverse posterior (same arithmetic as on the MI355X, three block rows)"""
     P.check_winv_guard_sweep(emu_ctx, n=384, min_blocks=2, m=200,
                              sweep=((2, (1e-3, 1e-9)), (1, (1e-7, 1e-10, 1e-12))))
+
+
+def test_george_kernel_api_slice(emu_ctx):
+    """the slice of george's kernel API the reference and its tests use (robo_amd/kernels.py): a kernel WITHOUT an
+    amplitude factor has no amplitude parameter (len = D; the library's log amp is pinned at 0), ``b * kernel`` has one
+    (len = 1 + D); ``axes`` covering all columns; ``get_value`` for one and for two point sets"""
+    from oracle import gp_oracle as O
+    from robo_amd.kernels import ExpSquaredKernel, Matern52Kernel
+    from robo_amd.models import GaussianProcess, GaussianProcessMCMC
+    rs = np.random.RandomState(8)
+    X, Z = rs.rand(14, 2), rs.rand(5, 2)
+    y = np.sin(4 * X.sum(axis=1))
+    bare, full = Matern52Kernel(np.array([0.3, 0.6]), ndim=2), 1.0 * Matern52Kernel(np.array([0.3, 0.6]), ndim=2)
+    assert len(bare) == 2 and len(full) == 3 and bare.fixed_head() == (0.0,) and full.fixed_head() == ()
+    np.testing.assert_array_equal(bare.get_parameter_vector(), np.log([0.3, 0.6]))
+    np.testing.assert_array_equal(bare[:], np.log([0.3, 0.6]))
+    bare.set_parameter_vector(np.log([0.4, 0.5]))
+    assert len((2 * bare)) == 3 and (2 * bare).get_parameter_vector()[0] == np.log(2.0 / 2)
+    np.testing.assert_array_equal((2 * bare).get_parameter_vector()[1:], np.log([0.4, 0.5]))
+    bare.set_parameter_vector(np.log([0.3, 0.6]))
+    assert len(Matern52Kernel(np.array([1]), axes=0, ndim=1)) == 1 and len(ExpSquaredKernel(0.5, ndim=2, axes=[0, 1])) == 2
+    with pytest.raises(NotImplementedError):
+        Matern52Kernel(np.array([0.01]), ndim=3, axes=1)
+    # values: the oracle's kernel with amplitude 1
+    theta_full = np.concatenate([[0.0], np.log([0.3, 0.6])])
+    np.testing.assert_allclose(bare.get_value(X), O.kernel_matrix("matern52", theta_full, X, X), rtol=1e-12, atol=1e-14)
+    np.testing.assert_allclose(bare.get_value(Z, X), O.kernel_matrix("matern52", theta_full, Z, X), rtol=1e-12, atol=1e-14)
+    # the two models with both kernels: same numbers, one parameter fewer
+    ga = GaussianProcess(bare, noise=1e-3, lower=np.zeros(2), upper=np.ones(2))
+    gb = GaussianProcess(1.0 * Matern52Kernel(np.array([0.3, 0.6]), ndim=2) * 2.0, noise=1e-3, lower=np.zeros(2), upper=np.ones(2))
+    ga.train(X, y, do_optimize=False)
+    gb.train(X, y, do_optimize=False)
+    assert ga.hypers.shape == (3,) and gb.hypers.shape == (4,)
+    t3 = np.array([np.log(0.2), np.log(0.7), np.log(1e-2)])
+    t4 = np.concatenate([[0.0], t3])
+    assert ga.nll(t3) == gb.nll(t4)
+    np.testing.assert_array_equal(ga.grad_nll(t3), gb.grad_nll(t4)[1:])
+    gb.kernel.set_parameter_vector(np.concatenate([[0.0], np.log([0.3, 0.6])]))
+    gb.train(X, y, do_optimize=False)
+    ga.train(X, y, do_optimize=False)       # (nll() leaves the handle fitted at ITS theta, as the reference's does)
+    np.testing.assert_array_equal(ga.predict(Z)[0], gb.predict(Z)[0])
+    assert ga.optimize().shape == (3,)
+    # test/test_models/test_gaussian_process_mcmc.py:16-23: six walkers are enough for D + 1 = 3 hyper-parameters
+    mc = GaussianProcessMCMC(Matern52Kernel(np.ones(2), ndim=2), n_hypers=6, burnin_steps=3, chain_length=4,
+                             rng=np.random.RandomState(1))
+    mc.train(X, y, do_optimize=True)
+    assert np.asarray(mc.hypers).shape == (6, 3) and len(mc.models) == 6
+    assert np.isfinite(mc.loglikelihood(np.array([0.2, 0.2, 0.001])))
+    m, v = mc.predict(Z)
+    assert m.shape == (5,) and np.all(v > 0)
