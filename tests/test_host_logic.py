@@ -238,3 +238,36 @@ def test_base_solver_helpers(tmp_path):
     s.output_file.close()
     line = json.loads(open(str(tmp_path / "run" / "results.json")).read().strip())
     assert sorted(line) == ["Acquisiton", "Model", "Solver", "Task"] and line["Model"] == {"tag": "m"}
+
+
+def test_compat_import_alias():
+    """robo_amd.compat: ``robo.x.y`` is the robo_amd module of the same path (same objects), ``george.kernels`` the kernel
+    module; out-of-scope modules raise ImportError; uninstall leaves nothing behind"""
+    import importlib
+    import robo_amd.compat as compat
+    saved = {k: v for k, v in sys.modules.items() if k in ("robo", "george") or k.startswith(("robo.", "george."))}
+    path = list(sys.path)
+    sys.path[:] = [p for p in sys.path if os.path.abspath(p or ".") != "/root/reference"]      # the real package out of reach
+    try:
+        compat.uninstall()
+        compat.install(force=True)
+        compat.install()                                           # idempotent
+        import robo_amd.fmin
+        import robo_amd.models.gaussian_process
+        assert importlib.import_module("robo.fmin").bayesian_optimization is robo_amd.fmin.bayesian_optimization
+        assert importlib.import_module("robo.models.gaussian_process") is robo_amd.models.gaussian_process
+        for path_ in ("robo.priors.default_priors", "robo.priors.env_priors", "robo.priors.base_prior",
+                      "robo.initial_design.init_grid", "robo.maximizers.base_maximizer", "robo.solver.base_solver",
+                      "robo.util.mc_part", "robo.acquisition_functions.marginalization"):
+            importlib.import_module(path_)
+        george = importlib.import_module("george")
+        k = 2 * george.kernels.Matern52Kernel(np.ones(3), ndim=3)
+        assert len(k) == 4 and len(george.kernels.Matern52Kernel(np.ones(3), ndim=3)) == 3
+        with pytest.raises(ImportError):
+            importlib.import_module("robo.models.random_forest")
+        assert not hasattr(george, "GP")
+    finally:
+        compat.uninstall()
+        sys.path[:] = path
+        assert "robo" not in sys.modules and "george" not in sys.modules
+        sys.modules.update(saved)

@@ -12,9 +12,6 @@ wraps it.
 Files that test components SURVEY.md section 8 puts out of scope are not collected: random forest, Bohamiann, Bayesian
 linear regression (models), GridSearch inside test_maximizers_* (the two files import it at module level).
 """
-import importlib
-import importlib.abc
-import importlib.util
 import os
 import sys
 import types
@@ -35,30 +32,13 @@ IN_SCOPE = [
 ]
 
 
-class _Alias(importlib.abc.MetaPathFinder, importlib.abc.Loader):
-    """robo[.x.y] -> robo_amd[.x.y] (the same module objects)"""
-
-    def find_spec(self, name, path=None, target=None):
-        if name == "robo" or name.startswith("robo."):
-            return importlib.util.spec_from_loader(name, self)
-        return None
-
-    def create_module(self, spec):
-        return importlib.import_module("robo_amd" + spec.name[len("robo"):])
-
-    def exec_module(self, module):
-        pass
-
-
 def install_aliases():
     if ROOT not in sys.path:
         sys.path.insert(0, ROOT)
-    sys.meta_path.insert(0, _Alias())
-    import robo_amd.kernels as K
-    george = types.ModuleType("george")
-    george.kernels = K
-    sys.modules["george"], sys.modules["george.kernels"] = george, K
-    # out-of-scope optional back ends some test modules import at the top
+    import robo_amd.compat
+    robo_amd.compat.install(force=True)            # robo[.x.y] -> robo_amd[.x.y], george.kernels -> robo_amd.kernels
+    # out-of-scope components some test modules import at the top: placeholders, so that the in-scope tests of the same
+    # file still load (their own tests fail, as listed in tests/test_reference_suite.py)
     for mod, names in (("robo.maximizers.grid_search", ("GridSearch",)), ("robo.fmin.random_search", ())):
         m = types.ModuleType(mod)
         for n in names:
@@ -67,8 +47,8 @@ def install_aliases():
     import robo_amd.fmin as F
     if not hasattr(F, "random_search"):
         F.random_search = None
+    import numpy as np
     for attr, val in (("Infinity", float("inf")), ("NAN", float("nan"))):      # NumPy-1 names the tests may use
-        import numpy as np
         if not hasattr(np, attr):
             setattr(np, attr, val)
     sys.path.insert(0, os.path.dirname(REF_TESTS))          # ``from test.dummy_model import DemoModel``
