@@ -2,3 +2,4 @@ from robo_amd.maximizers.random_sampling import (BaseMaximizer, DeviceRandomSamp
                                                     RandomSampling)
 from robo_amd.maximizers.scipy_optimizer import SciPyOptimizer  # noqa: F401
 from robo_amd.maximizers.differential_evolution import DifferentialEvolution  # noqa: F401
+from robo_amd.maximizers.grid_search import GridSearch  # noqa: F401

@@ -692,6 +692,7 @@ API_SURFACE = [
     ("robo.acquisition_functions.base_acquisition", "BaseAcquisitionFunction"),
     ("robo.maximizers.random_sampling", "RandomSampling"), ("robo.maximizers.scipy_optimizer", "SciPyOptimizer"),
     ("robo.maximizers.differential_evolution", "DifferentialEvolution"), ("robo.maximizers.base_maximizer", "BaseMaximizer"),
+    ("robo.maximizers.grid_search", "GridSearch"),
     ("robo.solver.bayesian_optimization", "BayesianOptimization"), ("robo.solver.base_solver", "BaseSolver"),
     ("robo.priors.default_priors", "DefaultPrior"), ("robo.priors.env_priors", "EnvPrior"),
     ("robo.priors.base_prior", "BasePrior"), ("robo.priors.base_prior", "TophatPrior"),

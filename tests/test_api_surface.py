@@ -27,6 +27,7 @@ HOME = {
     "robo.maximizers.random_sampling": "robo_amd.maximizers", "robo.maximizers.scipy_optimizer": "robo_amd.maximizers",
     "robo.maximizers.differential_evolution": "robo_amd.maximizers",
     "robo.maximizers.base_maximizer": "robo_amd.maximizers.random_sampling",
+    "robo.maximizers.grid_search": "robo_amd.maximizers",
     "robo.solver.bayesian_optimization": "robo_amd.solver", "robo.solver.base_solver": "robo_amd.solver",
     "robo.priors.default_priors": "robo_amd.priors", "robo.priors.env_priors": "robo_amd.priors",
     "robo.priors.base_prior": "robo_amd.priors",

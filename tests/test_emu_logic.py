@@ -318,3 +318,26 @@ def test_george_kernel_api_slice(emu_ctx):
     assert np.isfinite(mc.loglikelihood(np.array([0.2, 0.2, 0.001])))
     m, v = mc.predict(Z)
     assert m.shape == (5,) and np.all(v > 0)
+
+
+def test_grid_search_is_one_batched_call(emu_ctx):
+    """robo/maximizers/grid_search.py: the grid scored in ONE call picks the point the reference's point-by-point loop picks"""
+    from robo_amd.acquisition_functions import EI, LCB
+    from robo_amd.kernels import Matern52Kernel
+    from robo_amd.maximizers import GridSearch
+    from robo_amd.models import GaussianProcess
+    rs = np.random.RandomState(3)
+    lo, hi = np.array([0.0]), np.array([6.0])
+    X = rs.rand(8, 1) * 6
+    y = np.sin(3 * X[:, 0]) * 4 * (X[:, 0] - 1) * (X[:, 0] + 2)
+    model = GaussianProcess(2 * Matern52Kernel(np.ones(1), ndim=1), noise=1e-3, lower=lo, upper=hi)
+    model.train(X, y, do_optimize=False)
+    for acq in (EI(model), LCB(model)):
+        acq.update(model)
+        g = GridSearch(acq, lo, hi, resolution=200)
+        grid = np.linspace(0.0, 6.0, 200)
+        one_by_one = np.array([float(np.asarray(acq(np.array([[x]]))).reshape(-1)[0]) for x in grid])
+        x = g.maximize()
+        assert x.shape == (1,) and x[0] == grid[int(one_by_one.argmax())]
+    with pytest.raises(RuntimeError):
+        GridSearch(acq, np.zeros(2), np.ones(2))

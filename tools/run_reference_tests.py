@@ -10,7 +10,7 @@ librobo_hip.so on the GPU.  Needs /root/reference, so this runs in the build con
 wraps it.
 
 Files that test components SURVEY.md section 8 puts out of scope are not collected: random forest, Bohamiann, Bayesian
-linear regression (models), GridSearch inside test_maximizers_* (the two files import it at module level).
+linear regression (models).
 """
 import os
 import sys
@@ -39,7 +39,7 @@ def install_aliases():
     robo_amd.compat.install(force=True)            # robo[.x.y] -> robo_amd[.x.y], george.kernels -> robo_amd.kernels
     # out-of-scope components some test modules import at the top: placeholders, so that the in-scope tests of the same
     # file still load (their own tests fail, as listed in tests/test_reference_suite.py)
-    for mod, names in (("robo.maximizers.grid_search", ("GridSearch",)), ("robo.fmin.random_search", ())):
+    for mod, names in (("robo.fmin.random_search", ()),):
         m = types.ModuleType(mod)
         for n in names:
             setattr(m, n, None)
