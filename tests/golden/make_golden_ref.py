@@ -699,7 +699,7 @@ API_SURFACE = [
     ("robo.priors.base_prior", "HorseshoePrior"), ("robo.priors.base_prior", "LognormalPrior"),
     ("robo.priors.base_prior", "NormalPrior"),
     ("robo.fmin.bayesian_optimization", "bayesian_optimization"), ("robo.fmin.entropy_search", "entropy_search"),
-    ("robo.fmin.fabolas", "fabolas"),
+    ("robo.fmin.fabolas", "fabolas"), ("robo.fmin.random_search", "random_search"),
     ("robo.initial_design.init_random_uniform", "init_random_uniform"),
     ("robo.initial_design.init_latin_hypercube_sampling", "init_latin_hypercube_sampling"),
     ("robo.initial_design.init_grid", "init_grid"), ("robo.initial_design.init_random_normal", "init_random_normal"),

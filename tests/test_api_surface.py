@@ -32,7 +32,7 @@ HOME = {
     "robo.priors.default_priors": "robo_amd.priors", "robo.priors.env_priors": "robo_amd.priors",
     "robo.priors.base_prior": "robo_amd.priors",
     "robo.fmin.bayesian_optimization": "robo_amd.fmin", "robo.fmin.entropy_search": "robo_amd.fmin",
-    "robo.fmin.fabolas": "robo_amd.fmin",
+    "robo.fmin.fabolas": "robo_amd.fmin", "robo.fmin.random_search": "robo_amd.fmin",
     "robo.initial_design.init_random_uniform": "robo_amd.initial_design",
     "robo.initial_design.init_latin_hypercube_sampling": "robo_amd.initial_design",
     "robo.initial_design.init_grid": "robo_amd.initial_design",

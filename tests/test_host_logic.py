@@ -271,3 +271,30 @@ def test_compat_import_alias():
         sys.path[:] = path
         assert "robo" not in sys.modules and "george" not in sys.modules
         sys.modules.update(saved)
+
+
+def test_random_search_front_end(tmp_path):
+    """robo/fmin/random_search.py: result keys, incumbent = best so far, per-iteration JSON, no state carried between calls;
+    where the reference tree is present: its points and incumbents under the same seed (also its (1, 1) points in 1-D)"""
+    import json
+    from robo_amd.fmin import random_search
+    f = lambda x: float(np.sum((np.asarray(x) - 0.3) ** 2))      # noqa: E731
+    lo, hi = np.zeros(2), np.ones(2)
+    r = random_search(f, lo, hi, num_iterations=9, rng=np.random.RandomState(1), output_path=str(tmp_path))
+    assert sorted(r) == ["X", "f_opt", "incumbent_values", "incumbents", "overhead", "runtime", "time_func_eval", "x_opt", "y"]
+    assert len(r["X"]) == 9 and r["f_opt"] == min(r["y"]) and r["x_opt"] == r["X"][int(np.argmin(r["y"]))]
+    assert all(a >= b for a, b in zip(r["incumbent_values"], r["incumbent_values"][1:]))
+    assert json.load(open(str(tmp_path / "robo_iter_8.json")))["iteration"] == 8
+    again = random_search(f, lo, hi, num_iterations=9, rng=np.random.RandomState(1))
+    assert again["X"] == r["X"] and len(again["X"]) == 9
+    if os.path.isdir("/root/reference/robo"):
+        _ref()
+        import importlib.util
+        spec = importlib.util.spec_from_file_location("_ref_random_search", "/root/reference/robo/fmin/random_search.py")
+        mod = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(mod)
+        for lo_, hi_ in ((lo, hi), (np.array([0.0]), np.array([6.0]))):
+            a = mod.random_search(f, lo_, hi_, X_init=[], Y_init=[], num_iterations=7, rng=np.random.RandomState(4))
+            b = random_search(f, lo_, hi_, num_iterations=7, rng=np.random.RandomState(4))
+            for k in ("X", "y", "x_opt", "f_opt", "incumbents", "incumbent_values"):
+                assert a[k] == b[k], k

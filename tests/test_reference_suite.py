@@ -4,8 +4,8 @@ interpreter build.  Build container only (the reference tree is not on the GPU b
 hand if the tree is present).
 
 52 tests in the 19 files on or next to the hot path.  Expected not to pass, and nothing else:
-  * four front-end tests of out-of-scope model back ends (bohamiann, dngo, rf) and of random_search (SURVEY.md section 2
-    rows 6, 8, 21: out of scope);
+  * three front-end tests of out-of-scope model back ends (bohamiann, dngo, rf; SURVEY.md section 2 rows 6, 8: out of
+    scope);
   * test_information_gain.test_innovations hands 1-D points to a 2-D model with unseeded random data: it fails on the
     reference itself as well (checked with the reference's own classes); it may pass or fail here.
 """
@@ -25,7 +25,6 @@ OUT_OF_SCOPE = {
     "test.test_fmin.test_fmin_interface.TestFminInterface.test_bohamiann",
     "test.test_fmin.test_fmin_interface.TestFminInterface.test_dngo",
     "test.test_fmin.test_fmin_interface.TestFminInterface.test_rf",
-    "test.test_fmin.test_fmin_interface.TestFminInterface.test_random_search",
 }
 BROKEN_IN_THE_REFERENCE = {"test.test_acquisition_functions.test_information_gain.TestInformationGain.test_innovations"}
 
@@ -40,7 +39,7 @@ def _run(patterns):
 
 
 def test_reference_unit_tests_pass_against_robo_amd():
-    """everything but the Fabolas front-end test (next test): 51 tests, 46 must pass, 4 are out of scope, 1 is broken"""
+    """everything but the Fabolas front-end test (next test): 51 tests, 47 must pass, 3 are out of scope, 1 is broken"""
     files = ["test_acquisition_functions", "test_models", "test_solver", "test_initial_design", "test_util",
              "test_maximizer", "test_fmin_interface"]
     ran, bad, out = _run(files)

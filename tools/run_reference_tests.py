@@ -14,7 +14,6 @@ linear regression (models).
 """
 import os
 import sys
-import types
 import unittest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -37,16 +36,6 @@ def install_aliases():
         sys.path.insert(0, ROOT)
     import robo_amd.compat
     robo_amd.compat.install(force=True)            # robo[.x.y] -> robo_amd[.x.y], george.kernels -> robo_amd.kernels
-    # out-of-scope components some test modules import at the top: placeholders, so that the in-scope tests of the same
-    # file still load (their own tests fail, as listed in tests/test_reference_suite.py)
-    for mod, names in (("robo.fmin.random_search", ()),):
-        m = types.ModuleType(mod)
-        for n in names:
-            setattr(m, n, None)
-        sys.modules[mod] = m
-    import robo_amd.fmin as F
-    if not hasattr(F, "random_search"):
-        F.random_search = None
     import numpy as np
     for attr, val in (("Infinity", float("inf")), ("NAN", float("nan"))):      # NumPy-1 names the tests may use
         if not hasattr(np, attr):
