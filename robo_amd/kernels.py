@@ -28,9 +28,10 @@ class Kernel(object):
         assert metric.shape[0] == ndim, "metric must have ndim entries"
         if axes is not None and sorted(np.atleast_1d(axes).tolist()) != list(range(int(ndim))):
             # george restricts a kernel to a subset of the input columns with ``axes``; the one product of such kernels
-            # RoBO builds is the Fabolas kernel (robo/fmin/fabolas.py:104-117) -- FabolasKernel below
-            raise NotImplementedError("axes=%r with ndim=%d: only kernels over all input columns (or FabolasKernel)"
-                                      % (axes, ndim))
+            # RoBO builds is the Fabolas kernel (robo/fmin/fabolas.py:104-117): Matern52Kernel.__new__ turns a
+            # single-axis Matern-5/2 into a factor of that product; anything else has no device kernel
+            raise NotImplementedError("axes=%r with ndim=%d: only kernels over all input columns, or the single-axis "
+                                      "factors of the Fabolas product" % (axes, ndim))
         self.ndim = int(ndim)
         # george: ``Matern52Kernel(metric, ndim)`` ALONE has no amplitude parameter (len = D, amplitude 1); ``b * kernel``
         # puts a ConstantKernel in front (len = 1 + D).  The library's vector always starts with log amp: a kernel without
@@ -101,6 +102,12 @@ class Matern52Kernel(Kernel):
     """k = amp (1 + sqrt(5 r2) + 5 r2 / 3) exp(-sqrt(5 r2)),  r2 = sum_d (x_d - x'_d)^2 / m_d"""
     kind = "matern52"
 
+    def __new__(cls, metric=None, ndim=None, log_amp=None, axes=None):
+        # ``Matern52Kernel(m, ndim=D + 1, axes=d)``: one factor of the product robo/fmin/fabolas.py:104-117 multiplies up
+        if cls is Matern52Kernel and axes is not None and ndim is not None and int(ndim) > 1 and np.ndim(axes) == 0:
+            return _FabolasFactor("matern52", int(ndim), int(axes), [float(np.log(np.atleast_1d(metric)[0]))])
+        return super(Matern52Kernel, cls).__new__(cls)
+
 
 class ExpSquaredKernel(Kernel):
     """k = amp exp(-r2 / 2)"""
@@ -137,3 +144,61 @@ class FabolasKernel(Kernel):
         return out
 
     __mul__ = __rmul__
+
+
+class _FabolasFactor(object):
+    """One factor of george's product notation for the Fabolas kernel, and the product while it is being multiplied up:
+
+        kernel = cov_amp                                                        # a number
+        for d in range(D):
+            kernel *= Matern52Kernel(np.ones([1]) * 0.01, ndim=D + 1, axes=d)
+        kernel *= BayesianLinearRegressionKernel(log_a=0.1, log_b=0.1, ndim=D + 1, axes=D)
+
+    (robo/fmin/fabolas.py:104-117).  ``number * factor`` puts george's ConstantKernel(log(number / ndim)) in front; every
+    further ``*`` appends a factor; the product that has one Matern-5/2 per configuration column 0 .. D-1, in order, and
+    the Bayesian-linear-regression factor on column D IS a FabolasKernel and is returned as one.  Only this product has a
+    device kernel: an incomplete one raises when a model asks for its parameters."""
+
+    def __init__(self, kind, ndim, axis, params, log_const=None, parts=None):
+        self.kind_, self.ndim, self.axis, self.params = kind, ndim, axis, list(params)
+        self.log_const = log_const
+        self.parts = [self] if parts is None else parts
+
+    def __rmul__(self, b):
+        if isinstance(b, _FabolasFactor):
+            return b.__mul__(self)
+        const = np.log(float(b) / self.ndim) + (0.0 if self.log_const is None else self.log_const)
+        return _FabolasFactor(self.kind_, self.ndim, self.axis, self.params, const, list(self.parts))
+
+    def __mul__(self, other):
+        if not isinstance(other, _FabolasFactor):
+            return self.__rmul__(other)
+        assert other.ndim == self.ndim, "factors of one product share ndim"
+        const = None if self.log_const is None and other.log_const is None else \
+            (self.log_const or 0.0) + (other.log_const or 0.0)
+        prod = _FabolasFactor(self.kind_, self.ndim, self.axis, self.params, const, self.parts + other.parts)
+        return prod._finished() or prod
+
+    def _finished(self):
+        D = self.ndim - 1
+        kinds = [(p.kind_, p.axis) for p in self.parts]
+        if self.log_const is None or kinds != [("matern52", d) for d in range(D)] + [("blr", D)]:
+            return None
+        k = FabolasKernel(self.ndim, np.exp([p.params[0] for p in self.parts[:D]]), self.parts[D].params[0],
+                          self.parts[D].params[1])
+        k._vector[0] = self.log_const
+        return k
+
+    def _incomplete(self, *a, **kw):
+        raise NotImplementedError("a product of single-axis kernels has a device kernel only as the complete Fabolas "
+                                  "product: number * Matern52Kernel(axes=0) * ... * Matern52Kernel(axes=D-1) * "
+                                  "BayesianLinearRegressionKernel(axes=D)  (have: %s)"
+                                  % [(p.kind_, p.axis) for p in self.parts])
+
+    __len__ = get_parameter_vector = set_parameter_vector = get_value = __getitem__ = _incomplete
+
+
+def BayesianLinearRegressionKernel(log_a=0.0, log_b=0.0, ndim=1, axes=0):
+    """george's degree-1 Bayesian-linear-regression kernel on ONE input column, as a factor of the Fabolas product
+    (robo/fmin/fabolas.py:113-117); see FabolasKernel for the formula this project states for it"""
+    return _FabolasFactor("blr", int(ndim), int(axes), [float(log_a), float(log_b)])
