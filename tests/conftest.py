@@ -16,7 +16,7 @@ def pytest_configure(config):
 @pytest.hookimpl(tryfirst=True)
 def pytest_cmdline_main(config):
     """The CPU suite (`-m "not gpu"` on a box without a GPU) is ~9 minutes of single-threaded interpreter work in twelve
-    independent files: run the files on four worker processes (pytest-xdist, --dist loadfile: a file's tests stay together
+    independent files: run the files on four to six worker processes (pytest-xdist, --dist loadfile: a file's tests stay together
     and in order, module fixtures are per worker) unless the caller chose a process count, asked for a serial run
     (ROBO_TESTS_SERIAL=1) or xdist is absent.  NEVER on a GPU box: the `-m gpu` tests share one device and time things."""
     try:
@@ -29,7 +29,7 @@ def pytest_cmdline_main(config):
             return None
         if getattr(opt, "collectonly", False) or getattr(opt, "usepdb", False) or (os.cpu_count() or 1) < 4:
             return None
-        opt.numprocesses = 4
+        opt.numprocesses = max(4, min(6, (os.cpu_count() or 4) - 2))
         opt.dist = "loadfile"
     except Exception:        # noqa: BLE001 -- any surprise: the plain serial run
         pass
