@@ -266,6 +266,12 @@ def test_compat_import_alias():
         with pytest.raises(ImportError):
             importlib.import_module("robo.models.random_forest")
         assert not hasattr(george, "GP")
+        compat.uninstall()
+        if os.path.isdir("/root/reference/robo"):
+            sys.path.insert(0, "/root/reference")                  # the real package within reach: refuse unless forced
+            with pytest.raises(RuntimeError):
+                compat.install()
+            sys.path.remove("/root/reference")
     finally:
         compat.uninstall()
         sys.path[:] = path
