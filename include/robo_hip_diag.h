@@ -29,6 +29,14 @@ int32_t robo_microbench_mfma_f64_detail(robo_ctx* ctx, int32_t iters, double* ou
 int32_t robo_microbench_gemm_f64(robo_ctx* ctx, int32_t variant, int32_t wgs, int32_t k, int32_t reps,
                                  double* out2);
 
+/* The stretch move of the hyper-parameter chain on arrays, through the very device functions the chain kernels inline
+ * (csrc/mcmc_dev.h): z[i] = ((a - 1) u[i] + 1)^2 / a,  q[i] = c[i] - z[i] (c[i] - s[i]),
+ * lnpdiff[i] = (P - 1) u[i] + c[i] - s[i] -- each operation rounded once, none fused, as NumPy / emcee 2 compute them
+ * (/root/reference robo/models/gaussian_process_mcmc.py:126-135 drives emcee's _propose_stretch).  Tests compare the
+ * three arrays with NumPy's bit for bit on the MI355X (round 5's q was contracted to a v_fma_f64).                 */
+int32_t robo_selftest_stretch_move(robo_ctx* ctx, const double* c, const double* s, const double* u, double a, int32_t P,
+                                   int32_t n, double* out_z, double* out_q, double* out_lnpdiff);
+
 /* Shader clock while other work runs: _begin launches eight one-wave sampler workgroups on a private stream; each
  * sleeps through window_us of the 100 MHz wall clock and records the shader cycles that passed.  _end waits for them:
  * out3 = {mean, min, max} shader MHz.  bench.py brackets one posterior step with it, so that the roofline block can

@@ -50,6 +50,7 @@ COMM_ID_BYTES = 128
 DIAG_SYMBOLS = [
     "robo_selftest_mfma_layout", "robo_microbench_mfma_f64", "robo_microbench_mfma_f64_detail", "robo_microbench_gemm_f64",
     "robo_selftest_diag_timeline", "robo_diag_clock_sample_begin", "robo_diag_clock_sample_end",
+    "robo_selftest_stretch_move",
 ]
 
 
@@ -227,7 +228,8 @@ def diag():
                        "robo_microbench_mfma_f64_detail": [vp, i32, _dp],
                        "robo_microbench_gemm_f64": [vp, i32, i32, i32, i32, _dp],
                        "robo_selftest_diag_timeline": [vp, _dp, _dp],
-                       "robo_diag_clock_sample_begin": [vp, i32], "robo_diag_clock_sample_end": [vp, _dp]}.items():
+                       "robo_diag_clock_sample_begin": [vp, i32], "robo_diag_clock_sample_end": [vp, _dp],
+                       "robo_selftest_stretch_move": [vp, _dp, _dp, _dp, C.c_double, i32, i32, _dp, _dp, _dp]}.items():
         fn = getattr(D, name)
         fn.argtypes = args
         fn.restype = i32
@@ -338,6 +340,15 @@ class Context(object):
         e = C.c_double(0)
         check(diag().robo_selftest_mfma_layout(self._h, C.byref(e)))
         return e.value
+
+    def selftest_stretch_move(self, c, s, u, a=2.0, P=18):
+        """-> (z, q, lnpdiff) of the chain's stretch-move device functions on arrays (include/robo_hip_diag.h)"""
+        c, s, u = (np.ascontiguousarray(v, dtype=np.float64) for v in (c, s, u))
+        assert c.shape == s.shape == u.shape and c.ndim == 1
+        z, q, d = np.empty_like(c), np.empty_like(c), np.empty_like(c)
+        check(diag().robo_selftest_stretch_move(self._h, _arr(c), _arr(s), _arr(u), float(a), int(P), c.size,
+                                                _arr(z), _arr(q), _arr(d)))
+        return z, q, d
 
     def microbench_mfma_f64_detail(self, iters=2000):
         """-> dict(full-chip tflops, issue interval of one lone wave in shader cycles, MHz under load)"""

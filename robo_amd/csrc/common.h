@@ -25,6 +25,29 @@ __device__ __forceinline__ v4d mfma_f64(double a, double b, v4d c) {
     return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0);
 }
 
+// Single correctly rounded fp64 operations that are NEVER contracted into a fused multiply-add, for the places whose
+// results must equal NumPy's bit for bit (the stretch-move proposal of the hyper-parameter chain, mcmc_dev.h).
+// ROCm's __dmul_rn / __dadd_rn / __dsub_rn are the plain operators (__clang_hip_math.h) and hipcc's default
+// -ffp-contract=fast-honor-pragmas fuses them: round 5's  c - z (c - s)  was compiled to  v_fma_f64 q = -z t + c  and
+// the chains left the reference's after a few hundred steps on the MI355X.  The pragma removes the `contract` flag
+// from the operation itself, so it stays unfused wherever it is inlined (tests/test_isa.py checks the machine code).
+__device__ __forceinline__ double rn_add(double a, double b) {
+#pragma clang fp contract(off)
+    return a + b;
+}
+__device__ __forceinline__ double rn_sub(double a, double b) {
+#pragma clang fp contract(off)
+    return a - b;
+}
+__device__ __forceinline__ double rn_mul(double a, double b) {
+#pragma clang fp contract(off)
+    return a * b;
+}
+__device__ __forceinline__ double rn_div(double a, double b) {
+#pragma clang fp contract(off)
+    return a / b;
+}
+
 // covariance function of the current theta (see kern_math.h)
 struct CovParams {
     int kind;   // robo_kernel_kind
@@ -329,6 +352,8 @@ int launch_uniform(robo_ctx* ctx, double* d_out, int64_t m, int64_t m_pad, int d
 int launch_sobol(robo_ctx* ctx, double* d_out, int64_t m, int64_t m_pad, int dim, const unsigned long long* d_sv,
                  const unsigned long long* d_shift, int bits, uint64_t first);
 int launch_mfma_selftest(robo_ctx* ctx, double* out_err);
+int launch_stretch_probe(robo_ctx* ctx, const double* h_c, const double* h_s, const double* h_u, double a, int P, int n,
+                         double* h_z, double* h_q, double* h_d);
 int launch_gemm_microbench(robo_ctx* ctx, int variant, int wgs, int K, int reps, double* out_tflops);
 int launch_clock_sampler(robo_ctx* ctx, int window_us);
 int collect_clock_sampler(double* out3);

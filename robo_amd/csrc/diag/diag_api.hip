@@ -59,6 +59,13 @@ int32_t robo_microbench_mfma_f64_detail(robo_ctx* ctx, int32_t iters, double* ou
     return launch_mfma_microbench(ctx, iters, out3, out3 + 1, out3 + 2, out3 + 3);
 }
 
+int32_t robo_selftest_stretch_move(robo_ctx* ctx, const double* c, const double* s, const double* u, double a, int32_t P,
+                                   int32_t n, double* out_z, double* out_q, double* out_lnpdiff) {
+    if (!ctx || !c || !s || !u || !out_z || !out_q || !out_lnpdiff || n < 1) return ROBO_BAD_ARGUMENT;
+    ROBO_HIP_CHECK(hipSetDevice(ctx->device));
+    return launch_stretch_probe(ctx, c, s, u, a, P, n, out_z, out_q, out_lnpdiff);
+}
+
 int32_t robo_diag_clock_sample_begin(robo_ctx* ctx, int32_t window_us) {
     if (!ctx) return ROBO_BAD_ARGUMENT;
     ROBO_HIP_CHECK(hipSetDevice(ctx->device));

@@ -5,6 +5,7 @@
 //     on (the local microarchitecture guide lists no fp64 MFMA peak; the datasheet figure is
 //     78.6 TFLOP/s).
 #include "../common.h"
+#include "../mcmc_dev.h"
 
 namespace robo {
 
@@ -61,6 +62,52 @@ __global__ __launch_bounds__(64) void mfma_chain_kernel(double* __restrict__ sin
     if (c0[0] + c0[1] == 12345.678) sink[threadIdx.x] = c0[0];
     const long long t1 = clock64();
     if (threadIdx.x == 0) clocks[0] = t1 - t0;
+}
+
+// The stretch move's arithmetic (mcmc_dev.h: mcmc_stretch_z / mcmc_stretch_q / mcmc_lnpdiff, the functions the chain
+// kernels inline) on arrays: tests compare the results with NumPy's bit for bit on the MI355X, and tests/test_isa.py
+// reads these kernels' machine code -- stretch_q_probe_kernel must hold v_mul_f64 / v_add_f64 and no v_fma_f64.
+__global__ __launch_bounds__(256) void stretch_q_probe_kernel(const double* __restrict__ c, const double* __restrict__ s,
+                                                              const double* __restrict__ z, double* __restrict__ q, int n) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n) q[i] = mcmc_stretch_q(c[i], s[i], z[i]);
+}
+__global__ __launch_bounds__(256) void stretch_z_probe_kernel(const double* __restrict__ u, double a, double* __restrict__ z,
+                                                              int n) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n) z[i] = mcmc_stretch_z(a, u[i]);
+}
+// (P - 1) * lz + lp_new - lp_old with lz given (the device's log is not NumPy's: only the arithmetic around it is probed)
+__global__ __launch_bounds__(256) void lnpdiff_probe_kernel(const double* __restrict__ lz, const double* __restrict__ lpn,
+                                                            const double* __restrict__ lpo, int P, double* __restrict__ out,
+                                                            int n) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n) out[i] = mcmc_lnpdiff(P, lz[i], lpn[i], lpo[i]);
+}
+
+int launch_stretch_probe(robo_ctx* ctx, const double* h_c, const double* h_s, const double* h_u, double a, int P, int n,
+                         double* h_z, double* h_q, double* h_d) {
+    double* d = nullptr;
+    const size_t bytes = (size_t)n * sizeof(double);
+    ROBO_HIP_CHECK(hipMalloc(&d, 6 * bytes));
+    double *dc = d, *ds = d + n, *du = d + 2 * (size_t)n, *dz = d + 3 * (size_t)n, *dq = d + 4 * (size_t)n, *dd = d + 5 * (size_t)n;
+    ROBO_HIP_CHECK(hipMemcpyAsync(dc, h_c, bytes, hipMemcpyHostToDevice, ctx->stream));
+    ROBO_HIP_CHECK(hipMemcpyAsync(ds, h_s, bytes, hipMemcpyHostToDevice, ctx->stream));
+    ROBO_HIP_CHECK(hipMemcpyAsync(du, h_u, bytes, hipMemcpyHostToDevice, ctx->stream));
+    const int blocks = (n + 255) / 256;
+    hipLaunchKernelGGL(stretch_z_probe_kernel, dim3(blocks), dim3(256), 0, ctx->stream, (const double*)du, a, dz, n);
+    hipLaunchKernelGGL(stretch_q_probe_kernel, dim3(blocks), dim3(256), 0, ctx->stream, (const double*)dc, (const double*)ds,
+                       (const double*)dz, dq, n);
+    // the accept statistic on (u as "log z", c, s)
+    hipLaunchKernelGGL(lnpdiff_probe_kernel, dim3(blocks), dim3(256), 0, ctx->stream, (const double*)du, (const double*)dc,
+                       (const double*)ds, P, dd, n);
+    ROBO_LAUNCH_CHECK();
+    ROBO_HIP_CHECK(hipMemcpyAsync(h_z, dz, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    ROBO_HIP_CHECK(hipMemcpyAsync(h_q, dq, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    ROBO_HIP_CHECK(hipMemcpyAsync(h_d, dd, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    ROBO_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    ROBO_HIP_CHECK(hipFree(d));
+    return ROBO_OK;
 }
 
 int launch_mfma_selftest(robo_ctx* ctx, double* out_err) {

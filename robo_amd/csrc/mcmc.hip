@@ -18,7 +18,8 @@
 // (potrf.hip: mcmc_block_step_kernel; same decisions, likelihoods within an ulp of this file's form).
 // The random numbers do not depend on the chain, so the caller draws them up front in emcee 2's order (per half-step:
 // rand for z, randint for the partners, rand for the accept test) -- same stream, same chain as the reference's sampler
-// up to the rounding of exp / log on the device.  q is formed without fused multiply-adds (numpy has none).
+// up to the rounding of exp / log on the device.  z and q are formed by the rn_* operations of common.h: the compiler
+// may not contract them into fused multiply-adds (numpy has none; round 5's q was a v_fma_f64, tests/test_isa.py).
 #include "common.h"
 #include "mcmc_dev.h"
 
@@ -76,7 +77,7 @@ __global__ __launch_bounds__(256) void mcmc_accept_kernel(McmcState st, int star
         }
         const int sw = h * half + w;
         const size_t r = ((size_t)it * 2 + h) * half + w;
-        const double lnpdiff = ((double)st.P - 1.0) * log(st.d_z[w]) + lp - st.d_lnp[sw];
+        const double lnpdiff = mcmc_lnpdiff(st.P, log(st.d_z[w]), lp, st.d_lnp[sw]);
         if (lnpdiff > log(st.d_ua[r])) {
             const double* q = st.d_q + (size_t)w * st.P;
             for (int p = 0; p < st.P; ++p) st.d_pos[(size_t)sw * st.P + p] = q[p];

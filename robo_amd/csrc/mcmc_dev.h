@@ -40,10 +40,19 @@ __device__ __forceinline__ double prior_lnprob(int kind, const double* th, int P
     return lp + hs;
 }
 
+// emcee 2's stretch move (EnsembleSampler._propose_stretch), operation for operation and unfused:
+//     zz = ((a - 1.) * rand + 1) ** 2. / a            (NumPy's x ** 2. is x * x)
+//     q  = c - zz * (c - s)
+__device__ __forceinline__ double mcmc_stretch_z(double a, double u) {
+    const double t = rn_add(rn_mul(rn_sub(a, 1.0), u), 1.0);
+    return rn_div(rn_mul(t, t), a);
+}
+__device__ __forceinline__ double mcmc_stretch_q(double c, double s, double z) { return rn_sub(c, rn_mul(z, rn_sub(c, s))); }
+
 // The proposal of walker w by the whole block (thread p <-> parameter p): q into sq[0 .. P), z into *sz, the inverse
 // square-root metrics of q (of the unit kernel when q violates the reference's |theta| <= 20 bound) into sism[0 .. D).
-// Returns that bound test.  Contains barriers: every thread of the block calls it.  q is formed without fused
-// multiply-adds (numpy has none).
+// Returns that bound test.  Contains barriers: every thread of the block calls it.  z and q are formed from
+// rn_* operations (common.h): no fused multiply-add, as in NumPy / emcee  zz = ((a - 1) u + 1)**2 / a,  q = c - zz (c - s).
 // start == 1: the walker itself (first evaluation of the start positions), walker `first + w`
 // start == 0: stretch move of walker w of half h at step it
 __device__ __forceinline__ bool mcmc_block_proposal(const McmcState& st, int start, int first, int h, int it, int w,
@@ -53,8 +62,7 @@ __device__ __forceinline__ bool mcmc_block_proposal(const McmcState& st, int sta
         double z = 1.0;
         if (!start) {
             const size_t r = ((size_t)it * 2 + h) * half + w;
-            const double t = __dadd_rn(__dmul_rn(st.a - 1.0, st.d_uz[r]), 1.0);
-            z = __ddiv_rn(__dmul_rn(t, t), st.a);
+            z = mcmc_stretch_z(st.a, st.d_uz[r]);
         }
         *sz = z;
         *sbad = 0;
@@ -69,7 +77,7 @@ __device__ __forceinline__ bool mcmc_block_proposal(const McmcState& st, int sta
             const size_t r = ((size_t)it * 2 + h) * half + w;
             const double s = st.d_pos[(size_t)(h * half + w) * P + p];
             const double c = st.d_pos[(size_t)((1 - h) * half + st.d_partner[r]) * P + p];
-            q = __dsub_rn(c, __dmul_rn(*sz, __dsub_rn(c, s)));
+            q = mcmc_stretch_q(c, s, *sz);
         }
         sq[p] = q;
         bad = bad || !(q >= -20.0 && q <= 20.0);          // also true for NaN / inf
@@ -105,6 +113,11 @@ __device__ __forceinline__ double mcmc_lnprob(double prior, int fail, double qua
         lp = ll + lp;
     }
     return lp;
+}
+
+// emcee 2's accept statistic  lnpdiff = (ndim - 1) log z + lnp(q) - lnp(s)  in its order of operations, unfused
+__device__ __forceinline__ double mcmc_lnpdiff(int P, double log_z, double lp_new, double lp_old) {
+    return rn_sub(rn_add(rn_mul((double)P - 1.0, log_z), lp_new), lp_old);
 }
 
 }  // namespace robo

@@ -737,7 +737,7 @@ __global__ __launch_bounds__(256 * NG) void mcmc_block_step_kernel(McmcState st,
             st.d_lnp[sw] = lp;
         } else {
             const size_t r = ((size_t)it * 2 + h) * half + w;
-            const double lnpdiff = ((double)P - 1.0) * log(z) + lp - st.d_lnp[sw];
+            const double lnpdiff = mcmc_lnpdiff(P, log(z), lp, st.d_lnp[sw]);
             if (lnpdiff > log(st.d_ua[r])) {
                 acc = 1;
                 st.d_lnp[sw] = lp;

@@ -133,7 +133,9 @@ class GaussianProcessMCMC(BaseModel):
             self.y = y
         self.mean = np.mean(self.y, axis=0)
         gp = self._ensure_gp(self.X.shape[0], self.X.shape[1])
-        if self._walker_shard() and do_optimize:
+        if self._walker_shard() and (do_optimize or self.walker_gps):
+            # (existing walker handles receive EVERY training's data, also a do_optimize=False one: loglikelihood_batch
+            # scores through them and must never mix two data sets -- the solver's train_interval > 1, Fabolas)
             if not self.walker_gps:
                 self.walker_gps = [_lib.DeviceGP(c, self.kernel.kind, gp.n_max, gp.dim, fixed_head=gp.fixed_head)
                                    for c in self._multi().ctxs[1:]]

@@ -13,6 +13,12 @@ import subprocess
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(os.path.dirname(HERE))
 OUT = os.path.join(HERE, "_build", "librobo_emu.so")
+# The CONTRACTING variant: the device compiler's own front end (clang) on the host with its default contraction rule
+# (-ffp-contract=fast-honor-pragmas) and x86 FMA enabled, so every  a * b + c  the device compiler may fuse IS fused
+# here too, and `#pragma clang fp contract(off)` means what it means on the device.  g++ (the variant above) never
+# fuses and ignores that pragma: it is stricter than the MI355X and hid round 5's fused stretch-move proposal.
+OUT_FMA = os.path.join(HERE, "_build", "librobo_emu_fma.so")
+HOST_CLANG = os.environ.get("HIPEMU_CLANG", "/opt/rocm/lib/llvm/bin/clang++")
 
 
 @contextlib.contextmanager
@@ -32,7 +38,15 @@ def build(force=False):
         return _build(force)
 
 
-def _build(force=False):
+def build_fma(force=False):
+    """the contracting interpreter (see OUT_FMA)"""
+    with _build_lock():
+        return _build(force, out=OUT_FMA, compiler=[HOST_CLANG, "-ffp-contract=fast-honor-pragmas", "-mfma",
+                                                    "-Wno-pass-failed"], tag="fma.")
+
+
+def _build(force=False, out=OUT, compiler=("g++", "-Wno-psabi"), tag=""):
+    OUT = out
     srcs = sorted(glob.glob(os.path.join(ROOT, "robo_amd", "csrc", "*.hip")) +
                   glob.glob(os.path.join(ROOT, "robo_amd", "csrc", "diag", "*.hip")))   # one interpreter library
     deps = srcs + glob.glob(os.path.join(ROOT, "robo_amd", "csrc", "*.h")) + \
@@ -43,12 +57,12 @@ def _build(force=False):
     os.makedirs(os.path.dirname(OUT), exist_ok=True)
     objs = []
     for s in srcs + [os.path.join(HERE, "hipemu.cpp")]:
-        o = os.path.join(HERE, "_build", os.path.basename(s) + ".o")
-        cmd = ["g++", "-O2", "-g", "-std=c++17", "-fPIC", "-Wno-psabi", "-Wno-unknown-pragmas", "-I", HERE,
-               "-x", "c++", "-c", s, "-o", o]
+        o = os.path.join(HERE, "_build", tag + os.path.basename(s) + ".o")
+        cmd = list(compiler) + ["-O2", "-g", "-std=c++17", "-fPIC", "-Wno-unknown-pragmas", "-I", HERE,
+                                "-x", "c++", "-c", s, "-o", o]
         subprocess.check_call(cmd)
         objs.append(o)
-    subprocess.check_call(["g++", "-shared", "-o", OUT] + objs)
+    subprocess.check_call([compiler[0], "-shared", "-o", OUT] + objs)
     return OUT
 
 

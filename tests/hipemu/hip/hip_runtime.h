@@ -192,12 +192,16 @@ static inline void __builtin_amdgcn_sched_barrier(int) {}
 // v_rsq_f64 has ~2^-26 relative accuracy on the hardware; the interpreter returns the rounded value
 static inline double __builtin_amdgcn_rsq(double x) { return 1.0 / std::sqrt(x); }
 static inline double __builtin_amdgcn_rcp(double x) { return 1.0 / x; }
-// round-to-nearest arithmetic without contraction (g++ -O2 on x86-64 does not fuse unless -ffp-contract=fast with FMA
-// enabled; volatile keeps the intermediate rounded either way)
-static inline double __dadd_rn(double a, double b) { volatile double r = a + b; return r; }
-static inline double __dsub_rn(double a, double b) { volatile double r = a - b; return r; }
-static inline double __dmul_rn(double a, double b) { volatile double r = a * b; return r; }
-static inline double __ddiv_rn(double a, double b) { volatile double r = a / b; return r; }
+// ROCm's __clang_hip_math.h defines these as the PLAIN operators (unless OCML_BASIC_ROUNDED_OPERATIONS): the compiler
+// may contract them.  Mirrored exactly -- round 5 kept the intermediates in `volatile` here, stricter than the MI355X,
+// and the interpreter could not see the fused stretch-move proposal the hardware executed.  The product sources use
+// common.h's rn_* (contract(off)) where NumPy's rounding matters; the contracting interpreter build (build_emu.build_fma:
+// clang++ -ffp-contract=fast-honor-pragmas -mfma, the device compiler's own front end and contraction rule on the host)
+// fuses whatever the device compiler would be allowed to.
+static inline double __dadd_rn(double a, double b) { return a + b; }
+static inline double __dsub_rn(double a, double b) { return a - b; }
+static inline double __dmul_rn(double a, double b) { return a * b; }
+static inline double __ddiv_rn(double a, double b) { return a / b; }
 static inline int __ffsll(long long x) { return __builtin_ffsll(x); }
 static inline int __builtin_amdgcn_readlane(int v, int lane) { return hipemu::shfl_any(v, lane); }
 static inline int __double2loint(double x) { uint64_t u; std::memcpy(&u, &x, 8); return (int)(uint32_t)u; }
@@ -230,6 +234,8 @@ template <class T> static inline T atomicCAS(T* p, T cmp, T v) { T o = *p; if (o
 #ifndef __HIP_MEMORY_SCOPE_AGENT
 #define __HIP_MEMORY_SCOPE_AGENT 4
 #endif
+#ifndef __clang__   // (clang knows them as builtins on every target; its host lowering is an ordinary atomic)
 template <class T> static inline T __hip_atomic_fetch_add(T* p, T v, int, int) { T o = *p; *p = o + v; return o; }
 template <class T> static inline T __hip_atomic_load(const T* p, int, int) { return *p; }
 template <class T> static inline void __hip_atomic_store(T* p, T v, int, int) { *p = v; }
+#endif

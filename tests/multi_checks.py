@@ -280,3 +280,14 @@ def check_walker_shard(devices, N=60, D=3, n_hypers=10):
     Xc = rs.rand(50, D)
     for a, b in zip(many.predict(Xc), one.predict(Xc)):
         np.testing.assert_allclose(a, b, rtol=1e-8, atol=1e-12)
+    # a later train(do_optimize=False) on MORE data (the solver's train_interval > 1, Fabolas keeping its samples): the
+    # walker handles of devices 1.. must see the new data too -- a direct likelihood call afterwards scores every theta
+    # against it (round-5 advice: they kept the previous data set and the batch silently mixed two)
+    thetas = np.array(one.hypers) + 0.01 * rs.randn(n_hypers, D + 2)       # (inside the prior's support)
+    X2 = np.vstack([X, rs.rand(7, D)])
+    y2 = np.sin(3 * X2.sum(axis=1))
+    many.train(X2, y2, do_optimize=False)
+    one.train(X2, y2, do_optimize=False)
+    ll = one.loglikelihood_batch(thetas)
+    assert np.all(np.isfinite(ll))
+    np.testing.assert_array_equal(many.loglikelihood_batch(thetas), ll)

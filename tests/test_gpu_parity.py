@@ -31,6 +31,24 @@ def test_mfma_layout_selftest(ctx):
     assert ctx.selftest_mfma_layout() < 1e-12
 
 
+def test_stretch_move_bits(ctx):
+    """The stretch move's device functions (csrc/mcmc_dev.h, the ones the chain kernels inline) against NumPy / emcee 2's
+    expressions, BIT FOR BIT on 2^20 random triples: zz = ((a - 1) u + 1) ** 2 / a, q = c - zz (c - s),
+    lnpdiff = (P - 1) lz + lp_new - lp_old.  Round 5: q was compiled to a v_fma_f64 and the chains left the reference's
+    (a fused q differs from NumPy's in ~a quarter of random triples)."""
+    rng = np.random.RandomState(11)
+    n = 1 << 20
+    c = rng.randn(n) * rng.choice([1e-3, 1.0, 20.0], n)
+    s = rng.randn(n) * rng.choice([1e-3, 1.0, 20.0], n)
+    u = rng.rand(n)
+    for a in (2.0, 1.7):
+        z, q, d = ctx.selftest_stretch_move(c, s, u, a=a, P=18)
+        z_np = ((a - 1.0) * u + 1) ** 2.0 / a
+        np.testing.assert_array_equal(z, z_np)
+        np.testing.assert_array_equal(q, c - z_np * (c - s))
+        np.testing.assert_array_equal(d, (18 - 1.0) * u + c - s)
+
+
 @pytest.mark.parametrize("name", ["small_matern", "ragged_rbf_nout", "one_block_edge", "two_block"])
 def test_golden_cases(ctx, name):
     P.check_case(ctx, name)
