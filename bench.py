@@ -484,6 +484,34 @@ def launch_ranks(n, argv):
         shutil.rmtree(rdv, ignore_errors=True)
 
 
+def _hip_runtime():
+    import ctypes
+    for name in ("libamdhip64.so", "libamdhip64.so.7", "libamdhip64.so.6", "/opt/rocm/lib/libamdhip64.so"):
+        try:
+            return ctypes.CDLL(name)
+        except OSError:
+            continue
+    return None
+
+
+def _pin_host(arr):
+    """page-lock a NumPy array in place (hipHostRegister); False when the runtime is not loadable or declines"""
+    import ctypes
+    hip = _hip_runtime()
+    if hip is None or not hasattr(hip, "hipHostRegister"):
+        return False
+    hip.hipHostRegister.argtypes = [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_uint]
+    return hip.hipHostRegister(ctypes.c_void_p(arr.ctypes.data), arr.nbytes, 0) == 0
+
+
+def _unpin_host(arr):
+    import ctypes
+    hip = _hip_runtime()
+    if hip is not None and hasattr(hip, "hipHostUnregister"):
+        hip.hipHostUnregister.argtypes = [ctypes.c_void_p]
+        hip.hipHostUnregister(ctypes.c_void_p(arr.ctypes.data))
+
+
 def timed_steps(D_, ctx, step, steps, warmup):
     for _ in range(warmup):
         step()
@@ -844,17 +872,34 @@ def run_headline(args, D_, _lib, sharding):
         return evaluate()
 
     pcie_steps = max(2, args.steps // 2)
-    elapsed_pcie = None
+    elapsed_pcie = elapsed_pcie_pinned = None
     if not args.lean:
         elapsed_pcie, _, _ = timed_steps(D_, ctx, step_pcie, pcie_steps, 1)
+        # the same with the caller's candidate array page-locked (hipHostRegister on the NumPy buffer: what a caller who
+        # reuses its batch buffer would do; pageable memory goes through the runtime's own staging copy)
+        pinned = _pin_host(Xc)
+        if pinned:
+            try:
+                elapsed_pcie_pinned, _, _ = timed_steps(D_, ctx, step_pcie, pcie_steps, 1)
+            finally:
+                _unpin_host(Xc)
     # small candidate batches on the same fitted GP (the reference's default RandomSampling draws 500 candidates): latency,
     # not throughput -- the 16/32-candidate block-row step
     small_ms = {}
     if rank == 0 and not args.lean:
         # the explicit-inverse path (winv.hip): W = L^-1 is built lazily by the first small batch after a fit
         gp.fit(theta, mean_c)
+        first_ever = None
         for m_small in (500, 8192):
             cs = _lib.Candidates(ctx, np.random.RandomState(11).rand(m_small, D))
+            if m_small == 500:
+                # the very first small batch of this GP handle also ALLOCATES the n_pad^2 inverse (hipMalloc of 145 MB) and
+                # the handle's small-batch workspace: reported under its own name, then a fresh factor for the figure that
+                # holds only the W = L^-1 build (what every later refit pays)
+                t0 = time.perf_counter()
+                gp.acq(args.acq, 0.0, eta, cs, want_values=False)
+                first_ever = (time.perf_counter() - t0) * 1e3
+                gp.fit(theta, mean_c)
             t0 = time.perf_counter()
             gp.acq(args.acq, 0.0, eta, cs, want_values=False)
             first = (time.perf_counter() - t0) * 1e3
@@ -867,6 +912,7 @@ def run_headline(args, D_, _lib, sharding):
             small_ms["%d_kernel" % m_small] = cs.solve_kernel()
             if m_small == 500:
                 small_ms["500_first_call_after_fit_incl_inverse_build"] = first
+                small_ms["500_first_ever_call_incl_allocations"] = first_ever
             ctx.set_tuning("winv_max", 0)          # the block-row substitution on the same batch, for comparison
             gp.acq(args.acq, 0.0, eta, cs, want_values=False)
             ts = []
@@ -918,6 +964,10 @@ def run_headline(args, D_, _lib, sharding):
             "metric": METRIC, "value": value, "unit": "EI evals/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": args.scaling,
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            # which rate `value` is: the bench contract's (inputs resident in HBM when the timed region starts).  SURVEY
+            # 8(d)'s host-buffer definition of an EI eval (H2D of the batch + D2H of the result inside) is `pcie_inclusive`
+            "value_definition": "resident-input rate: candidates already in HBM; posterior + acquisition + argmax + D2H of "
+                                "(max, argmax) per step.  The PCIe-inclusive rate is pcie_inclusive.value, never this field",
             "config": {"workload": "GP Matern-5/2 ARD N=%d D=%d, %s, %s xi=0, fp64, "
                                    "candidate shard per GPU (%s)" % (N, D, shard_txt, args.acq.upper(), name),
                        "n_train": N, "dim": D, "candidates_per_gpu": M, "candidates_total": M_total,
@@ -942,6 +992,10 @@ def run_headline(args, D_, _lib, sharding):
                                      "ms_per_step": elapsed_pcie / pcie_steps * 1e3,
                                      "what": "SURVEY 8(d) definition: H2D of the %d x %d candidate batch (pageable host "
                                              "memory, into an existing handle) + evaluation + D2H of (max, argmax)" % (M, D)}
+            if elapsed_pcie_pinned is not None:
+                out["pcie_inclusive"]["pinned_host_memory"] = {
+                    "value": M_total * pcie_steps / elapsed_pcie_pinned, "ms_per_step": elapsed_pcie_pinned / pcie_steps * 1e3,
+                    "what": "the same with the caller's batch page-locked (hipHostRegister)"}
         if small_ms:
             out["small_batch_latency_ms"] = small_ms
         if other is not None:
@@ -959,6 +1013,10 @@ def run_headline(args, D_, _lib, sharding):
                 out["hyper_inference"]["n_train_100"] = {k_: small[k_] for k_ in ("later_iteration_ms", "likelihoods_per_s")}
                 # where the configurations live (BASELINE config 3: N = 2048; the headline: N = 4096), the reference's
                 # defaults (54 walkers, 200 chain steps per later iteration = 10 854 likelihoods)
+                for n_mid in (500, 1000):          # between the BO-typical sizes and the configurations'
+                    mid = hyper_inference(False, N=n_mid, first_iteration=False)
+                    out["hyper_inference"]["n_train_%d" % n_mid] = {k_: mid[k_] for k_ in (
+                        "later_iteration_ms", "likelihoods_per_s", "frac_of_fp64_mfma_peak")}
                 for n_big, budget in ((2048, 4.0), (4096, 6.0)):
                     out["hyper_inference"]["n_train_%d" % n_big] = hyper_inference(
                         not args.no_cpu_baseline, N=n_big, first_iteration=(n_big == 2048), cpu_budget_s=budget)
@@ -1363,6 +1421,25 @@ def run_inproc(args, _lib):
                 roofline=roofline_trsm(ctx0, N, shard_sizes(total)[0], trsm_ms, kernel=cshards.shards[0].solve_kernel()))
 
 
+CONFIG_DEFAULTS = {"headline": (4096, 16, 65536), "c2": (1024, 8, 65536), "c3": (2048, 16, 65536),
+                   "c4": (4096, 11, 8192), "c5": (8192, 64, 131072)}
+
+
+def config_args(args, cfg, lean=False):
+    """the argument set `--config cfg` would run with (its sizes, its sustained step counts), derived from a parsed one"""
+    import copy
+    a = copy.copy(args)
+    a.config = cfg
+    a.n, a.d, a.m = CONFIG_DEFAULTS[cfg]
+    a.steps = {"c2": 100, "c4": 50}.get(cfg, 5)
+    a.warmup = 5 if cfg in ("c2", "c4") else 2
+    a.scaling = "strong" if cfg == "c3" else "weak"
+    if lean:
+        a.lean = True
+        a.no_cpu_baseline = True
+    return a
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -1370,7 +1447,8 @@ def main():
                     help="timed steps (default 5; config c2: 100, c4: 50 -- their steps last 1.3 / 5.3 ms, and a 5-step run "
                          "ends before the part has left its idle power state)")
     ap.add_argument("--warmup", type=int, default=None, help="untimed steps in front (default 2; c2 / c4: 5)")
-    ap.add_argument("--config", default="headline", choices=["headline", "c2", "c3", "c4", "c5"])
+    ap.add_argument("--config", default="headline", choices=["headline", "c2", "c3", "c4", "c5", "all"],
+                    help="all: every configuration in turn, ONE JSON array of their lines")
     ap.add_argument("--n", type=int, default=None)
     ap.add_argument("--d", type=int, default=None)
     ap.add_argument("--m", type=int, default=None, help="candidates per GPU (config 3: candidates in total)")
@@ -1408,8 +1486,7 @@ def main():
     if args.config == "c3":
         args.scaling = "strong"
     args.scaling = args.scaling or "weak"
-    defaults = {"headline": (4096, 16, 65536), "c2": (1024, 8, 65536), "c3": (2048, 16, 65536),
-                "c4": (4096, 11, 8192), "c5": (8192, 64, 131072)}[args.config]
+    defaults = CONFIG_DEFAULTS["headline" if args.config == "all" else args.config]
     if args.scaling == "strong" and args.config in ("c4", "c5"):      # BASELINE's totals: 8 x 8192, 8 x 2^17
         defaults = defaults[:2] + (defaults[2] * 8,)
     args.n = args.n or defaults[0]
@@ -1434,8 +1511,40 @@ def main():
         _lib.diag()
     except Exception:
         pass
-    runner = {"headline": run_headline, "c2": run_headline, "c3": run_c3, "c4": run_c4, "c5": run_c5}[args.config]
-    out = runner(args, D_, _lib, sharding)
+    runners = {"headline": run_headline, "c2": run_headline, "c3": run_c3, "c4": run_c4, "c5": run_c5}
+    if args.config == "all":
+        # every configuration of BASELINE.json that fits one GPU, each its own complete line (own cpu_baseline unless
+        # --no-cpu-baseline), printed as ONE JSON array: `python bench.py --gpus 1 --config all`
+        lines = []
+        for cfg in ("headline", "c2", "c3", "c4", "c5"):
+            o = runners[cfg](config_args(args, cfg), D_, _lib, sharding)
+            if D_.rank == 0:
+                o.setdefault("exchange", D_.exchange or "none (single process, no communicator)")
+                lines.append(o)
+        if D_.rank == 0:
+            sys.stdout.write(json.dumps(lines) + "\n")
+            sys.stdout.flush()
+        D_.close()
+        return
+    out = runners[args.config](args, D_, _lib, sharding)
+    if D_.rank == 0 and D_.world == 1 and args.config == "headline" and (args.n, args.d) == (4096, 16) and not args.lean \
+            and os.environ.get("ROBO_BENCH_NO_CONFIGS") != "1":
+        # the DEFAULT run (what the round's driver times) also carries BASELINE's configurations 2-5 at their one-GPU
+        # sizes, each measured by its own runner in this process (sustained step counts as in `--config cN`; no CPU legs
+        # here -- `--config cN` / `--config all` print the full lines with their cpu_baseline blocks)
+        out["configs"] = {}
+        for cfg in ("c2", "c3", "c4", "c5"):
+            try:
+                t0 = time.perf_counter()
+                o = runners[cfg](config_args(args, cfg, lean=True), D_, _lib, sharding)
+                out["configs"][cfg] = {"workload": o["config"]["workload"], "value": o["value"], "unit": o["unit"],
+                                       "ms_per_step": o["ms_per_step"], "steps": o["steps"], "warmup": o["warmup"],
+                                       "dtype": o["dtype"], "argmax": o.get("argmax"),
+                                       "roofline": {k_: o.get("roofline", {}).get(k_) for k_ in (
+                                           "kernel", "bound", "achieved", "peak", "unit", "frac", "traffic")},
+                                       "wall_s_incl_setup": time.perf_counter() - t0}
+            except Exception as e:            # noqa: BLE001 -- an extra block; never costs the headline line
+                out["configs"][cfg] = {"error": "%s: %s" % (type(e).__name__, str(e)[:200])}
     if D_.rank == 0:
         out.setdefault("exchange", D_.exchange or "none (single process, no communicator)")
         D_.emit(out)

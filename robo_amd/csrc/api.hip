@@ -49,6 +49,8 @@ static const TuneKey TUNE_KEYS[] = {
     {"potrf_max_wg", nullptr, &Tuning::potrf_max_wg, 0},
     {"potrf_group", nullptr, &Tuning::potrf_group, 0},
     {"potrf_tail_split", nullptr, &Tuning::potrf_tail_split, 1},
+    {"potrf_follow", nullptr, &Tuning::potrf_follow, 0},
+    {"potrf_follow_from", nullptr, &Tuning::potrf_follow_from, 0},
     {"potrf_batch_tm4_min", nullptr, &Tuning::potrf_batch_tm4_min, 96},
     {"potrf_thin_last", nullptr, &Tuning::potrf_thin_last, 1},
     {"potrf_split", nullptr, &Tuning::potrf_split, 3},
@@ -92,6 +94,7 @@ static void ctx_free(robo_ctx* c) {
     }
     hipFree(c->d_scalars);
     hipFree(c->d_fail);
+    hipFree(c->d_prog);
     hipHostFree(c->h_pinned);
     if (c->own_stream) hipStreamDestroy(c->stream);
     delete c;
@@ -175,6 +178,7 @@ int32_t robo_ctx_create(int32_t device, void* hip_stream, robo_ctx** out) {
     c->num_cu = prop.multiProcessorCount;
     ROBO_TRY(dev_alloc(&c->d_scalars, 8));
     ROBO_TRY(dev_alloc(&c->d_fail, 4));
+    ROBO_TRY(dev_alloc(&c->d_prog, 2 * PROG_STRIDE));
     ROBO_HIP_CHECK(hipHostMalloc((void**)&c->h_pinned, (MAX_DIM + 64) * sizeof(double), 0));
     ++g_ctx_live;
     *out = c;
@@ -405,6 +409,7 @@ static FitBuffers own_buffers(robo_gp* g) {
     fb.Xs = g->d_Xs; fb.xs_stride = 0;
     fb.sp = g->d_sp;
     fb.fail = g->ctx->d_fail;
+    fb.prog = g->ctx->d_prog;
     fb.out = g->ctx->d_scalars;
     fb.ll_part = g->d_llpart;
     fb.LinvP = g->d_LinvP;
@@ -559,6 +564,7 @@ static int fit_batch_core(robo_gp* g, const double* thetas, int32_t S, double me
                                       hipMemcpyHostToDevice, c->stream));
         FitBuffers fb;
         fb.K = g->d_bK; fb.k_stride = np * np;
+        fb.prog = nullptr;
         fb.Linv = g->d_bLinv; fb.linv_stride = np * NB;
         fb.Xs = g->d_bXs; fb.xs_stride = np * D;
         fb.sp = g->d_bsp;
@@ -680,6 +686,7 @@ int32_t robo_gp_mcmc_run(robo_gp* g, double mean_c, int32_t prior_kind, const do
     ROBO_HIP_CHECK(hipMemsetAsync(st.d_nacc, 0, (size_t)k * sizeof(long long) + 8 * sizeof(int), s));
     FitBuffers fb;
     fb.K = g->d_bK; fb.k_stride = np * np;
+    fb.prog = nullptr;
     fb.Linv = g->d_bLinv; fb.linv_stride = np * NB;
     fb.Xs = g->d_bXs; fb.xs_stride = np * D;
     fb.sp = g->d_bsp;

@@ -17,6 +17,7 @@ constexpr int NB = 128;
 constexpr int WG = 256;          // threads per workgroup of every tiled kernel (4 wave64)
 constexpr double JITTER = 1.25e-12;  // george's diagonal jitter
 constexpr int MAX_DIM = 256;
+constexpr int PROG_STRIDE = 512;     // progress words per sample: one per panel (n_pad <= 65 536)
 
 // v_mfma_f64_16x16x4_f64 accumulator: 4 f64 per lane
 typedef double v4d __attribute__((vector_size(32)));
@@ -47,6 +48,23 @@ __device__ __forceinline__ double rn_div(double a, double b) {
 #pragma clang fp contract(off)
     return a / b;
 }
+
+// ---- hand-offs between workgroups of ONE launch (the factorisation's panel followers, potrf.hip) ------------------------
+// Per-XCD L2s are not coherent with each other and a CU's L1 is never refreshed by another CU's stores: a payload another
+// workgroup reads in the same launch is stored WRITE-THROUGH (relaxed agent-scope atomics = global_store ... sc1) and read
+// with L1-bypassing loads of the same kind; the producer drains its stores (s_waitcnt vmcnt(0)) before ONE lane stores the
+// progress word, the consumer polls that one word relaxed (MI355X guide, "inter-workgroup visibility": the sc1 / sc1 form).
+__device__ __forceinline__ void st_agent(double* p, double v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ double ld_agent(const double* p) {
+    return __hip_atomic_load(const_cast<double*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void st_agent_u32(unsigned* p, unsigned v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ unsigned ld_agent_u32(const unsigned* p) {
+    return __hip_atomic_load(const_cast<unsigned*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// every vector-memory operation of this wave has completed (vmcnt(0); expcnt / lgkmcnt fields left at their maxima)
+__device__ __forceinline__ void drain_vmem() { __builtin_amdgcn_s_waitcnt(0x0F70); }
+constexpr unsigned PROG_SPIN_LIMIT = 1u << 24;   // bounded spin (~seconds): a hand-off that never arrives ends in a flagged failure
 
 // covariance function of the current theta (see kern_math.h)
 struct CovParams {
@@ -131,6 +149,9 @@ struct Tuning {
     int potrf_split_min;         // ... from this many panels on (default 12: N >= 1408)
     int potrf_lead;              // ... first-group size step between sub-batches (-1: G / splits)
     int potrf_tail_split;        // fused step: the ragged last round of 128-row tiles as half / quarter tiles on more workgroups
+    int potrf_follow;            // single-theta fit: the panel solve of column k+1 FOLLOWS the diagonal block inside the step
+                                 // kernel (progress words, potrf_step_follow_kernel) instead of its own launch (0: off)
+    int potrf_follow_from;       // ... from this step on (earlier steps are bound by their trailing updates)
     int mcmc_block_step;         // ensemble half-step in ONE launch: 2 (default) every one-block problem, 1 only N <= 63, 0 never
 };
 void tuning_from_env(Tuning* t);
@@ -165,6 +186,7 @@ struct robo_ctx {
     // scratch shared by every call on this context
     double* d_scalars;   // [8]: quad, logdet, ...
     int* d_fail;         // first failing column + 1, or 0
+    unsigned* d_prog;    // [2][PROG_STRIDE] progress words of the follower hand-off (potrf.hip), zeroed per factorisation
     double* h_pinned;    // small pinned staging (64 doubles)
 };
 
@@ -279,6 +301,7 @@ struct FitBuffers {
     const double* Xs; size_t xs_stride;  // (n_pad x dim) per sample
     const FitSample* sp;                 // [S]
     int* fail;                           // [S]
+    unsigned* prog;                      // [S][PROG_STRIDE] progress words (single-theta fits), or nullptr
     double* out;                         // [S][2]: z.z, 2 sum log diag
     double* ll_part;                     // [S][n_pad/128][4] per block: z.z and sum log L_ii shares, min / max L_ii
     double* LinvP;                       // packed inverse fragments of the GP's own factor, or nullptr (batch workspace)

@@ -431,8 +431,36 @@ constexpr int TLD = SB + 2;   // padded leading dimension of the per-wave transp
 //   waves 1-3  : solves L_{i,s}, i >= s+2   [Bb]   block column s+1 and pivot block (s+2,s+2) receive all
 //                their updates (columns 0..s); the inverse advances by block row s, column by column (see the
 //                task list in the loop).  One product per block of row 7 of W is left after the last pivot.
+// ---- publication for the panel followers (potrf_step_follow_kernel) ---------------------------------------------------------
+// With pub != nullptr the diagonal workgroup hands block column s of L_kk and W_ss to the OTHER workgroups of its launch as
+// soon as they are final (after barrier Bb(s)), straight into their final places in K and in the inverse block -- so the
+// write-back at the end goes away -- with write-through stores by the three helper waves, issued at the START of their
+// half-interval and drained at its end (the pivot wave stores nothing: its chain is untouched); after barrier Ba(s+1) one
+// lane raises the panel's progress word to s + 1 ("columns < s + 1 are in memory").  Same arithmetic, same bits.
+struct DiagPub {
+    double* Kd;        // tile (k, k) in K (row-major, leading dimension ld)
+    int ld;
+    double* Wg;        // the 128 x 128 inverse block of panel k (its eight diagonal sub-blocks are written)
+    unsigned* prog;    // progress word of panel k
+};
+// one wave: 16 x 16 LDS block (bidx layout) -> 16 rows of a row-major global matrix, write-through
+__device__ __forceinline__ void blk_publish(const double* b, double* dst, int ld, int lane) {
+    const int r = lane >> 2, c0 = (lane & 3) * 4;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) st_agent(dst + (size_t)r * ld + c0 + q, b[bidx(r, c0 + q)]);
+}
+// block column c of L (rows c .. 7) and W_cc, blocks dealt round-robin to `nw` waves (this wave: `w`)
+__device__ __forceinline__ void diag_publish_column(const double* sL, const double* sW, const DiagPub& pub, int c, int w,
+                                                    int nw, int lane) {
+    int t = 0;
+    for (int bi = c; bi < NSB; ++bi, ++t)
+        if (t % nw == w) blk_publish(sL + blk_off(bi, c), pub.Kd + (size_t)(bi * SB) * pub.ld + c * SB, pub.ld, lane);
+    if (t % nw == w) blk_publish(sW + blk_off(c, c), pub.Wg + (size_t)(c * SB) * NB + c * SB, NB, lane);
+}
+
 __device__ __forceinline__ void diag128_factor_invert(double* sL, double* sW, double* sT, double* sRd, double* sCol,
-                                                      int kbase, int n_real, int* fail, long long* dbg) {
+                                                      int kbase, int n_real, int* fail, long long* dbg,
+                                                      const DiagPub* pub = nullptr) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     int* ctr = reinterpret_cast<int*>(sRd);     // one task counter per interval
     if (tid >= 64 && tid < 64 + NSB) ctr[tid - 64] = 0;
@@ -489,6 +517,7 @@ __device__ __forceinline__ void diag128_factor_invert(double* sL, double* sW, do
         __syncthreads();                                          // Bb(s): block column s of L is final
         if (dbg && tid == 0 && s == 0) dbg[3] = clock64();
         if (dbg && tid == 0) dbg[24 + 4 * s + 1] = clock64();     // through Bb(s)
+        if (pub && wave != 0) diag_publish_column(sL, sW, *pub, s, wave - 1, 3, lane);
         if (wave == 0) {
             const int f = potf2_16(sL + blk_off(s + 1, s + 1), sW + blk_off(s + 1, s + 1), sCol, lane,
                                    kbase + (s + 1) * SB, n_real);
@@ -528,8 +557,17 @@ __device__ __forceinline__ void diag128_factor_invert(double* sL, double* sW, do
                 for (int r = 0; r < 4; ++r) C[co[r]] = acc[r];
             }
         }
+        if (pub && wave != 0) drain_vmem();                       // this wave's share of column s has left the CU
         __syncthreads();                                          // Ba(s+1)
+        if (pub && tid == 64) st_agent_u32(pub->prog, (unsigned)(s + 1));
         if (dbg && tid == 0) dbg[4 + s] = clock64();
+    }
+    if (pub) {
+        // what the loop did not hand over: the last factored block column (nsb - 1) and the identity padding behind it
+        for (int c = nsb - 1; c < NSB; ++c) diag_publish_column(sL, sW, *pub, c, wave, 4, lane);
+        drain_vmem();
+        __syncthreads();
+        if (tid == 0) st_agent_u32(pub->prog, (unsigned)NSB);
     }
     if (dbg && tid == 0) dbg[11] = clock64();
 }
@@ -1127,11 +1165,15 @@ __device__ __forceinline__ void tri_decode(int t, int& ii, int& jj) {
 //     current one, and the barrier + first fragment read of the next k-tile sit in the MIDDLE of that step's MFMAs.
 // Measured: k-loop 42.5k -> 40.1k cycles, two tiles 52-59 -> 50 us, three 81 -> 75 us, fit 1.87 -> 1.82 ms.
 // Same arithmetic as gemm_nt<4, true> on acc = C: products are accumulated on top of the stored value in ascending k.
+// shift = 1: t indexes the triangle WITHOUT its first block row and column (tiles (ii + 1, jj + 1): the follower form of the
+// step kernel, whose first-column tiles belong to the panel followers)
 __device__ __forceinline__ void update_tiles_persistent(double* __restrict__ K, int ld, int k, int t0, int stride,
-                                                        int ntiles, double* smem) {
+                                                        int ntiles, double* smem, int shift = 0) {
     constexpr int SA = stage_a<4>(), ST = SA + STAGE_B, NK = NB / BK;
     int ii, jj;
     tri_decode(t0, ii, jj);
+    ii += shift;
+    jj += shift;
     const double* A = K + ((size_t)(k + 1 + ii) * NB) * ld + (size_t)k * NB;
     const double* B = K + ((size_t)(k + 1 + jj) * NB) * ld + (size_t)k * NB;
     double* C = K + ((size_t)(k + 1 + ii) * NB) * ld + (size_t)(k + 1 + jj) * NB;
@@ -1150,6 +1192,8 @@ __device__ __forceinline__ void update_tiles_persistent(double* __restrict__ K, 
         double* Cn = C;
         if (more) {
             tri_decode(tn_, ii, jj);
+            ii += shift;
+            jj += shift;
             An = K + ((size_t)(k + 1 + ii) * NB) * ld + (size_t)k * NB;
             Bn = K + ((size_t)(k + 1 + jj) * NB) * ld + (size_t)k * NB;
             Cn = K + ((size_t)(k + 1 + ii) * NB) * ld + (size_t)(k + 1 + jj) * NB;
@@ -1243,9 +1287,12 @@ __device__ __forceinline__ void update_tiles_persistent(double* __restrict__ K, 
 // 32 TM rows of tile t (row-major index in the lower triangle of the trailing matrix) by this workgroup: the plain NT GEMM on
 // top of the stored C, ascending k -- the same bits as the 128-row tile kernel leaves there
 template <int TM>
-__device__ __forceinline__ void update_subtile(double* __restrict__ K, int ld, int k, int t, int h, double* smem) {
+__device__ __forceinline__ void update_subtile(double* __restrict__ K, int ld, int k, int t, int h, double* smem,
+                                               int shift = 0) {
     int ii, jj;
     tri_decode(t, ii, jj);
+    ii += shift;
+    jj += shift;
     const size_t row0 = (size_t)(k + 1 + ii) * NB + (size_t)h * (32 * TM);
     const double* A = K + row0 * ld + (size_t)k * NB;
     const double* B = K + ((size_t)(k + 1 + jj) * NB) * ld + (size_t)k * NB;
@@ -1383,6 +1430,143 @@ __global__ __launch_bounds__(256) void potrf_step_kernel(double* __restrict__ K,
             for (int r = 0; r < 4; ++r) C[(size_t)acc_row<TM>(tm, r) * ld + acc_col(tn)] = acc.t[tm][tn][r];
 }
 
+// ---- the panel solve as a FOLLOWER of the diagonal block (r06) -----------------------------------------------------------
+// potrf_panel_kernel's substitution, column by column instead of row by row: as soon as block column c of L_kk and W_cc are
+// published (diag128_factor_invert with a DiagPub, progress word >= c + 1)
+//      Y_c = W_cc t_c ;   t_s -= L_sc Y_c   for s > c
+// -- every t_s still receives its updates in ascending c and every product its four MFMAs in the same order, so the strips
+// are the panel kernel's bit for bit.  One 16-row strip per wave (64 rows per workgroup), operands of ONE column at a time
+// in 16 KB of LDS (slot s: L_sc for s > c, slot c: W_cc; rows and columns permuted as in the panel kernel).
+// The chain   panel (11 us) -> launch boundary -> tile update + 128 pivots   of the launch-per-phase factorisation loses its
+// first link: the strips are final one hand-off (a few us) after the diagonal block's last pivot.
+__device__ __forceinline__ void panel_follow(double* __restrict__ K, int ld, int kc, size_t row0, const unsigned* prog,
+                                             const double* __restrict__ Wg, double* smem, int* fail) {
+    // kc: block column being solved; row0: first of this workgroup's 64 rows; prog: progress word of panel kc
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const double* Kd = K + ((size_t)kc * NB) * ld + (size_t)kc * NB;
+    double* Arow = K + (row0 + wave * 16 + (lane & 15)) * ld + (size_t)kc * NB + 4 * (lane >> 4);
+    v4d y[NSB];
+#pragma unroll
+    for (int s = 0; s < NSB; ++s) {
+        const double2* p = reinterpret_cast<const double2*>(Arow + s * SB);
+        const double2 lo = p[0], hi = p[1];
+        y[s] = v4d{lo.x, lo.y, hi.x, hi.y};
+    }
+    const int r = tid >> 4, c16 = tid & 15;
+    const int pos = bidx(pi16(r), pi16(c16));
+    int* sflag = reinterpret_cast<int*>(smem + NSB * BLK);
+#pragma unroll
+    for (int c = 0; c < NSB; ++c) {
+        if (tid == 0) {
+            unsigned spins = 0;
+            int ok = 1;
+            while (ld_agent_u32(prog) < (unsigned)(c + 1)) {
+                __builtin_amdgcn_s_sleep(2);
+                if (++spins > PROG_SPIN_LIMIT) {
+                    ok = 0;
+                    break;
+                }
+            }
+            *sflag = ok;
+        }
+        __syncthreads();                 // the column is in memory (and the previous column's fragment reads are over)
+        if (*sflag == 0) {               // the producer never arrived: flag the factorisation, leave the strips alone
+            if (tid == 0 && *fail == 0) *fail = kc * NB + 1;
+            return;
+        }
+        // stage W_cc (slot c) and L_sc, s > c (slot s): one element per thread and block, L1-bypassing loads
+        double v[NSB];
+#pragma unroll
+        for (int sl = c; sl < NSB; ++sl)
+            v[sl] = sl == c ? ld_agent(Wg + (size_t)(c * SB + r) * NB + c * SB + c16)
+                            : ld_agent(Kd + (size_t)(sl * SB + r) * ld + c * SB + c16);
+#pragma unroll
+        for (int sl = c; sl < NSB; ++sl) smem[sl * BLK + pos] = v[sl];
+        __syncthreads();
+        {
+            const Frag4 w = frag_row(smem + c * BLK, lane);
+            v4d o = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+            for (int q = 0; q < 4; ++q) o = mfma_f64(w.v[q], y[c][q], o);
+            y[c] = o;
+        }
+#pragma unroll
+        for (int sl = c + 1; sl < NSB; ++sl) {
+            const Frag4 a = frag_row(smem + sl * BLK, lane);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) y[sl] = mfma_f64(-a.v[q], y[c][q], y[sl]);
+        }
+    }
+#pragma unroll
+    for (int s = 0; s < NSB; ++s) {
+        double2* p = reinterpret_cast<double2*>(Arow + s * SB);
+        p[0] = make_double2(y[s][0], y[s][1]);
+        p[1] = make_double2(y[s][2], y[s][3]);
+    }
+}
+
+// Step k of the single-theta factorisation with the NEXT panel inside (potrf_follow):
+//   workgroup 0            tile (k+1, k+1): update by panel k, 128 pivots -- publishing block column after block column
+//   workgroups 1 .. nfol   two per block row i >= k+2: their 64 rows of tile (i, k+1) receive panel k (the 64-row sub-tile of
+//                          the trailing update), then follow workgroup 0: panel k+1 is final a hand-off after its last pivot
+//   the others             the remaining tiles (ii >= jj >= 1 of the trailing triangle), persistent as in potrf_step_kernel
+// k = -1: the first diagonal block and panel 0 (nothing to update: workgroup 0 loads its tile, the followers their strips).
+// Every workgroup carries the diagonal block's 150-KB LDS image, i.e. one per CU: with the grid <= the CU count all of them
+// are resident and workgroup 0 -- dispatched first, waiting for nobody -- always makes progress; the followers' polls are bounded.
+__global__ __launch_bounds__(256) void potrf_step_follow_kernel(double* __restrict__ K, size_t k_stride, int ld, int k,
+                                                                int n_real, double* __restrict__ Linv, size_t linv_stride,
+                                                                int* __restrict__ fail, unsigned* __restrict__ prog,
+                                                                int nfol, int ntiles, int tail_split) {
+    __shared__ double smem[DIAG_SMEM_DOUBLES];
+    K += (size_t)blockIdx.y * k_stride;
+    Linv += (size_t)blockIdx.y * linv_stride;
+    fail += blockIdx.y;
+    prog += (size_t)blockIdx.y * PROG_STRIDE + (k + 1);
+    const int b = (int)blockIdx.x;
+    const size_t d0 = (size_t)(k + 1) * NB;
+    double* Wg = Linv + (size_t)(k + 1) * NB * NB;
+    if (b == 0) {
+        double* C = K + d0 * ld + d0;
+        const DiagSmem m = diag_carve(smem);
+        if (k >= 0) {
+            diag_tile_update(K + d0 * ld + (size_t)k * NB, C, ld, m.sW, m.sL);   // staging in the (still unused) W image
+        } else {
+            const int tid = threadIdx.x;
+            for (int bi = 0; bi < NSB; ++bi)
+                for (int bj = 0; bj <= bi; ++bj)
+                    m.sL[blk_off(bi, bj) + bidx(tid >> 4, tid & 15)] = C[(size_t)(bi * SB + (tid >> 4)) * ld + bj * SB + (tid & 15)];
+        }
+        __syncthreads();
+        const DiagPub pub = {C, ld, Wg, prog};
+        diag128_factor_invert(m.sL, m.sW, m.sT, m.sRd, m.sCol, (k + 1) * NB, n_real, fail, nullptr, &pub);
+        return;
+    }
+    if (b <= nfol) {
+        const int ii = 1 + (b - 1) / 2, h = (b - 1) & 1;           // block row k + 1 + ii, rows 64 h .. 64 h + 63
+        if (k >= 0) {
+            update_subtile<2>(K, ld, k, ii * (ii + 1) / 2, h, smem);
+            __syncthreads();             // this workgroup's stores before its own strip loads (and the staging area's reuse)
+        }
+        panel_follow(K, ld, k + 1, (size_t)(k + 1 + ii) * NB + (size_t)h * 64, prog, Wg, smem, fail);
+        return;
+    }
+    // the remaining tiles of the trailing update: the triangle without its first block row and column
+    const int q = b - 1 - nfol, W = (int)gridDim.x - 1 - nfol;
+    int full_end = ntiles, split = 0, left = 0;
+    if (tail_split != 0 && ntiles > W) {
+        const int R = ntiles / W;
+        left = ntiles - R * W;
+        if (left > 0) split = 4 * left <= W ? 4 : (2 * left <= W ? 2 : 0);
+        if (split) full_end = R * W;
+    }
+    if (q < full_end) update_tiles_persistent(K, ld, k, q, W, full_end, smem, 1);
+    if (split && q < split * left) {
+        __syncthreads();
+        if (split == 4) update_subtile<1>(K, ld, k, full_end + q / 4, q % 4, smem, 1);
+        else update_subtile<2>(K, ld, k, full_end + q / 2, q % 2, smem, 1);
+    }
+}
+
 // Linv blocks -> packed A-operand fragments for the transposed block-row solve (predict.hip, trsm_step_t_kernel):
 // fragment s = wp_offset(cb) + 4 jb + kk of diagonal block b, lane l:
 //     Linv_b[16 cb + pi16(l & 15)][16 jb + 4 kk + (l >> 4)]
@@ -1455,6 +1639,10 @@ int launch_pack_linv(robo_gp* gp) {
     return ROBO_OK;
 }
 
+// the follower form of the step kernel needs all its workgroups resident (one per CU): the diagonal workgroup, two followers
+// per block row below the first panel, and at least a quarter of the chip left for the other tiles
+static bool tiles_ok_for_follow(int nb, int max_wg) { return 1 + 2 * (nb - 1) + max_wg / 4 <= max_wg; }
+
 int launch_potrf(robo_gp* gp, const FitBuffers& fb, bool with_gram) {
     robo_ctx* ctx = gp->ctx;
     const int ld = gp->n_pad, nb = gp->n_pad / NB, S = fb.S;
@@ -1506,11 +1694,39 @@ int launch_potrf(robo_gp* gp, const FitBuffers& fb, bool with_gram) {
         // single theta: trailing update of step k + diagonal block k+1 (workgroup 0) in one launch
         hipStream_t st = ctx->stream;
         if (!gram_done) ROBO_TRY(launch_gram(gp, fb));
-        diag(st, 0, S, 0);
+        // potrf_follow: from step `ffrom` on the panel solve of column k+1 runs INSIDE step k's launch, following the
+        // diagonal workgroup (potrf_step_follow_kernel); ffrom = -1: the first diagonal block and panel 0 too.  Needs every
+        // workgroup resident: 1 + two followers per block row + at least a quarter of the chip for the other tiles.
+        const bool can_follow = tune.potrf_follow != 0 && fb.prog != nullptr && tiles_ok_for_follow(nb, max_wg);
+        const int ffrom = can_follow ? (tune.potrf_follow_from < 0 ? -1 : tune.potrf_follow_from) : nb;
+        auto follow = [&](int k) {
+            // block rows below k+1: two followers each; the other tiles of the trailing triangle (none in front of panel 0)
+            const int nfol = 2 * (nb - k - 2), r1 = nb - k - 2, rest = k < 0 ? 0 : r1 * (r1 + 1) / 2;
+            int W = max_wg - 1 - nfol;
+            W = W < 1 ? 1 : W;
+            W = W < rest ? W : rest;
+            hipLaunchKernelGGL(potrf_step_follow_kernel, dim3(1 + nfol + W, S), dim3(256), 0, st, fb.K, fb.k_stride,
+                               ld, k, gp->n, fb.Linv, fb.linv_stride, fb.fail, fb.prog, nfol, rest,
+                               tune.potrf_tail_split != 0 ? 1 : 0);
+        };
+        if (can_follow) ROBO_HIP_CHECK(hipMemsetAsync(fb.prog, 0, (size_t)S * PROG_STRIDE * sizeof(unsigned), st));
+        bool panel_done = false;              // panel of the CURRENT column k already solved (by the previous follow step)
+        if (ffrom < 0 && nbf >= 1 && nb > 1) {
+            follow(-1);
+            panel_done = true;
+        } else {
+            diag(st, 0, S, 0);
+        }
         for (int k = 0; k + 1 < nb; ++k) {
             const int rem = nb - k - 1, tiles = rem * (rem + 1) / 2;
-            panel(st, 0, S, k);
+            if (!panel_done) panel(st, 0, S, k);
+            panel_done = false;
             if (k + 1 >= nbf) break;          // what is left is the augmented row's own block: nothing to factor
+            if (k >= ffrom) {
+                follow(k);                    // update by panel k, diagonal block k+1, panel k+1
+                panel_done = true;
+                continue;
+            }
             // 128-row tiles: one diagonal workgroup + at most (CUs - 1) persistent tile workgroups (one per CU: the
             // diagonal block's LDS image sizes every workgroup of the launch)
             if (tiles * S >= tm4_min)

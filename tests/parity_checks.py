@@ -1428,3 +1428,51 @@ def check_winv_guard_sweep(ctx, n=768, min_blocks=None, m=400, verbose=True,
     return table
 
 
+
+
+def check_panel_followers(ctx, sizes=((520, 3), (512, 3), (300, 3), (130, 2)), caps=(64, 16, 13), froms=(-1, 0, 2), emulated=True):
+    """potrf_follow: the panel solve of column k+1 inside step k's launch, FOLLOWING the diagonal workgroup through progress
+    words (potrf_step_follow_kernel) -- the same factor, likelihood and posterior, BIT FOR BIT, as the launch-per-phase
+    form, whichever step the hand-off starts at, however many workgroups share the other tiles, N a multiple of 128 or not.
+    (On the CPU the interpreter runs workgroup 0 first, so this checks arithmetic and indexing; the hand-off itself --
+    write-through stores, polls, L1-bypassing loads across XCDs -- is what the MI355X run of the same check is for.)"""
+    from oracle import gp_oracle as O
+    keys = ("potrf_tm4_min", "potrf_max_wg", "potrf_tail_split", "potrf_follow", "potrf_follow_from")
+    for N, D in sizes:
+        rs = np.random.RandomState(13 + N)
+        X = rs.rand(N, D)
+        y = np.cos(3 * X.sum(axis=1))
+        theta = np.concatenate([[0.1], np.log(0.5 + 0.2 * np.arange(D)), [np.log(1e-2)]])
+        ogp = O.OracleGP("matern52", theta, normalize_input=False)
+        ogp.train(X, y)
+        g = _lib.DeviceGP(ctx, "matern52", N, D)
+        g.set_data(X, y)
+        Xc = rs.rand(40, D)
+        try:
+            ctx.set_tuning("potrf_follow", 0)
+            ll0 = g.fit(theta, ogp.mean)
+            L0 = g.factor().copy()
+            mu0, v0 = g.predict(Xc)
+            np.testing.assert_allclose(ll0, ogp.loglikelihood(theta), rtol=1e-10)
+            np.testing.assert_allclose(L0, ogp.L, rtol=0, atol=1e-10)
+            if emulated:
+                ctx.set_tuning("potrf_tm4_min", 1)
+            for frm in froms:
+                for cap in caps:
+                    for split in ((1, 0) if emulated else (1,)):
+                        ctx.set_tuning("potrf_follow", 1)
+                        ctx.set_tuning("potrf_follow_from", frm)
+                        if cap is not None:
+                            ctx.set_tuning("potrf_max_wg", cap)
+                        ctx.set_tuning("potrf_tail_split", split)
+                        for rep in range(1 if emulated else 3):
+                            ll = g.fit(theta, ogp.mean)
+                            assert ll == ll0, (N, frm, cap, split, rep, ll, ll0)
+                            np.testing.assert_array_equal(g.factor(), L0, err_msg=str((N, frm, cap, split, rep)))
+                        mu, v = g.predict(Xc)
+                        np.testing.assert_array_equal(mu, mu0)
+                        np.testing.assert_array_equal(v, v0)
+        finally:
+            for key in keys:
+                ctx.set_tuning(key, None)
+            g.close()

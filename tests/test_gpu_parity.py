@@ -49,6 +49,14 @@ def test_stretch_move_bits(ctx):
         np.testing.assert_array_equal(d, (18 - 1.0) * u + c - s)
 
 
+def test_panel_followers_hand_off(ctx):
+    """potrf_follow on the hardware: the panel workgroups read what the diagonal workgroup of the SAME launch published
+    (write-through stores, progress word, L1-bypassing loads, across XCDs) -- factor, likelihood and posterior equal the
+    launch-per-phase form's bit for bit, three fits per setting, at sizes from two blocks to the headline's 33"""
+    P.check_panel_followers(ctx, sizes=((4096, 16), (4000, 8), (2048, 16), (1000, 4), (300, 3)), caps=(None,), froms=(-1, 0, 5, 11),
+                            emulated=False)
+
+
 @pytest.mark.parametrize("name", ["small_matern", "ragged_rbf_nout", "one_block_edge", "two_block"])
 def test_golden_cases(ctx, name):
     P.check_case(ctx, name)

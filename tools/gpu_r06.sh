@@ -137,6 +137,49 @@ import json; d=json.load(open('$OUT/bench_pair${pair}_$rep.json')); print('trsm_
   find $OUT/pmc_pair1 -size +30M -delete
   python tools/make_traffic_json.py $OUT/pmc_summary_pair1.txt $(cat .git_head 2>/dev/null || echo unknown) trsm_pair_gen_kernel headline 4096 16 65536 > $OUT/trsm_traffic_pair1.json 2>> $OUT/summary.txt
   grep -h "bytes_per_launch\|launches" $OUT/trsm_traffic_pair1.json >> $OUT/summary.txt ;;
+trace2048)
+  # the batched factorisation where the default front end lives: 26 thetas at N = 2048 (one ensemble half-step), kernel trace
+  for v in "0,3,-1" "0,1,-1"; do
+    name=$(echo $v | tr ',' '_')
+    BATCH_AB="$v" timeout 300 rocprofv3 --kernel-trace -d $OUT/batch2048_$name -o t -- python tools/batched_fit_ab.py 2048 16 26 2 > $OUT/batch2048_$name.log 2>&1
+    python tools/batch_trace.py $OUT/batch2048_$name 400 > $OUT/batch2048_trace_$name.txt 2>&1
+    find $OUT/batch2048_$name -size +5M -delete
+    head -1 $OUT/batch2048_trace_$name.txt >> $OUT/summary.txt
+  done
+  BATCH_AB="0,3,-1;0,1,-1" timeout 300 python tools/batched_fit_ab.py 2048 16 26 7 > $OUT/batch2048_ab.txt 2>&1; grep "round 1" $OUT/batch2048_ab.txt >> $OUT/summary.txt ;;
+storefloor)
+  # what a pure store stream of K1's size costs on this part (torch fill of 67.6 MB, HIP events): the floor under gram_kernel
+  timeout 300 python - > $OUT/storefloor.txt 2>&1 <<PY
+import torch
+n = 67649536 // 8
+x = torch.empty(n, dtype=torch.float64, device="cuda")
+y = torch.empty(n // 2, dtype=torch.float64, device="cuda")
+for name, t in (("fill 67.6 MB", x), ("fill 33.8 MB (fp32-sized K)", y)):
+    for _ in range(5): t.fill_(1.0)
+    torch.cuda.synchronize()
+    ts = []
+    for _ in range(20):
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record(); t.fill_(2.0); b.record(); torch.cuda.synchronize()
+        ts.append(a.elapsed_time(b) * 1e3)
+    ts.sort()
+    print("%s: median %.1f us min %.1f us -> %.2f TB/s" % (name, ts[len(ts)//2], ts[0], t.numel() * 8 / ts[len(ts)//2] / 1e6))
+PY
+  cat $OUT/storefloor.txt >> $OUT/summary.txt ;;
+follow)
+  # the follower form of the single-theta factorisation: hardware parity test first (hand-off across XCDs), then the A/B
+  timeout 900 python -m pytest tests/test_gpu_parity.py -m gpu -q -x -k "panel_followers" > $OUT/follow_test.log 2>&1; echo "follow test rc=$?" >> $OUT/summary.txt
+  tail -5 $OUT/follow_test.log >> $OUT/summary.txt
+  for cfg in "4096 16" "2048 16" "1024 8" "8192 64"; do
+    timeout 300 python tools/follow_ab.py $cfg 15 >> $OUT/follow_ab.txt 2>&1
+  done
+  grep "single-theta\|round 1" $OUT/follow_ab.txt >> $OUT/summary.txt
+  for f in 0 1; do
+    ROBO_POTRF_FOLLOW=$f ROBO_POTRF_FOLLOW_FROM=-1 FIT_N=4096 FIT_REPS=4 timeout 300 rocprofv3 --kernel-trace -d $OUT/prof_follow$f -o fit -- python tools/fit_only.py > $OUT/prof_follow$f.log 2>&1
+    python tools/fit_trace.py $OUT/prof_follow$f > $OUT/trace_4096_follow$f.txt 2>&1
+    find $OUT/prof_follow$f -size +5M -delete
+    tail -2 $OUT/trace_4096_follow$f.txt >> $OUT/summary.txt
+  done ;;
 small)
   timeout 300 python tools/small_m_timing.py > $OUT/small_m.txt 2>&1; cat $OUT/small_m.txt >> $OUT/summary.txt ;;
 *) echo "unknown step $what" >> $OUT/summary.txt ;;
