@@ -62,6 +62,9 @@ __device__ __forceinline__ void st_agent_u32(unsigned* p, unsigned v) { __hip_at
 __device__ __forceinline__ unsigned ld_agent_u32(const unsigned* p) {
     return __hip_atomic_load(const_cast<unsigned*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
+__device__ __forceinline__ void add_agent_u32(unsigned* p, unsigned v) {
+    __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
 // every vector-memory operation of this wave has completed (vmcnt(0); expcnt / lgkmcnt fields left at their maxima)
 __device__ __forceinline__ void drain_vmem() { __builtin_amdgcn_s_waitcnt(0x0F70); }
 constexpr unsigned PROG_SPIN_LIMIT = 1u << 24;   // bounded spin (~seconds): a hand-off that never arrives ends in a flagged failure

@@ -93,6 +93,14 @@ struct robo_multi {
     double* d_recv;
     size_t recv_cap;
     double* h_pinned;   // [8] on the first device's context: status pair of the ordered sum at [4]
+    // device g -> first device: 1 = peer access enabled (hipMemcpyPeerAsync moves the bytes over xGMI), 0 = the two devices
+    // cannot address each other (hipDeviceCanAccessPeer said no, or ROBO_MULTI_NO_PEER=1): gathers are staged explicitly
+    // through `h_stage` (pinned; D2H on the source device, H2D on the first device's stream)
+    std::vector<int> peer;
+    double* h_stage;
+    size_t stage_cap;
+    // the object is NOT re-entrant (one job slot per worker, shared exchange buffers): entry points hold this for the call
+    std::mutex call_mu;
 };
 
 using namespace robo;
@@ -181,6 +189,32 @@ static bool better(double v, int64_t i, double bv, int64_t bi) {
 
 extern "C" {
 
+// `bytes` from device slot g's `src` to `dst` on the first device, ordered on the first device's stream.  Peers: one
+// hipMemcpyPeerAsync (xGMI).  No peer access: staged through pinned host memory -- the source device's copy is complete
+// before the first device's stream picks the bytes up, and the staging area is free again when this returns.
+static int gather_to_first(robo_multi* m, int g, double* dst, const double* src, size_t bytes) {
+    robo_ctx* c0 = m->ctx[0];
+    robo_ctx* cg = m->ctx[(size_t)g];
+    if (m->peer[(size_t)g]) {
+        ROBO_HIP_CHECK(hipMemcpyPeerAsync(dst, c0->device, src, cg->device, bytes, c0->stream));
+        return ROBO_OK;
+    }
+    if (bytes > m->stage_cap) {
+        if (m->h_stage) ROBO_HIP_CHECK(hipHostFree(m->h_stage));
+        m->h_stage = nullptr;
+        m->stage_cap = 0;
+        ROBO_HIP_CHECK(hipHostMalloc((void**)&m->h_stage, bytes, 0));
+        m->stage_cap = bytes;
+    }
+    ROBO_HIP_CHECK(hipSetDevice(cg->device));
+    ROBO_HIP_CHECK(hipMemcpyAsync(m->h_stage, src, bytes, hipMemcpyDeviceToHost, cg->stream));
+    ROBO_HIP_CHECK(hipStreamSynchronize(cg->stream));
+    ROBO_HIP_CHECK(hipSetDevice(c0->device));
+    ROBO_HIP_CHECK(hipMemcpyAsync(dst, m->h_stage, bytes, hipMemcpyHostToDevice, c0->stream));
+    ROBO_HIP_CHECK(hipStreamSynchronize(c0->stream));
+    return ROBO_OK;
+}
+
 int32_t robo_multi_create(robo_ctx* const* ctxs, int32_t n_ctx, robo_multi** out) {
     if (!ctxs || !out || n_ctx < 1 || n_ctx > 64) return ROBO_BAD_ARGUMENT;
     for (int g = 0; g < n_ctx; ++g) {
@@ -205,6 +239,25 @@ int32_t robo_multi_create(robo_ctx* const* ctxs, int32_t n_ctx, robo_multi** out
         set_error("robo_multi_create: pinned staging on device %d failed", ctxs[0]->device);
         delete m;
         return ROBO_RUNTIME_ERROR;
+    }
+    m->h_stage = nullptr;
+    m->stage_cap = 0;
+    m->peer.assign((size_t)n_ctx, 1);
+    {
+        const char* np = getenv("ROBO_MULTI_NO_PEER");
+        const bool no_peer = np && atoi(np) != 0;
+        for (int g = 1; g < n_ctx; ++g) {
+            const int d0 = ctxs[0]->device, dg = ctxs[g]->device;
+            if (dg == d0) continue;                       // two contexts on one device: an ordinary device-to-device copy
+            int can = 0;
+            if (no_peer || hipDeviceCanAccessPeer(&can, d0, dg) != hipSuccess || !can) {
+                m->peer[(size_t)g] = 0;
+                continue;
+            }
+            const hipError_t en = hipDeviceEnablePeerAccess(dg, 0);     // (current device: d0, set above)
+            if (en != hipSuccess && en != hipErrorPeerAccessAlreadyEnabled) m->peer[(size_t)g] = 0;
+            (void)hipGetLastError();
+        }
     }
     if (m->threads)
         for (int g = 0; g < n_ctx; ++g) {
@@ -236,6 +289,7 @@ int32_t robo_multi_destroy(robo_multi* m) {
     hipSetDevice(m->ctx[0]->device);
     if (m->d_recv) hipFree(m->d_recv);
     if (m->h_pinned) hipHostFree(m->h_pinned);
+    if (m->h_stage) hipHostFree(m->h_stage);
     const std::vector<robo_ctx*> ctxs = m->ctx;
     delete m;
     for (robo_ctx* c : ctxs) ctx_release(c);
@@ -253,6 +307,7 @@ int32_t robo_multi_info(robo_multi* m, int32_t* out_n, int32_t* out_devices, int
 
 int32_t robo_gp_set_data_multi(robo_multi* m, robo_gp* const* gps, const double* X, const double* y, int32_t n) {
     if (!m || !gps || !X || !y) return ROBO_BAD_ARGUMENT;
+    std::lock_guard<std::mutex> call_lock(m->call_mu);   // one call at a time per robo_multi (not re-entrant)
     for (int g = 0; g < m->G; ++g) {
         if (!gps[g]) return ROBO_BAD_ARGUMENT;
         ROBO_TRY(check_on(m, g, gps[g]->ctx, "robo_gp_set_data_multi", "the GP"));
@@ -263,6 +318,7 @@ int32_t robo_gp_set_data_multi(robo_multi* m, robo_gp* const* gps, const double*
 int32_t robo_gp_fit_multi(robo_multi* m, robo_gp* const* gps, const double* theta, double mean_c, double* out_loglik,
                           int32_t* out_fail_col) {
     if (!m || !gps || !theta) return ROBO_BAD_ARGUMENT;
+    std::lock_guard<std::mutex> call_lock(m->call_mu);   // one call at a time per robo_multi (not re-entrant)
     for (int g = 0; g < m->G; ++g) {
         if (!gps[g]) return ROBO_BAD_ARGUMENT;
         ROBO_TRY(check_on(m, g, gps[g]->ctx, "robo_gp_fit_multi", "the GP"));
@@ -289,6 +345,7 @@ int32_t robo_gp_fit_multi(robo_multi* m, robo_gp* const* gps, const double* thet
 int32_t robo_gp_loglik_batch_multi(robo_multi* m, robo_gp* const* gps, const double* thetas, int32_t S, double mean_c,
                                    double* out_loglik, int32_t* out_status) {
     if (!m || !gps || !thetas || S < 0 || !out_loglik) return ROBO_BAD_ARGUMENT;
+    std::lock_guard<std::mutex> call_lock(m->call_mu);   // one call at a time per robo_multi (not re-entrant)
     for (int g = 0; g < m->G; ++g) {
         if (!gps[g]) return ROBO_BAD_ARGUMENT;
         ROBO_TRY(check_on(m, g, gps[g]->ctx, "robo_gp_loglik_batch_multi", "the GP"));
@@ -306,6 +363,7 @@ int32_t robo_gp_loglik_batch_multi(robo_multi* m, robo_gp* const* gps, const dou
 int32_t robo_gp_fit_batch_multi(robo_multi* m, robo_gp* const* gps, const int32_t* S_dev, const double* thetas, double mean_c,
                                 double* out_loglik, int32_t* out_status) {
     if (!m || !gps || !S_dev || !thetas || !out_loglik || !out_status) return ROBO_BAD_ARGUMENT;
+    std::lock_guard<std::mutex> call_lock(m->call_mu);   // one call at a time per robo_multi (not re-entrant)
     std::vector<int> off((size_t)m->G + 1, 0);
     for (int g = 0; g < m->G; ++g) {
         if (S_dev[g] < 0) return ROBO_BAD_ARGUMENT;
@@ -354,6 +412,7 @@ int32_t robo_acq_eval_cand_multi(robo_multi* m, robo_gp* const* gps, int32_t acq
                                  robo_cand* const* cands, const int64_t* global_offsets, double* out_acq, double* out_max,
                                  int64_t* out_argmax, int32_t* out_owner, uint32_t* out_flags) {
     if (!m || !gps || !cands || !global_offsets) return ROBO_BAD_ARGUMENT;
+    std::lock_guard<std::mutex> call_lock(m->call_mu);   // one call at a time per robo_multi (not re-entrant)
     std::vector<int64_t> pos((size_t)m->G + 1, 0);
     std::vector<char> have((size_t)m->G, 0);
     for (int g = 0; g < m->G; ++g) {
@@ -383,6 +442,7 @@ int32_t robo_ig_eval_per_cost_cand_multi(robo_multi* m, robo_gp* const* gps, rob
                                          robo_cand* const* cost_cands, double overhead, const int64_t* global_offsets,
                                          double* out_values, double* out_max, int64_t* out_argmax, int32_t* out_owner) {
     if (!m || !gps || !cands || !reps || !cost_gps || !cost_cands || !global_offsets) return ROBO_BAD_ARGUMENT;
+    std::lock_guard<std::mutex> call_lock(m->call_mu);   // one call at a time per robo_multi (not re-entrant)
     std::vector<int64_t> pos((size_t)m->G + 1, 0);
     std::vector<char> have((size_t)m->G, 0);
     for (int g = 0; g < m->G; ++g) {
@@ -414,6 +474,7 @@ int32_t robo_ig_eval_cand_multi(robo_multi* m, robo_gp* const* gps, robo_cand* c
                                 const int64_t* global_offsets, double* out_dh, double* out_max, int64_t* out_argmax,
                                 int32_t* out_owner) {
     if (!m || !gps || !cands || !reps || !global_offsets) return ROBO_BAD_ARGUMENT;
+    std::lock_guard<std::mutex> call_lock(m->call_mu);   // one call at a time per robo_multi (not re-entrant)
     std::vector<int64_t> pos((size_t)m->G + 1, 0);
     std::vector<char> have((size_t)m->G, 0);
     for (int g = 0; g < m->G; ++g) {
@@ -441,6 +502,7 @@ int32_t robo_acq_eval_marginal_cand_multi(robo_multi* m, robo_gp* const* gps, co
                                           double par, const double* etas, robo_cand* const* cands, double* out_acq,
                                           double* out_max, int64_t* out_argmax, uint32_t* out_flags) {
     if (!m || !gps || !S_dev || !etas || !cands || !cands[0]) return ROBO_BAD_ARGUMENT;
+    std::lock_guard<std::mutex> call_lock(m->call_mu);   // one call at a time per robo_multi (not re-entrant)
     std::vector<int> off((size_t)m->G + 1, 0);
     const long long mm = (long long)cands[0]->m;
     for (int g = 0; g < m->G; ++g) {
@@ -491,8 +553,8 @@ int32_t robo_acq_eval_marginal_cand_multi(robo_multi* m, robo_gp* const* gps, co
     robo_cand* k0 = cands[0];
     ROBO_HIP_CHECK(hipSetDevice(c0->device));
     for (int g = 0; g < m->G; ++g)
-        ROBO_HIP_CHECK(hipMemcpyPeerAsync(m->d_recv + (size_t)g * ((size_t)mm + 2), c0->device, m->d_send[(size_t)g],
-                                          m->ctx[(size_t)g]->device, ((size_t)mm + 2) * sizeof(double), c0->stream));
+        ROBO_TRY(gather_to_first(m, g, m->d_recv + (size_t)g * ((size_t)mm + 2), m->d_send[(size_t)g],
+                                 ((size_t)mm + 2) * sizeof(double)));
     ROBO_TRY(api_clear_flags(k0, launch_comm_ordered_sum(c0->stream, m->d_recv, mm + 2, m->G, mm, k0->d_acq_sum, k0->d_flags,
                                                          reinterpret_cast<int*>(m->h_pinned + 4))));
     ROBO_TRY(api_clear_flags(k0, launch_argmax(k0, k0->d_acq_sum, (double)S_total)));
@@ -502,6 +564,7 @@ int32_t robo_acq_eval_marginal_cand_multi(robo_multi* m, robo_gp* const* gps, co
 int32_t robo_gp_predict_mixture_cand_multi(robo_multi* m, robo_gp* const* gps, const int32_t* S_dev, robo_cand* const* cands,
                                            double* out_mean, double* out_var) {
     if (!m || !gps || !S_dev || !cands || !cands[0]) return ROBO_BAD_ARGUMENT;
+    std::lock_guard<std::mutex> call_lock(m->call_mu);   // one call at a time per robo_multi (not re-entrant)
     std::vector<int> off((size_t)m->G + 1, 0);
     for (int g = 0; g < m->G; ++g) {
         if (S_dev[g] < 0 || (S_dev[g] > 0 && !cands[g])) return ROBO_BAD_ARGUMENT;
@@ -530,10 +593,8 @@ int32_t robo_gp_predict_mixture_cand_multi(robo_multi* m, robo_gp* const* gps, c
     for (int g = 1; g < m->G; ++g) {
         if (S_dev[g] == 0) continue;
         const size_t rows = (size_t)S_dev[g] * mp * sizeof(double), at = (size_t)off[(size_t)g] * mp;
-        ROBO_HIP_CHECK(hipMemcpyPeerAsync(k0->d_mu_all + at, c0->device, cands[g]->d_mu_all, m->ctx[(size_t)g]->device, rows,
-                                          c0->stream));
-        ROBO_HIP_CHECK(hipMemcpyPeerAsync(k0->d_var_all + at, c0->device, cands[g]->d_var_all, m->ctx[(size_t)g]->device, rows,
-                                          c0->stream));
+        ROBO_TRY(gather_to_first(m, g, k0->d_mu_all + at, cands[g]->d_mu_all, rows));
+        ROBO_TRY(gather_to_first(m, g, k0->d_var_all + at, cands[g]->d_var_all, rows));
     }
     ROBO_TRY(launch_mixture(k0, S_total));
     if (out_mean)

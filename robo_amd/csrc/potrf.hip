@@ -435,8 +435,22 @@ constexpr int TLD = SB + 2;   // padded leading dimension of the per-wave transp
 // With pub != nullptr the diagonal workgroup hands block column s of L_kk and W_ss to the OTHER workgroups of its launch as
 // soon as they are final (after barrier Bb(s)), straight into their final places in K and in the inverse block -- so the
 // write-back at the end goes away -- with write-through stores by the three helper waves, issued at the START of their
-// half-interval and drained at its end (the pivot wave stores nothing: its chain is untouched); after barrier Ba(s+1) one
-// lane raises the panel's progress word to s + 1 ("columns < s + 1 are in memory").  Same arithmetic, same bits.
+// half-interval (the pivot wave stores nothing: its chain is untouched).  The progress word COUNTS publications: every
+// helper wave adds 1 once ITS stores of column s have left the CU -- no barrier between the three -- so column c is in memory
+// when the word reads >= 3 (c + 1).  When: in the first intervals the helpers are the longer side of the interval (their
+// update tasks, r05z_diag_timeline), so they drain and count AFTER their tasks, when the stores have long completed; from
+// interval PUB_EARLY on they have time to spare and count at once -- the followers then work on column s while the pivot
+// wave runs potf2(s+1), and only the last column (16 x 16: W_77) is left when the diagonal block ends.  After the last pivot
+// all four waves publish what the loop did not (column nsb - 1 and the identity padding) and add 1 each:
+// the word ends at 3 (nsb - 1) + 4 = diag_prog_done(nsb).  Same arithmetic, same bits.
+constexpr int PUB_EARLY = 3;
+__host__ __device__ constexpr unsigned diag_prog_need(int c, int nsb) {      // value of the progress word from which column c is readable
+    return c < nsb - 1 ? 3u * (unsigned)(c + 1) : 3u * (unsigned)(nsb - 1) + 4u;
+}
+__host__ __device__ constexpr int diag_nsb(int n_real, int kbase) {          // 16-row blocks of a diagonal block that are factored
+    const int v = (n_real + 1 - kbase + SB - 1) / SB;
+    return v < 1 ? 1 : (v > NSB ? NSB : v);
+}
 struct DiagPub {
     double* Kd;        // tile (k, k) in K (row-major, leading dimension ld)
     int ld;
@@ -467,8 +481,7 @@ __device__ __forceinline__ void diag128_factor_invert(double* sL, double* sW, do
     // 16-row blocks that hold training rows or the augmented row; the ones behind them are identity padding (their
     // factor and inverse are the identity and nothing couples them to the rest), so the chain stops there: at the
     // N < 128 of a Bayesian-optimisation run the single diagonal block is mostly padding (N = 30: 2 of 8 blocks).
-    int nsb = (n_real + 1 - kbase + SB - 1) / SB;
-    nsb = nsb < 1 ? 1 : (nsb > NSB ? NSB : nsb);
+    const int nsb = diag_nsb(n_real, kbase);
     for (int bi = nsb; bi < NSB; ++bi) sW[blk_off(bi, bi) + bidx(tid >> 4, tid & 15)] = (tid >> 4) == (tid & 15) ? 1.0 : 0.0;
     // this lane's offsets inside a 16x16 block: fragment form [lane & 15][4 kk + (lane >> 4)], accumulator form
     // [(lane >> 4) + 4 r][lane & 15]
@@ -517,7 +530,13 @@ __device__ __forceinline__ void diag128_factor_invert(double* sL, double* sW, do
         __syncthreads();                                          // Bb(s): block column s of L is final
         if (dbg && tid == 0 && s == 0) dbg[3] = clock64();
         if (dbg && tid == 0) dbg[24 + 4 * s + 1] = clock64();     // through Bb(s)
-        if (pub && wave != 0) diag_publish_column(sL, sW, *pub, s, wave - 1, 3, lane);
+        if (pub && wave != 0) {
+            diag_publish_column(sL, sW, *pub, s, wave - 1, 3, lane);
+            if (s >= PUB_EARLY) {
+                drain_vmem();
+                if (lane == 0) add_agent_u32(pub->prog, 1u);
+            }
+        }
         if (wave == 0) {
             const int f = potf2_16(sL + blk_off(s + 1, s + 1), sW + blk_off(s + 1, s + 1), sCol, lane,
                                    kbase + (s + 1) * SB, n_real);
@@ -557,17 +576,18 @@ __device__ __forceinline__ void diag128_factor_invert(double* sL, double* sW, do
                 for (int r = 0; r < 4; ++r) C[co[r]] = acc[r];
             }
         }
-        if (pub && wave != 0) drain_vmem();                       // this wave's share of column s has left the CU
+        if (pub && wave != 0 && s < PUB_EARLY) {
+            drain_vmem();                                         // this wave's share of column s has left the CU
+            if (lane == 0) add_agent_u32(pub->prog, 1u);
+        }
         __syncthreads();                                          // Ba(s+1)
-        if (pub && tid == 64) st_agent_u32(pub->prog, (unsigned)(s + 1));
         if (dbg && tid == 0) dbg[4 + s] = clock64();
     }
     if (pub) {
         // what the loop did not hand over: the last factored block column (nsb - 1) and the identity padding behind it
         for (int c = nsb - 1; c < NSB; ++c) diag_publish_column(sL, sW, *pub, c, wave, 4, lane);
         drain_vmem();
-        __syncthreads();
-        if (tid == 0) st_agent_u32(pub->prog, (unsigned)NSB);
+        if (lane == 0) add_agent_u32(pub->prog, 1u);
     }
     if (dbg && tid == 0) dbg[11] = clock64();
 }
@@ -1440,7 +1460,7 @@ __global__ __launch_bounds__(256) void potrf_step_kernel(double* __restrict__ K,
 // The chain   panel (11 us) -> launch boundary -> tile update + 128 pivots   of the launch-per-phase factorisation loses its
 // first link: the strips are final one hand-off (a few us) after the diagonal block's last pivot.
 __device__ __forceinline__ void panel_follow(double* __restrict__ K, int ld, int kc, size_t row0, const unsigned* prog,
-                                             const double* __restrict__ Wg, double* smem, int* fail) {
+                                             const double* __restrict__ Wg, double* smem, int* fail, int n_real) {
     // kc: block column being solved; row0: first of this workgroup's 64 rows; prog: progress word of panel kc
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const double* Kd = K + ((size_t)kc * NB) * ld + (size_t)kc * NB;
@@ -1455,12 +1475,14 @@ __device__ __forceinline__ void panel_follow(double* __restrict__ K, int ld, int
     const int r = tid >> 4, c16 = tid & 15;
     const int pos = bidx(pi16(r), pi16(c16));
     int* sflag = reinterpret_cast<int*>(smem + NSB * BLK);
+    const int nsb = diag_nsb(n_real, kc * NB);
 #pragma unroll
     for (int c = 0; c < NSB; ++c) {
         if (tid == 0) {
             unsigned spins = 0;
             int ok = 1;
-            while (ld_agent_u32(prog) < (unsigned)(c + 1)) {
+            const unsigned need = diag_prog_need(c, nsb);
+            while (ld_agent_u32(prog) < need) {
                 __builtin_amdgcn_s_sleep(2);
                 if (++spins > PROG_SPIN_LIMIT) {
                     ok = 0;
@@ -1547,7 +1569,7 @@ __global__ __launch_bounds__(256) void potrf_step_follow_kernel(double* __restri
             update_subtile<2>(K, ld, k, ii * (ii + 1) / 2, h, smem);
             __syncthreads();             // this workgroup's stores before its own strip loads (and the staging area's reuse)
         }
-        panel_follow(K, ld, k + 1, (size_t)(k + 1 + ii) * NB + (size_t)h * 64, prog, Wg, smem, fail);
+        panel_follow(K, ld, k + 1, (size_t)(k + 1 + ii) * NB + (size_t)h * 64, prog, Wg, smem, fail, n_real);
         return;
     }
     // the remaining tiles of the trailing update: the triangle without its first block row and column

@@ -34,7 +34,8 @@ struct dim3 {
 };
 
 typedef int hipError_t;
-enum { hipSuccess = 0, hipErrorInvalidValue = 1, hipErrorOutOfMemory = 2, hipErrorInvalidDevice = 101, hipErrorNotReady = 600 };
+enum { hipSuccess = 0, hipErrorInvalidValue = 1, hipErrorOutOfMemory = 2, hipErrorInvalidDevice = 101, hipErrorNotReady = 600,
+       hipErrorPeerAccessAlreadyEnabled = 704 };
 typedef struct hipemuStream* hipStream_t;
 typedef struct hipemuEvent* hipEvent_t;
 enum hipMemcpyKind { hipMemcpyHostToHost, hipMemcpyHostToDevice, hipMemcpyDeviceToHost,
@@ -104,6 +105,8 @@ hipError_t hipSetDevice(int d);
 hipError_t hipGetDevice(int* d);
 hipError_t hipGetDeviceCount(int* n);
 hipError_t hipMemcpyPeerAsync(void* d, int d_dev, const void* s, int s_dev, size_t n, hipStream_t st = 0);
+hipError_t hipDeviceCanAccessPeer(int* can, int dev, int peer);      // HIPEMU_NO_PEER=1: the emulated devices are no peers
+hipError_t hipDeviceEnablePeerAccess(int peer, unsigned flags);
 hipError_t hipGetDeviceProperties(hipDeviceProp_t* p, int d);
 hipError_t hipEventCreate(hipEvent_t* e);
 hipError_t hipEventCreateWithFlags(hipEvent_t* e, unsigned flags);

@@ -494,6 +494,9 @@ hipError_t hipSetDevice(int d) {
 hipError_t hipGetDevice(int* d) { *d = t_device; return hipSuccess; }
 hipError_t hipGetDeviceCount(int* n) { *n = emu_device_count(); return hipSuccess; }
 hipError_t hipMemcpyPeerAsync(void* d, int, const void* s, int, size_t n, hipStream_t st) { return copy_async(d, s, n, st); }
+static bool no_peer() { const char* e = getenv("HIPEMU_NO_PEER"); return e && atoi(e) != 0; }
+hipError_t hipDeviceCanAccessPeer(int* can, int, int) { *can = no_peer() ? 0 : 1; return hipSuccess; }
+hipError_t hipDeviceEnablePeerAccess(int, unsigned) { return no_peer() ? hipErrorInvalidDevice : hipSuccess; }
 hipError_t hipGetDeviceProperties(hipDeviceProp_t* p, int d) {
     if (d < 0 || d >= emu_device_count()) return hipErrorInvalidDevice;
     std::memset(p, 0, sizeof(*p));

@@ -112,6 +112,16 @@ def test_inproc_strong(single, world):
         assert key in out, key
 
 
+def test_inproc_eight_devices_dry_run(single):
+    """the round-end scaling run's shape, `bench.py --gpus 8 --launcher inproc --scaling strong`, on eight emulated
+    devices: one line, eight shards, and the strong-scaled argmax IS the one-device argmax (value and global index)"""
+    out = _line(_run(["--gpus", "8", "--launcher", "inproc", "--scaling", "strong"], env_extra={"HIPEMU_DEVICES": "8"}))
+    assert out["n_gpus"] == 8 and out["devices"] == list(range(8)) and out["worker_threads"] == 8
+    assert out["config"]["candidates_total"] == 601 and out["config"]["candidates_per_gpu"] == 76
+    assert out["argmax"] == single["argmax"]
+    assert out["other_scaling"]["candidates_total"] == 601 * 8
+
+
 def test_inproc_two_contexts_on_one_device(single):
     out = _line(_run(["--gpus", "2", "--launcher", "inproc", "--devices", "0,0", "--scaling", "strong"]))
     assert out["devices"] == [0, 0] and out["argmax"] == single["argmax"]

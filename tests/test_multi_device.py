@@ -66,6 +66,25 @@ def test_same_results_without_worker_threads(emu3, monkeypatch):
         _lib._multis.clear()
 
 
+def test_sample_shard_between_devices_that_are_no_peers(emu3, monkeypatch):
+    """hipDeviceCanAccessPeer says no (HIPEMU_NO_PEER; on hardware ROBO_MULTI_NO_PEER=1 forces the same path): the partial
+    sums and per-sample posteriors of a sample shard reach the first device through pinned host memory
+    (multi.hip gather_to_first) -- same bits as the peer copies, same bits as one device"""
+    monkeypatch.setenv("HIPEMU_NO_PEER", "1")
+    _lib._multis.clear()
+    try:
+        MC.check_sample_shard([0, 1, 2])
+        MC.check_fits_and_mixture([0, 1, 2])
+    finally:
+        _lib._multis.clear()
+    monkeypatch.delenv("HIPEMU_NO_PEER")
+    monkeypatch.setenv("ROBO_MULTI_NO_PEER", "1")       # the library's own switch, devices that WOULD be peers
+    try:
+        MC.check_sample_shard([0, 1])
+    finally:
+        _lib._multis.clear()
+
+
 def test_device_resolution(emu3):
     assert _lib.resolve_devices(None, None) is None
     assert _lib.resolve_devices(None, 1) is None
