@@ -155,6 +155,7 @@ struct Tuning {
     int potrf_follow;            // single-theta fit: the panel solve of column k+1 FOLLOWS the diagonal block inside the step
                                  // kernel (progress words, potrf_step_follow_kernel) instead of its own launch (0: off)
     int potrf_follow_from;       // ... from this step on (earlier steps are bound by their trailing updates)
+    int potrf_pub_early;         // ... the diagonal block's helper waves count a published column at once from this interval on
     int mcmc_block_step;         // ensemble half-step in ONE launch: 2 (default) every one-block problem, 1 only N <= 63, 0 never
 };
 void tuning_from_env(Tuning* t);

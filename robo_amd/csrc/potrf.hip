@@ -439,11 +439,10 @@ constexpr int TLD = SB + 2;   // padded leading dimension of the per-wave transp
 // helper wave adds 1 once ITS stores of column s have left the CU -- no barrier between the three -- so column c is in memory
 // when the word reads >= 3 (c + 1).  When: in the first intervals the helpers are the longer side of the interval (their
 // update tasks, r05z_diag_timeline), so they drain and count AFTER their tasks, when the stores have long completed; from
-// interval PUB_EARLY on they have time to spare and count at once -- the followers then work on column s while the pivot
+// interval `early` on (potrf_pub_early, default 5: one or no task per wave) they have time to spare and count at once -- the followers then work on column s while the pivot
 // wave runs potf2(s+1), and only the last column (16 x 16: W_77) is left when the diagonal block ends.  After the last pivot
 // all four waves publish what the loop did not (column nsb - 1 and the identity padding) and add 1 each:
 // the word ends at 3 (nsb - 1) + 4 = diag_prog_done(nsb).  Same arithmetic, same bits.
-constexpr int PUB_EARLY = 3;
 __host__ __device__ constexpr unsigned diag_prog_need(int c, int nsb) {      // value of the progress word from which column c is readable
     return c < nsb - 1 ? 3u * (unsigned)(c + 1) : 3u * (unsigned)(nsb - 1) + 4u;
 }
@@ -456,6 +455,7 @@ struct DiagPub {
     int ld;
     double* Wg;        // the 128 x 128 inverse block of panel k (its eight diagonal sub-blocks are written)
     unsigned* prog;    // progress word of panel k
+    int early;         // first interval whose helper waves count right after publishing (see below)
 };
 // one wave: 16 x 16 LDS block (bidx layout) -> 16 rows of a row-major global matrix, write-through
 __device__ __forceinline__ void blk_publish(const double* b, double* dst, int ld, int lane) {
@@ -532,7 +532,7 @@ __device__ __forceinline__ void diag128_factor_invert(double* sL, double* sW, do
         if (dbg && tid == 0) dbg[24 + 4 * s + 1] = clock64();     // through Bb(s)
         if (pub && wave != 0) {
             diag_publish_column(sL, sW, *pub, s, wave - 1, 3, lane);
-            if (s >= PUB_EARLY) {
+            if (s >= pub->early) {
                 drain_vmem();
                 if (lane == 0) add_agent_u32(pub->prog, 1u);
             }
@@ -576,7 +576,7 @@ __device__ __forceinline__ void diag128_factor_invert(double* sL, double* sW, do
                 for (int r = 0; r < 4; ++r) C[co[r]] = acc[r];
             }
         }
-        if (pub && wave != 0 && s < PUB_EARLY) {
+        if (pub && wave != 0 && s < pub->early) {
             drain_vmem();                                         // this wave's share of column s has left the CU
             if (lane == 0) add_agent_u32(pub->prog, 1u);
         }
@@ -1511,6 +1511,11 @@ __device__ __forceinline__ void panel_follow(double* __restrict__ K, int ld, int
 #pragma unroll
             for (int q = 0; q < 4; ++q) o = mfma_f64(w.v[q], y[c][q], o);
             y[c] = o;
+            // column c of the strip is final: on its way to memory while the later columns are still being solved (only
+            // the last 16 columns are left to store when the diagonal block ends)
+            double2* p = reinterpret_cast<double2*>(Arow + c * SB);
+            p[0] = make_double2(o[0], o[1]);
+            p[1] = make_double2(o[2], o[3]);
         }
 #pragma unroll
         for (int sl = c + 1; sl < NSB; ++sl) {
@@ -1518,12 +1523,6 @@ __device__ __forceinline__ void panel_follow(double* __restrict__ K, int ld, int
 #pragma unroll
             for (int q = 0; q < 4; ++q) y[sl] = mfma_f64(-a.v[q], y[c][q], y[sl]);
         }
-    }
-#pragma unroll
-    for (int s = 0; s < NSB; ++s) {
-        double2* p = reinterpret_cast<double2*>(Arow + s * SB);
-        p[0] = make_double2(y[s][0], y[s][1]);
-        p[1] = make_double2(y[s][2], y[s][3]);
     }
 }
 
@@ -1538,7 +1537,7 @@ __device__ __forceinline__ void panel_follow(double* __restrict__ K, int ld, int
 __global__ __launch_bounds__(256) void potrf_step_follow_kernel(double* __restrict__ K, size_t k_stride, int ld, int k,
                                                                 int n_real, double* __restrict__ Linv, size_t linv_stride,
                                                                 int* __restrict__ fail, unsigned* __restrict__ prog,
-                                                                int nfol, int ntiles, int tail_split) {
+                                                                int nfol, int ntiles, int tail_split, int pub_early) {
     __shared__ double smem[DIAG_SMEM_DOUBLES];
     K += (size_t)blockIdx.y * k_stride;
     Linv += (size_t)blockIdx.y * linv_stride;
@@ -1559,7 +1558,7 @@ __global__ __launch_bounds__(256) void potrf_step_follow_kernel(double* __restri
                     m.sL[blk_off(bi, bj) + bidx(tid >> 4, tid & 15)] = C[(size_t)(bi * SB + (tid >> 4)) * ld + bj * SB + (tid & 15)];
         }
         __syncthreads();
-        const DiagPub pub = {C, ld, Wg, prog};
+        const DiagPub pub = {C, ld, Wg, prog, pub_early};
         diag128_factor_invert(m.sL, m.sW, m.sT, m.sRd, m.sCol, (k + 1) * NB, n_real, fail, nullptr, &pub);
         return;
     }
@@ -1729,7 +1728,7 @@ int launch_potrf(robo_gp* gp, const FitBuffers& fb, bool with_gram) {
             W = W < rest ? W : rest;
             hipLaunchKernelGGL(potrf_step_follow_kernel, dim3(1 + nfol + W, S), dim3(256), 0, st, fb.K, fb.k_stride,
                                ld, k, gp->n, fb.Linv, fb.linv_stride, fb.fail, fb.prog, nfol, rest,
-                               tune.potrf_tail_split != 0 ? 1 : 0);
+                               tune.potrf_tail_split != 0 ? 1 : 0, tune.potrf_pub_early);
         };
         if (can_follow) ROBO_HIP_CHECK(hipMemsetAsync(fb.prog, 0, (size_t)S * PROG_STRIDE * sizeof(unsigned), st));
         bool panel_done = false;              // panel of the CURRENT column k already solved (by the previous follow step)
