@@ -1474,55 +1474,83 @@ __device__ __forceinline__ void panel_follow(double* __restrict__ K, int ld, int
     }
     const int r = tid >> 4, c16 = tid & 15;
     const int pos = bidx(pi16(r), pi16(c16));
-    int* sflag = reinterpret_cast<int*>(smem + NSB * BLK);
+    int* sflag = reinterpret_cast<int*>(smem + NBLK * BLK);
     const int nsb = diag_nsb(n_real, kc * NB);
-#pragma unroll
-    for (int c = 0; c < NSB; ++c) {
+    // A hand-off is two round trips (the poll, then the payload: ~1.5 + ~2 us on a busy chip) -- more than the ~2.9 us per
+    // column the diagonal block needs.  So every pass takes ALL the columns that are in memory by now: a follower that is
+    // behind (it starts late: its own tile update comes first) catches up several columns per pass, and one that keeps
+    // pace pays the two round trips per pass, not per column.  LDS: the panel kernel's image, slot blk_off(s, c) =
+    // L_sc (s > c) or W_cc (s = c), rows and columns permuted.
+    int c = 0;
+    while (c < NSB) {
         if (tid == 0) {
-            unsigned spins = 0;
-            int ok = 1;
+            unsigned spins = 0, v;
+            int hi = -1;
             const unsigned need = diag_prog_need(c, nsb);
-            while (ld_agent_u32(prog) < need) {
+            while ((v = ld_agent_u32(prog)) < need) {
                 __builtin_amdgcn_s_sleep(2);
-                if (++spins > PROG_SPIN_LIMIT) {
-                    ok = 0;
-                    break;
-                }
+                if (++spins > PROG_SPIN_LIMIT) break;
             }
-            *sflag = ok;
+            if (v >= need) {
+                hi = c;
+                while (hi + 1 < NSB && v >= diag_prog_need(hi + 1, nsb)) ++hi;
+            }
+            *sflag = hi;
         }
-        __syncthreads();                 // the column is in memory (and the previous column's fragment reads are over)
-        if (*sflag == 0) {               // the producer never arrived: flag the factorisation, leave the strips alone
+        __syncthreads();                 // (also: the previous pass's fragment reads are over)
+        const int chi = *sflag;
+        if (chi < 0) {                   // the producer never arrived: flag the factorisation, leave the strips alone
             if (tid == 0 && *fail == 0) *fail = kc * NB + 1;
             return;
         }
-        // stage W_cc (slot c) and L_sc, s > c (slot s): one element per thread and block, L1-bypassing loads
-        double v[NSB];
-#pragma unroll
-        for (int sl = c; sl < NSB; ++sl)
-            v[sl] = sl == c ? ld_agent(Wg + (size_t)(c * SB + r) * NB + c * SB + c16)
-                            : ld_agent(Kd + (size_t)(sl * SB + r) * ld + c * SB + c16);
-#pragma unroll
-        for (int sl = c; sl < NSB; ++sl) smem[sl * BLK + pos] = v[sl];
-        __syncthreads();
+        // stage columns c .. chi: one element per thread and block, L1-bypassing loads, four blocks in flight per thread
         {
-            const Frag4 w = frag_row(smem + c * BLK, lane);
-            v4d o = {0.0, 0.0, 0.0, 0.0};
+            int col = c, sl = c;             // blocks (s, col), col = c .. chi, s = col .. 7, column by column
+            const int nblk = (chi - c + 1) * NSB - ((chi * (chi + 1)) / 2 - (c * (c - 1)) / 2);
+            for (int i = 0; i < nblk; i += 4) {
+                double v[4];
+                int slot[4];
 #pragma unroll
-            for (int q = 0; q < 4; ++q) o = mfma_f64(w.v[q], y[c][q], o);
-            y[c] = o;
-            // column c of the strip is final: on its way to memory while the later columns are still being solved (only
-            // the last 16 columns are left to store when the diagonal block ends)
-            double2* p = reinterpret_cast<double2*>(Arow + c * SB);
-            p[0] = make_double2(o[0], o[1]);
-            p[1] = make_double2(o[2], o[3]);
+                for (int u = 0; u < 4; ++u) {
+                    slot[u] = -1;
+                    if (i + u < nblk) {
+                        slot[u] = blk_off(sl, col);
+                        v[u] = sl == col ? ld_agent(Wg + (size_t)(col * SB + r) * NB + col * SB + c16)
+                                         : ld_agent(Kd + (size_t)(sl * SB + r) * ld + col * SB + c16);
+                        if (++sl == NSB) {
+                            ++col;
+                            sl = col;
+                        }
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+                    if (slot[u] >= 0) smem[slot[u] + pos] = v[u];
+            }
         }
+        __syncthreads();
 #pragma unroll
-        for (int sl = c + 1; sl < NSB; ++sl) {
-            const Frag4 a = frag_row(smem + sl * BLK, lane);
+        for (int cc = 0; cc < NSB; ++cc) {
+            if (cc < c || cc > chi) continue;
+            {
+                const Frag4 w = frag_row(smem + blk_off(cc, cc), lane);
+                v4d o = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-            for (int q = 0; q < 4; ++q) y[sl] = mfma_f64(-a.v[q], y[c][q], y[sl]);
+                for (int q = 0; q < 4; ++q) o = mfma_f64(w.v[q], y[cc][q], o);
+                y[cc] = o;
+                // column cc of the strip is final: on its way to memory while the later columns are still being solved
+                double2* p = reinterpret_cast<double2*>(Arow + cc * SB);
+                p[0] = make_double2(o[0], o[1]);
+                p[1] = make_double2(o[2], o[3]);
+            }
+#pragma unroll
+            for (int sl = cc + 1; sl < NSB; ++sl) {
+                const Frag4 a = frag_row(smem + blk_off(sl, cc), lane);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) y[sl] = mfma_f64(-a.v[q], y[cc][q], y[sl]);
+            }
         }
+        c = chi + 1;
     }
 }
 

@@ -171,7 +171,7 @@ follow)
   timeout 900 python -m pytest tests/test_gpu_parity.py -m gpu -q -x -k "panel_followers" > $OUT/follow_test.log 2>&1; echo "follow test rc=$?" >> $OUT/summary.txt
   tail -5 $OUT/follow_test.log >> $OUT/summary.txt
   for cfg in "4096 16" "2048 16" "1024 8"; do
-    FOLLOW_FROM="-1" FOLLOW_EARLY="3,4,5,6,8" timeout 300 python tools/follow_ab.py $cfg 15 >> $OUT/follow_ab.txt 2>&1
+    FOLLOW_FROM="-1,2" FOLLOW_EARLY="6,8" timeout 300 python tools/follow_ab.py $cfg 15 >> $OUT/follow_ab.txt 2>&1
   done
   FOLLOW_FROM="24,32" timeout 300 python tools/follow_ab.py 8192 64 9 >> $OUT/follow_ab.txt 2>&1
   grep "single-theta\|round 1" $OUT/follow_ab.txt >> $OUT/summary.txt
