@@ -153,8 +153,8 @@ struct Tuning {
     int potrf_lead;              // ... first-group size step between sub-batches (-1: G / splits)
     int potrf_tail_split;        // fused step: the ragged last round of 128-row tiles as half / quarter tiles on more workgroups
     int potrf_follow;            // single-theta fit: the panel solve of column k+1 FOLLOWS the diagonal block inside the step
-                                 // kernel (progress words, potrf_step_follow_kernel) instead of its own launch (0: off)
-    int potrf_follow_from;       // ... from this step on (earlier steps are bound by their trailing updates)
+                                 // kernel (progress words, potrf_step_follow_kernel) instead of its own launch (default 1; 0: the launch-per-phase form)
+    int potrf_follow_from;       // ... from this step on (-1: the first panel too; -2 = default: by size, launch_potrf)
     int potrf_pub_early;         // ... the diagonal block's helper waves count a published column at once from this interval on
     int mcmc_block_step;         // ensemble half-step in ONE launch: 2 (default) every one-block problem, 1 only N <= 63, 0 never
 };

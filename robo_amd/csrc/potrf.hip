@@ -1689,8 +1689,8 @@ int launch_pack_linv(robo_gp* gp) {
 }
 
 // the follower form of the step kernel needs all its workgroups resident (one per CU): the diagonal workgroup, two followers
-// per block row below the first panel, and at least a quarter of the chip left for the other tiles
-static bool tiles_ok_for_follow(int nb, int max_wg) { return 1 + 2 * (nb - 1) + max_wg / 4 <= max_wg; }
+// per block row below the panel (`rows_below` of them), and at least a quarter of the chip left for the other tiles
+static bool tiles_ok_for_follow(int rows_below, int max_wg) { return 1 + 2 * rows_below + max_wg / 4 <= max_wg; }
 
 int launch_potrf(robo_gp* gp, const FitBuffers& fb, bool with_gram) {
     robo_ctx* ctx = gp->ctx;
@@ -1746,8 +1746,19 @@ int launch_potrf(robo_gp* gp, const FitBuffers& fb, bool with_gram) {
         // potrf_follow: from step `ffrom` on the panel solve of column k+1 runs INSIDE step k's launch, following the
         // diagonal workgroup (potrf_step_follow_kernel); ffrom = -1: the first diagonal block and panel 0 too.  Needs every
         // workgroup resident: 1 + two followers per block row + at least a quarter of the chip for the other tiles.
-        const bool can_follow = tune.potrf_follow != 0 && fb.prog != nullptr && tiles_ok_for_follow(nb, max_wg);
-        const int ffrom = can_follow ? (tune.potrf_follow_from < 0 ? -1 : tune.potrf_follow_from) : nb;
+        // Measured (r06, ms per fit, launch-per-phase -> followers from the first panel on): N = 4096 1.70 -> 1.52, 3000 1.22 ->
+        // 1.13, 2048 0.83 -> 0.72, 1024 0.43 -> 0.37, 512 0.227 -> 0.214.  The followers are workgroups the trailing update does
+        // not have: while a step is bound by its tiles (early steps of a large factor) they cost more than the panel launch
+        // they replace -- N = 8192 (65 panels): followers from step 0 7.28, from step 16 6.11, from 24 / 32 5.88 against 6.06
+        // without.  potrf_follow_from = -2 (default): from the step on at which the followers are at most a quarter of the
+        // workgroups (k >= nb - 2 - max_wg / 8: every step up to N = 4096, step 31 at N = 8192).
+        const bool can_follow = tune.potrf_follow != 0 && fb.prog != nullptr && max_wg >= 16;
+        int ffrom = nb;
+        if (can_follow) {
+            ffrom = tune.potrf_follow_from >= -1 ? tune.potrf_follow_from : nb - 2 - max_wg / 8;
+            if (ffrom < -1) ffrom = -1;
+            while (ffrom < nb && !tiles_ok_for_follow(nb - 1 - ffrom, max_wg)) ++ffrom;   // (explicit settings: residency)
+        }
         auto follow = [&](int k) {
             // block rows below k+1: two followers each; the other tiles of the trailing triangle (none in front of panel 0)
             const int nfol = 2 * (nb - k - 2), r1 = nb - k - 2, rest = k < 0 ? 0 : r1 * (r1 + 1) / 2;
