@@ -220,9 +220,17 @@ class MarginalizationGPMCMC(BaseAcquisitionFunction):
         acquisition_values = np.zeros([len(self.model.models), X_test.shape[0]])
         by_ctx = {}
         for i, e in enumerate(self.estimators):
-            gp = getattr(getattr(e, "model", None), "gp", None)
-            by_ctx.setdefault(id(gp.ctx) if isinstance(gp, _lib.DeviceGP) else None, []).append(i)
-        if len(by_ctx) > 1 and None not in by_ctx and getattr(self.model, "devices", None):
+            # every context an estimator drives: its model's and, for the per-unit-cost form, its cost model's -- a context
+            # (stream, pinned read-back, scratch) is not thread-safe, so it may belong to ONE thread only
+            key = []
+            for mdl in (getattr(e, "model", None), getattr(e, "cost_model", None)):
+                gp = getattr(mdl, "gp", None)
+                if mdl is not None:
+                    key.append(id(gp.ctx) if isinstance(gp, _lib.DeviceGP) else None)
+            by_ctx.setdefault(tuple(key), []).append(i)
+        seen = [c for key in by_ctx for c in set(key)]
+        disjoint = len(seen) == len(set(seen)) and None not in seen
+        if len(by_ctx) > 1 and disjoint and getattr(self.model, "devices", None):
             # sub-models on several devices of this process (any acquisition function, e.g. the information gain per unit
             # cost of Fabolas): one host thread per device walks its estimators -- the library calls release the GIL, so
             # the devices work at the same time; the mean is still taken in sample order

@@ -36,10 +36,24 @@ class _RoboAlias(importlib.abc.MetaPathFinder, importlib.abc.Loader):
         return importlib.util.spec_from_loader(name, self)
 
     def create_module(self, spec):
-        return importlib.import_module("robo_amd" + spec.name[len("robo"):])
+        module = importlib.import_module("robo_amd" + spec.name[len("robo"):])
+        # importlib's _init_module_attrs overwrites __spec__ / __loader__ of whatever create_module returns with the
+        # ALIAS spec; the robo_amd module is live and must keep its own (reload, runpy, pkgutil and inspect read them):
+        # remembered here, put back in exec_module
+        self._own[id(module)] = (getattr(module, "__spec__", None), getattr(module, "__loader__", None),
+                                 getattr(module, "__package__", None), getattr(module, "__path__", None),
+                                 getattr(module, "__file__", None), getattr(module, "__cached__", None))
+        return module
 
     def exec_module(self, module):
-        pass
+        own = self._own.pop(id(module), None)
+        if own is None:
+            return
+        for attr, value in zip(("__spec__", "__loader__", "__package__", "__path__", "__file__", "__cached__"), own):
+            if value is not None:
+                setattr(module, attr, value)
+
+    _own = {}
 
 
 def install(force=False):

@@ -93,6 +93,14 @@ class GaussianProcessMCMC(BaseModel):
             groups[self._slot_of(i, len(self.models))].append(m)
         return groups
 
+    def _on_their_slots(self):
+        """every trained sub-model's handle lives on the context of ITS device slot (after a pickle round trip the
+        sub-models rematerialise on the default context -- GaussianProcess.__getstate__ drops the override -- and the
+        multi-device entry points would refuse them: then the plain per-model path is taken instead)"""
+        ctxs = self._multi().ctxs
+        return all(getattr(m, "gp", None) is not None and m.gp.ctx is ctxs[self._slot_of(i, len(self.models))]
+                   for i, m in enumerate(self.models))
+
     def __deepcopy__(self, memo):
         new = self.__class__.__new__(self.__class__)
         memo[id(self)] = new
@@ -352,7 +360,7 @@ class GaussianProcessMCMC(BaseModel):
                 return m, np.clip(v, np.finfo(v.dtype).eps, np.inf)
         gps = [getattr(m, "gp", None) for m in self.models]
         if self.devices and len(self.models) >= 1 and all(isinstance(g, _lib.DeviceGP) for g in gps) and \
-                all(m.is_trained for m in self.models):
+                all(m.is_trained for m in self.models) and self._on_their_slots():
             # the samples live on several devices: per-device posteriors, gathered and mixed on the first device
             groups = self._groups()
             m0 = self.models[0]

@@ -256,6 +256,11 @@ def test_compat_import_alias():
         import robo_amd.models.gaussian_process
         assert importlib.import_module("robo.fmin").bayesian_optimization is robo_amd.fmin.bayesian_optimization
         assert importlib.import_module("robo.models.gaussian_process") is robo_amd.models.gaussian_process
+        # the aliased modules keep their OWN import attributes (importlib would stamp the alias spec on them: reload
+        # would become a no-op through the alias loader, runpy / pkgutil / inspect would see the wrong name)
+        assert robo_amd.fmin.__spec__.name == "robo_amd.fmin" and robo_amd.fmin.__name__ == "robo_amd.fmin"
+        assert robo_amd.models.gaussian_process.__spec__.name == "robo_amd.models.gaussian_process"
+        assert type(robo_amd.models.gaussian_process.__spec__.loader).__name__ != "_RoboAlias"
         for path_ in ("robo.priors.default_priors", "robo.priors.env_priors", "robo.priors.base_prior",
                       "robo.initial_design.init_grid", "robo.maximizers.base_maximizer", "robo.solver.base_solver",
                       "robo.util.mc_part", "robo.acquisition_functions.marginalization"):

@@ -273,6 +273,12 @@ def test_more_devices_than_samples_and_copies(emu3):
     clone = pickle.loads(pickle.dumps(m3))
     for a, b in zip(clone.predict(Xc), m1.predict(Xc)):
         np.testing.assert_array_equal(a, b)
+    # ... and AGAIN: the first call rematerialised the sub-models' handles on the default context (the pickle drops
+    # their device slots); the second must not hand them to the multi-device entry point (round-5 advice: it did, and
+    # failed with a context mismatch) but take the per-model path, same numbers to rounding
+    assert not clone._on_their_slots()
+    for a, b in zip(clone.predict(Xc), m1.predict(Xc)):
+        np.testing.assert_allclose(a, b, rtol=1e-12, atol=1e-14)
 
 
 def test_reference_gp_mcmc_run_replayed_on_3_devices(emu3):
