@@ -141,6 +141,14 @@ def test_gp_mcmc_classes_on_devices(emu3):
     a3.update(m3)
     np.testing.assert_allclose(a3.compute(Xc), a1.compute(Xc), rtol=1e-12)
     assert a3.argmax(Xc) == a1.argmax(Xc) == int(np.argmax(a1.compute(Xc)))
+    # a pickled copy: ten samples whose handles rematerialise on the DEFAULT context at the first predict (the pickle drops
+    # the sub-models' device slots); the second predict must see that and keep off the multi-device entry point
+    import pickle
+    clone = pickle.loads(pickle.dumps(m3))
+    for rep in range(2):
+        for a, b in zip(clone.predict(Xc), (mu1, v1)):
+            np.testing.assert_allclose(a, b, rtol=1e-12, atol=1e-14)
+        assert not clone._on_their_slots()
     # walkers split over the devices per half-step (host sampler around robo_gp_loglik_batch_multi): the same chain
     MC.check_walker_shard([0, 1, 2])
 
@@ -276,7 +284,6 @@ def test_more_devices_than_samples_and_copies(emu3):
     # ... and AGAIN: the first call rematerialised the sub-models' handles on the default context (the pickle drops
     # their device slots); the second must not hand them to the multi-device entry point (round-5 advice: it did, and
     # failed with a context mismatch) but take the per-model path, same numbers to rounding
-    assert not clone._on_their_slots()
     for a, b in zip(clone.predict(Xc), m1.predict(Xc)):
         np.testing.assert_allclose(a, b, rtol=1e-12, atol=1e-14)
 
