@@ -154,14 +154,18 @@ __global__ __launch_bounds__(256, KIND == ROBO_KERNEL_FABOLAS ? 3 : 6) void gram
     if constexpr (sizeof(T) == 8 && KIND != ROBO_KERNEL_FABOLAS) pair_cov_dot<KIND>(cp, Xs, i0, j0, sI, sJ, sN, cov);
     else pair_cov<T, KIND>(cp, Xs, Xs, i0, j0, sI, sJ, cov);
     const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+    // which columns of the tile this thread's four entries per row are (gram_tile.h: the fp64 stationary kernels' tiles use
+    // gram_col, the others four consecutive columns); c0 / c2: first column of the entry pairs (0, 1) and (2, 3)
+    constexpr bool DOT = sizeof(T) == 8 && KIND != ROBO_KERNEL_FABOLAS;
+    const int c0 = DOT ? gram_col(tx, 0) : 4 * tx, c2 = DOT ? gram_col(tx, 2) : 4 * tx + 2;
     if (bi != bj && (int)i0 + GT <= n) {
         // interior tile (all rows and columns are training points, no diagonal entry): the values as they are --
         // a workgroup-uniform branch instead of ~10 compare/select instructions per entry (the kernel is VALU bound)
 #pragma unroll
         for (int a = 0; a < 4; ++a) {
-            double2* dst = reinterpret_cast<double2*>(K + (size_t)(i0 + ty * 4 + a) * n_pad + j0 + tx * 4);
-            dst[0] = make_double2(cov[a][0], cov[a][1]);
-            dst[1] = make_double2(cov[a][2], cov[a][3]);
+            double* row = K + (size_t)(i0 + ty * 4 + a) * n_pad + j0;
+            *reinterpret_cast<double2*>(row + c0) = make_double2(cov[a][0], cov[a][1]);
+            *reinterpret_cast<double2*>(row + c2) = make_double2(cov[a][2], cov[a][3]);
         }
         return;
     }
@@ -171,7 +175,7 @@ __global__ __launch_bounds__(256, KIND == ROBO_KERNEL_FABOLAS ? 3 : 6) void gram
         double v[4];
 #pragma unroll
         for (int b = 0; b < 4; ++b) {
-            const int gj = (int)j0 + tx * 4 + b;
+            const int gj = (int)j0 + (b < 2 ? c0 + b : c2 + b - 2);
             double val;
             if (gi < n && gj < n) {
                 val = cov[a][b];
@@ -187,9 +191,9 @@ __global__ __launch_bounds__(256, KIND == ROBO_KERNEL_FABOLAS ? 3 : 6) void gram
             }
             v[b] = val;
         }
-        double2* dst = reinterpret_cast<double2*>(K + (size_t)gi * n_pad + j0 + tx * 4);
-        dst[0] = make_double2(v[0], v[1]);
-        dst[1] = make_double2(v[2], v[3]);
+        double* row = K + (size_t)gi * n_pad + j0;
+        *reinterpret_cast<double2*>(row + c0) = make_double2(v[0], v[1]);
+        *reinterpret_cast<double2*>(row + c2) = make_double2(v[2], v[3]);
     }
 }
 

@@ -9,6 +9,22 @@ constexpr int GT = 64;      // tile edge
 constexpr int GD = 16;      // dims per LDS pass
 constexpr int GLD = GT + 2; // LDS leading dimension (doubles)
 
+// Column of the 64-wide tile that micro-tile entry b (0..3) of thread column tx (0..15) holds in pair_cov_dot's tiles.
+// ROBO_GRAM_COLMAP = 1: {2 tx, 2 tx + 1, 32 + 2 tx, 33 + 2 tx} -- the sixteen lanes of a row then write 256 CONTIGUOUS bytes
+// per 16-byte store instruction (two whole 128-byte lines) instead of sixteen 16-byte pieces at a 32-byte stride (every line
+// of the row half-written by each of the two instructions); 0: the plain {4 tx .. 4 tx + 3} (A/B build).  Same entries, same
+// arithmetic per entry.
+#ifndef ROBO_GRAM_COLMAP
+#define ROBO_GRAM_COLMAP 1
+#endif
+__host__ __device__ constexpr int gram_col(int tx, int b) {
+#if ROBO_GRAM_COLMAP == 1
+    return (b >> 1) * 32 + 2 * tx + (b & 1);
+#else
+    return 4 * tx + b;
+#endif
+}
+
 // fp64 stationary kernels in K1: squared distances through  r2 = |x_i|^2 + |x_j|^2 - 2 x_i . x_j  with the row norms
 // reduced once per tile from the staged coordinates -- one FMA per pair and dimension instead of a subtraction and an
 // FMA.  K1 is bound by fp64 VALU issue (r02i PMC), and at D = 16 the 32 distance instructions were the largest
@@ -60,7 +76,7 @@ __device__ __forceinline__ void pair_cov_dot(const CovParams& cp, const double* 
 #pragma unroll
             for (int a = 0; a < 4; ++a) {
                 xi[a] = sI[d * GLD + ty * 4 + a];
-                xj[a] = sJ[d * GLD + tx * 4 + a];
+                xj[a] = sJ[d * GLD + gram_col(tx, a)];
             }
 #pragma unroll
             for (int a = 0; a < 4; ++a)
@@ -75,7 +91,7 @@ __device__ __forceinline__ void pair_cov_dot(const CovParams& cp, const double* 
 #pragma unroll
     for (int a = 0; a < 4; ++a) {
         ni[a] = sN[ty * 4 + a];
-        nj[a] = sN[GT + tx * 4 + a];
+        nj[a] = sN[GT + gram_col(tx, a)];
     }
 #pragma unroll
     for (int a = 0; a < 4; ++a)
@@ -83,7 +99,7 @@ __device__ __forceinline__ void pair_cov_dot(const CovParams& cp, const double* 
         for (int b = 0; b < 4; ++b) {
             double r2 = fma(-2.0, dot[a][b], ni[a] + nj[b]);
             r2 = r2 > 0.0 ? r2 : 0.0;
-            if (i0 + ty * 4 + a == j0 + tx * 4 + b) r2 = 0.0;     // the diagonal is exact
+            if (i0 + ty * 4 + a == j0 + gram_col(tx, b)) r2 = 0.0;     // the diagonal is exact
             cov[a][b] = cov_finish<double, KIND>(cp, r2, 0.0);
         }
 }

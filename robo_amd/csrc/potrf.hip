@@ -743,7 +743,7 @@ __global__ __launch_bounds__(256 * NG) void mcmc_block_step_kernel(McmcState st,
             const int gi = bi * GT + ty * 4 + a;
 #pragma unroll
             for (int b = 0; b < 4; ++b) {
-                const int gj = bj * GT + tx * 4 + b;
+                const int gj = bj * GT + gram_col(tx, b);
                 double val;
                 if (gi < n && gj < n) {
                     val = cov[a][b];
