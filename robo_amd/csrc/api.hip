@@ -58,7 +58,7 @@ static const TuneKey TUNE_KEYS[] = {
     {"potrf_gram_split", nullptr, &Tuning::potrf_gram_split, 0},
     {"potrf_split_min", nullptr, &Tuning::potrf_split_min, 12},
     {"potrf_lead", nullptr, &Tuning::potrf_lead, -1},
-    {"mcmc_block_step", nullptr, &Tuning::mcmc_block_step, 2},
+    {"mcmc_block_step", nullptr, &Tuning::mcmc_block_step, 3},
 };
 
 static void tune_set(Tuning* t, const TuneKey& k, long long v) {
@@ -703,8 +703,11 @@ int32_t robo_gp_mcmc_run(robo_gp* g, double mean_c, int32_t prior_kind, const do
     const int bs = c->tune.mcmc_block_step;
     const bool one_block = (bs >= 2 ? g->n_pad == NB : (bs == 1 && g->n + 1 <= 64)) && !g->fp32_gram &&
                            g->kind != ROBO_KERNEL_FABOLAS;
+    // two-block problems (128 <= N <= 254): likewise one launch, block row 1 through the batch workspace (tuning: 3 = default)
+    const bool two_block = bs >= 3 && g->n_pad == 2 * NB && g->n >= NB && !g->fp32_gram && g->kind != ROBO_KERNEL_FABOLAS;
     auto half_step = [&](int start, int first, int h, int it) -> int {
         if (one_block) return launch_mcmc_block_step(g, st, start, first, h, it);
+        if (two_block) return launch_mcmc_block2_step(g, st, start, first, h, it, g->d_bK, np * np);
         ROBO_TRY(launch_mcmc_propose_scale(c, st, start, first, h, it, g->d_X, g->d_bXs, g->n, g->n_pad, np * D));
         ROBO_TRY(launch_potrf(g, fb, true));        // gram + factorisation
         return launch_mcmc_accept(c, st, start, first, h, it);

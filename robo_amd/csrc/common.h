@@ -156,7 +156,8 @@ struct Tuning {
                                  // kernel (progress words, potrf_step_follow_kernel) instead of its own launch (default 1; 0: the launch-per-phase form)
     int potrf_follow_from;       // ... from this step on (-1: the first panel too; -2 = default: by size, launch_potrf)
     int potrf_pub_early;         // ... the diagonal block's helper waves count a published column at once from this interval on
-    int mcmc_block_step;         // ensemble half-step in ONE launch: 2 (default) every one-block problem, 1 only N <= 63, 0 never
+    int mcmc_block_step;         // ensemble half-step in ONE launch: 3 (default) one- and two-block problems (N <= 254), 2 one-block
+                                 // problems only, 1 only N <= 63, 0 never
 };
 void tuning_from_env(Tuning* t);
 }  // namespace robo
@@ -344,6 +345,7 @@ int launch_mcmc_propose_scale(robo_ctx* ctx, const McmcState& st, int start, int
                               double* d_Xs, int64_t rows_real, int64_t rows_pad, size_t xs_stride);
 int launch_mcmc_accept(robo_ctx* ctx, const McmcState& st, int start, int first, int h, int it);
 int launch_mcmc_block_step(robo_gp* gp, const McmcState& st, int start, int first, int h, int it);
+int launch_mcmc_block2_step(robo_gp* gp, const McmcState& st, int start, int first, int h, int it, double* d_K, size_t k_stride);
 // with_gram: the gram matrices are built here too, every sub-batch's on the stream its factorisation runs on
 int launch_potrf(robo_gp* gp, const FitBuffers& fb, bool with_gram = false);
 int launch_diag_timeline(robo_gp* gp, long long* d_stamps);

@@ -1616,6 +1616,241 @@ __global__ __launch_bounds__(256) void potrf_step_follow_kernel(double* __restri
     }
 }
 
+// ---- two-block problems (128 <= N <= 254): the same, ONE launch per ensemble half-step (r06) -------------------------------
+// A Bayesian-optimisation run spends most of its life at these sizes, and the launch-per-phase half-step there was nine
+// launches (proposal + scaling, gram, two diagonal blocks, panel, column update, likelihood shares, finish, accept): 93 us at
+// N = 200, a third of it boundaries and phases that leave the chip idle.  Here one workgroup per walker runs the whole chain
+//     proposal -> K (ten 64 x 64 tiles, three at a time) -> 128 pivots -> panel (eight strips) -> tile update -> 128 pivots
+//     -> likelihood terms -> accept test
+// with block (0, 0) of K written straight into the factorisation's LDS image and block row 1 through the walker's matrix of
+// the batch workspace (read back by the same workgroup: L2).  The pieces are the launch path's own device functions in its
+// order -- diag128_factor_invert, potrf_panel_kernel's substitution, diag_tile_update, potrf_inverse_kernel's likelihood
+// shares added block by block -- so the log-likelihoods are the launch path's bit for bit and the chain is the same chain.
+template <int KIND, int NG>
+__global__ __launch_bounds__(256 * NG) void mcmc_block2_step_kernel(McmcState st, int start, int first, int h, int it,
+                                                               const double* __restrict__ X, const double* __restrict__ y,
+                                                               double* __restrict__ Kws, size_t k_stride) {
+    __shared__ double smem[DIAG_SMEM_DOUBLES];
+    __shared__ int sfail;
+    const DiagSmem m = diag_carve(smem);
+    const int grp = threadIdx.x >> 8, tid = threadIdx.x & 255, w = blockIdx.x, P = st.P, n = st.n;
+    constexpr int LD = 2 * NB;
+    double* Kw = Kws + (size_t)w * k_stride;                 // this walker's 256 x 256 matrix: block row 1 lives there
+    double* sq = m.sW;
+    double* sism = sq + MAX_DIM + 8;
+    double* sz = sism + MAX_DIM;
+    int* sflag = reinterpret_cast<int*>(sz + 1);
+    double* sI = sz + 2 + grp * (2 * GD * GLD + 2 * GT);     // per group: sI, sJ, sN
+    double* sJ = sI + GD * GLD;
+    double* sN = sJ + GD * GLD;
+    const bool ok = mcmc_block_proposal(st, start, first, h, it, w, sq, sism, sz, sflag);
+    const FitSample sp = mcmc_fit_sample(st, sq, ok);
+    const double z = *sz;
+    double prior = 0.0;
+    if (threadIdx.x == 0) {
+        if (ok && st.prior_kind != 0) prior = prior_lnprob(st.prior_kind, sq, P, st.prior_par);
+        if (!ok) prior = -__builtin_huge_val();
+        sfail = 0;
+    }
+    const double q0 = tid < P ? sq[tid] : 0.0, q1 = tid + 256 < P ? sq[tid + 256] : 0.0;   // (group 0) thread p keeps q[p]
+    // ---- K: the ten lower 64 x 64 tiles of the 4 x 4 grid, NG per round (the tile routine's barriers are workgroup-wide:
+    // a group without a tile in the last round recomputes tile 9 and drops it); entries as gram_kernel writes them.
+    // NG = 2 (512 threads): the register budget of the tile update and the panel (256 per thread; at 768 threads the
+    // compiler spilled 261 of them) costs one more round of tiles than NG = 3 would take.
+#pragma nounroll
+    for (int round = 0; round < (10 + NG - 1) / NG; ++round) {
+        const int t = round * NG + grp;
+        int bi, bj;
+        tri_tile(t < 10 ? t : 9, bi, bj);
+        const int tx = tid & 15, ty = tid >> 4;
+        double cov[4][4];
+        pair_cov_dot<KIND>(sp.cov, X, (long long)bi * GT, (long long)bj * GT, sI, sJ, sN, cov, sism, (long long)n, tid);
+        if (t < 10) {
+#pragma unroll
+            for (int a = 0; a < 4; ++a) {
+                const int gi = bi * GT + ty * 4 + a;
+#pragma unroll
+                for (int b = 0; b < 4; ++b) {
+                    const int gj = bj * GT + gram_col(tx, b);
+                    double val;
+                    if (gi < n && gj < n) {
+                        val = cov[a][b];
+                        if (gi == gj) val += sp.noise;
+                    } else if (gi == gj) {
+                        val = 1.0;
+                    } else if (gi == n && gj < n) {
+                        val = y[gj] - sp.mean_c;
+                    } else if (gj == n && gi < n) {
+                        val = y[gi] - sp.mean_c;
+                    } else {
+                        val = 0.0;
+                    }
+                    if (gi < NB) {
+                        if ((gj >> 4) <= (gi >> 4)) m.sL[blk_off(gi >> 4, gj >> 4) + bidx(gi & 15, gj & 15)] = val;
+                    } else {
+                        Kw[(size_t)gi * LD + gj] = val;
+                    }
+                }
+            }
+        }
+    }
+    __syncthreads();
+    if (grp != 0) return;
+    const int lane = tid & 63, wave = tid >> 6;
+    // ---- diagonal block 0
+    diag128_factor_invert(m.sL, m.sW, m.sT, m.sRd, m.sCol, 0, n, &sfail, nullptr);
+    __syncthreads();
+    // block 0's log-diagonal share (all 128 rows are training rows here), before the image is reused
+    double lg = tid < NB ? log(m.sL[blk_off(tid >> 4, tid >> 4) + bidx(tid & 15, tid & 15)]) : 0.0;
+    // ---- the panel kernel's operand image in the W image: strictly lower blocks of L_00 and, in the diagonal slots, the W_ss,
+    // rows and columns permuted (potrf_panel_kernel)
+    {
+        const int r = tid >> 4, c = tid & 15, src = bidx(r, c), pos = bidx(pi16(r), pi16(c));
+        double wv[NSB];
+#pragma unroll
+        for (int s2 = 0; s2 < NSB; ++s2) wv[s2] = m.sW[blk_off(s2, s2) + src];
+        __syncthreads();
+#pragma unroll
+        for (int s2 = 0; s2 < NSB; ++s2) m.sW[blk_off(s2, s2) + pos] = wv[s2];
+        for (int bi = 1; bi < NSB; ++bi)
+            for (int bj = 0; bj < bi; ++bj) m.sW[blk_off(bi, bj) + pos] = m.sL[blk_off(bi, bj) + src];
+    }
+    __syncthreads();
+    // ---- panel: block row 1's eight 16-row strips, two per wave one after the other (the panel kernel's substitution)
+#pragma nounroll
+    for (int half = 0; half < 2; ++half) {
+        double* Arow = Kw + (size_t)(NB + (wave + 4 * half) * 16 + (lane & 15)) * LD + 4 * (lane >> 4);
+        v4d yv[NSB];
+#pragma unroll
+        for (int s2 = 0; s2 < NSB; ++s2) {
+            const double2* p = reinterpret_cast<const double2*>(Arow + s2 * SB);
+            const double2 lo = p[0], hi = p[1];
+            yv[s2] = v4d{lo.x, lo.y, hi.x, hi.y};
+        }
+#pragma unroll
+        for (int s2 = 0; s2 < NSB; ++s2) {
+            v4d t = yv[s2];
+#pragma unroll
+            for (int c = 0; c < s2; ++c) {
+                const Frag4 a = frag_row(m.sW + blk_off(s2, c), lane);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) t = mfma_f64(-a.v[r], yv[c][r], t);
+            }
+            const Frag4 wf = frag_row(m.sW + blk_off(s2, s2), lane);
+            v4d o = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+            for (int r = 0; r < 4; ++r) o = mfma_f64(wf.v[r], t[r], o);
+            yv[s2] = o;
+        }
+#pragma unroll
+        for (int s2 = 0; s2 < NSB; ++s2) {
+            double2* p = reinterpret_cast<double2*>(Arow + s2 * SB);
+            p[0] = make_double2(yv[s2][0], yv[s2][1]);
+            p[1] = make_double2(yv[s2][2], yv[s2][3]);
+        }
+    }
+    __syncthreads();                          // the strips are in memory for this workgroup's own reads
+    // ---- block 0's shares of (z.z, sum log L_ii): potrf_inverse_kernel's likelihood branch, its order
+    double part_q[2], part_l[2];
+    double* red = m.sT;                       // (the transposition scratch is idle between the factorisations)
+    {
+        double q = 0.0;
+        if (tid < NB) {
+            const double zi = Kw[(size_t)n * LD + tid];
+            q = zi * zi;
+        } else {
+            lg = 0.0;
+        }
+        for (int o = 32; o > 0; o >>= 1) {
+            q += __shfl_xor(q, o);
+            lg += __shfl_xor(lg, o);
+        }
+        if ((tid & 63) == 0 && tid < NB) {
+            red[tid >> 6] = q;
+            red[2 + (tid >> 6)] = lg;
+        }
+        __syncthreads();
+        part_q[0] = red[0] + red[1];
+        part_l[0] = red[2] + red[3];
+        __syncthreads();
+    }
+    // ---- tile (1, 1) <- C - P P^T into the LDS image, second diagonal block
+    diag_tile_update(Kw + (size_t)NB * LD, Kw + (size_t)NB * LD + NB, LD, m.sW, m.sL);
+    __syncthreads();
+    diag128_factor_invert(m.sL, m.sW, m.sT, m.sRd, m.sCol, NB, n, &sfail, nullptr);
+    __syncthreads();
+    {
+        double q = 0.0;
+        lg = 0.0;
+        const int r = NB + tid;
+        if (tid < NB && r < n) {
+            const int zr = n - NB;
+            const double zi = m.sL[blk_off(zr >> 4, tid >> 4) + bidx(zr & 15, tid & 15)];
+            q = zi * zi;
+            lg = log(m.sL[blk_off(tid >> 4, tid >> 4) + bidx(tid & 15, tid & 15)]);
+        }
+        for (int o = 32; o > 0; o >>= 1) {
+            q += __shfl_xor(q, o);
+            lg += __shfl_xor(lg, o);
+        }
+        __syncthreads();
+        if ((tid & 63) == 0 && tid < NB) {
+            red[tid >> 6] = q;
+            red[2 + (tid >> 6)] = lg;
+        }
+        __syncthreads();
+        part_q[1] = red[0] + red[1];
+        part_l[1] = red[2] + red[3];
+    }
+    // ---- accept test (mcmc_accept_kernel's, for this walker); the sums block by block as loglik_finish_kernel adds them
+    const int half_k = st.k / 2, sw = start ? first + w : h * half_k + w;
+    if (tid == 0) {
+        double sq_ = 0.0, sl_ = 0.0;
+        sq_ += part_q[0];
+        sl_ += part_l[0];
+        sq_ += part_q[1];
+        sl_ += part_l[1];
+        const double lp = mcmc_lnprob(prior, sfail, sq_, 2.0 * sl_, n);
+        if (lp != lp) atomicOr(st.d_err, 1);
+        int acc = 0;
+        if (start) {
+            if (lp == __builtin_huge_val()) atomicOr(st.d_err, 2);
+            st.d_lnp[sw] = lp;
+        } else {
+            const size_t r = ((size_t)it * 2 + h) * half_k + w;
+            const double lnpdiff = mcmc_lnpdiff(P, log(z), lp, st.d_lnp[sw]);
+            if (lnpdiff > log(st.d_ua[r])) {
+                acc = 1;
+                st.d_lnp[sw] = lp;
+                st.d_nacc[sw] += 1;
+            }
+            if (st.d_lnprob) st.d_lnprob[(size_t)sw * st.n_steps + it] = st.d_lnp[sw];
+        }
+        *sflag = acc;
+    }
+    __syncthreads();
+    if (start) return;
+    const bool acc = *sflag != 0;
+    for (int p = tid, e = 0; p < P; p += 256, ++e) {
+        double* pp = st.d_pos + (size_t)sw * P + p;
+        const double v = acc ? (e == 0 ? q0 : q1) : *pp;
+        if (acc) *pp = v;
+        if (st.d_chain) st.d_chain[((size_t)sw * st.n_steps + it) * P + p] = v;
+    }
+}
+
+int launch_mcmc_block2_step(robo_gp* gp, const McmcState& st, int start, int first, int h, int it, double* d_K, size_t k_stride) {
+    const int ns = start ? st.ns_eval : st.k / 2;
+#define ROBO_BLOCK2_STEP(KIND)                                                                                          \
+    hipLaunchKernelGGL((mcmc_block2_step_kernel<KIND, 2>), dim3(ns), dim3(512), 0, gp->ctx->stream, st, start, first, h, it, \
+                       (const double*)gp->d_X, (const double*)gp->d_y, d_K, k_stride)
+    if (gp->kind == ROBO_KERNEL_MATERN52_ARD) ROBO_BLOCK2_STEP(ROBO_KERNEL_MATERN52_ARD);
+    else ROBO_BLOCK2_STEP(ROBO_KERNEL_RBF_ARD);
+#undef ROBO_BLOCK2_STEP
+    ROBO_LAUNCH_CHECK();
+    return ROBO_OK;
+}
+
 // Linv blocks -> packed A-operand fragments for the transposed block-row solve (predict.hip, trsm_step_t_kernel):
 // fragment s = wp_offset(cb) + 4 jb + kk of diagonal block b, lane l:
 //     Linv_b[16 cb + pi16(l & 15)][16 jb + 4 kk + (l >> 4)]

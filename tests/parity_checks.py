@@ -169,9 +169,9 @@ def check_device_chain(ctx, cases=(("matern52", 150, 3, 10, 14), ("rbf", 40, 2, 
             return smp.chain, smp.lnprobability, smp.naccepted.copy(), pos2, lnp2, state
 
         dev = run(lnprob_batch=lnprob_host, device_chain=lambda p, lnp, n, uz, pa, ua, a: g.mcmc_run(mean, par, p, lnp, n, uz, pa, ua, a))
-        if N <= 126:
-            # one-block problems: the half-step fused into ONE launch (default; one tile group below 64 points, three
-            # above) against the four-launch form -- same accept
+        if N <= 254 and kind != "fabolas":
+            # one- and two-block problems: the half-step fused into ONE launch (default; one tile group below 64 points,
+            # three above; N >= 128: mcmc_block2_step_kernel) against the launch-per-phase form -- same accept
             # decisions; likelihoods bit-identical on the emulator, within an ulp on the MI355X (fused-multiply-add
             # contraction is decided per kernel)
             ctx.set_tuning("mcmc_block_step", 0)

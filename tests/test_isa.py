@@ -112,8 +112,9 @@ def ir(tmp_path_factory):
 
 def test_stretch_move_is_not_contractable_in_the_chain_kernels(ir):
     kernels = {k: v for src in ir.values() for k, v in src.items()
-               if "mcmc_propose_scale_kernel" in k or "mcmc_block_step_kernel" in k}
-    assert len(kernels) == 5, sorted(kernels)          # the launch-per-phase proposal + four one-block instantiations
+               if "mcmc_propose_scale_kernel" in k or "mcmc_block_step_kernel" in k or "mcmc_block2_step_kernel" in k}
+    # the launch-per-phase proposal + four one-block instantiations + two two-block ones
+    assert len(kernels) == 7, sorted(kernels)
     for name, lines in kernels.items():
         q = _stretch_q_sites(lines)
         z = _stretch_z_sites(lines)
@@ -148,7 +149,8 @@ def test_the_check_sees_a_contractable_proposal(tmp_path):
 
 
 def test_accept_statistic_is_not_contractable(ir):
-    for src, name in (("mcmc.hip", "mcmc_accept_kernel"), ("potrf.hip", "mcmc_block_step_kernel")):
+    for src, name in (("mcmc.hip", "mcmc_accept_kernel"), ("potrf.hip", "mcmc_block_step_kernel"),
+                      ("potrf.hip", "mcmc_block2_step_kernel")):
         for k, lines in ir[src].items():
             if name not in k:
                 continue

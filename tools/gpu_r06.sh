@@ -185,6 +185,9 @@ k1ab)
   # K1 (gram_kernel) between builds: robo_amd/librobo_hip.so against every robo_amd/librobo_hip_*.so variant shipped beside it
   timeout 600 python tools/k1_ab.py default $(ls robo_amd/librobo_hip_*.so | grep -v diag) > $OUT/k1_ab.txt 2>&1; cat $OUT/k1_ab.txt >> $OUT/summary.txt
   timeout 300 python tools/k1_ab.py default $(ls robo_amd/librobo_hip_*.so | grep -v diag) --n 2048 --d 16 > $OUT/k1_ab_2048.txt 2>&1; grep "round 1" $OUT/k1_ab_2048.txt >> $OUT/summary.txt ;;
+chain)
+  timeout 600 python -m pytest tests/test_gpu_parity.py -m gpu -q -x -k "device_resident_chain or mcmc" > $OUT/chain_test.log 2>&1; echo "chain tests rc=$?" >> $OUT/summary.txt; tail -3 $OUT/chain_test.log >> $OUT/summary.txt
+  timeout 600 python tools/chain_ab.py > $OUT/chain_ab.txt 2>&1; cat $OUT/chain_ab.txt >> $OUT/summary.txt ;;
 small)
   timeout 300 python tools/small_m_timing.py > $OUT/small_m.txt 2>&1; cat $OUT/small_m.txt >> $OUT/summary.txt ;;
 *) echo "unknown step $what" >> $OUT/summary.txt ;;
