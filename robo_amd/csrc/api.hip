@@ -58,7 +58,7 @@ static const TuneKey TUNE_KEYS[] = {
     {"potrf_gram_split", nullptr, &Tuning::potrf_gram_split, 0},
     {"potrf_split_min", nullptr, &Tuning::potrf_split_min, 12},
     {"potrf_lead", nullptr, &Tuning::potrf_lead, -1},
-    {"mcmc_block_step", nullptr, &Tuning::mcmc_block_step, 3},
+    {"mcmc_block_step", nullptr, &Tuning::mcmc_block_step, 2},
 };
 
 static void tune_set(Tuning* t, const TuneKey& k, long long v) {
@@ -703,7 +703,8 @@ int32_t robo_gp_mcmc_run(robo_gp* g, double mean_c, int32_t prior_kind, const do
     const int bs = c->tune.mcmc_block_step;
     const bool one_block = (bs >= 2 ? g->n_pad == NB : (bs == 1 && g->n + 1 <= 64)) && !g->fp32_gram &&
                            g->kind != ROBO_KERNEL_FABOLAS;
-    // two-block problems (128 <= N <= 254): likewise one launch, block row 1 through the batch workspace (tuning: 3 = default)
+    // two-block problems (128 <= N <= 254): likewise one launch, block row 1 through the batch workspace -- tuning value 3,
+    // NOT the default: measured slower than the launch path (r06i: 122 vs 91 us per half-step at N = 200; potrf.hip)
     const bool two_block = bs >= 3 && g->n_pad == 2 * NB && g->n >= NB && !g->fp32_gram && g->kind != ROBO_KERNEL_FABOLAS;
     auto half_step = [&](int start, int first, int h, int it) -> int {
         if (one_block) return launch_mcmc_block_step(g, st, start, first, h, it);

@@ -1626,6 +1626,11 @@ __global__ __launch_bounds__(256) void potrf_step_follow_kernel(double* __restri
 // the batch workspace (read back by the same workgroup: L2).  The pieces are the launch path's own device functions in its
 // order -- diag128_factor_invert, potrf_panel_kernel's substitution, diag_tile_update, potrf_inverse_kernel's likelihood
 // shares added block by block -- so the log-likelihoods are the launch path's bit for bit and the chain is the same chain.
+// MEASURED SLOWER (r06i, 52 walkers, D = 16, us per half-step, this kernel / launch path): N = 150 114 / 84, 200 122 / 91,
+// 254 130 / 99 -- same walkers, same accept decisions.  One CU per walker runs in sequence what the launch path spreads
+// over the chip (ten K tiles, eight panel strips, the tile update: ~35 us of the 120), the two 128-pivot chains (45 us) are
+// on the path either way, and at 512 threads the compiler spills 150 registers in the panel and the tile update.  The nine
+// launch boundaries it removes are worth ~15 us.  Kept as an option (mcmc_block_step = 3) with its tests; NOT the default.
 template <int KIND, int NG>
 __global__ __launch_bounds__(256 * NG) void mcmc_block2_step_kernel(McmcState st, int start, int first, int h, int it,
                                                                const double* __restrict__ X, const double* __restrict__ y,

@@ -174,8 +174,12 @@ def check_device_chain(ctx, cases=(("matern52", 150, 3, 10, 14), ("rbf", 40, 2, 
             # three above; N >= 128: mcmc_block2_step_kernel) against the launch-per-phase form -- same accept
             # decisions; likelihoods bit-identical on the emulator, within an ulp on the MI355X (fused-multiply-add
             # contraction is decided per kernel)
-            ctx.set_tuning("mcmc_block_step", 0)
             try:
+                if N > 126:      # the two-block form is an option (mcmc_block_step = 3), not the default: run it explicitly
+                    ctx.set_tuning("mcmc_block_step", 3)
+                    dev = run(lnprob_batch=lnprob_host,
+                              device_chain=lambda p, lnp, n, uz, pa, ua, a: g.mcmc_run(mean, par, p, lnp, n, uz, pa, ua, a))
+                ctx.set_tuning("mcmc_block_step", 0)
                 dev4 = run(lnprob_batch=lnprob_host,
                            device_chain=lambda p, lnp, n, uz, pa, ua, a: g.mcmc_run(mean, par, p, lnp, n, uz, pa, ua, a))
             finally:
