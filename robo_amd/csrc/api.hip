@@ -52,6 +52,7 @@ static const TuneKey TUNE_KEYS[] = {
     {"potrf_follow", nullptr, &Tuning::potrf_follow, 1},
     {"potrf_follow_from", nullptr, &Tuning::potrf_follow_from, -2},
     {"potrf_pub_early", nullptr, &Tuning::potrf_pub_early, 6},
+    {"potrf_batch_follow", nullptr, &Tuning::potrf_batch_follow, 0},
     {"potrf_batch_tm4_min", nullptr, &Tuning::potrf_batch_tm4_min, 96},
     {"potrf_thin_last", nullptr, &Tuning::potrf_thin_last, 1},
     {"potrf_split", nullptr, &Tuning::potrf_split, 3},
@@ -328,6 +329,7 @@ int32_t robo_gp_destroy(robo_gp* g) {
     hipFree(g->d_bout);
     hipFree(g->d_bsp);
     hipFree(g->d_bfail);
+    hipFree(g->d_bprog);
     if (g->h_bstage) hipHostFree(g->h_bstage);
     robo_ctx* ctx = g->ctx;
     delete g;
@@ -503,6 +505,8 @@ static int batch_ensure(robo_gp* g, int S) {
     if (g->b_cap >= S && g->b_npad == g->n_pad) return ROBO_OK;
     hipFree(g->d_bK); hipFree(g->d_bLinv); hipFree(g->d_bXs); hipFree(g->d_bout);
     hipFree(g->d_bsp); hipFree(g->d_bfail); hipFree(g->d_bllpart); hipFree(g->d_bkeep);   // d_bism lives in d_bsp's block
+    hipFree(g->d_bprog);
+    g->d_bprog = nullptr;
     if (g->h_bstage) hipHostFree(g->h_bstage);
     g->d_bK = g->d_bLinv = g->d_bXs = g->d_bism = g->d_bout = g->h_bstage = nullptr;
     g->d_bsp = nullptr; g->d_bfail = nullptr; g->d_bllpart = nullptr; g->d_bkeep = nullptr;
@@ -520,6 +524,7 @@ static int batch_ensure(robo_gp* g, int S) {
         g->d_bism = reinterpret_cast<double*>(g->d_bsp + S);
     }
     ROBO_TRY(dev_alloc(&g->d_bfail, (size_t)S));
+    ROBO_TRY(dev_alloc(&g->d_bprog, (size_t)S * PROG_STRIDE));
     ROBO_TRY(dev_alloc(&g->d_bllpart, (size_t)S * (np / NB) * 4));
     ROBO_TRY(dev_alloc(&g->d_bkeep, (size_t)S * sizeof(KeepDst)));
     // pinned staging: [S x FitSample | S x D ism] up, [S x 5 doubles] down (written by the device)
@@ -565,7 +570,7 @@ static int fit_batch_core(robo_gp* g, const double* thetas, int32_t S, double me
                                       hipMemcpyHostToDevice, c->stream));
         FitBuffers fb;
         fb.K = g->d_bK; fb.k_stride = np * np;
-        fb.prog = nullptr;
+        fb.prog = g->d_bprog;
         fb.Linv = g->d_bLinv; fb.linv_stride = np * NB;
         fb.Xs = g->d_bXs; fb.xs_stride = np * D;
         fb.sp = g->d_bsp;
@@ -687,7 +692,7 @@ int32_t robo_gp_mcmc_run(robo_gp* g, double mean_c, int32_t prior_kind, const do
     ROBO_HIP_CHECK(hipMemsetAsync(st.d_nacc, 0, (size_t)k * sizeof(long long) + 8 * sizeof(int), s));
     FitBuffers fb;
     fb.K = g->d_bK; fb.k_stride = np * np;
-    fb.prog = nullptr;
+    fb.prog = g->d_bprog;
     fb.Linv = g->d_bLinv; fb.linv_stride = np * NB;
     fb.Xs = g->d_bXs; fb.xs_stride = np * D;
     fb.sp = g->d_bsp;

@@ -156,6 +156,7 @@ struct Tuning {
                                  // kernel (progress words, potrf_step_follow_kernel) instead of its own launch (default 1; 0: the launch-per-phase form)
     int potrf_follow_from;       // ... from this step on (-1: the first panel too; -2 = default: by size, launch_potrf)
     int potrf_pub_early;         // ... the diagonal block's helper waves count a published column at once from this interval on
+    int potrf_batch_follow;      // batched fits: diagonal block + panel of a step in one launch, the panel following (0: off)
     int mcmc_block_step;         // ensemble half-step in ONE launch: 2 (default) every one-block problem, 1 only N <= 63, 0 never;
                                  // 3: two-block problems (N <= 254) too -- built in r06, measured SLOWER than the launch path
 };
@@ -233,6 +234,7 @@ struct robo_gp {
     double *d_bK, *d_bLinv, *d_bXs, *d_bism, *d_bout, *h_bstage;
     robo::FitSample* d_bsp;
     int* d_bfail;
+    unsigned* d_bprog;  // [b_cap][PROG_STRIDE] progress words of the batched follower form
     double *d_llpart, *d_bllpart;   // log-likelihood partials of the tail kernel (own factor / batch workspace)
     char* d_bkeep;                  // [b_cap] KeepDst records of robo_gp_fit_batch
     // workspace of robo_gp_grad_loglik (lazy, sized for n_pad_max): W^T, A = alpha alpha^T - K^-1, ...

@@ -1459,18 +1459,25 @@ __global__ __launch_bounds__(256) void potrf_step_kernel(double* __restrict__ K,
 // in 16 KB of LDS (slot s: L_sc for s > c, slot c: W_cc; rows and columns permuted as in the panel kernel).
 // The chain   panel (11 us) -> launch boundary -> tile update + 128 pivots   of the launch-per-phase factorisation loses its
 // first link: the strips are final one hand-off (a few us) after the diagonal block's last pivot.
+// NS: 16-row strips per wave (64 NS rows per workgroup; strip j of wave w = rows 64 j + 16 w ..): 1 in the single-theta step
+// kernel (two followers per block row), 2 in the batched form (one follower per block row: half as many workgroups spin).
+template <int NS = 1>
 __device__ __forceinline__ void panel_follow(double* __restrict__ K, int ld, int kc, size_t row0, const unsigned* prog,
                                              const double* __restrict__ Wg, double* smem, int* fail, int n_real) {
-    // kc: block column being solved; row0: first of this workgroup's 64 rows; prog: progress word of panel kc
+    // kc: block column being solved; row0: first of this workgroup's 64 NS rows; prog: progress word of panel kc
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const double* Kd = K + ((size_t)kc * NB) * ld + (size_t)kc * NB;
-    double* Arow = K + (row0 + wave * 16 + (lane & 15)) * ld + (size_t)kc * NB + 4 * (lane >> 4);
-    v4d y[NSB];
+    double* Arow[NS];
+    v4d y[NS][NSB];
 #pragma unroll
-    for (int s = 0; s < NSB; ++s) {
-        const double2* p = reinterpret_cast<const double2*>(Arow + s * SB);
-        const double2 lo = p[0], hi = p[1];
-        y[s] = v4d{lo.x, lo.y, hi.x, hi.y};
+    for (int j = 0; j < NS; ++j) {
+        Arow[j] = K + (row0 + j * 64 + wave * 16 + (lane & 15)) * ld + (size_t)kc * NB + 4 * (lane >> 4);
+#pragma unroll
+        for (int s = 0; s < NSB; ++s) {
+            const double2* p = reinterpret_cast<const double2*>(Arow[j] + s * SB);
+            const double2 lo = p[0], hi = p[1];
+            y[j][s] = v4d{lo.x, lo.y, hi.x, hi.y};
+        }
     }
     const int r = tid >> 4, c16 = tid & 15;
     const int pos = bidx(pi16(r), pi16(c16));
@@ -1534,20 +1541,25 @@ __device__ __forceinline__ void panel_follow(double* __restrict__ K, int ld, int
             if (cc < c || cc > chi) continue;
             {
                 const Frag4 w = frag_row(smem + blk_off(cc, cc), lane);
-                v4d o = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-                for (int q = 0; q < 4; ++q) o = mfma_f64(w.v[q], y[cc][q], o);
-                y[cc] = o;
-                // column cc of the strip is final: on its way to memory while the later columns are still being solved
-                double2* p = reinterpret_cast<double2*>(Arow + cc * SB);
-                p[0] = make_double2(o[0], o[1]);
-                p[1] = make_double2(o[2], o[3]);
+                for (int j = 0; j < NS; ++j) {
+                    v4d o = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) o = mfma_f64(w.v[q], y[j][cc][q], o);
+                    y[j][cc] = o;
+                    // column cc of the strip is final: on its way to memory while the later columns are still being solved
+                    double2* p = reinterpret_cast<double2*>(Arow[j] + cc * SB);
+                    p[0] = make_double2(o[0], o[1]);
+                    p[1] = make_double2(o[2], o[3]);
+                }
             }
 #pragma unroll
             for (int sl = cc + 1; sl < NSB; ++sl) {
                 const Frag4 a = frag_row(smem + blk_off(sl, cc), lane);
 #pragma unroll
-                for (int q = 0; q < 4; ++q) y[sl] = mfma_f64(-a.v[q], y[cc][q], y[sl]);
+                for (int j = 0; j < NS; ++j)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) y[j][sl] = mfma_f64(-a.v[q], y[j][cc][q], y[j][sl]);
             }
         }
         c = chi + 1;
@@ -1614,6 +1626,40 @@ __global__ __launch_bounds__(256) void potrf_step_follow_kernel(double* __restri
         if (split == 4) update_subtile<1>(K, ld, k, full_end + q / 4, q % 4, smem, 1);
         else update_subtile<2>(K, ld, k, full_end + q / 2, q % 2, smem, 1);
     }
+}
+
+// Batched fits: diagonal block k and panel k of EVERY sample in one launch (potrf_batch_follow).  Grid (samples, 1 + block
+// rows below k): the x index is the sample, so the S diagonal workgroups (y = 0) are dispatched before any follower, and a
+// follower (y >= 1: all 128 rows of block row k + y, two strips per wave) waits for the diagonal workgroup of ITS sample only.
+// Replaces potrf_diag_kernel + potrf_panel_kernel of the launch-per-phase form: the panel's ~12-40 us per step (S samples'
+// strips behind a launch boundary) shrink to the hand-off behind the last pivot plus the followers that did not fit on the
+// chip beside the diagonal workgroups (every workgroup carries the diagonal block's LDS image: one per CU) and run after them
+// at the panel kernel's speed.  Same strips, bit for bit.
+__global__ __launch_bounds__(256) void potrf_diag_follow_kernel(double* __restrict__ K, size_t k_stride, int ld, int k,
+                                                                int n_real, double* __restrict__ Linv, size_t linv_stride,
+                                                                int* __restrict__ fail, unsigned* __restrict__ prog,
+                                                                int pub_early) {
+    __shared__ double smem[DIAG_SMEM_DOUBLES];
+    const int smp = (int)blockIdx.x, role = (int)blockIdx.y;
+    K += (size_t)smp * k_stride;
+    Linv += (size_t)smp * linv_stride;
+    fail += smp;
+    prog += (size_t)smp * PROG_STRIDE + k;
+    const size_t d0 = (size_t)k * NB;
+    double* Wg = Linv + (size_t)k * NB * NB;
+    if (role == 0) {
+        double* C = K + d0 * ld + d0;
+        const DiagSmem m = diag_carve(smem);
+        const int tid = threadIdx.x;
+        for (int bi = 0; bi < NSB; ++bi)
+            for (int bj = 0; bj <= bi; ++bj)
+                m.sL[blk_off(bi, bj) + bidx(tid >> 4, tid & 15)] = C[(size_t)(bi * SB + (tid >> 4)) * ld + bj * SB + (tid & 15)];
+        __syncthreads();
+        const DiagPub pub = {C, ld, Wg, prog, pub_early};
+        diag128_factor_invert(m.sL, m.sW, m.sT, m.sRd, m.sCol, k * NB, n_real, fail, nullptr, &pub);
+        return;
+    }
+    panel_follow<2>(K, ld, k, (size_t)(k + role) * NB, prog, Wg, smem, fail, n_real);
 }
 
 // ---- two-block problems (128 <= N <= 254): the same, ONE launch per ensemble half-step (r06) -------------------------------
@@ -2048,11 +2094,22 @@ int launch_potrf(robo_gp* gp, const FitBuffers& fb, bool with_gram) {
         const int G = tune.potrf_group < 1 ? (nb <= 25 ? 3 : 5) : (tune.potrf_group > 16 ? 16 : tune.potrf_group);
         // `lead` = size of the FIRST group (1..G); all later groups hold G panels.  Where the group boundaries fall
         // changes which launches carry which products, never the order in which an element accumulates them.
+        // potrf_batch_follow: diagonal block and panel of a step in ONE launch, the panel following the diagonal workgroups
+        // through progress words (potrf_diag_follow_kernel); needs the batch's progress words (zeroed in front of the fork)
+        const bool bfollow = tune.potrf_batch_follow != 0 && fb.prog != nullptr && nb <= PROG_STRIDE;
+        if (bfollow) ROBO_HIP_CHECK(hipMemsetAsync(fb.prog, 0, (size_t)S * PROG_STRIDE * sizeof(unsigned), ctx->stream));
         auto group = [&](hipStream_t st, int s0, int ns, int k0, int g) {
             for (int kk = k0; kk < k0 + g; ++kk) {
                 if (kk >= nbf) break;         // the augmented row's own block
                 // left-looking inside the group: block column kk <- panels k0 .. kk-1, all rows >= kk
                 if (kk > k0) update(st, s0, ns, nb - kk, kk - 1, k0, (kk - k0) * NB, 1);
+                if (bfollow && kk + 1 < nb) {
+                    hipLaunchKernelGGL(potrf_diag_follow_kernel, dim3(ns, nb - kk), dim3(256), 0, st,
+                                       fb.K + (size_t)s0 * fb.k_stride, fb.k_stride, ld, kk, gp->n,
+                                       fb.Linv + (size_t)s0 * fb.linv_stride, fb.linv_stride, fb.fail + s0,
+                                       fb.prog + (size_t)s0 * PROG_STRIDE, tune.potrf_pub_early);
+                    continue;
+                }
                 diag(st, s0, ns, kk);
                 if (kk + 1 < nb) panel(st, s0, ns, kk);
             }

@@ -188,6 +188,15 @@ k1ab)
 chain)
   timeout 600 python -m pytest tests/test_gpu_parity.py -m gpu -q -x -k "device_resident_chain or mcmc" > $OUT/chain_test.log 2>&1; echo "chain tests rc=$?" >> $OUT/summary.txt; tail -3 $OUT/chain_test.log >> $OUT/summary.txt
   timeout 600 python tools/chain_ab.py > $OUT/chain_ab.txt 2>&1; cat $OUT/chain_ab.txt >> $OUT/summary.txt ;;
+bfollow)
+  # batched fits: diagonal block + panel in one launch (potrf_batch_follow) against the launch-per-phase form, one and three streams
+  : > $OUT/bfollow_ab.txt
+  for cfg in "2048 16 26 7" "4096 16 27 5" "1024 8 26 9" "3072 16 26 5"; do
+    for bf in 0 1; do
+      BATCH_TUNE="potrf_batch_follow=$bf" BATCH_AB="0,3,-1;0,1,-1;0,2,-1" timeout 600 python tools/batched_fit_ab.py $cfg 2>&1 | sed "s/^round/follow=$bf round/" >> $OUT/bfollow_ab.txt
+    done
+  done
+  grep "batched fit\|round 1" $OUT/bfollow_ab.txt >> $OUT/summary.txt ;;
 small)
   timeout 300 python tools/small_m_timing.py > $OUT/small_m.txt 2>&1; cat $OUT/small_m.txt >> $OUT/summary.txt ;;
 *) echo "unknown step $what" >> $OUT/summary.txt ;;
