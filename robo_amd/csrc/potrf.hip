@@ -2096,7 +2096,12 @@ int launch_potrf(robo_gp* gp, const FitBuffers& fb, bool with_gram) {
         // changes which launches carry which products, never the order in which an element accumulates them.
         // potrf_batch_follow: diagonal block and panel of a step in ONE launch, the panel following the diagonal workgroups
         // through progress words (potrf_diag_follow_kernel); needs the batch's progress words (zeroed in front of the fork)
-        const bool bfollow = tune.potrf_batch_follow != 0 && fb.prog != nullptr && nb <= PROG_STRIDE;
+        // Measured (r06j, 26-27 thetas, three streams, ms per theta, launch-per-phase -> merged): N = 1024 0.0289 -> 0.0262,
+        // 2048 0.0928 -> 0.0902, 3072 0.2288 -> 0.2324, 4096 0.4682 -> 0.4787 -- every workgroup of the merged launch carries
+        // the diagonal block's 150-KB LDS image, so at large N the followers (one CU each) crowd out the other sub-batches'
+        // update workgroups.  potrf_batch_follow = -1 (default): up to 17 panels (N <= 2048); 0 / 1: never / always.
+        const bool bfollow = fb.prog != nullptr && nb <= PROG_STRIDE &&
+                             (tune.potrf_batch_follow < 0 ? nb <= 17 : tune.potrf_batch_follow != 0);
         if (bfollow) ROBO_HIP_CHECK(hipMemsetAsync(fb.prog, 0, (size_t)S * PROG_STRIDE * sizeof(unsigned), ctx->stream));
         auto group = [&](hipStream_t st, int s0, int ns, int k0, int g) {
             for (int kk = k0; kk < k0 + g; ++kk) {

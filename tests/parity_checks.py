@@ -1480,3 +1480,58 @@ def check_panel_followers(ctx, sizes=((520, 3), (512, 3), (300, 3), (130, 2)), c
             for key in keys:
                 ctx.set_tuning(key, None)
             g.close()
+
+
+def check_batched_followers(ctx, sizes=((520, 3, 5), (512, 3, 4), (300, 2, 7)), emulated=True):
+    """potrf_batch_follow: diagonal block + panel of a batched step in ONE launch (potrf_diag_follow_kernel: the x grid index
+    is the sample, so all diagonal workgroups are dispatched before any follower; 128-row followers, two strips per wave) --
+    likelihoods, kept factors and posteriors of the kept factors equal the launch-per-phase form's BIT FOR BIT, with one,
+    two and three sub-batch streams and every group size."""
+    keys = ("potrf_batch_follow", "potrf_split", "potrf_split_min", "potrf_group", "potrf_batch_tm4_min")
+    for N, D, S in sizes:
+        rs = np.random.RandomState(N)
+        X = rs.rand(N, D)
+        y = np.cos(3 * X.sum(axis=1))
+        th = np.concatenate([[0.1], np.log(0.5 + 0.2 * np.arange(D)), [np.log(1e-2)]])
+        thetas = th[None, :] + 0.1 * rs.randn(S, th.size)
+        g = _lib.DeviceGP(ctx, "matern52", N, D)
+        g.set_data(X, y)
+        gps = [_lib.DeviceGP(ctx, "matern52", N, D) for _ in range(S)]
+        gps[0].set_data(X, y)
+        try:
+            ref = None
+            for bf in (0, 1):
+                for split, smin in ((1, 12), (2, 2), (3, 2)):
+                    for grp in ((0, 1, 2) if emulated else (0,)):
+                        ctx.set_tuning("potrf_batch_follow", bf)
+                        ctx.set_tuning("potrf_split", split)
+                        ctx.set_tuning("potrf_split_min", smin)
+                        ctx.set_tuning("potrf_group", grp)
+                        if emulated:
+                            ctx.set_tuning("potrf_batch_tm4_min", 1)
+                        g.loglik_batch(thetas + 0.01, 0.0)         # other matrices through the workspace first
+                        for rep in range(1 if emulated else 3):
+                            ll, st = g.loglik_batch(thetas, 0.0)
+                            assert np.all(st == _lib.OK), st
+                            if ref is None:
+                                ref = ll.copy()
+                            np.testing.assert_array_equal(ll, ref, err_msg=str((N, bf, split, grp, rep)))
+            for key in keys:
+                ctx.set_tuning(key, None)
+            ctx.set_tuning("potrf_batch_follow", 0)
+            _lib.fit_batch(gps, thetas, 0.0)
+            L0 = [h.factor().copy() for h in gps]
+            v0 = [h.predict(X[:9] + 0.01) for h in gps]
+            ctx.set_tuning("potrf_batch_follow", 1)
+            _lib.fit_batch(gps, thetas, 0.0)
+            for h, L, pv in zip(gps, L0, v0):
+                np.testing.assert_array_equal(h.factor(), L)
+                mu, var = h.predict(X[:9] + 0.01)
+                np.testing.assert_array_equal(mu, pv[0])
+                np.testing.assert_array_equal(var, pv[1])
+        finally:
+            for key in keys:
+                ctx.set_tuning(key, None)
+            for h in gps:
+                h.close()
+            g.close()

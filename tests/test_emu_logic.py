@@ -234,11 +234,6 @@ def test_persistent_tile_updates(emu_ctx, monkeypatch):
     g.close()
 
 
-def test_panel_followers(emu_ctx):
-    """the follower form of the single-theta factorisation (potrf_follow): same bits as the launch-per-phase form"""
-    P.check_panel_followers(emu_ctx)
-
-
 def test_predictive_gradients(emu_ctx):
     P.check_predictive_gradients(emu_ctx, cases=(("matern52", 70, 3, 9), ("fabolas", 60, 3, 7)))
 

@@ -57,6 +57,12 @@ def test_panel_followers_hand_off(ctx):
                             emulated=False)
 
 
+def test_batched_followers_hand_off(ctx):
+    """potrf_batch_follow on the hardware: S diagonal workgroups publish, their samples' followers read in the same launch --
+    likelihoods, kept factors and posteriors equal the launch-per-phase form's bit for bit (three passes per setting)"""
+    P.check_batched_followers(ctx, sizes=((2048, 16, 26), (1000, 8, 13), (300, 3, 7)), emulated=False)
+
+
 @pytest.mark.parametrize("name", ["small_matern", "ragged_rbf_nout", "one_block_edge", "two_block"])
 def test_golden_cases(ctx, name):
     P.check_case(ctx, name)
