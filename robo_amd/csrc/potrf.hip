@@ -1577,7 +1577,8 @@ __device__ __forceinline__ void panel_follow(double* __restrict__ K, int ld, int
 __global__ __launch_bounds__(256) void potrf_step_follow_kernel(double* __restrict__ K, size_t k_stride, int ld, int k,
                                                                 int n_real, double* __restrict__ Linv, size_t linv_stride,
                                                                 int* __restrict__ fail, unsigned* __restrict__ prog,
-                                                                int nfol, int ntiles, int tail_split, int pub_early) {
+                                                                int nfol, int ntiles, int tail_split, int pub_early,
+                                                                int fol_rows) {
     __shared__ double smem[DIAG_SMEM_DOUBLES];
     K += (size_t)blockIdx.y * k_stride;
     Linv += (size_t)blockIdx.y * linv_stride;
@@ -1603,6 +1604,17 @@ __global__ __launch_bounds__(256) void potrf_step_follow_kernel(double* __restri
         return;
     }
     if (b <= nfol) {
+        if (fol_rows == 128) {
+            // one follower per block row (two strips per wave): half as many workgroups leave the trailing update; the
+            // whole 128-row tile first, so this follower starts ~10 us later and catches up several columns per pass
+            const int ii = b;
+            if (k >= 0) {
+                update_subtile<4>(K, ld, k, ii * (ii + 1) / 2, 0, smem);
+                __syncthreads();
+            }
+            panel_follow<2>(K, ld, k + 1, (size_t)(k + 1 + ii) * NB, prog, Wg, smem, fail, n_real);
+            return;
+        }
         const int ii = 1 + (b - 1) / 2, h = (b - 1) & 1;           // block row k + 1 + ii, rows 64 h .. 64 h + 63
         if (k >= 0) {
             update_subtile<2>(K, ld, k, ii * (ii + 1) / 2, h, smem);
@@ -2047,13 +2059,18 @@ int launch_potrf(robo_gp* gp, const FitBuffers& fb, bool with_gram) {
         }
         auto follow = [&](int k) {
             // block rows below k+1: two followers each; the other tiles of the trailing triangle (none in front of panel 0)
-            const int nfol = 2 * (nb - k - 2), r1 = nb - k - 2, rest = k < 0 ? 0 : r1 * (r1 + 1) / 2;
+            const int r1 = nb - k - 2, rest = k < 0 ? 0 : r1 * (r1 + 1) / 2;
+            // followers per block row: two (64 rows each) or one (128 rows, potrf_follow_rows = 128; -1 = by step: one while
+            // the other tiles need more than one round of the workgroups that two per row would leave)
+            int frows = tune.potrf_follow_rows == 128 ? 128 : 64;
+            if (tune.potrf_follow_rows < 0 && rest > max_wg - 1 - 2 * r1) frows = 128;
+            const int nfol = frows == 128 ? r1 : 2 * r1;
             int W = max_wg - 1 - nfol;
             W = W < 1 ? 1 : W;
             W = W < rest ? W : rest;
             hipLaunchKernelGGL(potrf_step_follow_kernel, dim3(1 + nfol + W, S), dim3(256), 0, st, fb.K, fb.k_stride,
                                ld, k, gp->n, fb.Linv, fb.linv_stride, fb.fail, fb.prog, nfol, rest,
-                               tune.potrf_tail_split != 0 ? 1 : 0, tune.potrf_pub_early);
+                               tune.potrf_tail_split != 0 ? 1 : 0, tune.potrf_pub_early, frows);
         };
         if (can_follow) ROBO_HIP_CHECK(hipMemsetAsync(fb.prog, 0, (size_t)S * PROG_STRIDE * sizeof(unsigned), st));
         bool panel_done = false;              // panel of the CURRENT column k already solved (by the previous follow step)

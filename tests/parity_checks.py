@@ -1441,7 +1441,7 @@ def check_panel_followers(ctx, sizes=((520, 3), (512, 3), (300, 3), (130, 2)), c
     (On the CPU the interpreter runs workgroup 0 first, so this checks arithmetic and indexing; the hand-off itself --
     write-through stores, polls, L1-bypassing loads across XCDs -- is what the MI355X run of the same check is for.)"""
     from oracle import gp_oracle as O
-    keys = ("potrf_tm4_min", "potrf_max_wg", "potrf_tail_split", "potrf_follow", "potrf_follow_from")
+    keys = ("potrf_tm4_min", "potrf_max_wg", "potrf_tail_split", "potrf_follow", "potrf_follow_from", "potrf_follow_rows")
     for N, D in sizes:
         rs = np.random.RandomState(13 + N)
         X = rs.rand(N, D)
@@ -1462,8 +1462,10 @@ def check_panel_followers(ctx, sizes=((520, 3), (512, 3), (300, 3), (130, 2)), c
             if emulated:
                 ctx.set_tuning("potrf_tm4_min", 1)
             for frm in froms:
+              for frows in (64, 128, -1):              # followers per block row: two, one, by step
                 for cap in caps:
                     for split in ((1, 0) if emulated else (1,)):
+                        ctx.set_tuning("potrf_follow_rows", frows)
                         ctx.set_tuning("potrf_follow", 1)
                         ctx.set_tuning("potrf_follow_from", frm)
                         if cap is not None:
@@ -1471,8 +1473,8 @@ def check_panel_followers(ctx, sizes=((520, 3), (512, 3), (300, 3), (130, 2)), c
                         ctx.set_tuning("potrf_tail_split", split)
                         for rep in range(1 if emulated else 3):
                             ll = g.fit(theta, ogp.mean)
-                            assert ll == ll0, (N, frm, cap, split, rep, ll, ll0)
-                            np.testing.assert_array_equal(g.factor(), L0, err_msg=str((N, frm, cap, split, rep)))
+                            assert ll == ll0, (N, frm, frows, cap, split, rep, ll, ll0)
+                            np.testing.assert_array_equal(g.factor(), L0, err_msg=str((N, frm, frows, cap, split, rep)))
                         mu, v = g.predict(Xc)
                         np.testing.assert_array_equal(mu, mu0)
                         np.testing.assert_array_equal(v, v0)

@@ -30,7 +30,7 @@ def emu_ctx():
 def test_panel_followers(emu_ctx):
     """the follower form of the single-theta factorisation: same bits as the launch-per-phase form, whichever step the
     hand-off starts at, however many workgroups share the other tiles"""
-    P.check_panel_followers(emu_ctx)
+    P.check_panel_followers(emu_ctx, sizes=((520, 3), (512, 3), (130, 2)), froms=(-1, 2))
 
 
 def test_batched_followers(emu_ctx):

@@ -25,10 +25,12 @@ g = _lib.DeviceGP(ctx, "matern52", N, D)
 g.set_data(X, y)
 ref = None
 print("single-theta fit, N=%d D=%d, %d reps each (ms: median / min)" % (N, D, REPS))
-early = [int(v) for v in os.environ.get("FOLLOW_EARLY", "5").split(",")]
+early = [int(v) for v in os.environ.get("FOLLOW_EARLY", "6").split(",")]
+rows = [int(v) for v in os.environ.get("FOLLOW_ROWS", "64").split(",")]
 for rnd in range(2):
-    for follow, frm, ea in [(0, 0, 5)] + [(1, f, e) for f in froms for e in early]:
+    for follow, frm, ea, fr in [(0, 0, 6, 64)] + [(1, f, e, r) for f in froms for e in early for r in rows]:
         ctx.set_tuning("potrf_pub_early", ea)
+        ctx.set_tuning("potrf_follow_rows", fr)
         ctx.set_tuning("potrf_follow", follow)
         ctx.set_tuning("potrf_follow_from", frm)
         ll = g.fit(theta, 0.0)
@@ -39,6 +41,6 @@ for rnd in range(2):
             t0 = time.perf_counter()
             g.fit(theta, 0.0)
             ts.append((time.perf_counter() - t0) * 1e3)
-        print("round %d  follow %d from %2d early %d : %.4f / %.4f ms   bits %s" % (
-            rnd, follow, frm, ea, sorted(ts)[len(ts) // 2], min(ts), "same" if ll == ref else "DIFFER (%r vs %r)" % (ll, ref)), flush=True)
+        print("round %d  follow %d from %2d early %d rows %3d : %.4f / %.4f ms   bits %s" % (
+            rnd, follow, frm, ea, fr, sorted(ts)[len(ts) // 2], min(ts), "same" if ll == ref else "DIFFER (%r vs %r)" % (ll, ref)), flush=True)
 g.close()

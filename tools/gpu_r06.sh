@@ -170,13 +170,13 @@ follow)
   # the follower form of the single-theta factorisation: hardware parity test first (hand-off across XCDs), then the A/B
   timeout 900 python -m pytest tests/test_gpu_parity.py -m gpu -q -x -k "panel_followers" > $OUT/follow_test.log 2>&1; echo "follow test rc=$?" >> $OUT/summary.txt
   tail -5 $OUT/follow_test.log >> $OUT/summary.txt
-  for cfg in "4096 16" "2048 16" "1024 8"; do
-    FOLLOW_FROM="-1,2" FOLLOW_EARLY="6,8" timeout 300 python tools/follow_ab.py $cfg 15 >> $OUT/follow_ab.txt 2>&1
+  for cfg in "4096 16" "2048 16" "1024 8" "3000 16"; do
+    FOLLOW_FROM="-1" FOLLOW_ROWS="64,128,-1" timeout 300 python tools/follow_ab.py $cfg 15 >> $OUT/follow_ab.txt 2>&1
   done
-  FOLLOW_FROM="24,32" timeout 300 python tools/follow_ab.py 8192 64 9 >> $OUT/follow_ab.txt 2>&1
+  FOLLOW_FROM="0,8,16,31" FOLLOW_ROWS="64,128,-1" timeout 600 python tools/follow_ab.py 8192 64 9 >> $OUT/follow_ab.txt 2>&1
   grep "single-theta\|round 1" $OUT/follow_ab.txt >> $OUT/summary.txt
   for f in 0 1; do
-    ROBO_POTRF_FOLLOW=$f ROBO_POTRF_FOLLOW_FROM=-1 FIT_N=4096 FIT_REPS=4 timeout 300 rocprofv3 --kernel-trace -d $OUT/prof_follow$f -o fit -- python tools/fit_only.py > $OUT/prof_follow$f.log 2>&1
+    ROBO_POTRF_FOLLOW=$f ROBO_POTRF_FOLLOW_FROM=-1 ROBO_POTRF_FOLLOW_ROWS=-1 FIT_N=4096 FIT_REPS=4 timeout 300 rocprofv3 --kernel-trace -d $OUT/prof_follow$f -o fit -- python tools/fit_only.py > $OUT/prof_follow$f.log 2>&1
     python tools/fit_trace.py $OUT/prof_follow$f > $OUT/trace_4096_follow$f.txt 2>&1
     find $OUT/prof_follow$f -size +5M -delete
     tail -2 $OUT/trace_4096_follow$f.txt >> $OUT/summary.txt
