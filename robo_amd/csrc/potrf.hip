@@ -2048,12 +2048,13 @@ int launch_potrf(robo_gp* gp, const FitBuffers& fb, bool with_gram) {
         // 1.13, 2048 0.83 -> 0.72, 1024 0.43 -> 0.37, 512 0.227 -> 0.214.  The followers are workgroups the trailing update does
         // not have: while a step is bound by its tiles (early steps of a large factor) they cost more than the panel launch
         // they replace -- N = 8192 (65 panels): followers from step 0 7.28, from step 16 6.11, from 24 / 32 5.88 against 6.06
-        // without.  potrf_follow_from = -2 (default): from the step on at which the followers are at most a quarter of the
-        // workgroups (k >= nb - 2 - max_wg / 8: every step up to N = 4096, step 31 at N = 8192).
+        // without; with one 128-row follower per block row in the tile-bound steps (potrf_follow_rows = -1, below): from step
+        // 0 6.08, 8 5.88, 16 5.80, 31 5.85.  potrf_follow_from = -2 (default): k >= nb - 2 - 3 max_wg / 16 (every step up to
+        // N = 6144, step 15 at N = 8192).
         const bool can_follow = tune.potrf_follow != 0 && fb.prog != nullptr && max_wg >= 16;
         int ffrom = nb;
         if (can_follow) {
-            ffrom = tune.potrf_follow_from >= -1 ? tune.potrf_follow_from : nb - 2 - max_wg / 8;
+            ffrom = tune.potrf_follow_from >= -1 ? tune.potrf_follow_from : nb - 2 - 3 * max_wg / 16;
             if (ffrom < -1) ffrom = -1;
             while (ffrom < nb && !tiles_ok_for_follow(nb - 1 - ffrom, max_wg)) ++ffrom;   // (explicit settings: residency)
         }
@@ -2062,8 +2063,11 @@ int launch_potrf(robo_gp* gp, const FitBuffers& fb, bool with_gram) {
             const int r1 = nb - k - 2, rest = k < 0 ? 0 : r1 * (r1 + 1) / 2;
             // followers per block row: two (64 rows each) or one (128 rows, potrf_follow_rows = 128; -1 = by step: one while
             // the other tiles need more than one round of the workgroups that two per row would leave)
+            // Measured (r06k, N = 4096, us per step, two / one per row): step 0 70.2 / 60.9, 1 63.1 / 59.3, 2 57.2 / 52.4,
+            // 3 56.8 / 51.8, 4 49.8 / 51.1, 8 45.6 / 50.8 -- one per row (its 128-row tile takes 24 us before it can follow)
+            // pays while the other tiles need more than two rounds of the workgroups left
             int frows = tune.potrf_follow_rows == 128 ? 128 : 64;
-            if (tune.potrf_follow_rows < 0 && rest > max_wg - 1 - 2 * r1) frows = 128;
+            if (tune.potrf_follow_rows < 0 && rest > 2 * (max_wg - 1 - 2 * r1)) frows = 128;
             const int nfol = frows == 128 ? r1 : 2 * r1;
             int W = max_wg - 1 - nfol;
             W = W < 1 ? 1 : W;
