@@ -1450,6 +1450,24 @@ __global__ __launch_bounds__(256) void potrf_step_kernel(double* __restrict__ K,
             for (int r = 0; r < 4; ++r) C[(size_t)acc_row<TM>(tm, r) * ld + acc_col(tn)] = acc.t[tm][tn][r];
 }
 
+// The LAST column of a panel is one block, W_77 = L_77^-1, and it is what every follower waits for when the diagonal block
+// ends.  Its 256 entries are their own flag: follow_init_kernel fills the slot with W_SENTINEL (a NaN no arithmetic produces)
+// in front of the factorisation, the diagonal workgroup's ordinary publication overwrites it, and a follower re-reads ITS
+// element until it is no sentinel -- one round trip (the payload) instead of two (progress word, then payload) behind the
+// last pivot.  Also zeroes the progress words (what a memset did before).
+constexpr long long W_SENTINEL = 0x7FF8DEAD00C0FFEELL;
+__global__ __launch_bounds__(256) void follow_init_kernel(unsigned* __restrict__ prog, double* __restrict__ Linv,
+                                                          size_t linv_stride, int nbf) {
+    const int smp = (int)blockIdx.y, tid = threadIdx.x;
+    unsigned* pr = prog + (size_t)smp * PROG_STRIDE;
+    if (blockIdx.x == 0)
+        for (int i = tid; i < PROG_STRIDE; i += 256) pr[i] = 0u;
+    double* W = Linv + (size_t)smp * linv_stride;
+    for (int k = (int)blockIdx.x; k < nbf; k += (int)gridDim.x)
+        W[(size_t)k * NB * NB + (size_t)((NSB - 1) * SB + (tid >> 4)) * NB + (NSB - 1) * SB + (tid & 15)] =
+            __longlong_as_double(W_SENTINEL);
+}
+
 // ---- the panel solve as a FOLLOWER of the diagonal block (r06) -----------------------------------------------------------
 // potrf_panel_kernel's substitution, column by column instead of row by row: as soon as block column c of L_kk and W_cc are
 // published (diag128_factor_invert with a DiagPub, progress word >= c + 1)
@@ -1490,6 +1508,40 @@ __device__ __forceinline__ void panel_follow(double* __restrict__ K, int ld, int
     // L_sc (s > c) or W_cc (s = c), rows and columns permuted.
     int c = 0;
     while (c < NSB) {
+        if (c == NSB - 1) {
+            // the last column: W_77's entries are their own flag (W_SENTINEL until the diagonal workgroup's store lands)
+            const double* src = Wg + (size_t)((NSB - 1) * SB + r) * NB + (NSB - 1) * SB + c16;
+            double v = 0.0;
+            int ok = 0;
+            for (unsigned spins = 0; spins <= PROG_SPIN_LIMIT; ++spins) {
+                v = ld_agent(src);
+                __syncthreads();         // (first pass: the previous pass's fragment reads are over; later: sflag was read)
+                if (tid == 0) *sflag = 1;
+                __syncthreads();
+                if (__double_as_longlong(v) == W_SENTINEL) *sflag = 0;
+                __syncthreads();
+                ok = *sflag;
+                if (ok) break;
+                __builtin_amdgcn_s_sleep(1);
+            }
+            if (!ok) {
+                if (tid == 0 && *fail == 0) *fail = kc * NB + 1;
+                return;
+            }
+            smem[blk_off(NSB - 1, NSB - 1) + pos] = v;
+            __syncthreads();
+            const Frag4 w = frag_row(smem + blk_off(NSB - 1, NSB - 1), lane);
+#pragma unroll
+            for (int j = 0; j < NS; ++j) {
+                v4d o = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+                for (int q = 0; q < 4; ++q) o = mfma_f64(w.v[q], y[j][NSB - 1][q], o);
+                double2* p = reinterpret_cast<double2*>(Arow[j] + (NSB - 1) * SB);
+                p[0] = make_double2(o[0], o[1]);
+                p[1] = make_double2(o[2], o[3]);
+            }
+            return;
+        }
         if (tid == 0) {
             unsigned spins = 0, v;
             int hi = -1;
@@ -1500,7 +1552,7 @@ __device__ __forceinline__ void panel_follow(double* __restrict__ K, int ld, int
             }
             if (v >= need) {
                 hi = c;
-                while (hi + 1 < NSB && v >= diag_prog_need(hi + 1, nsb)) ++hi;
+                while (hi + 1 < NSB - 1 && v >= diag_prog_need(hi + 1, nsb)) ++hi;      // (the last column: above)
             }
             *sflag = hi;
         }
@@ -2076,7 +2128,8 @@ int launch_potrf(robo_gp* gp, const FitBuffers& fb, bool with_gram) {
                                ld, k, gp->n, fb.Linv, fb.linv_stride, fb.fail, fb.prog, nfol, rest,
                                tune.potrf_tail_split != 0 ? 1 : 0, tune.potrf_pub_early, frows);
         };
-        if (can_follow) ROBO_HIP_CHECK(hipMemsetAsync(fb.prog, 0, (size_t)S * PROG_STRIDE * sizeof(unsigned), st));
+        if (can_follow)        // progress words to zero, every panel's W_77 slot to the sentinel
+            hipLaunchKernelGGL(follow_init_kernel, dim3(nbf < 64 ? nbf : 64, S), dim3(256), 0, st, fb.prog, fb.Linv, fb.linv_stride, nbf);
         bool panel_done = false;              // panel of the CURRENT column k already solved (by the previous follow step)
         if (ffrom < 0 && nbf >= 1 && nb > 1) {
             follow(-1);
@@ -2123,7 +2176,9 @@ int launch_potrf(robo_gp* gp, const FitBuffers& fb, bool with_gram) {
         // update workgroups.  potrf_batch_follow = -1 (default): up to 17 panels (N <= 2048); 0 / 1: never / always.
         const bool bfollow = fb.prog != nullptr && nb <= PROG_STRIDE &&
                              (tune.potrf_batch_follow < 0 ? nb <= 17 : tune.potrf_batch_follow != 0);
-        if (bfollow) ROBO_HIP_CHECK(hipMemsetAsync(fb.prog, 0, (size_t)S * PROG_STRIDE * sizeof(unsigned), ctx->stream));
+        if (bfollow)
+            hipLaunchKernelGGL(follow_init_kernel, dim3(nbf < 64 ? nbf : 64, S), dim3(256), 0, ctx->stream, fb.prog, fb.Linv,
+                               fb.linv_stride, nbf);
         auto group = [&](hipStream_t st, int s0, int ns, int k0, int g) {
             for (int kk = k0; kk < k0 + g; ++kk) {
                 if (kk >= nbf) break;         // the augmented row's own block
