@@ -1484,7 +1484,7 @@ def check_panel_followers(ctx, sizes=((520, 3), (512, 3), (300, 3), (130, 2)), c
             g.close()
 
 
-def check_batched_followers(ctx, sizes=((520, 3, 5), (512, 3, 4), (300, 2, 7)), emulated=True):
+def check_batched_followers(ctx, sizes=((520, 3, 5), (512, 3, 4), (300, 2, 7)), emulated=True, groups=(0, 1, 2)):
     """potrf_batch_follow: diagonal block + panel of a batched step in ONE launch (potrf_diag_follow_kernel: the x grid index
     is the sample, so all diagonal workgroups are dispatched before any follower; 128-row followers, two strips per wave) --
     likelihoods, kept factors and posteriors of the kept factors equal the launch-per-phase form's BIT FOR BIT, with one,
@@ -1504,7 +1504,7 @@ def check_batched_followers(ctx, sizes=((520, 3, 5), (512, 3, 4), (300, 2, 7)), 
             ref = None
             for bf in (0, 1):
                 for split, smin in ((1, 12), (2, 2), (3, 2)):
-                    for grp in ((0, 1, 2) if emulated else (0,)):
+                    for grp in (groups if emulated else (0,)):
                         ctx.set_tuning("potrf_batch_follow", bf)
                         ctx.set_tuning("potrf_split", split)
                         ctx.set_tuning("potrf_split_min", smin)
