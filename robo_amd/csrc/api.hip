@@ -460,6 +460,13 @@ int32_t robo_gp_fit(robo_gp* g, const double* theta, double mean_c, double* out_
     double* hp = c->h_pinned;
     ROBO_HIP_CHECK(hipStreamSynchronize(c->stream));
     const int fail = (int)hp[2];
+    if (fail < 0) {
+        // a panel follower's bounded poll ran out (potrf.hip panel_follow): a workgroup of the step kernel never saw the
+        // diagonal workgroup's progress -- not a property of the matrix
+        if (out_loglik) *out_loglik = -HUGE_VAL;
+        set_error("factorisation hand-off timed out (tuning potrf_follow=0 selects the launch-per-phase form)");
+        return ROBO_RUNTIME_ERROR;
+    }
     if (fail != 0) {
         if (out_fail_col) *out_fail_col = fail - 1;
         if (out_loglik) *out_loglik = -HUGE_VAL;
@@ -588,7 +595,8 @@ static int fit_batch_core(robo_gp* g, const double* thetas, int32_t S, double me
         for (int s = 0; s < ns; ++s) {
             double ll = -HUGE_VAL;
             if (status[s] == ROBO_OK) {
-                if (hout[5 * s + 2] != 0.0) status[s] = ROBO_NOT_POSITIVE_DEFINITE;
+                if (hout[5 * s + 2] < 0.0) status[s] = ROBO_RUNTIME_ERROR;      // a follower's hand-off timed out (potrf.hip)
+                else if (hout[5 * s + 2] != 0.0) status[s] = ROBO_NOT_POSITIVE_DEFINITE;
                 else ll = -0.5 * (hout[5 * s] + hout[5 * s + 1] + (double)g->n * std::log(2.0 * M_PI));
             }
             out_loglik[s0 + s] = ll;
@@ -746,6 +754,10 @@ int32_t robo_gp_mcmc_run(robo_gp* g, double mean_c, int32_t prior_kind, const do
     if (herr[1] & 2) {
         set_error("The initial lnprob was +inf.");
         return ROBO_BAD_ARGUMENT;
+    }
+    if (herr[1] & 4) {
+        set_error("factorisation hand-off timed out inside the chain (tuning potrf_batch_follow=0 selects the launch-per-phase form)");
+        return ROBO_RUNTIME_ERROR;
     }
     return ROBO_OK;
 }

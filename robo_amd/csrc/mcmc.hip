@@ -70,6 +70,7 @@ __global__ __launch_bounds__(256) void mcmc_accept_kernel(McmcState st, int star
     for (int w = threadIdx.x; w < ns; w += blockDim.x) {
         const double lp = mcmc_lnprob(st.d_prior[w], st.d_fail[w], st.d_out[2 * w], st.d_out[2 * w + 1], st.n);
         if (lp != lp) atomicOr(st.d_err, 1);       // emcee: "lnprob returned NaN."
+        if (st.d_fail[w] < 0) atomicOr(st.d_err, 4);   // a panel follower's hand-off timed out (potrf.hip): not a rejection
         if (start) {
             if (lp == __builtin_huge_val()) atomicOr(st.d_err, 2);   // "The initial lnprob was +inf."
             st.d_lnp[first + w] = lp;

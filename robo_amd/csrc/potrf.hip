@@ -1525,7 +1525,7 @@ __device__ __forceinline__ void panel_follow(double* __restrict__ K, int ld, int
                 __builtin_amdgcn_s_sleep(1);
             }
             if (!ok) {
-                if (tid == 0 && *fail == 0) *fail = kc * NB + 1;
+                if (tid == 0) *fail = -1;                 // (api.hip: reported as a run-time error, not as a matrix property)
                 return;
             }
             smem[blk_off(NSB - 1, NSB - 1) + pos] = v;
@@ -1559,7 +1559,7 @@ __device__ __forceinline__ void panel_follow(double* __restrict__ K, int ld, int
         __syncthreads();                 // (also: the previous pass's fragment reads are over)
         const int chi = *sflag;
         if (chi < 0) {                   // the producer never arrived: flag the factorisation, leave the strips alone
-            if (tid == 0 && *fail == 0) *fail = kc * NB + 1;
+            if (tid == 0) *fail = -1;                 // (api.hip: reported as a run-time error, not as a matrix property)
             return;
         }
         // stage columns c .. chi: one element per thread and block, L1-bypassing loads, four blocks in flight per thread
