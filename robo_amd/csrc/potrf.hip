@@ -464,17 +464,33 @@ __device__ __forceinline__ void blk_publish(const double* b, double* dst, int ld
     for (int q = 0; q < 4; ++q) st_agent(dst + (size_t)r * ld + c0 + q, b[bidx(r, c0 + q)]);
 }
 // block column c of L (rows c .. 7) and W_cc, blocks dealt round-robin to `nw` waves (this wave: `w`)
-__device__ __forceinline__ void diag_publish_column(const double* sL, const double* sW, const DiagPub& pub, int c, int w,
+// (Wc: the LDS block that holds W_cc, or nullptr: the identity -- a padding block of the rolling layout, which keeps no image of W)
+__device__ __forceinline__ void diag_publish_column(const double* sL, const double* Wc, const DiagPub& pub, int c, int w,
                                                     int nw, int lane) {
     int t = 0;
     for (int bi = c; bi < NSB; ++bi, ++t)
         if (t % nw == w) blk_publish(sL + blk_off(bi, c), pub.Kd + (size_t)(bi * SB) * pub.ld + c * SB, pub.ld, lane);
-    if (t % nw == w) blk_publish(sW + blk_off(c, c), pub.Wg + (size_t)(c * SB) * NB + c * SB, NB, lane);
+    if (t % nw == w) {
+        double* dst = pub.Wg + (size_t)(c * SB) * NB + c * SB;
+        if (Wc) {
+            blk_publish(Wc, dst, NB, lane);
+        } else {
+            const int r = lane >> 2, c0 = (lane & 3) * 4;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) st_agent(dst + (size_t)r * NB + c0 + q, r == c0 + q ? 1.0 : 0.0);
+        }
+    }
 }
 
+// ROLL (publishing callers only): sW is TWO 16 x 16 slots instead of a 36-block image -- W_ss lives in slot s & 1 from
+// potf2(s) until it has been published (interval s), potf2(s + 2) may overwrite it a barrier later; the whole LDS image of a
+// diagonal workgroup is then 80 KB (L image + 2 slots + exchange buffers): TWO workgroups per CU (r05g's layout, which had
+// nowhere to put the W_ss; the publication gives them a place at once).
+template <bool ROLL = false>
 __device__ __forceinline__ void diag128_factor_invert(double* sL, double* sW, double* sT, double* sRd, double* sCol,
                                                       int kbase, int n_real, int* fail, long long* dbg,
                                                       const DiagPub* pub = nullptr) {
+    auto wslot = [sW](int s_) { return ROLL ? sW + (s_ & 1) * BLK : sW + blk_off(s_, s_); };
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     int* ctr = reinterpret_cast<int*>(sRd);     // one task counter per interval
     if (tid >= 64 && tid < 64 + NSB) ctr[tid - 64] = 0;
@@ -482,7 +498,8 @@ __device__ __forceinline__ void diag128_factor_invert(double* sL, double* sW, do
     // factor and inverse are the identity and nothing couples them to the rest), so the chain stops there: at the
     // N < 128 of a Bayesian-optimisation run the single diagonal block is mostly padding (N = 30: 2 of 8 blocks).
     const int nsb = diag_nsb(n_real, kbase);
-    for (int bi = nsb; bi < NSB; ++bi) sW[blk_off(bi, bi) + bidx(tid >> 4, tid & 15)] = (tid >> 4) == (tid & 15) ? 1.0 : 0.0;
+    if (!ROLL)
+        for (int bi = nsb; bi < NSB; ++bi) sW[blk_off(bi, bi) + bidx(tid >> 4, tid & 15)] = (tid >> 4) == (tid & 15) ? 1.0 : 0.0;
     // this lane's offsets inside a 16x16 block: fragment form [lane & 15][4 kk + (lane >> 4)], accumulator form
     // [(lane >> 4) + 4 r][lane & 15]
     int fo[4], co[4];
@@ -492,7 +509,7 @@ __device__ __forceinline__ void diag128_factor_invert(double* sL, double* sW, do
         co[q] = bidx((lane >> 4) + 4 * q, lane & 15);
     }
     if (wave == 0) {
-        const int f = potf2_16(sL + blk_off(0, 0), sW + blk_off(0, 0), sCol, lane, kbase, n_real);
+        const int f = potf2_16(sL + blk_off(0, 0), wslot(0), sCol, lane, kbase, n_real);
         if (f != 0 && lane == 0 && *fail == 0) *fail = f;
     }
     __syncthreads();                                              // Ba(0)
@@ -508,7 +525,7 @@ __device__ __forceinline__ void diag128_factor_invert(double* sL, double* sW, do
             double* C = sL + blk_off(s + 1, s + 1);
             v4d t = blk_load_c(C, lane);
             v4d q = {0.0, 0.0, 0.0, 0.0};
-            q = blk_mma_nt<false>(sW + blk_off(s, s), P, lane, q);
+            q = blk_mma_nt<false>(wslot(s), P, lane, q);
 #pragma unroll
             for (int r = 0; r < 4; ++r) t = mfma_f64(-q[r], q[r], t);
             blk_store_c(C, lane, t);
@@ -522,7 +539,7 @@ __device__ __forceinline__ void diag128_factor_invert(double* sL, double* sW, do
             for (int bi = s + 2 + (wave - 1); bi < nsb; bi += 3) {
                 double* A = sL + blk_off(bi, s);
                 v4d acc = {0.0, 0.0, 0.0, 0.0};
-                acc = blk_mma_nt<false>(A, sW + blk_off(s, s), lane, acc);
+                acc = blk_mma_nt<false>(A, wslot(s), lane, acc);
                 wave_lds_fence();
                 blk_store_c(A, lane, acc);
             }
@@ -531,14 +548,14 @@ __device__ __forceinline__ void diag128_factor_invert(double* sL, double* sW, do
         if (dbg && tid == 0 && s == 0) dbg[3] = clock64();
         if (dbg && tid == 0) dbg[24 + 4 * s + 1] = clock64();     // through Bb(s)
         if (pub && wave != 0) {
-            diag_publish_column(sL, sW, *pub, s, wave - 1, 3, lane);
+            diag_publish_column(sL, wslot(s), *pub, s, wave - 1, 3, lane);
             if (s >= pub->early) {
                 drain_vmem();
                 if (lane == 0) add_agent_u32(pub->prog, 1u);
             }
         }
         if (wave == 0) {
-            const int f = potf2_16(sL + blk_off(s + 1, s + 1), sW + blk_off(s + 1, s + 1), sCol, lane,
+            const int f = potf2_16(sL + blk_off(s + 1, s + 1), wslot(s + 1), sCol, lane,
                                    kbase + (s + 1) * SB, n_real);
             if (f != 0 && lane == 0 && *fail == 0) *fail = f;
             if (dbg && tid == 0) dbg[24 + 4 * s + 2] = clock64() + (long long)(f == 12345678);   // potf2(s+1) done
@@ -585,7 +602,8 @@ __device__ __forceinline__ void diag128_factor_invert(double* sL, double* sW, do
     }
     if (pub) {
         // what the loop did not hand over: the last factored block column (nsb - 1) and the identity padding behind it
-        for (int c = nsb - 1; c < NSB; ++c) diag_publish_column(sL, sW, *pub, c, wave, 4, lane);
+        for (int c = nsb - 1; c < NSB; ++c)
+            diag_publish_column(sL, (ROLL && c >= nsb) ? nullptr : wslot(c), *pub, c, wave, 4, lane);
         drain_vmem();
         if (lane == 0) add_agent_u32(pub->prog, 1u);
     }
@@ -1699,11 +1717,13 @@ __global__ __launch_bounds__(256) void potrf_step_follow_kernel(double* __restri
 // strips behind a launch boundary) shrink to the hand-off behind the last pivot plus the followers that did not fit on the
 // chip beside the diagonal workgroups (every workgroup carries the diagonal block's LDS image: one per CU) and run after them
 // at the panel kernel's speed.  Same strips, bit for bit.
-__global__ __launch_bounds__(256) void potrf_diag_follow_kernel(double* __restrict__ K, size_t k_stride, int ld, int k,
+constexpr int ROLL_SMEM_DOUBLES = NBLK * BLK + 2 * BLK + NB + 8 * SB;   // L image + two W slots + counters + column exchange: 80 KB
+template <bool ROLL>
+__global__ __launch_bounds__(256, ROLL ? 2 : 1) void potrf_diag_follow_kernel(double* __restrict__ K, size_t k_stride, int ld, int k,
                                                                 int n_real, double* __restrict__ Linv, size_t linv_stride,
                                                                 int* __restrict__ fail, unsigned* __restrict__ prog,
                                                                 int pub_early) {
-    __shared__ double smem[DIAG_SMEM_DOUBLES];
+    __shared__ double smem[ROLL ? ROLL_SMEM_DOUBLES : DIAG_SMEM_DOUBLES];
     const int smp = (int)blockIdx.x, role = (int)blockIdx.y;
     K += (size_t)smp * k_stride;
     Linv += (size_t)smp * linv_stride;
@@ -1713,16 +1733,22 @@ __global__ __launch_bounds__(256) void potrf_diag_follow_kernel(double* __restri
     double* Wg = Linv + (size_t)k * NB * NB;
     if (role == 0) {
         double* C = K + d0 * ld + d0;
-        const DiagSmem m = diag_carve(smem);
+        DiagSmem m = diag_carve(smem);
+        if (ROLL) {                       // sL | two W slots | counters | column exchange (no transposition scratch, no W image)
+            m.sT = nullptr;
+            m.sRd = m.sW + 2 * BLK;
+            m.sCol = m.sRd + NB;
+        }
         const int tid = threadIdx.x;
         for (int bi = 0; bi < NSB; ++bi)
             for (int bj = 0; bj <= bi; ++bj)
                 m.sL[blk_off(bi, bj) + bidx(tid >> 4, tid & 15)] = C[(size_t)(bi * SB + (tid >> 4)) * ld + bj * SB + (tid & 15)];
         __syncthreads();
         const DiagPub pub = {C, ld, Wg, prog, pub_early};
-        diag128_factor_invert(m.sL, m.sW, m.sT, m.sRd, m.sCol, k * NB, n_real, fail, nullptr, &pub);
+        diag128_factor_invert<ROLL>(m.sL, m.sW, m.sT, m.sRd, m.sCol, k * NB, n_real, fail, nullptr, &pub);
         return;
     }
+    static_assert(NBLK * BLK + 8 <= ROLL_SMEM_DOUBLES, "the follower's operand image fits the rolling layout");
     panel_follow<2>(K, ld, k, (size_t)(k + role) * NB, prog, Wg, smem, fail, n_real);
 }
 
@@ -2185,10 +2211,16 @@ int launch_potrf(robo_gp* gp, const FitBuffers& fb, bool with_gram) {
                 // left-looking inside the group: block column kk <- panels k0 .. kk-1, all rows >= kk
                 if (kk > k0) update(st, s0, ns, nb - kk, kk - 1, k0, (kk - k0) * NB, 1);
                 if (bfollow && kk + 1 < nb) {
-                    hipLaunchKernelGGL(potrf_diag_follow_kernel, dim3(ns, nb - kk), dim3(256), 0, st,
-                                       fb.K + (size_t)s0 * fb.k_stride, fb.k_stride, ld, kk, gp->n,
-                                       fb.Linv + (size_t)s0 * fb.linv_stride, fb.linv_stride, fb.fail + s0,
-                                       fb.prog + (size_t)s0 * PROG_STRIDE, tune.potrf_pub_early);
+                    if (tune.potrf_batch_roll != 0)
+                        hipLaunchKernelGGL(potrf_diag_follow_kernel<true>, dim3(ns, nb - kk), dim3(256), 0, st,
+                                           fb.K + (size_t)s0 * fb.k_stride, fb.k_stride, ld, kk, gp->n,
+                                           fb.Linv + (size_t)s0 * fb.linv_stride, fb.linv_stride, fb.fail + s0,
+                                           fb.prog + (size_t)s0 * PROG_STRIDE, tune.potrf_pub_early);
+                    else
+                        hipLaunchKernelGGL(potrf_diag_follow_kernel<false>, dim3(ns, nb - kk), dim3(256), 0, st,
+                                           fb.K + (size_t)s0 * fb.k_stride, fb.k_stride, ld, kk, gp->n,
+                                           fb.Linv + (size_t)s0 * fb.linv_stride, fb.linv_stride, fb.fail + s0,
+                                           fb.prog + (size_t)s0 * PROG_STRIDE, tune.potrf_pub_early);
                     continue;
                 }
                 diag(st, s0, ns, kk);

@@ -197,6 +197,15 @@ bfollow)
     done
   done
   grep "batched fit\|round 1" $OUT/bfollow_ab.txt >> $OUT/summary.txt ;;
+broll)
+  # batched merged launch: 150-KB image against the 80-KB rolling layout (two workgroups per CU), against the launch-per-phase form
+  : > $OUT/broll_ab.txt
+  for cfg in "2048 16 26 7" "4096 16 27 5" "1024 8 26 9" "3072 16 26 5"; do
+    for tune in "potrf_batch_follow=0" "potrf_batch_follow=1,potrf_batch_roll=0" "potrf_batch_follow=1,potrf_batch_roll=1"; do
+      BATCH_TUNE="$tune" BATCH_AB="0,3,-1;0,1,-1" timeout 600 python tools/batched_fit_ab.py $cfg 2>&1 | sed "s/^round/$tune round/" >> $OUT/broll_ab.txt
+    done
+  done
+  grep "batched fit\|round 1" $OUT/broll_ab.txt >> $OUT/summary.txt ;;
 small)
   timeout 300 python tools/small_m_timing.py > $OUT/small_m.txt 2>&1; cat $OUT/small_m.txt >> $OUT/summary.txt ;;
 *) echo "unknown step $what" >> $OUT/summary.txt ;;
