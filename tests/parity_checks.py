@@ -1489,7 +1489,7 @@ def check_batched_followers(ctx, sizes=((520, 3, 5), (512, 3, 4), (300, 2, 7)), 
     is the sample, so all diagonal workgroups are dispatched before any follower; 128-row followers, two strips per wave) --
     likelihoods, kept factors and posteriors of the kept factors equal the launch-per-phase form's BIT FOR BIT, with one,
     two and three sub-batch streams and every group size."""
-    keys = ("potrf_batch_follow", "potrf_split", "potrf_split_min", "potrf_group", "potrf_batch_tm4_min")
+    keys = ("potrf_batch_follow", "potrf_batch_roll", "potrf_split", "potrf_split_min", "potrf_group", "potrf_batch_tm4_min")
     for N, D, S in sizes:
         rs = np.random.RandomState(N)
         X = rs.rand(N, D)
@@ -1502,10 +1502,11 @@ def check_batched_followers(ctx, sizes=((520, 3, 5), (512, 3, 4), (300, 2, 7)), 
         gps[0].set_data(X, y)
         try:
             ref = None
-            for bf in (0, 1):
+            for bf in (0, 1, 2):          # launch-per-phase; merged launch; merged launch, 80-KB rolling layout
                 for split, smin in ((1, 12), (2, 2), (3, 2)):
                     for grp in (groups if emulated else (0,)):
-                        ctx.set_tuning("potrf_batch_follow", bf)
+                        ctx.set_tuning("potrf_batch_follow", min(bf, 1))
+                        ctx.set_tuning("potrf_batch_roll", 1 if bf == 2 else 0)
                         ctx.set_tuning("potrf_split", split)
                         ctx.set_tuning("potrf_split_min", smin)
                         ctx.set_tuning("potrf_group", grp)
