@@ -53,6 +53,7 @@ static const TuneKey TUNE_KEYS[] = {
     {"potrf_follow_from", nullptr, &Tuning::potrf_follow_from, -2},
     {"potrf_pub_early", nullptr, &Tuning::potrf_pub_early, 6},
     {"potrf_follow_rows", nullptr, &Tuning::potrf_follow_rows, -1},
+    {"potrf_poll_sleep", nullptr, &Tuning::potrf_poll_sleep, 1},
     {"potrf_batch_roll", nullptr, &Tuning::potrf_batch_roll, 0},
     {"potrf_batch_follow", nullptr, &Tuning::potrf_batch_follow, -1},
     {"potrf_batch_tm4_min", nullptr, &Tuning::potrf_batch_tm4_min, 96},

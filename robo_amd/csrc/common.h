@@ -157,6 +157,7 @@ struct Tuning {
     int potrf_follow_from;       // ... from this step on (-1: the first panel too; -2 = default: by size, launch_potrf)
     int potrf_pub_early;         // ... the diagonal block's helper waves count a published column at once from this interval on
     int potrf_follow_rows;       // ... rows per follower workgroup: 64 (two per block row), 128 (one), -1: by step (launch_potrf)
+    int potrf_poll_sleep;        // ... pauses (x 128 cycles) between two polls of a follower
     int potrf_batch_roll;        // ... with the diagonal workgroup's 80-KB rolling layout (two workgroups per CU); 0: the 150-KB image
     int potrf_batch_follow;      // batched fits: diagonal block + panel of a step in one launch, the panel following (-1 = default: up to 17 panels; 0 / 1)
     int mcmc_block_step;         // ensemble half-step in ONE launch: 2 (default) every one-block problem, 1 only N <= 63, 0 never;

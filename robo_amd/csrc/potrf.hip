@@ -1499,8 +1499,10 @@ __global__ __launch_bounds__(256) void follow_init_kernel(unsigned* __restrict__
 // kernel (two followers per block row), 2 in the batched form (one follower per block row: half as many workgroups spin).
 template <int NS = 1>
 __device__ __forceinline__ void panel_follow(double* __restrict__ K, int ld, int kc, size_t row0, const unsigned* prog,
-                                             const double* __restrict__ Wg, double* smem, int* fail, int n_real) {
-    // kc: block column being solved; row0: first of this workgroup's 64 NS rows; prog: progress word of panel kc
+                                             const double* __restrict__ Wg, double* smem, int* fail, int n_real,
+                                             int poll_sleep = 1) {
+    // kc: block column being solved; row0: first of this workgroup's 64 NS rows; prog: progress word of panel kc;
+    // poll_sleep: pauses of 128 cycles between two polls of the progress word (dozens of followers poll ONE word)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const double* Kd = K + ((size_t)kc * NB) * ld + (size_t)kc * NB;
     double* Arow[NS];
@@ -1565,7 +1567,7 @@ __device__ __forceinline__ void panel_follow(double* __restrict__ K, int ld, int
             int hi = -1;
             const unsigned need = diag_prog_need(c, nsb);
             while ((v = ld_agent_u32(prog)) < need) {
-                __builtin_amdgcn_s_sleep(2);
+                for (int z = 0; z < poll_sleep; ++z) __builtin_amdgcn_s_sleep(2);
                 if (++spins > PROG_SPIN_LIMIT) break;
             }
             if (v >= need) {
@@ -1648,7 +1650,7 @@ __global__ __launch_bounds__(256) void potrf_step_follow_kernel(double* __restri
                                                                 int n_real, double* __restrict__ Linv, size_t linv_stride,
                                                                 int* __restrict__ fail, unsigned* __restrict__ prog,
                                                                 int nfol, int ntiles, int tail_split, int pub_early,
-                                                                int fol_rows) {
+                                                                int fol_rows, int poll_sleep) {
     __shared__ double smem[DIAG_SMEM_DOUBLES];
     K += (size_t)blockIdx.y * k_stride;
     Linv += (size_t)blockIdx.y * linv_stride;
@@ -1682,7 +1684,7 @@ __global__ __launch_bounds__(256) void potrf_step_follow_kernel(double* __restri
                 update_subtile<4>(K, ld, k, ii * (ii + 1) / 2, 0, smem);
                 __syncthreads();
             }
-            panel_follow<2>(K, ld, k + 1, (size_t)(k + 1 + ii) * NB, prog, Wg, smem, fail, n_real);
+            panel_follow<2>(K, ld, k + 1, (size_t)(k + 1 + ii) * NB, prog, Wg, smem, fail, n_real, poll_sleep);
             return;
         }
         const int ii = 1 + (b - 1) / 2, h = (b - 1) & 1;           // block row k + 1 + ii, rows 64 h .. 64 h + 63
@@ -1690,7 +1692,7 @@ __global__ __launch_bounds__(256) void potrf_step_follow_kernel(double* __restri
             update_subtile<2>(K, ld, k, ii * (ii + 1) / 2, h, smem);
             __syncthreads();             // this workgroup's stores before its own strip loads (and the staging area's reuse)
         }
-        panel_follow(K, ld, k + 1, (size_t)(k + 1 + ii) * NB + (size_t)h * 64, prog, Wg, smem, fail, n_real);
+        panel_follow(K, ld, k + 1, (size_t)(k + 1 + ii) * NB + (size_t)h * 64, prog, Wg, smem, fail, n_real, poll_sleep);
         return;
     }
     // the remaining tiles of the trailing update: the triangle without its first block row and column
@@ -2152,7 +2154,8 @@ int launch_potrf(robo_gp* gp, const FitBuffers& fb, bool with_gram) {
             W = W < rest ? W : rest;
             hipLaunchKernelGGL(potrf_step_follow_kernel, dim3(1 + nfol + W, S), dim3(256), 0, st, fb.K, fb.k_stride,
                                ld, k, gp->n, fb.Linv, fb.linv_stride, fb.fail, fb.prog, nfol, rest,
-                               tune.potrf_tail_split != 0 ? 1 : 0, tune.potrf_pub_early, frows);
+                               tune.potrf_tail_split != 0 ? 1 : 0, tune.potrf_pub_early, frows,
+                               tune.potrf_poll_sleep < 1 ? 1 : tune.potrf_poll_sleep);
         };
         if (can_follow)        // progress words to zero, every panel's W_77 slot to the sentinel
             hipLaunchKernelGGL(follow_init_kernel, dim3(nbf < 64 ? nbf : 64, S), dim3(256), 0, st, fb.prog, fb.Linv, fb.linv_stride, nbf);

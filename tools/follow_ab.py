@@ -26,9 +26,11 @@ g.set_data(X, y)
 ref = None
 print("single-theta fit, N=%d D=%d, %d reps each (ms: median / min)" % (N, D, REPS))
 early = [int(v) for v in os.environ.get("FOLLOW_EARLY", "6").split(",")]
-rows = [int(v) for v in os.environ.get("FOLLOW_ROWS", "64").split(",")]
+rows = [int(v) for v in os.environ.get("FOLLOW_ROWS", "-1").split(",")]
+sleeps = [int(v) for v in os.environ.get("FOLLOW_SLEEP", "1").split(",")]
 for rnd in range(2):
-    for follow, frm, ea, fr in [(0, 0, 6, 64)] + [(1, f, e, r) for f in froms for e in early for r in rows]:
+    for follow, frm, ea, fr, sl in [(0, 0, 6, 64, 1)] + [(1, f, e, r, z) for f in froms for e in early for r in rows for z in sleeps]:
+        ctx.set_tuning("potrf_poll_sleep", sl)
         ctx.set_tuning("potrf_pub_early", ea)
         ctx.set_tuning("potrf_follow_rows", fr)
         ctx.set_tuning("potrf_follow", follow)
@@ -41,6 +43,6 @@ for rnd in range(2):
             t0 = time.perf_counter()
             g.fit(theta, 0.0)
             ts.append((time.perf_counter() - t0) * 1e3)
-        print("round %d  follow %d from %2d early %d rows %3d : %.4f / %.4f ms   bits %s" % (
-            rnd, follow, frm, ea, fr, sorted(ts)[len(ts) // 2], min(ts), "same" if ll == ref else "DIFFER (%r vs %r)" % (ll, ref)), flush=True)
+        print("round %d  follow %d from %2d early %d rows %3d sleep %2d : %.4f / %.4f ms   bits %s" % (
+            rnd, follow, frm, ea, fr, sl, sorted(ts)[len(ts) // 2], min(ts), "same" if ll == ref else "DIFFER (%r vs %r)" % (ll, ref)), flush=True)
 g.close()
