@@ -2131,7 +2131,7 @@ int launch_potrf(robo_gp* gp, const FitBuffers& fb, bool with_gram) {
         // without; with one 128-row follower per block row in the tile-bound steps (potrf_follow_rows = -1, below): from step
         // 0 6.08, 8 5.88, 16 5.80, 31 5.85.  potrf_follow_from = -2 (default): k >= nb - 2 - 3 max_wg / 16 (every step up to
         // N = 6144, step 15 at N = 8192).
-        const bool can_follow = tune.potrf_follow != 0 && fb.prog != nullptr && max_wg >= 16;
+        const bool can_follow = tune.potrf_follow != 0 && fb.prog != nullptr && max_wg >= 16 && nb <= PROG_STRIDE;
         int ffrom = nb;
         if (can_follow) {
             ffrom = tune.potrf_follow_from >= -1 ? tune.potrf_follow_from : nb - 2 - 3 * max_wg / 16;
