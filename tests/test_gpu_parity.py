@@ -57,6 +57,20 @@ def test_panel_followers_hand_off(ctx):
                             emulated=False)
 
 
+def test_follower_hand_offs_under_concurrent_load():
+    """tools/follow_stress.py: follower fits (single-theta and batched) while another context of the device runs large
+    posterior evaluations -- uneven load, foreign lines in L1 / L2 -- every likelihood and every word of the sampled factors
+    equal the launch-per-phase reference, iteration after iteration (150 iterations per size: profiles/r06q_*)"""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    res = subprocess.run([sys.executable, os.path.join(root, "tools", "follow_stress.py"), "25"], capture_output=True, text=True,
+                         timeout=900, cwd=root)
+    print(res.stdout[-1500:])
+    assert res.returncode == 0, res.stdout[-3000:] + res.stderr[-3000:]
+    assert res.stdout.count("all bit-identical") == 3
+
+
 def test_batched_followers_hand_off(ctx):
     """potrf_batch_follow on the hardware: S diagonal workgroups publish, their samples' followers read in the same launch --
     likelihoods, kept factors and posteriors equal the launch-per-phase form's bit for bit (three passes per setting)"""
