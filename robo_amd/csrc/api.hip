@@ -37,8 +37,6 @@ static const TuneKey TUNE_KEYS[] = {
     {"trsm_small_deep", nullptr, &Tuning::trsm_small_deep, -1},
     {"trsm_rows", nullptr, &Tuning::trsm_rows, 1},
     {"trsm_pair", nullptr, &Tuning::trsm_pair, 0},
-    {"trsm_skew", nullptr, &Tuning::trsm_skew, 0},
-    {"trsm_skew_shift", nullptr, &Tuning::trsm_skew_shift, 8},
     {"predict_stepwise", nullptr, &Tuning::predict_stepwise, 0},
     {"winv_max", &Tuning::winv_max, nullptr, 32768},
     {"winv_min_blocks", nullptr, &Tuning::winv_min_blocks, 6},

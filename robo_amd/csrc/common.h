@@ -133,7 +133,6 @@ struct Tuning {
     int trsm_small_narrow;       // -1 auto, 0 / 1 force 32 / 16 candidates per workgroup
     int trsm_small_deep;         // -1 auto, 0 / 1 force 1 / 2 k-tiles per staging stage
     int trsm_rows;               // block rows per launch of the 128-candidate step
-    int trsm_skew, trsm_skew_shift;   // block-row step: hold every second workgroup (bit skew_shift of its index) back by ~skew us
     int trsm_pair;               // 1: two block rows per launch on one read of V (trsm_pair_gen_kernel; measured slower: default 0)
     int predict_stepwise;        // 1: cross-gram in memory + trsm_step_kernel (A/B)
     long long winv_max;          // batches <= this (and >= winv_min_blocks block rows) go through W = L^-1 (0: never)

@@ -265,14 +265,8 @@ __global__ __launch_bounds__(256, 2) void trsm_step_gen_kernel(const double* __r
                                                                int ldv, const double* __restrict__ L, int ld,
                                                                const double* __restrict__ LinvP, int i0, int i1, int n,
                                                                double* __restrict__ q, double* __restrict__ mu,
-                                                               long long c0, CovParams cp, int skew, int skew_shift) {
+                                                               long long c0, CovParams cp) {
     __shared__ double smem[GEMM_SMEM_DOUBLES];
-    // Two workgroups share a CU, and all workgroups of a launch start together: both generate their K* tiles at the same
-    // time (fp64 VALU, shared: 2 g) and then both multiply (matrix pipe, shared: 2 p).  `skew` > 0 holds every second
-    // workgroup (bit `skew_shift` of its index) back by ~skew microseconds, so that one generates while the other multiplies;
-    // no arithmetic changes (r06: measured, see launch_predict_fused).
-    if (skew > 0 && ((blockIdx.x >> skew_shift) & 1))
-        for (int z = 0; z < skew; ++z) __builtin_amdgcn_s_sleep(32);
     double* Vrow = V + (size_t)blockIdx.x * NB * ldv;
     const long long cw = c0 + (long long)blockIdx.x * NB;   // first candidate of this workgroup
     // block rows i0 .. i1-1 in one launch (ROBO_TRSM_ROWS, default 1): a block row only reads columns this same
@@ -814,8 +808,7 @@ int launch_predict_fused(robo_gp* gp, robo_cand* cand, int64_t c0, int64_t cn) {
     hipLaunchKernelGGL(trsm_step_gen_kernel<KIND>, grid, dim3(256), 0, gp->ctx->stream,                        \
                        (const double*)cand->d_Xcs, (const double*)gp->d_Xs, cand->d_V, gp->n_pad,             \
                        (const double*)gp->d_K, gp->n_pad, (const double*)gp->d_LinvP, i,                      \
-                       (i + rows < nbk ? i + rows : nbk), gp->n, cand->d_q, cand->d_mu, (long long)c0, gp->cov,       \
-                       tune.trsm_skew, tune.trsm_skew_shift)
+                       (i + rows < nbk ? i + rows : nbk), gp->n, cand->d_q, cand->d_mu, (long long)c0, gp->cov)
     cand->solve_kernel = "trsm_step_gen_kernel";
     const int rows = tune.trsm_rows < 1 ? 1 : tune.trsm_rows;
     int i_first = 0;
