@@ -61,7 +61,7 @@ def test_the_build_really_contracts(emu_fma):
 
 def test_chain_ends_on_the_reference_walkers(emu_fma):
     """the reference's own gp_mcmc + LogEI run (fixture ref_branin_gpmcmc): robo_amd's device-resident chains, started from
-    the reference's generator state, end on the reference's walkers at ALL 8 trainings (2 300 ensemble steps in total),
+    the reference's generator state, end on the reference's walkers at ALL 8 trainings (1 700 ensemble steps in total),
     and the marginal LogEI picks the reference's candidate each time"""
     checked, gap = R.check_ref_branin_gpmcmc_replay(chain=True)
     assert checked == 8 and gap > 1e-7, (checked, gap)
