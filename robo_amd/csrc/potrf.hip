@@ -2075,7 +2075,13 @@ int launch_potrf(robo_gp* gp, const FitBuffers& fb, bool with_gram) {
     const int ld = gp->n_pad, nb = gp->n_pad / NB, S = fb.S;
     // fb.fail[0 .. S) is zeroed by the gram kernel, which always precedes the factorisation of its samples
     const Tuning& tune = ctx->tune;
-    const bool fused = S <= 2 && tune.potrf_fused != 0;
+    // fused step kernels (update + next diagonal block + next panel per launch): single fits, and batches whose factors are
+    // so small that the per-theta CHAIN, not the matrix pipe, is what a pass costs (potrf_fused_panels: up to this many panels)
+    // -1: by residency -- every workgroup of the first step's launch (per sample: the diagonal workgroup, two followers per
+    // block row, one workgroup per other tile) finds a CU: 26 walkers up to three panels (N <= 382)
+    const int fused_wgs = 1 + 2 * (nb - 1) + (nb - 1) * nb / 2;
+    const bool fused = tune.potrf_fused != 0 &&
+                       (S <= 2 || (tune.potrf_fused_panels < 0 ? S * fused_wgs <= ctx->num_cu : nb <= tune.potrf_fused_panels));
     bool gram_done = !with_gram;
     // n a multiple of 128 (every BASELINE size): the last block holds the augmented row ALONE.  Its diagonal entry is never
     // read -- z = L^-1 (y - mean) is complete once the last REAL panel has passed over row n, the likelihood needs z.z and the
