@@ -45,7 +45,7 @@ static const TuneKey TUNE_KEYS[] = {
     {"winv_kc_shift", nullptr, &Tuning::winv_kc_shift, -1},
     {"winv_gemv", nullptr, &Tuning::winv_gemv, -1},
     {"potrf_fused", nullptr, &Tuning::potrf_fused, 1},
-    {"potrf_fused_panels", nullptr, &Tuning::potrf_fused_panels, 0},
+    {"potrf_fused_panels", nullptr, &Tuning::potrf_fused_panels, -1},
     {"potrf_tm4_min", nullptr, &Tuning::potrf_tm4_min, 96},
     {"potrf_max_wg", nullptr, &Tuning::potrf_max_wg, 0},
     {"potrf_group", nullptr, &Tuning::potrf_group, 0},

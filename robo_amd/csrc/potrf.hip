@@ -2079,6 +2079,9 @@ int launch_potrf(robo_gp* gp, const FitBuffers& fb, bool with_gram) {
     // so small that the per-theta CHAIN, not the matrix pipe, is what a pass costs (potrf_fused_panels: up to this many panels)
     // -1: by residency -- every workgroup of the first step's launch (per sample: the diagonal workgroup, two followers per
     // block row, one workgroup per other tile) finds a CU: 26 walkers up to three panels (N <= 382)
+    // Measured (r06t, device chain, 26 walkers per half-step, us per half-step, grouped batched path -> fused): N = 200 86.8 ->
+    // 84.2, 300 137.8 -> 131.7, 380 150.3 -> 142.4, same walkers and accept decisions (the fused form saves the column-update
+    // launch of every step; its 128-deep updates at one workgroup per CU do not matter at three panels).
     const int fused_wgs = 1 + 2 * (nb - 1) + (nb - 1) * nb / 2;
     const bool fused = tune.potrf_fused != 0 &&
                        (S <= 2 || (tune.potrf_fused_panels < 0 ? S * fused_wgs <= ctx->num_cu : nb <= tune.potrf_fused_panels));

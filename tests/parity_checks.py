@@ -1489,7 +1489,8 @@ def check_batched_followers(ctx, sizes=((520, 3, 5), (512, 3, 4), (300, 2, 7)), 
     is the sample, so all diagonal workgroups are dispatched before any follower; 128-row followers, two strips per wave) --
     likelihoods, kept factors and posteriors of the kept factors equal the launch-per-phase form's BIT FOR BIT, with one,
     two and three sub-batch streams and every group size."""
-    keys = ("potrf_batch_follow", "potrf_batch_roll", "potrf_split", "potrf_split_min", "potrf_group", "potrf_batch_tm4_min")
+    keys = ("potrf_batch_follow", "potrf_batch_roll", "potrf_split", "potrf_split_min", "potrf_group", "potrf_batch_tm4_min",
+            "potrf_fused_panels", "potrf_max_wg")
     for N, D, S in sizes:
         rs = np.random.RandomState(N)
         X = rs.rand(N, D)
@@ -1505,6 +1506,7 @@ def check_batched_followers(ctx, sizes=((520, 3, 5), (512, 3, 4), (300, 2, 7)), 
             for bf in (0, 1, 2):          # launch-per-phase; merged launch; merged launch, 80-KB rolling layout
                 for split, smin in ((1, 12), (2, 2), (3, 2)):
                     for grp in (groups if emulated else (0,)):
+                        ctx.set_tuning("potrf_fused_panels", 0)
                         ctx.set_tuning("potrf_batch_follow", min(bf, 1))
                         ctx.set_tuning("potrf_batch_roll", 1 if bf == 2 else 0)
                         ctx.set_tuning("potrf_split", split)
@@ -1521,17 +1523,29 @@ def check_batched_followers(ctx, sizes=((520, 3, 5), (512, 3, 4), (300, 2, 7)), 
                             np.testing.assert_array_equal(ll, ref, err_msg=str((N, bf, split, grp, rep)))
             for key in keys:
                 ctx.set_tuning(key, None)
+            # batches of SMALL factors through the fused step kernels (potrf_fused_panels; default: by residency): same bits
+            for fp in (0, 64):
+                ctx.set_tuning("potrf_fused_panels", fp)
+                if emulated:
+                    ctx.set_tuning("potrf_max_wg", 256)
+                g.loglik_batch(thetas + 0.01, 0.0)
+                ll, st = g.loglik_batch(thetas, 0.0)
+                assert np.all(st == _lib.OK), st
+                np.testing.assert_array_equal(ll, ref, err_msg="fused batch %d" % fp)
+            ctx.set_tuning("potrf_fused_panels", 0)
             ctx.set_tuning("potrf_batch_follow", 0)
             _lib.fit_batch(gps, thetas, 0.0)
             L0 = [h.factor().copy() for h in gps]
             v0 = [h.predict(X[:9] + 0.01) for h in gps]
-            ctx.set_tuning("potrf_batch_follow", 1)
-            _lib.fit_batch(gps, thetas, 0.0)
-            for h, L, pv in zip(gps, L0, v0):
-                np.testing.assert_array_equal(h.factor(), L)
-                mu, var = h.predict(X[:9] + 0.01)
-                np.testing.assert_array_equal(mu, pv[0])
-                np.testing.assert_array_equal(var, pv[1])
+            for bf, fp in ((1, 0), (0, 64)):          # merged diagonal-block + panel launch; fused step kernels
+                ctx.set_tuning("potrf_batch_follow", bf)
+                ctx.set_tuning("potrf_fused_panels", fp)
+                _lib.fit_batch(gps, thetas, 0.0)
+                for h, L, pv in zip(gps, L0, v0):
+                    np.testing.assert_array_equal(h.factor(), L)
+                    mu, var = h.predict(X[:9] + 0.01)
+                    np.testing.assert_array_equal(mu, pv[0])
+                    np.testing.assert_array_equal(var, pv[1])
         finally:
             for key in keys:
                 ctx.set_tuning(key, None)
