@@ -67,6 +67,7 @@ __device__ __forceinline__ void add_agent_u32(unsigned* p, unsigned v) {
 }
 // every vector-memory operation of this wave has completed (vmcnt(0); expcnt / lgkmcnt fields left at their maxima)
 __device__ __forceinline__ void drain_vmem() { __builtin_amdgcn_s_waitcnt(0x0F70); }
+constexpr long long FOLLOW_SENTINEL = 0x7FF8DEAD00C0FFEELL;   // a NaN no arithmetic produces: "W_77 of this panel is not published yet"
 constexpr unsigned PROG_SPIN_LIMIT = 1u << 24;   // bounded spin (~seconds): a hand-off that never arrives ends in a flagged failure
 
 // covariance function of the current theta (see kern_math.h)

@@ -137,9 +137,20 @@ template <class T, int KIND>
 __global__ __launch_bounds__(256, KIND == ROBO_KERNEL_FABOLAS ? 3 : 6) void gram_kernel(const double* __restrict__ Xs, size_t xs_stride,
                                                    const double* __restrict__ y, double* __restrict__ K,
                                                    size_t k_stride, int n, int n_pad,
-                                                   const FitSample* __restrict__ sp, int* __restrict__ fail) {
+                                                   const FitSample* __restrict__ sp, int* __restrict__ fail,
+                                                   unsigned* __restrict__ prog, double* __restrict__ Linv,
+                                                   size_t linv_stride, int nbf) {
     // the factorisation's failure flag of this sample starts at 0 (one memset launch less in front of the Cholesky)
     if (blockIdx.x == 0 && threadIdx.x == 0) fail[blockIdx.y] = 0;
+    // ... and so do the follower hand-off's words (potrf.hip: progress words to zero, every panel's W_77 slot to the sentinel
+    // that makes its entries their own flag) -- the launch that used to do this was 5 us of an 84-us ensemble half-step
+    if (prog) {
+        if (blockIdx.x == 0)
+            for (int i = threadIdx.x; i < PROG_STRIDE; i += 256) prog[(size_t)blockIdx.y * PROG_STRIDE + i] = 0u;
+        if ((int)blockIdx.x < nbf)
+            Linv[(size_t)blockIdx.y * linv_stride + (size_t)blockIdx.x * NB * NB +
+                 (size_t)(7 * 16 + (threadIdx.x >> 4)) * NB + 7 * 16 + (threadIdx.x & 15)] = __longlong_as_double(FOLLOW_SENTINEL);
+    }
     __shared__ double sI[GD * GLD];
     __shared__ double sJ[GD * GLD];
     __shared__ double sN[2 * GT];
@@ -261,12 +272,15 @@ int launch_scale_inputs(robo_ctx* ctx, const double* d_in, double* d_out, const 
 int launch_gram(robo_gp* gp, const FitBuffers& fb, hipStream_t stream, int s0, int ns) {
     const int T = gp->n_pad / GT;
     const int tiles = T * (T + 1) / 2;
+    const int nb = gp->n_pad / NB, nbf = (gp->n % NB == 0 && nb > 1) ? nb - 1 : nb;     // factored panels (launch_potrf)
     if (!stream) stream = gp->ctx->stream;
     if (ns < 0) ns = fb.S - s0;
 #define ROBO_GRAM_CALL(TYPE, KIND)                                                                              \
     hipLaunchKernelGGL((gram_kernel<TYPE, KIND>), dim3(tiles, ns), dim3(256), 0, stream,                        \
                        fb.Xs + (size_t)s0 * fb.xs_stride, fb.xs_stride, (const double*)gp->d_y,                 \
-                       fb.K + (size_t)s0 * fb.k_stride, fb.k_stride, gp->n, gp->n_pad, fb.sp + s0, fb.fail + s0)
+                       fb.K + (size_t)s0 * fb.k_stride, fb.k_stride, gp->n, gp->n_pad, fb.sp + s0, fb.fail + s0,           \
+                       fb.prog ? fb.prog + (size_t)s0 * PROG_STRIDE : (unsigned*)nullptr,                                \
+                       fb.Linv + (size_t)s0 * fb.linv_stride, fb.linv_stride, nbf)
     ROBO_DISPATCH_COV(gp->fp32_gram, gp->kind, ROBO_GRAM_CALL);
 #undef ROBO_GRAM_CALL
     ROBO_LAUNCH_CHECK();

@@ -1469,22 +1469,11 @@ __global__ __launch_bounds__(256) void potrf_step_kernel(double* __restrict__ K,
 }
 
 // The LAST column of a panel is one block, W_77 = L_77^-1, and it is what every follower waits for when the diagonal block
-// ends.  Its 256 entries are their own flag: follow_init_kernel fills the slot with W_SENTINEL (a NaN no arithmetic produces)
-// in front of the factorisation, the diagonal workgroup's ordinary publication overwrites it, and a follower re-reads ITS
-// element until it is no sentinel -- one round trip (the payload) instead of two (progress word, then payload) behind the
-// last pivot.  Also zeroes the progress words (what a memset did before).
-constexpr long long W_SENTINEL = 0x7FF8DEAD00C0FFEELL;
-__global__ __launch_bounds__(256) void follow_init_kernel(unsigned* __restrict__ prog, double* __restrict__ Linv,
-                                                          size_t linv_stride, int nbf) {
-    const int smp = (int)blockIdx.y, tid = threadIdx.x;
-    unsigned* pr = prog + (size_t)smp * PROG_STRIDE;
-    if (blockIdx.x == 0)
-        for (int i = tid; i < PROG_STRIDE; i += 256) pr[i] = 0u;
-    double* W = Linv + (size_t)smp * linv_stride;
-    for (int k = (int)blockIdx.x; k < nbf; k += (int)gridDim.x)
-        W[(size_t)k * NB * NB + (size_t)((NSB - 1) * SB + (tid >> 4)) * NB + (NSB - 1) * SB + (tid & 15)] =
-            __longlong_as_double(W_SENTINEL);
-}
+// ends.  Its 256 entries are their own flag: the gram kernel -- which precedes every factorisation -- fills the slot with
+// FOLLOW_SENTINEL (common.h) and zeroes the progress words, the diagonal workgroup's ordinary publication overwrites the
+// sentinel, and a follower re-reads ITS element until it is no sentinel -- one round trip (the payload) instead of two
+// (progress word, then payload) behind the last pivot.
+constexpr long long W_SENTINEL = FOLLOW_SENTINEL;
 
 // ---- the panel solve as a FOLLOWER of the diagonal block (r06) -----------------------------------------------------------
 // potrf_panel_kernel's substitution, column by column instead of row by row: as soon as block column c of L_kk and W_cc are
@@ -2166,8 +2155,7 @@ int launch_potrf(robo_gp* gp, const FitBuffers& fb, bool with_gram) {
                                tune.potrf_tail_split != 0 ? 1 : 0, tune.potrf_pub_early, frows,
                                tune.potrf_poll_sleep < 1 ? 1 : tune.potrf_poll_sleep);
         };
-        if (can_follow)        // progress words to zero, every panel's W_77 slot to the sentinel
-            hipLaunchKernelGGL(follow_init_kernel, dim3(nbf < 64 ? nbf : 64, S), dim3(256), 0, st, fb.prog, fb.Linv, fb.linv_stride, nbf);
+
         bool panel_done = false;              // panel of the CURRENT column k already solved (by the previous follow step)
         if (ffrom < 0 && nbf >= 1 && nb > 1) {
             follow(-1);
@@ -2214,9 +2202,7 @@ int launch_potrf(robo_gp* gp, const FitBuffers& fb, bool with_gram) {
         // update workgroups.  potrf_batch_follow = -1 (default): up to 17 panels (N <= 2048); 0 / 1: never / always.
         const bool bfollow = fb.prog != nullptr && nb <= PROG_STRIDE &&
                              (tune.potrf_batch_follow < 0 ? nb <= 17 : tune.potrf_batch_follow != 0);
-        if (bfollow)
-            hipLaunchKernelGGL(follow_init_kernel, dim3(nbf < 64 ? nbf : 64, S), dim3(256), 0, ctx->stream, fb.prog, fb.Linv,
-                               fb.linv_stride, nbf);
+
         auto group = [&](hipStream_t st, int s0, int ns, int k0, int g) {
             for (int kk = k0; kk < k0 + g; ++kk) {
                 if (kk >= nbf) break;         // the augmented row's own block
