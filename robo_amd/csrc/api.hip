@@ -64,6 +64,7 @@ static const TuneKey TUNE_KEYS[] = {
     {"potrf_split_min", nullptr, &Tuning::potrf_split_min, 12},
     {"potrf_lead", nullptr, &Tuning::potrf_lead, -1},
     {"mcmc_block_step", nullptr, &Tuning::mcmc_block_step, 2},
+    {"mcmc_fused_tail", nullptr, &Tuning::mcmc_fused_tail, 1},
 };
 
 static void tune_set(Tuning* t, const TuneKey& k, long long v) {
@@ -422,6 +423,7 @@ static FitBuffers own_buffers(robo_gp* g) {
     fb.LinvP = g->d_LinvP;
     fb.host_out = g->ctx->h_pinned;
     fb.want_inverse = true;
+    fb.skip_tail = false;
     fb.S = 1;
     return fb;
 }
@@ -591,6 +593,7 @@ static int fit_batch_core(robo_gp* g, const double* thetas, int32_t S, double me
         fb.LinvP = nullptr;
         fb.host_out = hout;
         fb.want_inverse = (bool)keep;      // likelihoods only: the posterior's inverse blocks are not formed
+        fb.skip_tail = false;
         fb.S = ns;
         ROBO_TRY(launch_scale_inputs(c, g->d_X, g->d_bXs, g->d_bism, g->n, g->n_pad, D, ns, np * D, (size_t)D));
         ROBO_TRY(launch_potrf(g, fb, true));   // gram + factorisation; its tail kernel also reduces the log-likelihood terms into fb.out
@@ -714,6 +717,7 @@ int32_t robo_gp_mcmc_run(robo_gp* g, double mean_c, int32_t prior_kind, const do
     fb.LinvP = nullptr;
     fb.host_out = nullptr;             // the likelihood terms are consumed on the device
     fb.want_inverse = false;
+    fb.skip_tail = c->tune.mcmc_fused_tail != 0 && g->n_pad > NB;     // (one-block factors reduce inside their diagonal kernel)
     fb.S = half;
     // one-block problems: the whole half-step in one launch (potrf.hip mcmc_block_step_kernel; tuning: 0 never,
     // 1 only below 64 points, 2 = default: every one-block problem)
@@ -728,6 +732,10 @@ int32_t robo_gp_mcmc_run(robo_gp* g, double mean_c, int32_t prior_kind, const do
         if (two_block) return launch_mcmc_block2_step(g, st, start, first, h, it, g->d_bK, np * np);
         ROBO_TRY(launch_mcmc_propose_scale(c, st, start, first, h, it, g->d_X, g->d_bXs, g->n, g->n_pad, np * D));
         ROBO_TRY(launch_potrf(g, fb, true));        // gram + factorisation
+        if (fb.skip_tail) {                          // likelihood terms + accept test + chain record: one launch
+            const int nbk = g->n_pad / NB, nbf = (g->n % NB == 0 && nbk > 1) ? nbk - 1 : nbk;
+            return launch_mcmc_tail(c, st, start, first, h, it, g->d_bK, np * np, g->n_pad, nbf, g->d_bfail);
+        }
         return launch_mcmc_accept(c, st, start, first, h, it);
     };
     if (eval_start) {

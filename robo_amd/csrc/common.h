@@ -163,6 +163,7 @@ struct Tuning {
     int potrf_poll_sleep;        // ... pauses (x 128 cycles) between two polls of a follower
     int potrf_batch_roll;        // ... with the diagonal workgroup's 80-KB rolling layout (two workgroups per CU); 0: the 150-KB image
     int potrf_batch_follow;      // batched fits: diagonal block + panel of a step in one launch, the panel following (-1 = default: up to 17 panels; 0 / 1)
+    int mcmc_fused_tail;         // device chain, multi-block factors: likelihood terms + accept test in one launch (1)
     int mcmc_block_step;         // ensemble half-step in ONE launch: 2 (default) every one-block problem, 1 only N <= 63, 0 never;
                                  // 3: two-block problems (N <= 254) too -- built in r06, measured SLOWER than the launch path
 };
@@ -320,6 +321,7 @@ struct FitBuffers {
     double* LinvP;                       // packed inverse fragments of the GP's own factor, or nullptr (batch workspace)
     double* host_out;                    // pinned host [S][5]: z.z, 2 sum log diag, failure flag, min / max L_ii -- or nullptr
     bool want_inverse;                   // false: log-likelihood only (no explicit inverse blocks, no fragments)
+    bool skip_tail;                      // the caller reduces the likelihood terms itself (mcmc.hip mcmc_tail_kernel)
     int S;
 };
 int launch_scale_inputs_theta(robo_ctx* ctx, const double* d_in, double* d_out, const ThetaArgs& ta, int64_t rows_real,
@@ -352,6 +354,8 @@ struct McmcState {
 int launch_mcmc_propose_scale(robo_ctx* ctx, const McmcState& st, int start, int first, int h, int it, const double* d_X,
                               double* d_Xs, int64_t rows_real, int64_t rows_pad, size_t xs_stride);
 int launch_mcmc_accept(robo_ctx* ctx, const McmcState& st, int start, int first, int h, int it);
+int launch_mcmc_tail(robo_ctx* ctx, const McmcState& st, int start, int first, int h, int it, const double* d_K, size_t k_stride,
+                     int ld, int nbf, const int* d_fail);
 int launch_mcmc_block_step(robo_gp* gp, const McmcState& st, int start, int first, int h, int it);
 int launch_mcmc_block2_step(robo_gp* gp, const McmcState& st, int start, int first, int h, int it, double* d_K, size_t k_stride);
 // with_gram: the gram matrices are built here too, every sub-batch's on the stream its factorisation runs on

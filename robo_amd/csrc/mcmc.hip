@@ -98,6 +98,82 @@ __global__ __launch_bounds__(256) void mcmc_accept_kernel(McmcState st, int star
         for (int w = threadIdx.x; w < st.k; w += blockDim.x) st.d_lnprob[(size_t)w * st.n_steps + it] = st.d_lnp[w];
 }
 
+// Tail of a multi-block ensemble half-step in ONE launch, one workgroup per walker (r06): the likelihood terms of the
+// factorisation's tail -- potrf_inverse_kernel's per-block shares added block by block as loglik_finish_kernel adds them, the
+// same operations in the same order, hence the same bits -- and then mcmc_accept_kernel's test, walker update and chain record
+// for THIS walker.  Three launches (shares, finish, accept: ~14 us of an 83-us half-step at N = 200) become one.
+__global__ __launch_bounds__(256) void mcmc_tail_kernel(McmcState st, int start, int first, int h, int it,
+                                                        const double* __restrict__ K, size_t k_stride, int ld, int nbf,
+                                                        const int* __restrict__ fail) {
+    __shared__ double red[4];
+    __shared__ int sacc;
+    const int w = blockIdx.x, tid = threadIdx.x, n = st.n, P = st.P;
+    const double* Ks = K + (size_t)w * k_stride;
+    double sq = 0.0, sl = 0.0;
+    for (int kb = 0; kb < nbf; ++kb) {
+        const int r = kb * NB + tid;
+        double q = 0.0, lg = 0.0;
+        if (tid < NB && r < n) {
+            const double zi = Ks[(size_t)n * ld + r];
+            q = zi * zi;
+            lg = log(Ks[(size_t)r * ld + r]);
+        }
+        for (int o = 32; o > 0; o >>= 1) {
+            q += __shfl_xor(q, o);
+            lg += __shfl_xor(lg, o);
+        }
+        if ((tid & 63) == 0 && tid < NB) {
+            red[tid >> 6] = q;
+            red[2 + (tid >> 6)] = lg;
+        }
+        __syncthreads();
+        sq += red[0] + red[1];
+        sl += red[2] + red[3];
+        __syncthreads();
+    }
+    const int half = st.k / 2, sw = start ? first + w : h * half + w;
+    if (tid == 0) {
+        const int f = fail[w];
+        const double lp = mcmc_lnprob(st.d_prior[w], f, sq, 2.0 * sl, n);
+        if (lp != lp) atomicOr(st.d_err, 1);       // emcee: "lnprob returned NaN."
+        if (f < 0) atomicOr(st.d_err, 4);          // a panel follower's hand-off timed out (potrf.hip)
+        int acc = 0;
+        if (start) {
+            if (lp == __builtin_huge_val()) atomicOr(st.d_err, 2);   // "The initial lnprob was +inf."
+            st.d_lnp[sw] = lp;
+        } else {
+            const size_t r = ((size_t)it * 2 + h) * half + w;
+            const double lnpdiff = mcmc_lnpdiff(P, log(st.d_z[w]), lp, st.d_lnp[sw]);
+            if (lnpdiff > log(st.d_ua[r])) {
+                acc = 1;
+                st.d_lnp[sw] = lp;
+                st.d_nacc[sw] += 1;
+            }
+            if (st.d_lnprob) st.d_lnprob[(size_t)sw * st.n_steps + it] = st.d_lnp[sw];
+        }
+        sacc = acc;
+    }
+    __syncthreads();
+    if (start) return;
+    const bool acc = sacc != 0;
+    const double* q = st.d_q + (size_t)w * P;
+    for (int p = tid; p < P; p += 256) {
+        double* pp = st.d_pos + (size_t)sw * P + p;
+        const double v = acc ? q[p] : *pp;
+        if (acc) *pp = v;
+        if (st.d_chain) st.d_chain[((size_t)sw * st.n_steps + it) * P + p] = v;
+    }
+}
+
+int launch_mcmc_tail(robo_ctx* ctx, const McmcState& st, int start, int first, int h, int it, const double* d_K, size_t k_stride,
+                     int ld, int nbf, const int* d_fail) {
+    const int ns = start ? st.ns_eval : st.k / 2;
+    hipLaunchKernelGGL(mcmc_tail_kernel, dim3(ns), dim3(256), 0, ctx->stream, st, start, first, h, it, d_K, k_stride, ld, nbf,
+                       d_fail);
+    ROBO_LAUNCH_CHECK();
+    return ROBO_OK;
+}
+
 int launch_mcmc_propose_scale(robo_ctx* ctx, const McmcState& st, int start, int first, int h, int it, const double* d_X,
                               double* d_Xs, int64_t rows_real, int64_t rows_pad, size_t xs_stride) {
     const int ns = start ? st.ns_eval : st.k / 2;

@@ -2279,6 +2279,7 @@ int launch_potrf(robo_gp* gp, const FitBuffers& fb, bool with_gram) {
         }
     }
 #undef ROBO_STEP
+    if (fb.skip_tail && !fb.want_inverse) return ROBO_OK;       // (the device chain's own tail kernel follows)
     // the explicit 128 x 128 inverses of all diagonal blocks, off the factorisation's critical path
     hipLaunchKernelGGL(potrf_inverse_kernel, dim3(nbf, S), dim3(256), 0, ctx->stream, (const double*)fb.K, fb.k_stride, ld,
                        fb.Linv, fb.linv_stride, gp->n, fb.LinvP, fb.ll_part, fb.want_inverse ? 1 : 0);

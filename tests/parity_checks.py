@@ -192,6 +192,19 @@ def check_device_chain(ctx, cases=(("matern52", 150, 3, 10, 14), ("rbf", 40, 2, 
             np.testing.assert_allclose(dev[1][fin4], dev4[1][fin4], rtol=1e-13, atol=0)
             if "hipemu" in ctx.name:
                 np.testing.assert_array_equal(dev[1][fin4], dev4[1][fin4])
+        if N > 126:
+            # multi-block factors: likelihood terms + accept test in ONE launch (mcmc_fused_tail, default) against the three
+            # launches of the factorisation's tail + the accept kernel: the same operations in the same order, the same chain
+            ctx.set_tuning("mcmc_fused_tail", 0)
+            try:
+                dev3 = run(lnprob_batch=lnprob_host,
+                           device_chain=lambda p, lnp, n, uz, pa, ua, a: g.mcmc_run(mean, par, p, lnp, n, uz, pa, ua, a))
+            finally:
+                ctx.set_tuning("mcmc_fused_tail", None)
+            np.testing.assert_array_equal(dev[2], dev3[2])
+            np.testing.assert_array_equal(dev[0], dev3[0])
+            np.testing.assert_array_equal(dev[1], dev3[1])
+            np.testing.assert_array_equal(dev[3], dev3[3])
         host = run(lnprob_batch=lnprob_host)
         orc = run(lnprob_batch=lnprob_oracle)
         assert dev[0].shape == (k, steps + 3, P) and np.all(np.isfinite(dev[0]))

@@ -149,7 +149,7 @@ def test_the_check_sees_a_contractable_proposal(tmp_path):
 
 
 def test_accept_statistic_is_not_contractable(ir):
-    for src, name in (("mcmc.hip", "mcmc_accept_kernel"), ("potrf.hip", "mcmc_block_step_kernel"),
+    for src, name in (("mcmc.hip", "mcmc_accept_kernel"), ("mcmc.hip", "mcmc_tail_kernel"), ("potrf.hip", "mcmc_block_step_kernel"),
                       ("potrf.hip", "mcmc_block2_step_kernel")):
         for k, lines in ir[src].items():
             if name not in k:
