@@ -201,10 +201,16 @@ def check_device_chain(ctx, cases=(("matern52", 150, 3, 10, 14), ("rbf", 40, 2, 
                            device_chain=lambda p, lnp, n, uz, pa, ua, a: g.mcmc_run(mean, par, p, lnp, n, uz, pa, ua, a))
             finally:
                 ctx.set_tuning("mcmc_fused_tail", None)
-            np.testing.assert_array_equal(dev[2], dev3[2])
-            np.testing.assert_array_equal(dev[0], dev3[0])
-            np.testing.assert_array_equal(dev[1], dev3[1])
+            np.testing.assert_array_equal(dev[2], dev3[2])                       # same accept decisions per walker
+            np.testing.assert_array_equal(dev[0], dev3[0])                       # hence the same walkers, bit for bit
             np.testing.assert_array_equal(dev[3], dev3[3])
+            fin3 = np.isfinite(dev3[1])
+            assert np.array_equal(fin3, np.isfinite(dev[1]))
+            # the log-probabilities: bit-identical through the interpreter, within an ulp on the MI355X (whether zi * zi and
+            # the sums around it contract is decided per kernel)
+            np.testing.assert_allclose(dev[1][fin3], dev3[1][fin3], rtol=1e-13, atol=0)
+            if "hipemu" in ctx.name:
+                np.testing.assert_array_equal(dev[1][fin3], dev3[1][fin3])
         host = run(lnprob_batch=lnprob_host)
         orc = run(lnprob_batch=lnprob_oracle)
         assert dev[0].shape == (k, steps + 3, P) and np.all(np.isfinite(dev[0]))
