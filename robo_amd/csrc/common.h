@@ -145,7 +145,7 @@ struct Tuning {
     long long winv_cond_max;     // ... while cond_inf(L) = |L|_inf |W|_inf stays below this (default 1e5)
     int potrf_fused;             // 0: never fuse the next diagonal block into the trailing update
     int potrf_fused_panels;      // ... also for batches of factors with at most this many panels (0: single fits only; -1 =
-                                 // default: while every workgroup of the first step's launch finds a CU -- 26 walkers: N <= 382)
+                                 // default: while the first step's launch is at most three rounds of CUs -- 26 walkers: N <= 766)
     int potrf_tm4_min, potrf_max_wg, potrf_group;
     int potrf_batch_tm4_min;     // batched updates: 128-row tiles from this many (tiles x samples) on, 32-row tiles below (96;
                                  // tests lower it so that the interpreter reaches the 128-row form at small N)

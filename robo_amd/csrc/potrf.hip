@@ -2066,14 +2066,17 @@ int launch_potrf(robo_gp* gp, const FitBuffers& fb, bool with_gram) {
     const Tuning& tune = ctx->tune;
     // fused step kernels (update + next diagonal block + next panel per launch): single fits, and batches whose factors are
     // so small that the per-theta CHAIN, not the matrix pipe, is what a pass costs (potrf_fused_panels: up to this many panels)
-    // -1: by residency -- every workgroup of the first step's launch (per sample: the diagonal workgroup, two followers per
-    // block row, one workgroup per other tile) finds a CU: 26 walkers up to three panels (N <= 382)
+    // -1: by the workgroups of the first step's launch (per sample: the diagonal workgroup, two followers per block row, one
+    // workgroup per other tile) against the chip -- up to three rounds of CUs: 26 walkers up to six panels (N <= 766).  (A
+    // follower only ever waits for the diagonal workgroup of ITS sample, which precedes it in dispatch order: workgroups that
+    // do not find a CU at once simply start later.)  r06w, us per half-step, grouped -> fused: N = 500 204 -> 182, 640 339 -> 331,
+    // 760 385 -> 372; N = 1000 (eight panels, 4.4 rounds) 573 -> 641: slower, stays on the grouped path.
     // Measured (r06t, device chain, 26 walkers per half-step, us per half-step, grouped batched path -> fused): N = 200 86.8 ->
     // 84.2, 300 137.8 -> 131.7, 380 150.3 -> 142.4, same walkers and accept decisions (the fused form saves the column-update
     // launch of every step; its 128-deep updates at one workgroup per CU do not matter at three panels).
     const int fused_wgs = 1 + 2 * (nb - 1) + (nb - 1) * nb / 2;
     const bool fused = tune.potrf_fused != 0 &&
-                       (S <= 2 || (tune.potrf_fused_panels < 0 ? S * fused_wgs <= ctx->num_cu : nb <= tune.potrf_fused_panels));
+                       (S <= 2 || (tune.potrf_fused_panels < 0 ? S * fused_wgs <= 3 * ctx->num_cu : nb <= tune.potrf_fused_panels));
     bool gram_done = !with_gram;
     // n a multiple of 128 (every BASELINE size): the last block holds the augmented row ALONE.  Its diagonal entry is never
     // read -- z = L^-1 (y - mean) is complete once the last REAL panel has passed over row n, the likelihood needs z.z and the
